@@ -1,0 +1,675 @@
+// raster_forward.hip -- forward pass of the MI355X-native 3D-Gaussian rasterizer (gfx950, wave64).
+//
+// What it computes is fixed by the reference (cuda_rasterizer/forward.cu, rasterizer_impl.cu:198-336);
+// HOW is redesigned for CDNA4:
+//
+//   reference (CUDA)                                   this file
+//   -------------------------------------------------  ----------------------------------------------------
+//   preprocessCUDA            forward.cu:155-256       preprocess_kernel (+ per-tile instance histogram in LDS)
+//   cub InclusiveSum over P + D2H sync  impl.cu:277-281 scan_tiles_kernel over V*T tile counts (ranges fall out of it;
+//                                                       identifyTileRanges / its memset disappear)
+//   duplicateWithKeys: 64-bit (tile|depth) keys :70-111 emit_instances_kernel: 32-bit depth RANK per instance, grouped by tile
+//   cub RadixSortPairs over N 64-bit keys  impl.cu:303  (a) 4-pass LSD radix sort of the P depth keys (P << N), then
+//                                                       (b) tile_sort_kernel: order-independent LDS bitmap of ranks +
+//                                                           popcount prefix = sorted tile list, O(len + P/32), no log factor
+//   renderCUDA                forward.cu:261-374       blend_forward_kernel (LDS-staged 48-byte records incl. colour,
+//                                                       per-Gaussian alpha cut-off so dead wave-iterations skip the exp)
+//
+// The final per-tile order is the reference's: (tile, depth bits, Gaussian index) -- a stable sort of the depth
+// keys breaks ties by index exactly like the reference's stable radix over emission order.
+// All V views of a call are processed by the same launches (grid.y / grid.z = view).
+#include <string.h>
+
+#include "dgs_device.h"
+#include "raster_state.h"
+#include "dgs_raster.h"
+
+namespace dgs {
+
+struct FwdParams {
+    int P, D, M, W, H, V, vps, gx, gy, T;
+    const float *bg, *means3D, *shs, *colors_pre, *opac, *scales, *rots, *cov_pre, *viewm, *projm, *campos, *tanfov;
+    float tanfovx, tanfovy, scale_mod;
+    int prefiltered, raw_act;
+    int* radii;
+    float* out_color;
+    GeomState g;
+    ImageState im;
+    BinningState bn;
+};
+
+// ---- small column-major 3x3 helper with glm's product order (type_mat3x3.inl:486-519) ----
+struct M3 { float c[3][3]; };
+__device__ __forceinline__ M3 m3_cols(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
+    M3 m;
+    m.c[0][0] = a0; m.c[0][1] = a1; m.c[0][2] = a2;
+    m.c[1][0] = a3; m.c[1][1] = a4; m.c[1][2] = a5;
+    m.c[2][0] = a6; m.c[2][1] = a7; m.c[2][2] = a8;
+    return m;
+}
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            R.c[j][i] = A.c[0][i] * B.c[j][0] + A.c[1][i] * B.c[j][1] + A.c[2][i] * B.c[j][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3& A) {
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) R.c[j][i] = A.c[i][j];
+    return R;
+}
+
+__device__ __forceinline__ void view_tanfov(const FwdParams& p, int v, float* tx, float* ty) {
+    if (p.tanfov) { *tx = p.tanfov[2 * v]; *ty = p.tanfov[2 * v + 1]; }
+    else { *tx = p.tanfovx; *ty = p.tanfovy; }
+}
+
+// auxiliary.h:46-56
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int* x0, int* y0, int* x1, int* y1) {
+    const float r = (float)radius;
+    *x0 = min(gx, max(0, f2i_sat((px - r) / (float)kTile)));
+    *y0 = min(gy, max(0, f2i_sat((py - r) / (float)kTile)));
+    *x1 = min(gx, max(0, f2i_sat((px + r + (float)(kTile - 1)) / (float)kTile)));
+    *y1 = min(gy, max(0, f2i_sat((py + r + (float)(kTile - 1)) / (float)kTile)));
+}
+
+// forward.cu:20-71, degree 0..3.  sh points at this Gaussian's M coefficients (3 floats each).
+__device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, float dx, float dy, float dz, float* out, unsigned* clamp_bits) {
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    unsigned bits = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#define SH(k) sh[3 * (k) + c]
+        float r = 0.28209479177387814f * SH(0);
+        if (deg > 0) {
+            r = r - 0.4886025119029199f * y * SH(1) + 0.4886025119029199f * z * SH(2) - 0.4886025119029199f * x * SH(3);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + 1.0925484305920792f * xy * SH(4) + -1.0925484305920792f * yz * SH(5) +
+                    0.31539156525252005f * (2.0f * zz - xx - yy) * SH(6) + -1.0925484305920792f * xz * SH(7) +
+                    0.5462742152960396f * (xx - yy) * SH(8);
+                if (deg > 2) {
+                    r = r + -0.5900435899266435f * y * (3.0f * xx - yy) * SH(9) + 2.890611442640554f * xy * z * SH(10) +
+                        -0.4570457994644658f * y * (4.0f * zz - xx - yy) * SH(11) +
+                        0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                        -0.4570457994644658f * x * (4.0f * zz - xx - yy) * SH(13) + 1.445305721320277f * z * (xx - yy) * SH(14) +
+                        -0.5900435899266435f * x * (xx - 3.0f * yy) * SH(15);
+                }
+            }
+        }
+#undef SH
+        r += 0.5f;
+        if (r < 0) bits |= 1u << c;
+        out[c] = fmaxf(r, 0.0f);
+    }
+    *clamp_bits = bits;
+}
+
+// One Gaussian of one view: everything preprocessCUDA does (forward.cu:155-256).  Returns visibility.
+__device__ __forceinline__ bool preprocess_one(const FwdParams& p, int v, int idx, int* rx0, int* ry0, int* rx1, int* ry1) {
+    const int s = v / p.vps;
+    const size_t gi = (size_t)v * p.P + idx;       // per-view state slot
+    const size_t si = (size_t)s * p.P + idx;       // per-set input slot
+    p.radii[gi] = 0;
+    p.g.tiles_touched[gi] = 0;
+    p.g.keys[0][gi] = 0xFFFFFFFFu;
+    const float* vm = p.viewm + 16 * v;
+    const float* pm = p.projm + 16 * v;
+    const float mx = p.means3D[3 * si], my = p.means3D[3 * si + 1], mz = p.means3D[3 * si + 2];
+    // in_frustum, auxiliary.h:139-164
+    const float hx = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
+    const float hy = pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13];
+    const float hw = pm[3] * mx + pm[7] * my + pm[11] * mz + pm[15];
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float projx = hx * pw, projy = hy * pw;
+    float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+    float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+    const float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+    if (tz <= 0.2f) {
+        if (p.prefiltered) p.im.totals[1] = DGS_ERR_PREFILTERED_CULLED;
+        return false;
+    }
+    float tanx, tany;
+    view_tanfov(p, v, &tanx, &tany);
+    const float focal_y = p.H / (2.0f * tany), focal_x = p.W / (2.0f * tanx);   // rasterizer_impl.cu:222-223
+
+    // ---- 3D covariance: precomputed or computeCov3D (forward.cu:118-152) ----
+    float c6[6];
+    if (p.cov_pre) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = p.cov_pre[6 * si + k];
+    } else {
+        float sx = p.scales[3 * si], sy = p.scales[3 * si + 1], sz = p.scales[3 * si + 2];
+        float qr = p.rots[4 * si], qx = p.rots[4 * si + 1], qy = p.rots[4 * si + 2], qz = p.rots[4 * si + 3];
+        if (p.raw_act) {   // gs_core.py:330-334 fused: exp / F.normalize
+            sx = det_expf(sx); sy = det_expf(sy); sz = det_expf(sz);
+            const float nrm = fmaxf(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
+            qr = qr / nrm; qx = qx / nrm; qy = qy / nrm; qz = qz / nrm;
+            p.g.act_scale[3 * gi] = sx; p.g.act_scale[3 * gi + 1] = sy; p.g.act_scale[3 * gi + 2] = sz;
+            p.g.act_rot[4 * gi] = qr; p.g.act_rot[4 * gi + 1] = qx; p.g.act_rot[4 * gi + 2] = qy; p.g.act_rot[4 * gi + 3] = qz;
+        }
+        M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
+        S.c[0][0] = p.scale_mod * sx; S.c[1][1] = p.scale_mod * sy; S.c[2][2] = p.scale_mod * sz;
+        const float r = qr, x = qx, y = qy, z = qz;
+        const M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                             2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                             2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+        const M3 Mm = m3_mul(S, R);
+        const M3 Sig = m3_mul(m3_t(Mm), Mm);
+        c6[0] = Sig.c[0][0]; c6[1] = Sig.c[0][1]; c6[2] = Sig.c[0][2];
+        c6[3] = Sig.c[1][1]; c6[4] = Sig.c[1][2]; c6[5] = Sig.c[2][2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.g.cov3D[6 * gi + k] = c6[k];
+    }
+    // ---- computeCov2D (forward.cu:74-113) ----
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    const float txtz = tx / tz, tytz = ty / tz;
+    tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    const M3 J = m3_cols(focal_x / tz, 0.0f, -(focal_x * tx) / (tz * tz), 0.0f, focal_y / tz, -(focal_y * ty) / (tz * tz), 0, 0, 0);
+    const M3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+    const M3 Tm = m3_mul(Wm, J);
+    const M3 Vrk = m3_cols(c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]);
+    const M3 cov = m3_mul(m3_mul(m3_t(Tm), m3_t(Vrk)), Tm);
+    const float ca = cov.c[0][0] + 0.3f, cb = cov.c[0][1], cc = cov.c[1][1] + 0.3f;
+    // ---- conic, radius, tile rect (forward.cu:215-236) ----
+    const float det = ca * cc - cb * cb;
+    if (det == 0.0f) return false;
+    const float det_inv = 1.f / det;
+    const float conx = cc * det_inv, cony = -cb * det_inv, conz = ca * det_inv;
+    const float mid = 0.5f * (ca + cc);
+    const float l1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float l2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+    const float px = (float)(((projx + 1.0) * p.W - 1.0) * 0.5);   // ndc2Pix, auxiliary.h:41-44 (double)
+    const float py = (float)(((projy + 1.0) * p.H - 1.0) * 0.5);
+    const int irad = f2i_sat(my_radius);
+    int x0, y0, x1, y1;
+    tile_rect(px, py, irad, p.gx, p.gy, &x0, &y0, &x1, &y1);
+    if ((x1 - x0) * (y1 - y0) == 0) return false;
+    // ---- colour (forward.cu:238-246) ----
+    float rgb[3];
+    unsigned cbits = 0;
+    if (p.colors_pre) {
+        rgb[0] = p.colors_pre[3 * si]; rgb[1] = p.colors_pre[3 * si + 1]; rgb[2] = p.colors_pre[3 * si + 2];
+    } else {
+        const float* cam = p.campos + 3 * v;
+        sh_to_rgb(p.D, p.shs + 3 * (size_t)p.M * si, mx - cam[0], my - cam[1], mz - cam[2], rgb, &cbits);
+    }
+    float op = p.opac[si];
+    if (p.raw_act) op = 1.0f / (1.0f + det_expf(-op));   // torch.sigmoid, gs_core.py:334
+    // Alpha cut-off: alpha = min(.99, op*exp(power)) < 1/255 whenever power < log(1/(255 op)) - margin; lets the blend
+    // skip the exponential for wave-iterations no lane needs.  Conservative by construction => results unchanged.
+    const float cut = (op > 0.0f) ? (__logf(1.0f / (255.0f * op)) - 0.004f) : __builtin_inff();
+    // ---- stores (forward.cu:248-255) ----
+    p.g.depths[gi] = tz;
+    p.radii[gi] = irad;
+    p.g.means2D[gi] = make_float2(px, py);
+    p.g.conic_opacity[gi] = make_float4(conx, cony, conz, op);
+    p.g.rgb_cut[gi] = make_float4(rgb[0], rgb[1], rgb[2], cut);
+    p.g.clamped[gi] = (uint8_t)cbits;
+    p.g.tiles_touched[gi] = (uint32_t)((y1 - y0) * (x1 - x0));
+    p.g.keys[0][gi] = __float_as_uint(tz);
+    *rx0 = x0; *ry0 = y0; *rx1 = x1; *ry1 = y1;
+    return true;
+}
+
+// grid (ceil(P/256), V), 256 threads.  LDS_HIST: per-block tile histogram in LDS (T*4 bytes), flushed with
+// one global atomic per touched tile; otherwise straight global atomics.
+template <bool LDS_HIST>
+__global__ __launch_bounds__(256) void preprocess_kernel(FwdParams p) {
+    DGS_DYNAMIC_LDS(smem);
+    uint32_t* lhist = reinterpret_cast<uint32_t*>(smem);
+    const int v = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (LDS_HIST) {
+        for (int i = threadIdx.x; i < p.T; i += 256) lhist[i] = 0;
+        __syncthreads();
+    }
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    bool vis = false;
+    if (idx < p.P) vis = preprocess_one(p, v, idx, &x0, &y0, &x1, &y1);
+    uint32_t* gcount = p.im.tile_count + (size_t)v * p.T;
+    if (vis)
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) atomicAdd(LDS_HIST ? &lhist[y * p.gx + x] : &gcount[y * p.gx + x], 1u);
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.T; i += 256) {
+            const uint32_t c = lhist[i];
+            if (c) atomicAdd(&gcount[i], c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depth radix sort of the P Gaussians of every view: 4 LSD passes of 8 bits, stable.
+// Pass = histogram (grid NB x V) -> column scan (grid 1 x V) -> scatter (grid NB x V).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint32_t* keys, uint32_t* hist, int P, int NB, int shift) {
+    __shared__ uint32_t h[256];
+    const int v = blockIdx.y, b = blockIdx.x;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t* k = keys + (size_t)v * P;
+    const int base = b * kSortTile;
+#pragma unroll 4
+    for (int r = 0; r < kSortItems; ++r) {
+        const int i = base + r * 256 + threadIdx.x;
+        if (i < P) atomicAdd(&h[(k[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[((size_t)v * NB + b) * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// thread d owns digit d: turns hist[v][b][d] into the exclusive prefix over blocks and writes the
+// exclusive scan of the digit totals to base[v][d].
+__global__ __launch_bounds__(256) void radix_colscan_kernel(uint32_t* hist, uint32_t* base, int NB) {
+    __shared__ uint32_t scratch[8];
+    const int v = blockIdx.y, d = threadIdx.x;
+    uint32_t* h = hist + (size_t)v * NB * 256;
+    uint32_t run = 0;
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t c = h[(size_t)b * 256 + d];
+        h[(size_t)b * 256 + d] = run;
+        run += c;
+    }
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<256>(run, scratch, &total);
+    base[v * 256 + d] = ex;
+}
+
+// Stable scatter.  Round r handles keys base + r*256 + tid (coalesced); inside a round the order is thread order:
+// same-digit lanes of a wave are ranked with ballots, waves are chained through LDS counters.
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                                                           uint32_t* vals_out, uint32_t* rank_of, const uint32_t* hist,
+                                                           const uint32_t* base, int P, int NB, int shift) {
+    __shared__ uint32_t wcount[4][256];
+    __shared__ uint32_t running[256];
+    const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const size_t vo = (size_t)v * P;
+    running[tid] = base[v * 256 + tid] + hist[((size_t)v * NB + b) * 256 + tid];
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < kSortItems; ++r) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
+        __syncthreads();
+        const int i = b * kSortTile + r * 256 + tid;
+        const bool valid = i < P;
+        const uint32_t key = valid ? keys_in[vo + i] : 0xFFFFFFFFu;
+        const uint32_t val = valid ? (vals_in ? vals_in[vo + i] : (uint32_t)i) : 0u;
+        const uint32_t dig = (key >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long m = __ballot((dig >> bit) & 1u);
+            peers &= ((dig >> bit) & 1u) ? m : ~m;
+        }
+        const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+        if (valid && rank_in_wave == 0) wcount[wave][dig] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[dig] + rank_in_wave;
+            for (int w = 0; w < wave; ++w) pos += wcount[w][dig];
+            keys_out[vo + pos] = key;
+            vals_out[vo + pos] = val;
+            if (rank_of) rank_of[vo + val] = pos;
+        }
+        __syncthreads();
+        running[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
+    }
+}
+
+// Exclusive scan of the V*T tile counts -> [start,end) ranges into the packed instance list (one workgroup).
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* count, uint2* ranges, uint32_t* cursor, int n,
+                                                         int32_t* totals, long long capacity) {
+    __shared__ uint32_t scratch[20];
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t c = (i < n) ? count[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan<1024>(c, scratch, &tot);
+        if (i < n) { ranges[i] = make_uint2(carry + ex, carry + ex + c); cursor[i] = 0; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = (int32_t)carry;
+        if (capacity >= 0 && (long long)carry > capacity) totals[1] = DGS_ERR_BINNING_OVERFLOW;
+    }
+}
+
+// grid (ceil(P/256), V).  Writes, for every (Gaussian, touched tile), the Gaussian's depth rank into that tile's segment.
+// Slot order inside a segment is arbitrary (tile_sort_kernel is order-independent).
+template <bool LDS_AGG>
+__global__ __launch_bounds__(256) void emit_instances_kernel(FwdParams p) {
+    DGS_DYNAMIC_LDS(smem);
+    uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* lbase = lcnt + p.T;
+    if (p.im.totals[1] != 0) return;
+    const int v = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const size_t gi = (size_t)v * p.P + idx;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    bool vis = false;
+    if (idx < p.P && p.radii[gi] > 0) {
+        const float2 m = p.g.means2D[gi];
+        tile_rect(m.x, m.y, p.radii[gi], p.gx, p.gy, &x0, &y0, &x1, &y1);
+        vis = true;
+    }
+    const uint32_t rank = vis ? p.g.rank_of[gi] : 0u;
+    const uint2* ranges = p.im.ranges + (size_t)v * p.T;
+    uint32_t* cursor = p.im.tile_cursor + (size_t)v * p.T;
+    if (LDS_AGG) {
+        for (int i = threadIdx.x; i < p.T; i += 256) lcnt[i] = 0;
+        __syncthreads();
+        if (vis)
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(&lcnt[y * p.gx + x], 1u);
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.T; i += 256) {
+            const uint32_t c = lcnt[i];
+            if (c) { lbase[i] = atomicAdd(&cursor[i], c); lcnt[i] = 0; }
+        }
+        __syncthreads();
+        if (vis)
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    const int t = y * p.gx + x;
+                    const uint32_t slot = ranges[t].x + lbase[t] + atomicAdd(&lcnt[t], 1u);
+                    p.bn.inst_rank[slot] = rank;
+                }
+    } else if (vis) {
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const int t = y * p.gx + x;
+                p.bn.inst_rank[ranges[t].x + atomicAdd(&cursor[t], 1u)] = rank;
+            }
+    }
+}
+
+// grid (T, V), 256 threads, dynamic LDS = window words * 4.  Sorts one tile's instances by depth rank:
+// ranks of one view are distinct integers in [0,P), so a bitmap (atomicOr, order-independent) plus a popcount
+// prefix sum IS the sorted sequence.  Windows of `wwords*32` ranks keep LDS bounded for any P.
+__global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords) {
+    DGS_DYNAMIC_LDS(smem);
+    uint32_t* bm = reinterpret_cast<uint32_t*>(smem);
+    __shared__ uint32_t scratch[8];
+    if (p.im.totals[1] != 0) return;
+    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const uint2 rg = p.im.ranges[(size_t)v * p.T + t];
+    if (rg.x == rg.y) return;
+    const uint32_t* order = p.g.vals[0] + (size_t)v * p.P;   // rank -> Gaussian index (after 4 passes the result is in buffer 0)
+    const int wpt = wwords / 256;                            // words per thread
+    uint32_t emitted = rg.x;
+    for (uint32_t w0 = 0; w0 < (uint32_t)p.P; w0 += (uint32_t)wwords * 32u) {
+        for (int i = tid; i < wwords; i += 256) bm[i] = 0;
+        __syncthreads();
+        for (uint32_t i = rg.x + tid; i < rg.y; i += 256) {
+            const uint32_t r = p.bn.inst_rank[i] - w0;       // unsigned wrap puts other windows out of range
+            if (r < (uint32_t)wwords * 32u) atomicOr(&bm[r >> 5], 1u << (r & 31u));
+        }
+        __syncthreads();
+        uint32_t cnt = 0;
+        for (int k = 0; k < wpt; ++k) cnt += (uint32_t)__popc(bm[tid * wpt + k]);
+        uint32_t total;
+        uint32_t off = emitted + block_exclusive_scan<256>(cnt, scratch, &total);
+        if (cnt)
+            for (int k = 0; k < wpt; ++k) {
+                uint32_t word = bm[tid * wpt + k];
+                while (word) {
+                    const int bit = __ffs((int)word) - 1;
+                    word &= word - 1;
+                    p.bn.point_list[off++] = order[w0 + (uint32_t)(tid * wpt + k) * 32u + (uint32_t)bit];
+                }
+            }
+        emitted += total;
+        __syncthreads();
+    }
+}
+
+// grid (gx, gy, V), block 16x16 = 4 wave64, each wave a 16x4 pixel strip.  forward.cu:261-374.
+__global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float4 s_rgbc[256];
+    const int v = blockIdx.z;
+    const int tid = threadIdx.y * 16 + threadIdx.x;
+    const int pxi = blockIdx.x * kTile + threadIdx.x, pyi = blockIdx.y * kTile + threadIdx.y;
+    const bool inside = pxi < p.W && pyi < p.H;
+    const float pfx = (float)pxi, pfy = (float)pyi;
+    const bool ok = p.im.totals[1] == 0;
+    uint2 rg = p.im.ranges[(size_t)v * p.T + blockIdx.y * p.gx + blockIdx.x];
+    if (!ok) rg.y = rg.x;
+    const int rounds = (int)((rg.y - rg.x + 255u) / 256u);
+    int todo = (int)(rg.y - rg.x);
+    const size_t vo = (size_t)v * p.P;
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t contributor = 0, last_contributor = 0;
+    for (int i = 0; i < rounds; ++i, todo -= 256) {
+        if (__syncthreads_count(done) == 256) break;
+        const uint32_t pos = rg.x + (uint32_t)i * 256u + (uint32_t)tid;
+        if (pos < rg.y) {
+            const uint32_t id = p.bn.point_list[pos];
+            s_xy[tid] = p.g.means2D[vo + id];
+            s_co[tid] = p.g.conic_opacity[vo + id];
+            s_rgbc[tid] = p.g.rgb_cut[vo + id];
+        }
+        __syncthreads();
+        const int nb = todo < 256 ? todo : 256;
+        for (int j = 0; !done && j < nb; ++j) {
+            contributor++;
+            const float2 xy = s_xy[j];
+            const float dx = xy.x - pfx, dy = xy.y - pfy;
+            const float4 co = s_co[j];
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float4 rc = s_rgbc[j];
+            if (power < rc.w) continue;                 // alpha < 1/255 guaranteed (see preprocess_one)
+            const float alpha = fminf(0.99f, co.w * det_expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1 - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            C0 += rc.x * alpha * T;
+            C1 += rc.y * alpha * T;
+            C2 += rc.z * alpha * T;
+            T = test_T;
+            last_contributor = contributor;
+        }
+    }
+    if (inside) {
+        const size_t pid = (size_t)p.W * pyi + pxi;
+        const size_t HW = (size_t)p.H * p.W;
+        p.im.final_T[(size_t)v * HW + pid] = T;
+        p.im.n_contrib[(size_t)v * HW + pid] = last_contributor;
+        float* out = p.out_color + (size_t)v * 3 * HW;
+        out[pid] = C0 + T * p.bg[0];
+        out[HW + pid] = C1 + T * p.bg[1];
+        out[2 * HW + pid] = C2 + T * p.bg[2];
+    }
+}
+
+__global__ void mark_visible_kernel(int P, const float* means, const float* vm, uint8_t* present) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    const float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+    present[i] = !(tz <= 0.2f);   // in_frustum, auxiliary.h:154
+}
+
+static int check(hipStream_t st, int debug) {
+    if (debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+static int pick_window_words(int P) {
+    int words = (P + 31) / 32;
+    words = ((words + 255) / 256) * 256;
+    const int kMax = 16128;   // 63 KiB of LDS per tile workgroup (static scratch shares the 64 KiB default limit)
+    return words < kMax ? words : kMax;
+}
+
+}  // namespace dgs
+
+using namespace dgs;
+
+extern "C" {
+
+int dgs_abi_version(void) { return DGS_ABI_VERSION; }
+
+const char* dgs_status_string(int s) {
+    switch (s) {
+        case DGS_OK: return "ok";
+        case DGS_ERR_INVALID_ARGUMENT: return "invalid argument (means3D must have dimensions (num_points, 3); sizes must be positive)";
+        case DGS_ERR_NEED_COLORS: return "provide exactly one of SHs or precomputed colors";
+        case DGS_ERR_NEED_COVARIANCE: return "provide exactly one of scale/rotation pair or precomputed 3D covariance";
+        case DGS_ERR_ALLOC: return "state-buffer allocation failed";
+        case DGS_ERR_DEVICE: return "HIP device error";
+        case DGS_ERR_PREFILTERED_CULLED: return "point is filtered although prefiltered is set";
+        case DGS_ERR_BINNING_OVERFLOW: return "num_rendered exceeds binning capacity";
+        default: return "unknown status";
+    }
+}
+
+size_t dgs_raster_geom_bytes(int32_t P, int32_t V) { size_t b; GeomState::carve(nullptr, (size_t)P, (size_t)V, &b); return b; }
+size_t dgs_raster_image_bytes(int32_t W, int32_t H, int32_t V) { size_t b; ImageState::carve(nullptr, (size_t)W, (size_t)H, (size_t)V, &b); return b; }
+size_t dgs_raster_binning_bytes(int64_t N) { size_t b; BinningState::carve(nullptr, (size_t)(N < 1 ? 1 : N), &b); return b; }
+
+int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!a || a->P < 0 || a->width <= 0 || a->height <= 0 || a->V < 1 || a->views_per_set < 1) return DGS_ERR_INVALID_ARGUMENT;
+    const int P = a->P, V = a->V, W = a->width, H = a->height;
+    a->num_rendered = 0;
+    if (!a->out_color || !a->geom_alloc || !a->img_alloc || !a->binning_alloc) return DGS_ERR_INVALID_ARGUMENT;
+    const size_t HW = (size_t)W * H;
+    if (P == 0) {   // rasterize_points.cu:68: outputs stay zero-initialised
+        hipMemsetAsync(a->out_color, 0, (size_t)V * 3 * HW * sizeof(float), st);
+        return check(st, a->debug);
+    }
+    if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->campos || !a->background || !a->radii) return DGS_ERR_INVALID_ARGUMENT;
+    if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) return DGS_ERR_NEED_COLORS;
+    if (a->cov3D_precomp ? (a->scales || a->rotations) : !(a->scales && a->rotations)) return DGS_ERR_NEED_COVARIANCE;
+    if (a->shs && (a->M < 1 || a->D < 0 || (a->D + 1) * (a->D + 1) > a->M || a->D > 3)) return DGS_ERR_INVALID_ARGUMENT;
+
+    FwdParams p{};
+    p.P = P; p.D = a->D; p.M = a->M; p.W = W; p.H = H; p.V = V; p.vps = a->views_per_set;
+    p.gx = (W + kTile - 1) / kTile; p.gy = (H + kTile - 1) / kTile; p.T = p.gx * p.gy;
+    p.bg = a->background; p.means3D = a->means3D; p.shs = a->shs; p.colors_pre = a->colors_precomp; p.opac = a->opacities;
+    p.scales = a->scales; p.rots = a->rotations; p.cov_pre = a->cov3D_precomp; p.viewm = a->viewmatrix; p.projm = a->projmatrix;
+    p.campos = a->campos; p.tanfov = a->tanfov; p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.scale_mod = a->scale_modifier;
+    p.prefiltered = a->prefiltered; p.raw_act = a->raw_activations; p.radii = a->radii; p.out_color = a->out_color;
+
+    size_t gbytes, ibytes;
+    GeomState::carve(nullptr, (size_t)P, (size_t)V, &gbytes);
+    ImageState::carve(nullptr, (size_t)W, (size_t)H, (size_t)V, &ibytes);
+    void* gbuf = a->geom_alloc(gbytes, a->geom_user);
+    void* ibuf = a->img_alloc(ibytes, a->img_user);
+    if (!gbuf || !ibuf) return DGS_ERR_ALLOC;
+    p.g = GeomState::carve(gbuf, (size_t)P, (size_t)V, nullptr);
+    p.im = ImageState::carve(ibuf, (size_t)W, (size_t)H, (size_t)V, nullptr);
+    const bool async = a->binning_capacity > 0;
+    void* bbuf = nullptr;
+    if (async) {
+        bbuf = a->binning_alloc(dgs_raster_binning_bytes(a->binning_capacity), a->binning_user);
+        if (!bbuf) return DGS_ERR_ALLOC;
+        p.bn = BinningState::carve(bbuf, (size_t)a->binning_capacity, nullptr);
+    }
+
+    const int VT = V * p.T;
+    hipMemsetAsync(p.im.tile_count, 0, (size_t)VT * sizeof(uint32_t), st);
+    hipMemsetAsync(p.im.totals, 0, 4 * sizeof(int32_t), st);
+    const dim3 gridP((P + 255) / 256, V);
+    const bool lds_tiles = p.T <= 4096;
+    if (lds_tiles) hipLaunchKernelGGL((preprocess_kernel<true>), gridP, dim3(256), (size_t)p.T * 4, st, p);
+    else hipLaunchKernelGGL((preprocess_kernel<false>), gridP, dim3(256), 0, st, p);
+    int rc = check(st, a->debug);
+    if (rc) return rc;
+
+    // depth sort of the P Gaussians of each view
+    const int NB = sort_blocks(P);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int in = pass & 1, out = in ^ 1;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], p.g.radix_hist, P, NB, 8 * pass);
+        hipLaunchKernelGGL(radix_colscan_kernel, dim3(1, V), dim3(256), 0, st, p.g.radix_hist, p.g.radix_base, NB);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], pass == 0 ? (const uint32_t*)nullptr : p.g.vals[in],
+                           p.g.keys[out], p.g.vals[out], pass == 3 ? p.g.rank_of : (uint32_t*)nullptr, p.g.radix_hist, p.g.radix_base, P, NB, 8 * pass);
+    }
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, p.im.ranges, p.im.tile_cursor, VT, p.im.totals,
+                       async ? (long long)a->binning_capacity : -1LL);
+    rc = check(st, a->debug);
+    if (rc) return rc;
+
+    if (!async) {   // the reference's blocking read of num_rendered (rasterizer_impl.cu:281)
+        int32_t tot[4] = {0, 0, 0, 0};
+        if (hipMemcpyAsync(tot, p.im.totals, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return DGS_ERR_DEVICE;
+        if (hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
+        if (tot[1] != 0) return tot[1];
+        a->num_rendered = (int64_t)(uint32_t)tot[0];
+        bbuf = a->binning_alloc(dgs_raster_binning_bytes(a->num_rendered), a->binning_user);
+        if (!bbuf) return DGS_ERR_ALLOC;
+        p.bn = BinningState::carve(bbuf, (size_t)(a->num_rendered < 1 ? 1 : a->num_rendered), nullptr);
+    } else {
+        a->num_rendered = -1;
+        if (a->num_rendered_dev)
+            hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    }
+
+    if (lds_tiles) hipLaunchKernelGGL((emit_instances_kernel<true>), gridP, dim3(256), (size_t)p.T * 8, st, p);
+    else hipLaunchKernelGGL((emit_instances_kernel<false>), gridP, dim3(256), 0, st, p);
+    const int wwords = pick_window_words(P);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(p.T, V), dim3(256), (size_t)wwords * 4, st, p, wwords);
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(p.gx, p.gy, V), dim3(kTile, kTile), 0, st, p);
+    return check(st, a->debug);
+}
+
+int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     dgs_stream_t stream) {
+    (void)projmatrix;
+    if (P < 0) return DGS_ERR_INVALID_ARGUMENT;
+    if (P == 0) return DGS_OK;
+    if (!means3D || !viewmatrix || !present) return DGS_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, means3D, viewmatrix, present);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+int64_t dgs_raster_state_read(const char* name, int32_t P, int32_t W, int32_t H, int32_t V, int64_t N, const void* gbuf,
+                              const void* bbuf, const void* ibuf, void* dst, int64_t dst_bytes, dgs_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const GeomState g = GeomState::carve(const_cast<void*>(gbuf), (size_t)P, (size_t)V, nullptr);
+    const ImageState im = ImageState::carve(const_cast<void*>(ibuf), (size_t)W, (size_t)H, (size_t)V, nullptr);
+    const BinningState bn = BinningState::carve(const_cast<void*>(bbuf), (size_t)(N < 1 ? 1 : N), nullptr);
+    const size_t n = (size_t)P * V, HW = (size_t)W * H * V;
+    const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * V;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    const auto is = [&](const char* s) { return strcmp(name, s) == 0; };
+    if (is("depths")) { src = g.depths; bytes = n * 4; }
+    else if (is("means2D")) { src = g.means2D; bytes = n * 8; }
+    else if (is("conic_opacity")) { src = g.conic_opacity; bytes = n * 16; }
+    else if (is("rgb")) { src = g.rgb_cut; bytes = n * 16; }
+    else if (is("tiles_touched")) { src = g.tiles_touched; bytes = n * 4; }
+    else if (is("clamped")) { src = g.clamped; bytes = n; }
+    else if (is("cov3D")) { src = g.cov3D; bytes = n * 24; }
+    else if (is("rank_of")) { src = g.rank_of; bytes = n * 4; }
+    else if (is("order")) { src = g.vals[0]; bytes = n * 4; }
+    else if (is("ranges")) { src = im.ranges; bytes = T * 8; }
+    else if (is("n_contrib")) { src = im.n_contrib; bytes = HW * 4; }
+    else if (is("final_T")) { src = im.final_T; bytes = HW * 4; }
+    else if (is("point_list")) { src = bn.point_list; bytes = (size_t)(N < 0 ? 0 : N) * 4; }
+    else return DGS_ERR_INVALID_ARGUMENT;
+    if ((int64_t)bytes > dst_bytes) return DGS_ERR_INVALID_ARGUMENT;
+    if (bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return DGS_ERR_DEVICE;
+    return (int64_t)bytes;
+}
+
+}  // extern "C"

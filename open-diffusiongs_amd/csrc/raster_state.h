@@ -1,0 +1,110 @@
+// raster_state.h -- layout of the three opaque state buffers (geometry / image / binning).
+//
+// The reference keeps GeometryState / ImageState / BinningState (rasterizer_impl.h:29-65) inside three
+// caller-owned byte buffers; the contents are private to the library, so the layout here is our own
+// (data laid out for the MI355X pipeline: SoA arrays per (view, Gaussian), 16-byte records for the blend
+// kernel's LDS staging, per-tile ranges instead of 64-bit sort keys).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <hip/hip_runtime.h>
+
+namespace dgs {
+
+constexpr int kTile = 16;
+constexpr int kSortItems = 16;                    // keys per thread in the depth radix sort
+constexpr int kSortTile = 256 * kSortItems;       // keys per workgroup
+constexpr size_t kAlign = 256;
+
+struct Carver {
+    char* base;
+    size_t off;
+    explicit Carver(void* b) : base(static_cast<char*>(b)), off(0) {}
+    template <class T>
+    T* take(size_t count) {
+        off = (off + kAlign - 1) & ~(kAlign - 1);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t bytes() const { return ((off + kAlign - 1) & ~(kAlign - 1)) + kAlign; }
+};
+
+inline int sort_blocks(int P) { return (P + kSortTile - 1) / kSortTile; }
+
+struct GeomState {                 // arrays indexed [view * P + gaussian]
+    float* depths;                 // p_view.z
+    float2* means2D;               // pixel coordinates
+    float4* conic_opacity;         // (conic.x, conic.y, conic.z, opacity)
+    float4* rgb_cut;               // (r, g, b, alpha-skip threshold on `power`)
+    float* cov3D;                  // 6 per Gaussian
+    uint8_t* clamped;              // bit c set: colour channel c was clamped at 0
+    int32_t* internal_radii;
+    uint32_t* tiles_touched;
+    uint32_t* keys[2];             // depth radix sort ping-pong (key = depth bits, 0xFFFFFFFF if culled)
+    uint32_t* vals[2];
+    uint32_t* rank_of;             // position of the Gaussian in its view's depth order
+    uint32_t* radix_hist;          // [V][blocks][256]
+    uint32_t* radix_base;          // [V][256]
+    float* act_scale;              // [V*P*3] activated scale  (raw_activations only; else unused)
+    float* act_rot;                // [V*P*4] normalised quaternion
+    static GeomState carve(void* buf, size_t P, size_t V, size_t* bytes) {
+        Carver c(buf);
+        GeomState g;
+        const size_t n = P * V;
+        g.depths = c.take<float>(n);
+        g.means2D = c.take<float2>(n);
+        g.conic_opacity = c.take<float4>(n);
+        g.rgb_cut = c.take<float4>(n);
+        g.cov3D = c.take<float>(6 * n);
+        g.clamped = c.take<uint8_t>(n);
+        g.internal_radii = c.take<int32_t>(n);
+        g.tiles_touched = c.take<uint32_t>(n);
+        for (int i = 0; i < 2; ++i) { g.keys[i] = c.take<uint32_t>(n); g.vals[i] = c.take<uint32_t>(n); }
+        g.rank_of = c.take<uint32_t>(n);
+        g.radix_hist = c.take<uint32_t>(V * (size_t)sort_blocks((int)P) * 256);
+        g.radix_base = c.take<uint32_t>(V * 256);
+        g.act_scale = c.take<float>(3 * n);
+        g.act_rot = c.take<float>(4 * n);
+        if (bytes) *bytes = c.bytes();
+        return g;
+    }
+};
+
+struct ImageState {
+    float* final_T;                // [V*H*W]
+    uint32_t* n_contrib;           // [V*H*W]
+    uint32_t* tile_count;          // [V*T]   instances per tile
+    uint32_t* tile_cursor;         // [V*T]   scatter cursors
+    uint2* ranges;                 // [V*T]   [start,end) into the packed instance list
+    int32_t* totals;               // [4]     {num_rendered, status, -, -}
+    static ImageState carve(void* buf, size_t W, size_t H, size_t V, size_t* bytes) {
+        Carver c(buf);
+        ImageState s;
+        const size_t T = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+        s.final_T = c.take<float>(V * W * H);
+        s.n_contrib = c.take<uint32_t>(V * W * H);
+        s.tile_count = c.take<uint32_t>(V * T);
+        s.tile_cursor = c.take<uint32_t>(V * T);
+        s.ranges = c.take<uint2>(V * T);
+        s.totals = c.take<int32_t>(4);
+        if (bytes) *bytes = c.bytes();
+        return s;
+    }
+};
+
+struct BinningState {
+    uint32_t* inst_rank;           // [N] unsorted: depth rank of the instance's Gaussian, grouped by tile
+    uint32_t* point_list;          // [N] per tile, front to back: Gaussian index
+    static BinningState carve(void* buf, size_t N, size_t* bytes) {
+        Carver c(buf);
+        BinningState b;
+        b.inst_rank = c.take<uint32_t>(N);
+        b.point_list = c.take<uint32_t>(N);
+        if (bytes) *bytes = c.bytes();
+        return b;
+    }
+};
+
+}  // namespace dgs

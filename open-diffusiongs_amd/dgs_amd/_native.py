@@ -1,0 +1,109 @@
+"""ctypes binding of the C ABI declared in include/dgs_raster.h (and include/dgs_dit.h).
+
+The product path loads exactly one library: open-diffusiongs_amd/lib/libdgs_hip.so (hipcc, gfx950).
+If it is missing the import fails loudly -- there is NO CPU / PyTorch fallback.  (The test-suite's CPU
+emulation build is opened explicitly by tests through `open_library(path)`; nothing here looks for it.)
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class DgsRasterForwardArgs(ctypes.Structure):
+    _fields_ = [
+        ("P", ctypes.c_int32), ("D", ctypes.c_int32), ("M", ctypes.c_int32),
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("V", ctypes.c_int32), ("views_per_set", ctypes.c_int32),
+        ("background", ctypes.c_void_p), ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p),
+        ("colors_precomp", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p),
+        ("rotations", ctypes.c_void_p), ("cov3D_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
+        ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p), ("tanfov", ctypes.c_void_p),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+        ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32), ("raw_activations", ctypes.c_int32),
+        ("out_color", ctypes.c_void_p), ("radii", ctypes.c_void_p),
+        ("geom_alloc", ALLOC_FN), ("geom_user", ctypes.c_void_p),
+        ("img_alloc", ALLOC_FN), ("img_user", ctypes.c_void_p),
+        ("binning_alloc", ALLOC_FN), ("binning_user", ctypes.c_void_p),
+        ("binning_capacity", ctypes.c_int64), ("num_rendered_dev", ctypes.c_void_p),
+        ("num_rendered", ctypes.c_int64),
+    ]
+
+
+class DgsRasterBackwardArgs(ctypes.Structure):
+    _fields_ = [
+        ("P", ctypes.c_int32), ("D", ctypes.c_int32), ("M", ctypes.c_int32), ("width", ctypes.c_int32),
+        ("height", ctypes.c_int32), ("V", ctypes.c_int32), ("views_per_set", ctypes.c_int32),
+        ("num_rendered", ctypes.c_int64),
+        ("background", ctypes.c_void_p), ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p),
+        ("colors_precomp", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p),
+        ("rotations", ctypes.c_void_p), ("cov3D_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
+        ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p), ("tanfov", ctypes.c_void_p),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+        ("debug", ctypes.c_int32), ("raw_activations", ctypes.c_int32),
+        ("radii", ctypes.c_void_p), ("dL_dpix", ctypes.c_void_p),
+        ("geom_buffer", ctypes.c_void_p), ("binning_buffer", ctypes.c_void_p), ("img_buffer", ctypes.c_void_p),
+        ("dL_dmeans2D", ctypes.c_void_p), ("dL_dconic", ctypes.c_void_p), ("dL_dcolors", ctypes.c_void_p),
+        ("dL_dcov3D", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p), ("dL_dmeans3D", ctypes.c_void_p),
+        ("dL_dsh", ctypes.c_void_p), ("dL_dscales", ctypes.c_void_p), ("dL_drotations", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/dgs_raster.h declares (checked by tests/test_abi.py)
+RASTER_SYMBOLS = ["dgs_abi_version", "dgs_status_string", "dgs_raster_geom_bytes", "dgs_raster_image_bytes",
+                  "dgs_raster_binning_bytes", "dgs_raster_forward", "dgs_raster_backward", "dgs_mark_visible",
+                  "dgs_raster_state_read"]
+
+
+def _declare(L):
+    L.dgs_abi_version.restype = ctypes.c_int
+    L.dgs_status_string.restype = ctypes.c_char_p
+    L.dgs_status_string.argtypes = [ctypes.c_int]
+    L.dgs_raster_geom_bytes.restype = ctypes.c_size_t
+    L.dgs_raster_geom_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    L.dgs_raster_image_bytes.restype = ctypes.c_size_t
+    L.dgs_raster_image_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.dgs_raster_binning_bytes.restype = ctypes.c_size_t
+    L.dgs_raster_binning_bytes.argtypes = [ctypes.c_int64]
+    L.dgs_raster_forward.restype = ctypes.c_int
+    L.dgs_raster_forward.argtypes = [ctypes.POINTER(DgsRasterForwardArgs), ctypes.c_void_p]
+    if hasattr(L, "dgs_raster_backward"):
+        L.dgs_raster_backward.restype = ctypes.c_int
+        L.dgs_raster_backward.argtypes = [ctypes.POINTER(DgsRasterBackwardArgs), ctypes.c_void_p]
+    L.dgs_mark_visible.restype = ctypes.c_int
+    L.dgs_mark_visible.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p]
+    L.dgs_raster_state_read.restype = ctypes.c_int64
+    L.dgs_raster_state_read.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_int64, ctypes.c_void_p]
+    return L
+
+
+def open_library(path):
+    """Open a library exporting the dgs C ABI and attach prototypes."""
+    return _declare(ctypes.CDLL(path))
+
+
+_lib = None
+
+
+def lib():
+    """The product library (HIP, gfx950).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"dgs_amd: HIP library {LIB_PATH} is missing. Build it with `python -m dgs_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _lib = open_library(LIB_PATH)
+        if _lib.dgs_abi_version() != 1:
+            raise RuntimeError("dgs_amd: ABI version mismatch between Python binding and libdgs_hip.so")
+    return _lib
+
+
+def status_string(L, code):
+    return L.dgs_status_string(int(code)).decode()

@@ -1,0 +1,146 @@
+"""Torch-tensor front end of the rasterizer C ABI (include/dgs_raster.h).
+
+`RasterBackend.rasterize_gaussians / rasterize_gaussians_backward / mark_visible` have exactly the
+argument lists and return tuples of the reference's pybind module `_C`
+(/root/reference/submodules/diff-gaussian-rasterization/rasterize_points.h:18-66), so
+diff_gaussian_rasterization/__init__.py can stay a verbatim mirror of the reference binding.
+PyTorch only provides device memory and the current HIP stream here.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+
+
+def _ptr(t):
+    """Device pointer of an optional tensor: empty tensors mean 'absent' (reference: torch.Tensor([]))."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _prep(t, device):
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+class RasterBackend:
+    def __init__(self, lib=None):
+        self.lib = lib if lib is not None else _native.lib()
+
+    # -- helpers ---------------------------------------------------------------------------
+    @staticmethod
+    def _stream(device):
+        if device.type == "cuda":
+            return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        return None
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = _native.status_string(self.lib, rc)
+            raise RuntimeError(f"dgs rasterizer: {msg} (status {rc})")
+
+    @staticmethod
+    def _allocator(holder, key, device):
+        def cb(nbytes, _user):
+            holder[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            return holder[key].data_ptr()
+        return _native.ALLOC_FN(cb)
+
+    # -- _C.rasterize_gaussians -----------------------------------------------------------
+    def rasterize_gaussians(self, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
+                            prefiltered, debug, raw_activations=False):
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:57-59
+        out = self.forward_views(background, means3D[None], colors, opacity, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix.reshape(1, 4, 4), projmatrix.reshape(1, 4, 4),
+                                 campos.reshape(1, 3), None, float(tanfovx), float(tanfovy), image_height, image_width,
+                                 sh, degree, prefiltered, debug, views_per_set=1, raw_activations=raw_activations)
+        num_rendered, color, radii, geom, binning, img = out
+        return num_rendered, color[0], radii[0], geom, binning, img
+
+    def forward_views(self, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                      viewmatrix, projmatrix, campos, tanfov, tanfovx, tanfovy, image_height, image_width, sh, degree,
+                      prefiltered, debug, views_per_set=1, raw_activations=False, binning_capacity=0):
+        """Batched entry: means3D [S,P,3] (other per-Gaussian inputs [S,P,...]); viewmatrix/projmatrix [V,4,4];
+        campos [V,3]; tanfov optional [V,2] tensor.  Returns (num_rendered, color[V,3,H,W], radii[V,P], geom, binning, img)."""
+        device = means3D.device
+        S, P = int(means3D.shape[0]), int(means3D.shape[1])
+        V = int(viewmatrix.shape[0])
+        H, W = int(image_height), int(image_width)
+        means3D = _prep(means3D, device)
+        keep = dict(bg=_prep(background, device), means=means3D, colors=_prep(colors, device), op=_prep(opacity, device),
+                    scales=_prep(scales, device), rots=_prep(rotations, device), cov=_prep(cov3D_precomp, device),
+                    vm=_prep(viewmatrix, device), pm=_prep(projmatrix, device), cam=_prep(campos, device),
+                    sh=_prep(sh, device), tanfov=_prep(tanfov, device))
+        M = 0
+        if keep["sh"] is not None:
+            M = int(keep["sh"].shape[-2])
+        out_color = torch.zeros((V, 3, H, W), dtype=torch.float32, device=device)    # rasterize_points.cu:64
+        radii = torch.zeros((V, P), dtype=torch.int32, device=device)                  # rasterize_points.cu:65
+        holder = {"geom": torch.empty(0, dtype=torch.uint8, device=device),
+                  "binning": torch.empty(0, dtype=torch.uint8, device=device),
+                  "img": torch.empty(0, dtype=torch.uint8, device=device)}
+        if P == 0:
+            return 0, out_color, radii, holder["geom"], holder["binning"], holder["img"]
+        a = _native.DgsRasterForwardArgs()
+        a.P, a.D, a.M, a.width, a.height, a.V, a.views_per_set = P, int(degree), M, W, H, V, int(views_per_set)
+        a.background = _ptr(keep["bg"]); a.means3D = _ptr(means3D); a.shs = _ptr(keep["sh"])
+        a.colors_precomp = _ptr(keep["colors"]); a.opacities = _ptr(keep["op"]); a.scales = _ptr(keep["scales"])
+        a.rotations = _ptr(keep["rots"]); a.cov3D_precomp = _ptr(keep["cov"]); a.viewmatrix = _ptr(keep["vm"])
+        a.projmatrix = _ptr(keep["pm"]); a.campos = _ptr(keep["cam"]); a.tanfov = _ptr(keep["tanfov"])
+        a.tanfovx, a.tanfovy, a.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
+        a.prefiltered, a.debug, a.raw_activations = int(bool(prefiltered)), int(bool(debug)), int(bool(raw_activations))
+        a.out_color = ctypes.c_void_p(out_color.data_ptr())
+        a.radii = ctypes.c_void_p(radii.data_ptr())
+        cbs = [self._allocator(holder, k, device) for k in ("geom", "img", "binning")]
+        a.geom_alloc, a.img_alloc, a.binning_alloc = cbs
+        a.binning_capacity = int(binning_capacity)
+        ndev = None
+        if binning_capacity > 0:
+            ndev = torch.zeros(2, dtype=torch.int32, device=device)
+            a.num_rendered_dev = ctypes.c_void_p(ndev.data_ptr())
+        rc = self.lib.dgs_raster_forward(ctypes.byref(a), self._stream(device))
+        self._check(rc)
+        num_rendered = int(a.num_rendered) if binning_capacity <= 0 else ndev
+        return num_rendered, out_color, radii, holder["geom"], holder["binning"], holder["img"]
+
+    # -- _C.mark_visible ------------------------------------------------------------------
+    def mark_visible(self, means3D, viewmatrix, projmatrix):
+        device = means3D.device
+        P = int(means3D.shape[0])
+        present = torch.zeros((P,), dtype=torch.bool, device=device)
+        if P:
+            m, vm, pm = _prep(means3D, device), _prep(viewmatrix, device), _prep(projmatrix, device)
+            rc = self.lib.dgs_mark_visible(P, _ptr(m), _ptr(vm), _ptr(pm), ctypes.c_void_p(present.data_ptr()),
+                                           self._stream(device))
+            self._check(rc)
+        return present
+
+    # -- parity-test introspection -----------------------------------------------------------
+    def state_read(self, name, P, W, H, V, num_rendered, geom, binning, img, dtype, count):
+        device = geom.device
+        dst = torch.empty((count,), dtype=dtype, device=device)
+        n = self.lib.dgs_raster_state_read(name.encode(), P, W, H, V, int(num_rendered), _ptr(geom), _ptr(binning), _ptr(img),
+                                           ctypes.c_void_p(dst.data_ptr()), dst.numel() * dst.element_size(),
+                                           self._stream(device))
+        if n < 0:
+            self._check(int(n))
+        return dst[: int(n) // dst.element_size()]
+
+
+_default = None
+
+
+def default_backend():
+    global _default
+    if _default is None:
+        _default = RasterBackend()
+    return _default

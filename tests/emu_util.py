@@ -1,0 +1,18 @@
+"""Loads the CPU-emulated build of the kernel library for `-m "not gpu"` logic tests (never a product path)."""
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, "hipemu"))
+
+_backend = None
+
+
+def emu_backend():
+    global _backend
+    if _backend is None:
+        import build_emu
+        from dgs_amd import _native
+        from dgs_amd.raster import RasterBackend
+        _backend = RasterBackend(lib=_native.open_library(build_emu.build()))
+    return _backend

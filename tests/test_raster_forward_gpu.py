@@ -1,0 +1,121 @@
+"""Parity tests proper: the gfx950 HIP rasterizer forward, called through the C ABI, against the CPU oracle.
+Bit-exact for every integer artefact (radii, tile counts, ranges, sorted per-tile lists, n_contrib) AND for the
+float ones (depth / mean2D / conic / colour / final_T bits): both sides execute the same IEEE operation sequence."""
+import numpy as np
+import pytest
+import torch
+
+from dgs_amd import synth
+from parity_util import assert_forward_parity, run_backend_forward
+from util_scene import small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _backend():
+    from dgs_amd.raster import default_backend
+    return default_backend()
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("deg,seed,H,W", [(0, 1, 40, 56), (3, 3, 33, 17), (1, 5, 64, 64), (2, 6, 128, 96)])
+def test_small_scenes_bit_exact(deg, seed, H, W):
+    sc, cams = small_scene(300, W, H, seed=seed, sh_degree=deg, n_views=2)
+    assert_forward_parity(_backend(), sc, cams, H, W, _dev(), bg=(0.3, 0.6, 0.9), sh_degree=deg)
+
+
+@pytest.mark.parametrize("res,regime,views", [(64, "trained", 4), (64, "init", 2), (128, "trained", 2), (256, "trained", 1)])
+def test_diffusiongs_shaped_bit_exact(res, regime, views):
+    sc = synth.gaussian_scene(res, regime=regime, seed=0)
+    cams, _, _ = synth.render_cameras(res, views, phase_deg=10)
+    assert_forward_parity(_backend(), sc, cams, res, res, _dev())
+
+
+def test_many_instances_ties_and_windows():
+    H, W = 48, 48
+    sc, cams = small_scene(5000, W, H, seed=9, log_scale=-1.2)
+    sc["xyz"][100:200] = sc["xyz"][100]
+    assert_forward_parity(_backend(), sc, cams, H, W, _dev())
+    P = 16128 * 32 + 5000
+    sc, cams = small_scene(P, 32, 32, seed=12, log_scale=-6.0, spread=0.8)
+    assert_forward_parity(_backend(), sc, cams, 32, 32, _dev())
+
+
+def test_two_sets_precomputed_colors():
+    H, W = 32, 48
+    a, cams = small_scene(64, W, H, seed=2, n_views=4)
+    b, _ = small_scene(64, W, H, seed=3)
+    sc = {k: np.stack([a[k], b[k]]) for k in a}
+    cols = np.random.default_rng(0).uniform(0, 1, size=(2, 64, 3)).astype(np.float32)
+    assert_forward_parity(_backend(), sc, cams, H, W, _dev(), views_per_set=2)
+    assert_forward_parity(_backend(), sc, cams, H, W, _dev(), views_per_set=2, colors_precomp=cols)
+
+
+def test_full_size_512_properties():
+    # BASELINE.json full size (512^2, P = 1,048,578): size-independent properties instead of an oracle run per view
+    res = 512
+    sc = synth.gaussian_scene(res, regime="trained", seed=1)
+    cams, _, _ = synth.render_cameras(res, 2, phase_deg=5)
+    be = _backend()
+    n, color, radii, geom, binning, img = run_backend_forward(be, sc, cams, res, res, _dev(), debug=False)
+    P, V, T = sc["xyz"].shape[0], 2, (res // 16) ** 2
+    rd = lambda name, dt, cnt: be.state_read(name, P, res, res, V, n, geom, binning, img, dt, cnt)
+    tiles = rd("tiles_touched", torch.int32, V * P).reshape(V, P).long()
+    ranges = rd("ranges", torch.int32, V * T * 2).reshape(V * T, 2).long()
+    plist = rd("point_list", torch.int32, n).long()
+    depths = rd("depths", torch.float32, V * P).reshape(V, P)
+    assert int(tiles.sum()) == n == int(ranges[-1, 1])
+    assert bool((ranges[1:, 0] == ranges[:-1, 1]).all())                 # packed, contiguous
+    assert bool(((tiles > 0) == (radii > 0)).all())
+    # every tile list is sorted by (depth, index) and contains no duplicates
+    seg = torch.repeat_interleave(torch.arange(V * T, device=plist.device), ranges[:, 1] - ranges[:, 0])
+    view = seg // T
+    d = depths[view, plist]
+    same = seg[1:] == seg[:-1]
+    ok = (d[1:] > d[:-1]) | ((d[1:] == d[:-1]) & (plist[1:] > plist[:-1]))
+    assert bool((ok | ~same).all())
+    # histogram of Gaussian ids equals tiles_touched (each instance emitted exactly once)
+    for v in range(V):
+        ids = plist[view == v]
+        assert bool((torch.bincount(ids, minlength=P) == tiles[v]).all())
+    assert bool(torch.isfinite(color).all()) and float(color.min()) >= 0.0
+    # idempotence / determinism: a second run is bit-identical (atomics only touch integers)
+    n2, color2, radii2, *_ = run_backend_forward(be, sc, cams, res, res, _dev(), debug=False)
+    assert n2 == n and bool((color2 == color).all()) and bool((radii2 == radii).all())
+
+
+def test_dropin_binding_matches_oracle():
+    import diff_gaussian_rasterization as dgr
+    from oracle.raster_oracle import RasterOracle
+    from util_scene import oracle_forward
+    H, W = 64, 80
+    sc, cams = small_scene(500, W, H, seed=31, sh_degree=1)
+    cam = cams[0]
+    dev = _dev()
+    t = lambda a: torch.as_tensor(a, device=dev)
+    settings = dgr.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=torch.tensor(cam["tanfovx"], device=dev), tanfovy=torch.tensor(cam["tanfovy"], device=dev),
+        bg=t(np.ones(3, np.float32)), scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]),
+        sh_degree=1, campos=t(cam["campos"]), prefiltered=False, debug=False)
+    rast = dgr.GaussianRasterizer(settings)
+    means2D = torch.zeros(500, 3, device=dev)
+    color, radii = rast(means3D=t(sc["xyz"]), means2D=means2D, shs=t(sc["shs"]), colors_precomp=None, opacities=t(sc["opacities"]),
+                        scales=t(sc["scales"]), rotations=t(sc["rotations"]), cov3D_precomp=None)
+    o = RasterOracle()
+    oracle_forward(o, sc, cam, H, W, sh_degree=1, exp_mode=1)
+    assert np.array_equal(color.cpu().numpy().view(np.uint32), o.get("out_color").view(np.uint32))
+    assert np.array_equal(radii.cpu().numpy(), o.get("radii"))
+    # libm-exp oracle (closest to the CUDA reference): PSNR >= 80 dB, far inside the 0.05 dB budget
+    o0 = RasterOracle()
+    oracle_forward(o0, sc, cam, H, W, sh_degree=1, exp_mode=0)
+    mse = float(((color.cpu().numpy().clip(0, 1) - o0.get("out_color").clip(0, 1)) ** 2).mean())
+    assert mse < 1e-8
+    from oracle.raster_oracle import mark_visible
+    vis = rast.markVisible(t(sc["xyz"]))
+    assert vis.dtype == torch.bool
+    assert np.array_equal(vis.cpu().numpy(), mark_visible(sc["xyz"], cam["viewmatrix"], cam["projmatrix"]))
+    with pytest.raises(Exception):
+        rast(means3D=t(sc["xyz"]), means2D=means2D, opacities=t(sc["opacities"]))

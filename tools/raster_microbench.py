@@ -1,0 +1,60 @@
+"""Rasterizer forward micro-benchmark (development tool; bench.py is the contract benchmark)."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "open-diffusiongs_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+from dgs_amd import synth
+from dgs_amd.raster import default_backend
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--regime", default="trained")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    be = default_backend()
+    sc = synth.gaussian_scene(a.res, regime=a.regime, seed=0)
+    cams, _, _ = synth.render_cameras(a.res, a.views, phase_deg=10)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
+    xyz, shs, sca, rot, op = (t(sc[k]) for k in ("xyz", "shs", "scales", "rotations", "opacities"))
+    vm = t(np.stack([c["viewmatrix"] for c in cams])); pm = t(np.stack([c["projmatrix"] for c in cams]))
+    cp = t(np.stack([c["campos"] for c in cams])); bg = t(np.ones(3, np.float32))
+
+    def run(cap=0):
+        return be.forward_views(bg, xyz[None], None, op, sca, rot, 1.0, None, vm, pm, cp, None, cams[0]["tanfovx"],
+                                cams[0]["tanfovy"], a.res, a.res, shs, 0, False, False, views_per_set=a.views,
+                                binning_capacity=cap)
+
+    n = run()[0]
+    P = xyz.shape[0]
+    print(f"res {a.res} views {a.views} regime {a.regime}: P={P} N_total={n} N/P/view={n / P / a.views:.2f}")
+    for label, cap in (("sync (reference-style num_rendered readback)", 0), ("async (preallocated binning)", int(n * 1.2))):
+        for _ in range(3):
+            run(cap)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(a.iters):
+            run(cap)
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / a.iters * 1e3
+        print(f"  {label}: {e0.elapsed_time(e1) / a.iters:.3f} ms/call (gpu events), {wall:.3f} ms wall "
+              f"-> {a.views / (e0.elapsed_time(e1) / a.iters) * 1e3:.0f} views/s")
+
+
+if __name__ == "__main__":
+    main()
