@@ -1,0 +1,148 @@
+/* ============================================================================
+ * dgs_dit.h -- C ABI of the MI355X-native DiffusionGS denoiser (DiT -> per-pixel Gaussians).
+ *
+ * The reference implements this half of the hot path in Python/PyTorch only
+ * (paths relative to /root/reference/diffusionGS/):
+ *
+ *   dgs_dit_forward        <- DGSDenoiser.image_to_gaussians     models/denoiser/denoiser.py:306-416
+ *                             (scene variant                      models/denoiser/denoiser_scene.py:292-420)
+ *   dgs_dit_gemm           <- nn.Linear inside timm Attention/Mlp models/transformers/utils_transformer.py:254-265
+ *                             (+ gated residual :286-289, GELU-tanh :259, tokenizer denoiser.py:216-221,
+ *                              decoder head denoiser.py:148-164)
+ *   dgs_dit_attention      <- F.scaled_dot_product_attention in timm==0.9.16 Attention.forward
+ *   dgs_dit_layernorm      <- nn.LayerNorm + modulate()           utils_transformer.py:26-27,271-290; denoiser.py:21-22
+ *   dgs_dit_rowlinear      <- adaLN_modulation / TimestepEmbedder / upsampler Linear on a handful of rows
+ *                                                                 utils_transformer.py:266-269; denoiser.py:26-72,122-136
+ *   dgs_dit_embed          <- ray/Plucker embedding + patchify    denoiser.py:312-334,210-215
+ *   dgs_dit_gaussians      <- GaussiansUpsampler.to_gs + hard pixel alignment   denoiser.py:103-120,370-413
+ *
+ * Plain C: raw device pointers + sizes + a HIP stream.  bf16 tensors are passed as uint16_t*.
+ * Internal token layout ("padded rows"): every sample owns `lpad` consecutive rows (lpad % 128 == 0,
+ * lpad >= L); rows [0, L-n_g) are the image tokens in the reference's (v, hh, ww) order, rows
+ * [L-n_g, L) are the n_g learned Gaussian tokens (the reference puts them FIRST; every operator of the
+ * block is permutation-equivariant over tokens, so only the final gather restores the order), rows
+ * [L, lpad) are padding that is computed but never observed (attention masks keys >= L).
+ * Return value: DGS_OK or a negative DgsStatus (dgs_raster.h).
+ * ==========================================================================*/
+#ifndef DGS_DIT_H_
+#define DGS_DIT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "dgs_raster.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum DgsGemmEpilogue {
+    DGS_EPI_BF16 = 0,          /* out_bf16[m,n] = acc + bias[n]                                       */
+    DGS_EPI_GELU_BF16 = 1,     /* out_bf16[m,n] = gelu_tanh(acc + bias[n])                            */
+    DGS_EPI_GATE_RESIDUAL = 2, /* out_f32[m,n] += gate[m / rows_per_batch, n] * (acc + bias[n])       */
+    DGS_EPI_F32 = 3,           /* out_f32[m,n]  = acc + bias[n]                                       */
+    DGS_EPI_QKV = 4            /* n < 2N/3: out_bf16[m,n] (ldo = 2N/3);  n >= 2N/3: V^T: vt[(b*N/3 + n-2N/3)*lpad + t],
+                                  b = m / lpad, t = m % lpad  (rows_per_batch = lpad)                 */
+} DgsGemmEpilogue;
+
+typedef struct DgsDitGemmArgs {
+    int32_t M, N, K;           /* M % 128 == 0, N % 128 == 0, K % 64 == 0                             */
+    const uint16_t* A;         /* bf16 [M, lda]                                                       */
+    int32_t lda;
+    const uint16_t* W;         /* bf16 [N, ldw]  (nn.Linear weight layout: out_features x in_features) */
+    int32_t ldw;
+    const float* bias;         /* [N] or NULL                                                         */
+    int32_t epilogue;          /* DgsGemmEpilogue                                                     */
+    void* out;                 /* bf16 or f32 [M, ldo]                                                */
+    int32_t ldo;
+    const float* gate;         /* [batch, gate_stride] (DGS_EPI_GATE_RESIDUAL)                        */
+    int32_t gate_stride;
+    int32_t rows_per_batch;
+    uint16_t* vt;              /* DGS_EPI_QKV: V^T bf16 [batch, N/3, rows_per_batch]                   */
+} DgsDitGemmArgs;
+
+typedef struct DgsDitAttentionArgs {
+    int32_t B, heads, L, lpad; /* head dim is 64; L valid tokens per sample, lpad padded rows         */
+    const uint16_t* qk;        /* bf16 [B*lpad, 2*heads*64]: q features then k features               */
+    const uint16_t* vt;        /* bf16 [B, heads*64, lpad]                                            */
+    uint16_t* out;             /* bf16 [B*lpad, heads*64]                                             */
+    float scale;               /* 1/sqrt(64)                                                          */
+} DgsDitAttentionArgs;
+
+typedef struct DgsDitLayerNormArgs {
+    int32_t rows, width;       /* width == 1024 (one wave per row, 16 elements per lane) or any multiple of 64 <= 2048 */
+    const float* x;            /* f32 [rows, width]                                                   */
+    const float* weight;       /* [width] or NULL                                                     */
+    const float* shift;        /* [batch, mod_stride] or NULL -> no modulate                           */
+    const float* scale;
+    int32_t mod_stride;
+    int32_t rows_per_batch;
+    float eps;
+    void* out;                 /* bf16 or f32 [rows, width]                                           */
+    int32_t out_f32;
+} DgsDitLayerNormArgs;
+
+typedef struct DgsDitRowLinearArgs {
+    int32_t M, N, K;           /* M <= 16 rows; K % 512 == 0 or K == 256                              */
+    const float* x;            /* f32 [M, K]                                                          */
+    int32_t silu_input;        /* 1: apply SiLU to x first (adaLN_modulation = Sequential(SiLU, Linear)) */
+    const uint16_t* W;         /* bf16 [N, K]                                                         */
+    const float* bias;         /* [N] or NULL                                                         */
+    int32_t silu_output;       /* 1: SiLU on the result (TimestepEmbedder mlp.1)                      */
+    float* out;                /* f32 [M, N]                                                          */
+} DgsDitRowLinearArgs;
+
+typedef struct DgsDitLayerWeights {
+    const uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;   /* bf16 [3W,W] [W,W] [4W,W] [W,4W]              */
+    const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+} DgsDitLayerWeights;
+
+typedef struct DgsDitModel {
+    int32_t width, heads, layers, patch, in_channels, n_gaussians, gs_channels;
+    int32_t scene;             /* 0: object model (denoiser.py), 1: scene model (denoiser_scene.py)   */
+    int32_t relative_plk;      /* ray_pe_type: 1 = 'relative_plk', 0 = 'plk'                          */
+    float range_near, range_far;
+    const uint16_t* t_w0; const float* t_b0;    /* t_embedder.mlp.0  [W,256]                           */
+    const uint16_t* t_w1; const float* t_b1;    /* t_embedder.mlp.2  [W,W]                             */
+    const uint16_t* tok_w;                      /* image_tokenizer.1.weight [W, in_channels*patch^2]   */
+    const float* pos_emb;                       /* gaussians_pos_embedding [n_gaussians, W]            */
+    const float* in_ln_w;                       /* transformer_input_layernorm.weight                  */
+    const DgsDitLayerWeights* layer;            /* HOST array [layers]                                 */
+    const uint16_t* ada_w; const float* ada_b;  /* all adaLN_modulation.1 stacked: [layers*6W + 2W + 2W, W]:
+                                                   block i rows [6W*i, 6W*(i+1)), then upsampler (2W), then image_token_decoder (2W) */
+    const float* up_ln_w;  const uint16_t* up_w;   /* upsampler.layernorm.weight, upsampler.linear.weight [gs_channels, W] */
+    const float* dec_ln_w; const uint16_t* dec_w;  /* image_token_decoder.*  linear [patch^2*gs_channels, W]             */
+} DgsDitModel;
+
+typedef struct DgsDitForwardArgs {
+    int32_t B, V, H, W;
+    const float* images;       /* [B,V,3,H,W] (first 3 channels of the reference's image tensor)      */
+    const float* ray_o;        /* [B,V,3,H,W]                                                         */
+    const float* ray_d;        /* [B,V,3,H,W]                                                         */
+    const int64_t* t;          /* [B] diffusion timestep                                              */
+    void* workspace;           /* dgs_dit_workspace_bytes(...) bytes, device                          */
+    size_t workspace_bytes;
+    /* outputs in the reference's Gaussian order: P = n_gaussians + V*H*W, index 0..n_g-1 = learned tokens,
+     * then (v, hh, ww, ph, pw) as denoiser.py:371-379 */
+    float* xyz;                /* [B,P,3]   pixel-aligned                                             */
+    float* features;           /* [B,P,1,3] (sh degree 0)                                             */
+    float* scaling;            /* [B,P,3]   raw log-scale after (s-2.3).clamp(max=-1.2)               */
+    float* rotation;           /* [B,P,4]   raw quaternion                                            */
+    float* opacity;            /* [B,P,1]   raw (o - 2.0)                                             */
+    float* aligned_xyz;        /* optional [B,V,3,H,W]                                                */
+    float* tokens;             /* optional [B,L,W] f32: tokens after the last block, reference order  */
+} DgsDitForwardArgs;
+
+int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream);
+int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream);
+int dgs_dit_layernorm(const DgsDitLayerNormArgs* a, dgs_stream_t stream);
+int dgs_dit_rowlinear(const DgsDitRowLinearArgs* a, dgs_stream_t stream);
+
+int32_t dgs_dit_lpad(int32_t L);   /* padded rows per sample */
+size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W);
+int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGS_DIT_H_ */

@@ -1,0 +1,290 @@
+// dit_elementwise.hip -- the HBM-bound kernels around the DiT GEMMs (gfx950, wave64):
+//   layernorm_kernel      nn.LayerNorm (+ optional weight) fused with modulate()   utils_transformer.py:26-27,271-290
+//   rowlinear_kernel      Linear on <= 16 rows (adaLN for all layers at once, TimestepEmbedder, upsampler head)
+//   timestep_freq_kernel  sinusoidal timestep embedding                            denoiser.py:46-67
+//   embed_patchify_kernel ray / Plucker embedding + 8x8 patchify -> bf16 GEMM operand   denoiser.py:312-334,210-215
+//   gaussians_kernel      GaussiansUpsampler.to_gs + hard pixel alignment           denoiser.py:103-120,370-413
+// All are one pass over their input with 16-byte accesses; nothing here is MFMA work.
+#include "dit_kernels.h"
+
+namespace dgs {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (+weight) (+modulate): one wave per row, each lane holds width/64 elements in registers.
+// Two-pass statistics in registers (mean, then centred variance) like torch's fp32 LayerNorm.
+// ------------------------------------------------------------------------------------------------
+
+template <int VPL>   // float4 vectors per lane: width = 256 * VPL
+__global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)row * p.width);
+    float4 v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = xr[i * 64 + lane];
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)p.width;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.width + p.eps);
+    const int b = row / p.rows_per_batch;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c4 = i * 64 + lane;   // float4 index inside the row
+        float4 y = make_float4(v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd);
+        if (p.weight) {
+            const float4 w = reinterpret_cast<const float4*>(p.weight)[c4];
+            y.x *= w.x; y.y *= w.y; y.z *= w.z; y.w *= w.w;
+        }
+        if (p.shift) {
+            const float4 sh = reinterpret_cast<const float4*>(p.shift + (size_t)b * p.mod_stride)[c4];
+            const float4 sc = reinterpret_cast<const float4*>(p.scale + (size_t)b * p.mod_stride)[c4];
+            y.x = y.x * (1.0f + sc.x) + sh.x; y.y = y.y * (1.0f + sc.y) + sh.y;
+            y.z = y.z * (1.0f + sc.z) + sh.z; y.w = y.w * (1.0f + sc.w) + sh.w;
+        }
+        if (p.out_f32) reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)row * p.width)[c4] = y;
+        else reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)row * p.width)[c4] =
+                 make_uint2(pack_bf2(y.x, y.y), pack_bf2(y.z, y.w));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear on M <= 16 rows: out[m, n] = act_out( sum_k act_in(x[m, k]) W[n, k] + bias[n] ).
+// Weight-streaming GEMV: one wave per output feature n, 16-byte bf16 loads along K, x staged in LDS as f32,
+// wave-reduce at the end.  HBM-bound on W (each weight byte is read exactly once).
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
+template <int MR>   // rows handled per pass (compile-time for register accumulators)
+__global__ __launch_bounds__(256) void rowlinear_kernel(RowLinParams p) {
+    DGS_DYNAMIC_LDS(smem);
+    float* xs = reinterpret_cast<float*>(smem);   // [MR][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < MR * p.K; i += 256) {
+        const int m = i / p.K;
+        float v = (m < p.M) ? p.x[i] : 0.0f;
+        if (p.silu_in) v = silu(v);
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= p.N) return;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+    const bf16_t* wr = p.W + (size_t)n * p.K;
+    for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
+        const uint4 w = *reinterpret_cast<const uint4*>(wr + k0);
+        const float wf[8] = {bf2f(w.x & 0xffffu), bf2f(w.x >> 16), bf2f(w.y & 0xffffu), bf2f(w.y >> 16),
+                             bf2f(w.z & 0xffffu), bf2f(w.z >> 16), bf2f(w.w & 0xffffu), bf2f(w.w >> 16)};
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const float4 xa = *reinterpret_cast<const float4*>(xs + m * p.K + k0);
+            const float4 xb = *reinterpret_cast<const float4*>(xs + m * p.K + k0 + 4);
+            acc[m] += wf[0] * xa.x + wf[1] * xa.y + wf[2] * xa.z + wf[3] * xa.w + wf[4] * xb.x + wf[5] * xb.y + wf[6] * xb.z + wf[7] * xb.w;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        float v = wave_sum(acc[m]);
+        if (lane == 0 && m < p.M) {
+            if (p.bias) v += p.bias[n];
+            if (p.silu_out) v = silu(v);
+            p.out[(size_t)m * p.N + n] = v;
+        }
+    }
+}
+
+// denoiser.py:46-67: emb[b] = [cos(t f_0..f_127), sin(t f_0..f_127)], f_i = exp(-ln(10000) i / 128)
+__global__ void timestep_freq_kernel(const int64_t* t, float* emb, int B) {
+    const int b = blockIdx.x, i = threadIdx.x;   // 128 threads
+    if (b >= B) return;
+    const float f = expf(-9.210340371976184f * (float)i / 128.0f);
+    const float a = (float)t[b] * f;
+    emb[b * 256 + i] = cosf(a);
+    emb[b * 256 + 128 + i] = sinf(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray embedding + patchify.  One thread per pixel: 9 channels -> 18 contiguous bytes of the token's GEMM row
+// (column order (ph pw c), denoiser.py:211-215).  Token row = b * lpad + v * (H/ps)(W/ps) + hh * (W/ps) + ww.
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void embed_patchify_kernel(EmbedParams p) {
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (size_t)p.B * p.V * HW) return;
+    const int w = (int)(pix % p.W), h = (int)((pix / p.W) % p.H);
+    const int bv = (int)(pix / HW), v = bv % p.V, b = bv / p.V;
+    const size_t base = (size_t)bv * 3 * HW + (size_t)h * p.W + w;
+    const float r = p.images[base], g = p.images[base + HW], bl = p.images[base + 2 * HW];
+    const float ox = p.ray_o[base], oy = p.ray_o[base + HW], oz = p.ray_o[base + 2 * HW];
+    const float dx = p.ray_d[base], dy = p.ray_d[base + HW], dz = p.ray_d[base + 2 * HW];
+    float c[9];
+    c[0] = r * 2.0f - 1.0f; c[1] = g * 2.0f - 1.0f; c[2] = bl * 2.0f - 1.0f;
+    if (p.relative_plk) {   // denoiser.py:316-322: cat(rgb, ray_d, ray_o + sum(-o d) d)
+        const float od = (-ox * dx) + (-oy * dy) + (-oz * dz);
+        c[3] = dx; c[4] = dy; c[5] = dz;
+        c[6] = ox + od * dx; c[7] = oy + od * dy; c[8] = oz + od * dz;
+    } else {                // denoiser.py:323-327: cat(rgb, cross(o, d), ray_d)
+        c[3] = oy * dz - oz * dy; c[4] = oz * dx - ox * dz; c[5] = ox * dy - oy * dx;
+        c[6] = dx; c[7] = dy; c[8] = dz;
+    }
+    const int ps = p.ps, np_w = p.W / ps, np = (p.H / ps) * np_w;
+    const size_t row = (size_t)b * p.lpad + (size_t)v * np + (size_t)(h / ps) * np_w + (w / ps);
+    bf16_t* dst = p.out + row * (size_t)(9 * ps * ps) + (size_t)((h % ps) * ps + (w % ps)) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dst[k] = (bf16_t)f2bf(c[k]);
+}
+
+// rows [L-n_g, L) of every sample <- gaussians_pos_embedding (denoiser.py:341-344)
+__global__ void pos_embed_kernel(const float* pe, float* x, int B, int lpad, int L, int ng, int width) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * ng * width) return;
+    const int c = i % width, g = (i / width) % ng, b = i / (width * ng);
+    x[((size_t)b * lpad + (L - ng) + g) * width + c] = pe[g * width + c];
+}
+
+// internal rows -> reference token order [B, L, width]: [gaussian tokens, image tokens]
+__global__ void gather_tokens_kernel(const float* x, float* out, int B, int lpad, int L, int ng, int width) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * L * width) return;
+    const int c = (int)(i % width);
+    const int tk = (int)((i / width) % L), b = (int)(i / ((size_t)width * L));
+    const int src = tk < ng ? (L - ng) + tk : tk - ng;
+    out[i] = x[((size_t)b * lpad + src) * width + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// to_gs + hard pixel alignment.  One thread per Gaussian.
+//   image Gaussians: raw[B*lpad rows][ps*ps*C] f32 (decoder GEMM output), Gaussian (v, hh, ww, ph, pw)
+//   learned Gaussians: up[B*ng][C] f32
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void gaussians_kernel(GsParams p) {
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t P = (size_t)p.ng + (size_t)p.V * HW;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)p.B * P) return;
+    const int b = (int)(gid / P);
+    const size_t i = gid % P;
+    float c[14];
+    float x, y, z;
+    if (i < (size_t)p.ng) {
+        const float* src = p.up + ((size_t)b * p.ng + i) * p.C;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) c[k] = src[k];
+        x = c[0]; y = c[1]; z = c[2];
+    } else {
+        const size_t j = i - p.ng;                       // (v, hh, ww, ph, pw)
+        const int pp = p.ps * p.ps;
+        const size_t tok = j / pp;
+        const int pi = (int)(j % pp);
+        const float* src = p.dec + ((size_t)b * p.lpad + tok) * (size_t)(pp * p.C) + (size_t)pi * p.C;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) c[k] = src[k];
+        const int np_w = p.W / p.ps, np = (p.H / p.ps) * np_w;
+        const int v = (int)(tok / np), hh = (int)((tok % np) / np_w), ww = (int)(tok % np_w);
+        const int h = hh * p.ps + pi / p.ps, w = ww * p.ps + pi % p.ps;
+        const size_t base = ((size_t)b * p.V + v) * 3 * HW + (size_t)h * p.W + w;
+        const float ox = p.ray_o[base], oy = p.ray_o[base + HW], oz = p.ray_o[base + 2 * HW];
+        const float dx = p.ray_d[base], dy = p.ray_d[base + HW], dz = p.ray_d[base + 2 * HW];
+        float depth = (c[0] + c[1] + c[2]) / 3.0f;       // .mean(dim=2)
+        depth = 1.0f / (1.0f + __expf(-depth));
+        if (p.scene) depth = depth * (p.range_far - p.range_near) + p.range_near;   // denoiser_scene.py:407-410
+        else if (p.relative_plk) depth = (2.0f * depth - 1.0f) * 1.8f + ((-ox * dx) + (-oy * dy) + (-oz * dz));
+        x = ox + depth * dx; y = oy + depth * dy; z = oz + depth * dz;
+        if (p.aligned) { p.aligned[base] = x; p.aligned[base + HW] = y; p.aligned[base + 2 * HW] = z; }
+    }
+    p.xyz[gid * 3] = x; p.xyz[gid * 3 + 1] = y; p.xyz[gid * 3 + 2] = z;
+    p.features[gid * 3] = c[3]; p.features[gid * 3 + 1] = c[4]; p.features[gid * 3 + 2] = c[5];
+    p.scaling[gid * 3] = fminf(c[6] - 2.3f, -1.2f);
+    p.scaling[gid * 3 + 1] = fminf(c[7] - 2.3f, -1.2f);
+    p.scaling[gid * 3 + 2] = fminf(c[8] - 2.3f, -1.2f);
+    p.rotation[gid * 4] = c[9]; p.rotation[gid * 4 + 1] = c[10]; p.rotation[gid * 4 + 2] = c[11]; p.rotation[gid * 4 + 3] = c[12];
+    p.opacity[gid] = c[13] - 2.0f;
+}
+
+static int launch_ok() { return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE; }
+
+int launch_layernorm(const DgsDitLayerNormArgs* a, hipStream_t st) {
+    if (!a || a->rows <= 0 || !a->x || !a->out || a->width % 256 || a->width > 2048 || a->width <= 0) return DGS_ERR_INVALID_ARGUMENT;
+    if ((a->shift == nullptr) != (a->scale == nullptr)) return DGS_ERR_INVALID_ARGUMENT;
+    LnParams p;
+    p.rows = a->rows; p.width = a->width; p.mod_stride = a->mod_stride;
+    p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->rows;
+    p.out_f32 = a->out_f32; p.eps = a->eps; p.x = a->x; p.weight = a->weight; p.shift = a->shift; p.scale = a->scale; p.out = a->out;
+    const dim3 grid((a->rows + 3) / 4), block(256);
+    switch (a->width / 256) {
+        case 1: hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<3>), grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, p); break;
+        case 8: hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, st, p); break;
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
+    return launch_ok();
+}
+
+int launch_rowlinear(const DgsDitRowLinearArgs* a, hipStream_t st) {
+    if (!a || a->M <= 0 || a->M > 16 || a->N <= 0 || a->K <= 0 || a->K % 8 || !a->x || !a->W || !a->out) return DGS_ERR_INVALID_ARGUMENT;
+    RowLinParams p;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.silu_in = a->silu_input; p.silu_out = a->silu_output;
+    p.x = a->x; p.W = a->W; p.bias = a->bias; p.out = a->out;
+    const dim3 grid((a->N + 3) / 4), block(256);
+    if (a->M <= 1) hipLaunchKernelGGL((rowlinear_kernel<1>), grid, block, (size_t)1 * a->K * 4, st, p);
+    else if (a->M <= 2) hipLaunchKernelGGL((rowlinear_kernel<2>), grid, block, (size_t)2 * a->K * 4, st, p);
+    else if (a->M <= 4) hipLaunchKernelGGL((rowlinear_kernel<4>), grid, block, (size_t)4 * a->K * 4, st, p);
+    else if (a->M <= 8) hipLaunchKernelGGL((rowlinear_kernel<8>), grid, block, (size_t)8 * a->K * 4, st, p);
+    else {
+        if ((size_t)16 * a->K * 4 > 65536) return DGS_ERR_INVALID_ARGUMENT;
+        hipLaunchKernelGGL((rowlinear_kernel<16>), grid, block, (size_t)16 * a->K * 4, st, p);
+    }
+    return launch_ok();
+}
+
+int launch_timestep(const int64_t* t, float* emb, int B, hipStream_t st) {
+    hipLaunchKernelGGL(timestep_freq_kernel, dim3(B), dim3(128), 0, st, t, emb, B);
+    return launch_ok();
+}
+
+int launch_embed(const EmbedParams& p, hipStream_t st) {
+    const size_t n = (size_t)p.B * p.V * p.H * p.W;
+    hipLaunchKernelGGL(embed_patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    return launch_ok();
+}
+
+int launch_pos_embed(const float* pe, float* x, int B, int lpad, int L, int ng, int width, hipStream_t st) {
+    hipLaunchKernelGGL(pos_embed_kernel, dim3((B * ng * width + 255) / 256), dim3(256), 0, st, pe, x, B, lpad, L, ng, width);
+    return launch_ok();
+}
+
+int launch_gather_tokens(const float* x, float* out, int B, int lpad, int L, int ng, int width, hipStream_t st) {
+    const size_t n = (size_t)B * L * width;
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, out, B, lpad, L, ng, width);
+    return launch_ok();
+}
+
+int launch_gaussians(const GsParams& p, hipStream_t st) {
+    const size_t n = (size_t)p.B * ((size_t)p.ng + (size_t)p.V * p.H * p.W);
+    hipLaunchKernelGGL(gaussians_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    return launch_ok();
+}
+
+}  // namespace dgs
+
+extern "C" int dgs_dit_layernorm(const DgsDitLayerNormArgs* a, dgs_stream_t stream) {
+    return dgs::launch_layernorm(a, static_cast<hipStream_t>(stream));
+}
+extern "C" int dgs_dit_rowlinear(const DgsDitRowLinearArgs* a, dgs_stream_t stream) {
+    return dgs::launch_rowlinear(a, static_cast<hipStream_t>(stream));
+}

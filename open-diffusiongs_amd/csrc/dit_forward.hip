@@ -1,0 +1,176 @@
+// dit_forward.hip -- host-side launch sequence of DGSDenoiser.image_to_gaussians (denoiser.py:306-416;
+// scene variant denoiser_scene.py) on one HIP stream: no host synchronisation, no allocation, every intermediate lives
+// in one caller-provided workspace.  Per DiT block: LN+modulate -> QKV GEMM (+V^T epilogue) -> flash attention ->
+// proj GEMM (+gate*y+residual) -> LN+modulate -> fc1 GEMM (+GELU) -> fc2 GEMM (+gate*y+residual): 7 launches, and the
+// adaLN modulation vectors of ALL blocks and both heads come from one weight-streaming GEMV up front (the
+// conditioning vector is the same for every block).
+#include "dit_kernels.h"
+#include "raster_state.h"
+
+namespace dgs {
+
+struct DitWorkspace {
+    float* x;        // [M, W]   residual stream, f32
+    bf16_t* xn;      // [M, W]   LN+modulate output (GEMM operand)
+    bf16_t* qk;      // [M, 2W]
+    bf16_t* vt;      // [B, W, lpad]
+    bf16_t* ao;      // [M, W]   attention output
+    bf16_t* h;       // [M, 4W]  MLP hidden
+    bf16_t* emb;     // [M, in_channels*ps*ps]
+    float* dec;      // [M, ps*ps*C]
+    float* temb;     // [B, 256]
+    float* c1;       // [B, W]
+    float* cvec;     // [B, W]
+    float* mod;      // [B, (6*layers + 4) * W]
+    float* upn;      // [B*ng, W]
+    float* up;       // [B*ng, C]
+    static DitWorkspace carve(void* buf, const DgsDitModel* m, size_t B, size_t lpad, size_t* bytes) {
+        Carver c(buf);
+        DitWorkspace w;
+        const size_t M = B * lpad, W = (size_t)m->width;
+        const size_t pp = (size_t)m->patch * m->patch;
+        w.x = c.take<float>(M * W);
+        w.xn = c.take<bf16_t>(M * W);
+        w.qk = c.take<bf16_t>(M * 2 * W);
+        w.vt = c.take<bf16_t>(M * W);
+        w.ao = c.take<bf16_t>(M * W);
+        w.h = c.take<bf16_t>(M * 4 * W);
+        w.emb = c.take<bf16_t>(M * pp * m->in_channels);
+        w.dec = c.take<float>(M * pp * m->gs_channels);
+        w.temb = c.take<float>(B * 256);
+        w.c1 = c.take<float>(B * W);
+        w.cvec = c.take<float>(B * W);
+        w.mod = c.take<float>(B * (6 * (size_t)m->layers + 4) * W);
+        w.upn = c.take<float>(B * m->n_gaussians * W);
+        w.up = c.take<float>(B * m->n_gaussians * m->gs_channels);
+        if (bytes) *bytes = c.bytes();
+        return w;
+    }
+};
+
+static int token_count(const DgsDitModel* m, int V, int H, int W) { return m->n_gaussians + V * (H / m->patch) * (W / m->patch); }
+
+}  // namespace dgs
+
+using namespace dgs;
+
+extern "C" int32_t dgs_dit_lpad(int32_t L) { return (L + 127) / 128 * 128; }
+
+extern "C" size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W) {
+    if (!m || B <= 0 || V <= 0 || H <= 0 || W <= 0 || m->patch <= 0) return 0;
+    size_t bytes = 0;
+    DitWorkspace::carve(nullptr, m, (size_t)B, (size_t)dgs_dit_lpad(token_count(m, V, H, W)), &bytes);
+    return bytes;
+}
+
+#define DGS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DGS_OK) return rc_; } while (0)
+
+extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream) {
+    if (!m || !a || a->B <= 0 || a->V <= 0 || a->H <= 0 || a->W <= 0) return DGS_ERR_INVALID_ARGUMENT;
+    if (m->width % 256 || m->width != m->heads * 64 || m->layers <= 0 || m->patch <= 0 || a->H % m->patch || a->W % m->patch)
+        return DGS_ERR_INVALID_ARGUMENT;
+    if (m->gs_channels != 14 || m->in_channels != 9 || (m->in_channels * m->patch * m->patch) % 64) return DGS_ERR_INVALID_ARGUMENT;
+    if (!a->images || !a->ray_o || !a->ray_d || !a->t || !a->workspace || !a->xyz || !a->features || !a->scaling || !a->rotation || !a->opacity)
+        return DGS_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int B = a->B, V = a->V, H = a->H, Wd = a->W, W = m->width, ng = m->n_gaussians, C = m->gs_channels;
+    const int L = token_count(m, V, H, Wd), lpad = dgs_dit_lpad(L), M = B * lpad;
+    const int pp = m->patch * m->patch, kin = m->in_channels * pp;
+    size_t need = 0;
+    DitWorkspace ws = DitWorkspace::carve(a->workspace, m, (size_t)B, (size_t)lpad, &need);
+    if (a->workspace_bytes < need) return DGS_ERR_ALLOC;
+    const int nmod = (6 * m->layers + 4) * W;
+
+    // ---- conditioning: t -> sinusoid -> MLP -> cvec; all adaLN modulations in one GEMV (denoiser.py:26-72; DiTBlock :266-272) ----
+    DGS_TRY(launch_timestep(a->t, ws.temb, B, st));
+    for (int b0 = 0; b0 < B; b0 += 16) {
+        const int mb = B - b0 < 16 ? B - b0 : 16;
+        DgsDitRowLinearArgs r{};
+        r.M = mb; r.N = W; r.K = 256; r.x = ws.temb + (size_t)b0 * 256; r.W = m->t_w0; r.bias = m->t_b0; r.silu_output = 1; r.out = ws.c1 + (size_t)b0 * W;
+        DGS_TRY(launch_rowlinear(&r, st));
+        r.K = W; r.x = ws.c1 + (size_t)b0 * W; r.W = m->t_w1; r.bias = m->t_b1; r.silu_output = 0; r.out = ws.cvec + (size_t)b0 * W;
+        DGS_TRY(launch_rowlinear(&r, st));
+        r.N = nmod; r.x = ws.cvec + (size_t)b0 * W; r.silu_input = 1; r.W = m->ada_w; r.bias = m->ada_b; r.out = ws.mod + (size_t)b0 * nmod;
+        DGS_TRY(launch_rowlinear(&r, st));
+    }
+
+    // ---- tokens: embed + patchify -> tokenizer GEMM -> learned tokens -> input LayerNorm (denoiser.py:312-347) ----
+    if (hipMemsetAsync(ws.emb, 0, (size_t)M * kin * sizeof(bf16_t), st) != hipSuccess) return DGS_ERR_DEVICE;
+    EmbedParams ep;
+    ep.B = B; ep.V = V; ep.H = H; ep.W = Wd; ep.ps = m->patch; ep.lpad = lpad; ep.relative_plk = m->relative_plk;
+    ep.images = a->images; ep.ray_o = a->ray_o; ep.ray_d = a->ray_d; ep.out = ws.emb;
+    DGS_TRY(launch_embed(ep, st));
+    DgsDitGemmArgs g{};
+    g.M = M; g.N = W; g.K = kin; g.A = ws.emb; g.lda = kin; g.W = m->tok_w; g.ldw = kin; g.epilogue = DGS_EPI_F32; g.out = ws.x; g.ldo = W;
+    DGS_TRY(dgs_dit_gemm(&g, stream));
+    DGS_TRY(launch_pos_embed(m->pos_emb, ws.x, B, lpad, L, ng, W, st));
+    DgsDitLayerNormArgs ln{};
+    ln.rows = M; ln.width = W; ln.x = ws.x; ln.weight = m->in_ln_w; ln.eps = 1e-5f; ln.out = ws.x; ln.out_f32 = 1; ln.rows_per_batch = lpad;
+    DGS_TRY(launch_layernorm(&ln, st));
+
+    // ---- 24 x DiTBlock (utils_transformer.py:271-290) ----
+    DgsDitAttentionArgs at{};
+    at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = ws.qk; at.vt = ws.vt; at.out = ws.ao; at.scale = 0.125f;
+    for (int i = 0; i < m->layers; ++i) {
+        const DgsDitLayerWeights& lw = m->layer[i];
+        const float* mod = ws.mod + (size_t)i * 6 * W;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        DgsDitLayerNormArgs l1{};
+        l1.rows = M; l1.width = W; l1.x = ws.x; l1.shift = mod; l1.scale = mod + W; l1.mod_stride = nmod; l1.rows_per_batch = lpad;
+        l1.eps = 1e-6f; l1.out = ws.xn;
+        DGS_TRY(launch_layernorm(&l1, st));
+        DgsDitGemmArgs q{};
+        q.M = M; q.N = 3 * W; q.K = W; q.A = ws.xn; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_QKV;
+        q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad;
+        DGS_TRY(dgs_dit_gemm(&q, stream));
+        DGS_TRY(dgs_dit_attention(&at, stream));
+        DgsDitGemmArgs pr{};
+        pr.M = M; pr.N = W; pr.K = W; pr.A = ws.ao; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
+        pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad;
+        DGS_TRY(dgs_dit_gemm(&pr, stream));
+        l1.shift = mod + 3 * W; l1.scale = mod + 4 * W;
+        DGS_TRY(launch_layernorm(&l1, st));
+        DgsDitGemmArgs f1{};
+        f1.M = M; f1.N = 4 * W; f1.K = W; f1.A = ws.xn; f1.lda = W; f1.W = lw.fc1_w; f1.ldw = W; f1.bias = lw.fc1_b;
+        f1.epilogue = DGS_EPI_GELU_BF16; f1.out = ws.h; f1.ldo = 4 * W;
+        DGS_TRY(dgs_dit_gemm(&f1, stream));
+        DgsDitGemmArgs f2{};
+        f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = ws.h; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
+        f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.out = ws.x; f2.ldo = W; f2.gate = mod + 5 * W; f2.gate_stride = nmod; f2.rows_per_batch = lpad;
+        DGS_TRY(dgs_dit_gemm(&f2, stream));
+    }
+    if (a->tokens) DGS_TRY(launch_gather_tokens(ws.x, a->tokens, B, lpad, L, ng, W, st));
+
+    // ---- heads (denoiser.py:122-136,155-164): LN(weight)+modulate -> Linear ----
+    const float* mod_up = ws.mod + (size_t)m->layers * 6 * W;   // shift, scale
+    const float* mod_dec = mod_up + 2 * W;
+    DgsDitLayerNormArgs ld{};
+    ld.rows = M; ld.width = W; ld.x = ws.x; ld.weight = m->dec_ln_w; ld.shift = mod_dec; ld.scale = mod_dec + W; ld.mod_stride = nmod;
+    ld.rows_per_batch = lpad; ld.eps = 1e-5f; ld.out = ws.xn;
+    DGS_TRY(launch_layernorm(&ld, st));
+    DgsDitGemmArgs dg{};
+    dg.M = M; dg.N = pp * C; dg.K = W; dg.A = ws.xn; dg.lda = W; dg.W = m->dec_w; dg.ldw = W; dg.epilogue = DGS_EPI_F32; dg.out = ws.dec; dg.ldo = pp * C;
+    DGS_TRY(dgs_dit_gemm(&dg, stream));
+    for (int b = 0; b < B; ++b) {
+        DgsDitLayerNormArgs lu{};
+        lu.rows = ng; lu.width = W; lu.x = ws.x + ((size_t)b * lpad + (L - ng)) * W; lu.weight = m->up_ln_w;
+        lu.shift = mod_up + (size_t)b * nmod; lu.scale = mod_up + W + (size_t)b * nmod; lu.mod_stride = nmod; lu.rows_per_batch = ng;
+        lu.eps = 1e-5f; lu.out = ws.upn + (size_t)b * ng * W; lu.out_f32 = 1;
+        DGS_TRY(launch_layernorm(&lu, st));
+    }
+    for (int r0 = 0; r0 < B * ng; r0 += 16) {
+        const int mr = B * ng - r0 < 16 ? B * ng - r0 : 16;
+        DgsDitRowLinearArgs r{};
+        r.M = mr; r.N = C; r.K = W; r.x = ws.upn + (size_t)r0 * W; r.W = m->up_w; r.out = ws.up + (size_t)r0 * C;
+        DGS_TRY(launch_rowlinear(&r, st));
+    }
+
+    // ---- to_gs + pixel alignment (denoiser.py:103-120,370-413) ----
+    GsParams gp;
+    gp.B = B; gp.V = V; gp.H = H; gp.W = Wd; gp.ps = m->patch; gp.lpad = lpad; gp.ng = ng; gp.C = C; gp.scene = m->scene;
+    gp.relative_plk = m->relative_plk; gp.range_near = m->range_near; gp.range_far = m->range_far;
+    gp.dec = ws.dec; gp.up = ws.up; gp.ray_o = a->ray_o; gp.ray_d = a->ray_d;
+    gp.xyz = a->xyz; gp.features = a->features; gp.scaling = a->scaling; gp.rotation = a->rotation; gp.opacity = a->opacity;
+    gp.aligned = a->aligned_xyz;
+    DGS_TRY(launch_gaussians(gp, st));
+    return DGS_OK;
+}

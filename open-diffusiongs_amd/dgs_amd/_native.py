@@ -107,3 +107,88 @@ def lib():
 
 def status_string(L, code):
     return L.dgs_status_string(int(code)).decode()
+
+
+# ---------------------------------------------------------------------------------------------------
+# include/dgs_dit.h
+# ---------------------------------------------------------------------------------------------------
+EPI_BF16, EPI_GELU_BF16, EPI_GATE_RESIDUAL, EPI_F32, EPI_QKV = range(5)
+
+
+class DgsDitGemmArgs(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("A", ctypes.c_void_p), ("lda", ctypes.c_int32), ("W", ctypes.c_void_p), ("ldw", ctypes.c_int32),
+                ("bias", ctypes.c_void_p), ("epilogue", ctypes.c_int32), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int32),
+                ("gate", ctypes.c_void_p), ("gate_stride", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32),
+                ("vt", ctypes.c_void_p)]
+
+
+class DgsDitAttentionArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("heads", ctypes.c_int32), ("L", ctypes.c_int32), ("lpad", ctypes.c_int32),
+                ("qk", ctypes.c_void_p), ("vt", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_float)]
+
+
+class DgsDitLayerNormArgs(ctypes.Structure):
+    _fields_ = [("rows", ctypes.c_int32), ("width", ctypes.c_int32), ("x", ctypes.c_void_p), ("weight", ctypes.c_void_p),
+                ("shift", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("mod_stride", ctypes.c_int32),
+                ("rows_per_batch", ctypes.c_int32), ("eps", ctypes.c_float), ("out", ctypes.c_void_p),
+                ("out_f32", ctypes.c_int32)]
+
+
+class DgsDitRowLinearArgs(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("x", ctypes.c_void_p),
+                ("silu_input", ctypes.c_int32), ("W", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("silu_output", ctypes.c_int32), ("out", ctypes.c_void_p)]
+
+
+class DgsDitLayerWeights(ctypes.Structure):
+    _fields_ = [("qkv_w", ctypes.c_void_p), ("proj_w", ctypes.c_void_p), ("fc1_w", ctypes.c_void_p), ("fc2_w", ctypes.c_void_p),
+                ("qkv_b", ctypes.c_void_p), ("proj_b", ctypes.c_void_p), ("fc1_b", ctypes.c_void_p), ("fc2_b", ctypes.c_void_p)]
+
+
+class DgsDitModel(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("heads", ctypes.c_int32), ("layers", ctypes.c_int32), ("patch", ctypes.c_int32),
+                ("in_channels", ctypes.c_int32), ("n_gaussians", ctypes.c_int32), ("gs_channels", ctypes.c_int32),
+                ("scene", ctypes.c_int32), ("relative_plk", ctypes.c_int32),
+                ("range_near", ctypes.c_float), ("range_far", ctypes.c_float),
+                ("t_w0", ctypes.c_void_p), ("t_b0", ctypes.c_void_p), ("t_w1", ctypes.c_void_p), ("t_b1", ctypes.c_void_p),
+                ("tok_w", ctypes.c_void_p), ("pos_emb", ctypes.c_void_p), ("in_ln_w", ctypes.c_void_p),
+                ("layer", ctypes.POINTER(DgsDitLayerWeights)),
+                ("ada_w", ctypes.c_void_p), ("ada_b", ctypes.c_void_p),
+                ("up_ln_w", ctypes.c_void_p), ("up_w", ctypes.c_void_p), ("dec_ln_w", ctypes.c_void_p), ("dec_w", ctypes.c_void_p)]
+
+
+class DgsDitForwardArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("V", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("images", ctypes.c_void_p), ("ray_o", ctypes.c_void_p), ("ray_d", ctypes.c_void_p), ("t", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("xyz", ctypes.c_void_p), ("features", ctypes.c_void_p), ("scaling", ctypes.c_void_p),
+                ("rotation", ctypes.c_void_p), ("opacity", ctypes.c_void_p), ("aligned_xyz", ctypes.c_void_p),
+                ("tokens", ctypes.c_void_p)]
+
+
+# every symbol include/dgs_dit.h declares (checked by tests/test_abi.py)
+DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
+               "dgs_dit_workspace_bytes", "dgs_dit_forward"]
+
+
+def _declare_dit(L):
+    for name, argt in (("dgs_dit_gemm", DgsDitGemmArgs), ("dgs_dit_attention", DgsDitAttentionArgs),
+                       ("dgs_dit_layernorm", DgsDitLayerNormArgs), ("dgs_dit_rowlinear", DgsDitRowLinearArgs)):
+        fn = getattr(L, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(argt), ctypes.c_void_p]
+    L.dgs_dit_lpad.restype = ctypes.c_int32
+    L.dgs_dit_lpad.argtypes = [ctypes.c_int32]
+    L.dgs_dit_workspace_bytes.restype = ctypes.c_size_t
+    L.dgs_dit_workspace_bytes.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.dgs_dit_forward.restype = ctypes.c_int
+    L.dgs_dit_forward.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitForwardArgs), ctypes.c_void_p]
+    return L
+
+
+_declare_raster = _declare
+
+
+def _declare(L):  # noqa: F811  (raster + DiT prototypes on one library)
+    return _declare_dit(_declare_raster(L))

@@ -1,0 +1,183 @@
+"""Torch-tensor front end of the DiT C ABI (include/dgs_dit.h).
+
+`DitEngine` owns the bf16 device copy of a DGSDenoiser state dict (reference key names) plus one
+workspace, and runs `DGSDenoiser.image_to_gaussians` (denoiser.py:306-416) as ONE C call that enqueues every kernel on
+the current HIP stream.  `DitOps` exposes the individual kernels for the parity tests.  PyTorch provides device memory
+and the stream only -- no torch op computes anything on this path.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import (DgsDitAttentionArgs, DgsDitForwardArgs, DgsDitGemmArgs, DgsDitLayerNormArgs, DgsDitLayerWeights,
+                      DgsDitModel, DgsDitRowLinearArgs)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    if device.type == "cuda":
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return None
+
+
+class DitOps:
+    """Kernel-level entry points (tests, microbenchmarks)."""
+
+    def __init__(self, lib=None):
+        self.lib = lib if lib is not None else _native.lib()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"dgs dit: {_native.status_string(self.lib, rc)} (status {rc})")
+
+    def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None):
+        """A bf16 [M,K], W bf16 [N,K] -> per epilogue (see dgs_dit.h).  `out` is required for GATE_RESIDUAL (in-place)."""
+        M, K = A.shape
+        N = W.shape[0]
+        dev = A.device
+        if epilogue == _native.EPI_QKV:
+            ldo = 2 * N // 3
+            if out is None:
+                out = torch.empty((M, ldo), dtype=torch.bfloat16, device=dev)
+            if vt is None:
+                vt = torch.empty((M // rows_per_batch, N // 3, rows_per_batch), dtype=torch.bfloat16, device=dev)
+        elif epilogue in (_native.EPI_BF16, _native.EPI_GELU_BF16):
+            ldo = N
+            if out is None:
+                out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        else:
+            ldo = N
+            if out is None:
+                out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        a = DgsDitGemmArgs()
+        a.M, a.N, a.K = M, N, K
+        a.A, a.lda, a.W, a.ldw = _p(A), A.stride(0), _p(W), W.stride(0)
+        a.bias, a.epilogue, a.out, a.ldo = _p(bias), epilogue, _p(out), ldo
+        a.gate, a.gate_stride, a.rows_per_batch, a.vt = _p(gate), (gate.stride(0) if gate is not None else 0), rows_per_batch, _p(vt)
+        self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))
+        return (out, vt) if epilogue == _native.EPI_QKV else out
+
+    def attention(self, qk, vt, L, heads):
+        """qk bf16 [B*lpad, 2*heads*64], vt bf16 [B, heads*64, lpad] -> bf16 [B*lpad, heads*64]."""
+        B, _, lpad = vt.shape
+        out = torch.zeros((B * lpad, heads * 64), dtype=torch.bfloat16, device=qk.device)
+        a = DgsDitAttentionArgs()
+        a.B, a.heads, a.L, a.lpad = B, heads, L, lpad
+        a.qk, a.vt, a.out, a.scale = _p(qk), _p(vt), _p(out), 0.125
+        self._check(self.lib.dgs_dit_attention(ctypes.byref(a), _stream(qk.device)))
+        return out
+
+    def layernorm(self, x, weight=None, shift=None, scale=None, rows_per_batch=0, eps=1e-6, out_f32=False):
+        rows, width = x.shape
+        out = torch.empty((rows, width), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        a = DgsDitLayerNormArgs()
+        a.rows, a.width, a.x, a.weight = rows, width, _p(x), _p(weight)
+        a.shift, a.scale = _p(shift), _p(scale)
+        a.mod_stride = shift.stride(0) if shift is not None else 0
+        a.rows_per_batch, a.eps, a.out, a.out_f32 = rows_per_batch, eps, _p(out), int(out_f32)
+        self._check(self.lib.dgs_dit_layernorm(ctypes.byref(a), _stream(x.device)))
+        return out
+
+    def rowlinear(self, x, W, bias=None, silu_input=False, silu_output=False):
+        M, K = x.shape
+        N = W.shape[0]
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        a = DgsDitRowLinearArgs()
+        a.M, a.N, a.K, a.x, a.silu_input = M, N, K, _p(x), int(silu_input)
+        a.W, a.bias, a.silu_output, a.out = _p(W), _p(bias), int(silu_output), _p(out)
+        self._check(self.lib.dgs_dit_rowlinear(ctypes.byref(a), _stream(x.device)))
+        return out
+
+
+class DitEngine:
+    """Device-resident DGSDenoiser weights + workspace; `image_to_gaussians` mirrors denoiser.py:306-416."""
+
+    def __init__(self, state_dict, width=1024, patch_size=8, n_gaussians=2, dim_heads=64, num_layers=24, in_channels=9,
+                 ray_pe_type="relative_plk", gaussians_sh_degree=0, scene=False, range_near=0.0, range_far=500.0,
+                 device="cuda", lib=None):
+        if gaussians_sh_degree != 0:
+            raise NotImplementedError("only gaussians_sh_degree 0 (every shipped config) is implemented")
+        self.lib = lib if lib is not None else _native.lib()
+        self.device = torch.device(device)
+        self.width, self.patch, self.ng, self.layers = width, patch_size, n_gaussians, num_layers
+        self.heads = width // dim_heads
+        self.gs_channels = 3 + 3 + 3 + 4 + 1
+        sd = state_dict
+        bf = lambda k: sd[k].detach().to(self.device, torch.bfloat16).contiguous()
+        f32 = lambda k: sd[k].detach().to(self.device, torch.float32).contiguous()
+        keep = {}
+        keep["t_w0"], keep["t_b0"] = bf("t_embedder.mlp.0.weight"), f32("t_embedder.mlp.0.bias")
+        keep["t_w1"], keep["t_b1"] = bf("t_embedder.mlp.2.weight"), f32("t_embedder.mlp.2.bias")
+        keep["tok_w"] = bf("image_tokenizer.1.weight")
+        keep["pos_emb"] = f32("gaussians_pos_embedding").reshape(n_gaussians, width).contiguous()
+        keep["in_ln_w"] = f32("transformer_input_layernorm.weight")
+        ada_w, ada_b = [], []
+        self._layers = (DgsDitLayerWeights * num_layers)()
+        for i in range(num_layers):
+            p = f"transformer.{i}."
+            for short, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+                keep[f"{i}.{short}_w"] = bf(p + key + ".weight")
+                keep[f"{i}.{short}_b"] = f32(p + key + ".bias")
+                setattr(self._layers[i], short + "_w", keep[f"{i}.{short}_w"].data_ptr())
+                setattr(self._layers[i], short + "_b", keep[f"{i}.{short}_b"].data_ptr())
+            ada_w.append(sd[p + "adaLN_modulation.1.weight"])
+            ada_b.append(sd[p + "adaLN_modulation.1.bias"])
+        for head in ("upsampler", "image_token_decoder"):
+            ada_w.append(sd[head + ".adaLN_modulation.1.weight"])
+            ada_b.append(sd[head + ".adaLN_modulation.1.bias"])
+        keep["ada_w"] = torch.cat([w.detach().float() for w in ada_w], 0).to(self.device, torch.bfloat16).contiguous()
+        keep["ada_b"] = torch.cat([b.detach().float() for b in ada_b], 0).to(self.device, torch.float32).contiguous()
+        keep["up_ln_w"], keep["up_w"] = f32("upsampler.layernorm.weight"), bf("upsampler.linear.weight")
+        keep["dec_ln_w"], keep["dec_w"] = f32("image_token_decoder.layernorm.weight"), bf("image_token_decoder.linear.weight")
+        self._keep = keep
+        m = DgsDitModel()
+        m.width, m.heads, m.layers, m.patch, m.in_channels = width, self.heads, num_layers, patch_size, in_channels
+        m.n_gaussians, m.gs_channels, m.scene = n_gaussians, self.gs_channels, int(bool(scene))
+        m.relative_plk = int(ray_pe_type == "relative_plk")
+        m.range_near, m.range_far = float(range_near), float(range_far)
+        for k in ("t_w0", "t_b0", "t_w1", "t_b1", "tok_w", "pos_emb", "in_ln_w", "ada_w", "ada_b", "up_ln_w", "up_w", "dec_ln_w", "dec_w"):
+            setattr(m, k, keep[k].data_ptr())
+        m.layer = ctypes.cast(self._layers, ctypes.POINTER(DgsDitLayerWeights))
+        self.model = m
+        self._ws = None
+
+    def _workspace(self, B, V, H, W):
+        need = int(self.lib.dgs_dit_workspace_bytes(ctypes.byref(self.model), B, V, H, W))
+        if need == 0:
+            raise RuntimeError("dgs dit: invalid shape for workspace")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def num_tokens(self, V, H, W):
+        return self.ng + V * (H // self.patch) * (W // self.patch)
+
+    def image_to_gaussians(self, images, ray_o, ray_d, t, return_tokens=False):
+        """images/ray_o/ray_d [B,V,>=3|3,H,W] f32, t [B] int64 -> (dict(xyz, features, scaling, rotation, opacity), aligned_xyz)."""
+        dev = self.device
+        B, V, _, H, W = images.shape
+        img = images[:, :, :3].to(dev, torch.float32).contiguous()
+        ro, rd = ray_o.to(dev, torch.float32).contiguous(), ray_d.to(dev, torch.float32).contiguous()
+        tt = t.to(dev, torch.int64).contiguous()
+        P = self.ng + V * H * W
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        out = dict(xyz=f(B, P, 3), features=f(B, P, 1, 3), scaling=f(B, P, 3), rotation=f(B, P, 4), opacity=f(B, P, 1))
+        aligned = f(B, V, 3, H, W)
+        tokens = f(B, self.num_tokens(V, H, W), self.width) if return_tokens else None
+        ws = self._workspace(B, V, H, W)
+        a = DgsDitForwardArgs()
+        a.B, a.V, a.H, a.W = B, V, H, W
+        a.images, a.ray_o, a.ray_d, a.t = _p(img), _p(ro), _p(rd), _p(tt)
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+        a.xyz, a.features, a.scaling, a.rotation, a.opacity = (_p(out[k]) for k in ("xyz", "features", "scaling", "rotation", "opacity"))
+        a.aligned_xyz, a.tokens = _p(aligned), _p(tokens)
+        rc = self.lib.dgs_dit_forward(ctypes.byref(self.model), ctypes.byref(a), _stream(dev))
+        if rc != 0:
+            raise RuntimeError(f"dgs dit forward: {_native.status_string(self.lib, rc)} (status {rc})")
+        if return_tokens:
+            out["tokens"] = tokens
+        return out, aligned
