@@ -145,6 +145,13 @@ int dgs_raster_backward(const DgsRasterBackwardArgs* args, dgs_stream_t stream);
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, dgs_stream_t stream);
 
+/* All cameras of a step in one launch; replaces the reference's per-view `Camera` module
+ * (diffusionGS/models/gsrenderer/gs_core.py:277-316).  c2w [n,16] row-major OpenCV camera-to-world, fxfycxcy [n,4]
+ * pixels -> viewmatrix [n,16] (= W2C^T), projmatrix [n,16] (= W2C^T P^T), campos [n,3], tanfov [n,2]; all device. */
+int dgs_cameras_from_c2w(int32_t n, const float* c2w, const float* fxfycxcy, int32_t height, int32_t width,
+                         float znear, float zfar, float* viewmatrix, float* projmatrix, float* campos, float* tanfov,
+                         dgs_stream_t stream);
+
 /* Introspection for the parity tests: copies a named array of the forward state out of the
  * opaque buffers into `dst` (device pointer, `dst_bytes` capacity).  Names: "depths", "means2D",
  * "conic_opacity", "rgb", "tiles_touched", "clamped", "cov3D", "ranges", "n_contrib", "final_T",

@@ -1,0 +1,263 @@
+"""Operator surface of the reference's denoiser models on top of the gfx950 kernels.
+
+Mirrors (names, Config fields, method signatures, state-dict keys) of
+  /root/reference/diffusionGS/models/denoiser/denoiser.py:166-447        DGSDenoiser  "diffusion-gs-model"
+  /root/reference/diffusionGS/models/denoiser/denoiser_scene.py:171-457  DGSDenoiser  "diffusion-gs-model-scene"
+  /root/reference/diffusionGS/models/gsrenderer/renderer.py:20-92        Renderer
+  /root/reference/diffusionGS/models/gsrenderer/gs_core.py:321-373,544-570  GaussianModel (set_data / get_* only)
+so the callers (systems/diffusion_gs_system.py:90-92, gaussian_diffusion.py:350,359, pipline_obj.py:298-308) can sit on
+top unchanged.  The parameters live in ordinary nn.Parameters under the reference's key names (checkpoints load with
+load_state_dict); compute is ONE C call into libdgs_hip.so for the DiT (dgs_amd.dit.DitEngine) and one batched C call
+for all (sample, view) rasterizations (dgs_amd.raster).  There is no PyTorch fallback.
+"""
+import copy
+import math
+from dataclasses import dataclass, fields
+
+import torch
+import torch.nn as nn
+
+from .dit import DitEngine
+from .raster import default_backend
+
+_REGISTRY = {}
+
+
+def register(name):
+    def deco(cls):
+        _REGISTRY[name] = cls
+        return cls
+    return deco
+
+
+def find(name):
+    """diffusionGS.find (diffusionGS/__init__.py:6-31)."""
+    return _REGISTRY[name]
+
+
+class AttrDict(dict):
+    """easydict.EasyDict stand-in (the reference returns edict(xyz=..., ...), denoiser.py:414)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.__dict__ = self
+
+
+class GaussianModel:
+    """Container + activations of gs_core.py:321-373,544-570 (exp / normalize / sigmoid)."""
+
+    def __init__(self, sh_degree, scaling_modifier=None):
+        self.sh_degree, self.scaling_modifier = sh_degree, scaling_modifier
+        self.empty()
+
+    def empty(self):
+        self._xyz = self._features_dc = self._scaling = self._rotation = self._opacity = torch.empty(0)
+        self._features_rest = torch.empty(0) if self.sh_degree > 0 else None
+
+    def set_data(self, xyz, features, scaling, rotation, opacity):
+        self._xyz = xyz
+        self._features_dc = features[:, :1, :].contiguous()
+        self._features_rest = features[:, 1:, :].contiguous() if self.sh_degree > 0 else None
+        self._scaling, self._rotation, self._opacity = scaling, rotation, opacity
+        return self
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        s = torch.exp(self._scaling)
+        return s * self.scaling_modifier if self.scaling_modifier is not None else s
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return self._features_dc if self._features_rest is None else torch.cat((self._features_dc, self._features_rest), dim=1)
+
+
+class Renderer(nn.Module):
+    """renderer.py:20-92.  forward(...) -> [b, v, 3, H, W] float32; all b*v views in one launch sequence."""
+
+    def __init__(self, config, backend=None):
+        super().__init__()
+        self.config = config
+        self._backend = backend          # None -> the product library (libdgs_hip.so); tests inject the CPU emulation build
+        self.scaling_modifier = None
+        self.gaussians_model = GaussianModel(config.gaussians_sh_degree, self.scaling_modifier)
+
+    def forward(self, xyz, features, scaling, rotation, opacity, height, width, C2W, fxfycxcy, deferred=True):
+        f = lambda t: t.float()      # custom_fwd(cast_inputs=float32), renderer.py:34
+        backend = self._backend if self._backend is not None else default_backend()
+        return backend.render_views(f(xyz), f(features), f(scaling), f(rotation), f(opacity), height, width,
+                                              f(C2W), f(fxfycxcy))
+
+
+SceneRenderer = Renderer
+
+
+class _Linear(nn.Module):
+    """Parameter holder with nn.Linear's state-dict keys (weight/bias); never called -- the GEMM runs in HIP."""
+
+    def __init__(self, i, o, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i))
+        self.bias = nn.Parameter(torch.zeros(o)) if bias else None
+
+
+class _LNWeight(nn.Module):
+    def __init__(self, w):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(w))
+
+
+def _seq(*mods):
+    """nn.Sequential keeps the reference's numeric sub-keys ('mlp.0', 'adaLN_modulation.1', 'image_tokenizer.1')."""
+    return nn.Sequential(*mods)
+
+
+class _Block(nn.Module):
+    def __init__(self, w):
+        super().__init__()
+        self.attn = nn.Module(); self.attn.qkv = _Linear(w, 3 * w); self.attn.proj = _Linear(w, w)
+        self.mlp = nn.Module(); self.mlp.fc1 = _Linear(w, 4 * w); self.mlp.fc2 = _Linear(4 * w, w)
+        self.adaLN_modulation = _seq(nn.Identity(), _Linear(w, 6 * w))
+
+
+class _Head(nn.Module):
+    def __init__(self, w, out):
+        super().__init__()
+        self.layernorm = _LNWeight(w)
+        self.linear = _Linear(w, out, bias=False)
+        self.adaLN_modulation = _seq(nn.Identity(), _Linear(w, 2 * w))
+
+
+@register("diffusion-gs-model")
+class DGSDenoiser(nn.Module):
+    SCENE = False
+
+    @dataclass
+    class Config:   # denoiser.py:174-196 (+ denoiser_scene.py:202-204)
+        pretrained_model_name_or_path: str = ""
+        use_downsample: bool = False
+        num_latents: int = 256
+        width: int = 1024
+        in_channels: int = 3
+        patch_size: int = 16
+        n_gaussians: int = 2
+        dim_heads: int = 64
+        num_layers: int = 24
+        ray_pe_type: str = "relative_plk"
+        hard_pixelalign: bool = True
+        clip_xyz: bool = True
+        gaussians_sh_degree: int = 0
+        use_gssplat: bool = False
+        prior_distribution: str = "gaussian"
+        use_flash: bool = False
+        use_checkpoint: bool = True
+        grad_checkpoint_every: int = 1
+        range_setting_type: str = "sigmoid"
+        range_setting_near: float = 0.0
+        range_setting_far: float = 500.0
+
+    def __init__(self, cfg=None, device="cuda", lib=None):
+        super().__init__()
+        self._lib = lib                  # None -> the product library; tests inject the CPU emulation build
+        known = {f.name for f in fields(self.Config)}
+        self.cfg = self.Config(**{k: v for k, v in dict(cfg or {}).items() if k in known})
+        c, w = self.cfg, self.cfg.width
+        if not c.hard_pixelalign:
+            raise NotImplementedError("only hard_pixelalign=True (every shipped config) is implemented")
+        self.device = torch.device(device)
+        self.t_embedder = nn.Module()
+        self.t_embedder.mlp = _seq(_Linear(256, w), nn.Identity(), _Linear(w, w))
+        self.image_tokenizer = _seq(nn.Identity(), _Linear(c.in_channels * c.patch_size ** 2, w, bias=False))
+        self.gaussians_pos_embedding = nn.Parameter(torch.empty((1, c.n_gaussians, w) if self.SCENE else (c.n_gaussians, w)))
+        self.transformer_input_layernorm = _LNWeight(w)
+        self.transformer = nn.ModuleList([_Block(w) for _ in range(c.num_layers)])
+        gs_ch = 3 + (c.gaussians_sh_degree + 1) ** 2 * 3 + 3 + 4 + 1
+        self.upsampler = _Head(w, gs_ch)
+        self.image_token_decoder = _Head(w, c.patch_size ** 2 * gs_ch)
+        from .raster import RasterBackend
+        self.gs_renderer = Renderer(c, backend=RasterBackend(lib) if lib is not None else None)
+        self.reset_parameters()
+        self._engine, self._engine_version = None, None
+        if c.pretrained_model_name_or_path:
+            self._load_pretrained(c.pretrained_model_name_or_path)
+
+    # -- initialisers of the reference (utils_transformer.py:30-36; denoiser.py:205-206,223,231,246-251) --------
+    def reset_parameters(self, seed=None):
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("layernorm.weight"):
+                    p.fill_(1.0)
+                elif name == "gaussians_pos_embedding":
+                    nn.init.trunc_normal_(p, std=0.02, generator=g)
+                elif name.endswith(".weight"):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+                elif name.startswith("t_embedder") and name.endswith(".bias"):
+                    bound = 1.0 / math.sqrt(256 if ".0." in name else self.cfg.width)   # nn.Linear default bias init
+                    p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+                else:
+                    p.zero_()
+
+    def _load_pretrained(self, path):   # denoiser.py:256-282
+        ckpt = torch.load(path, map_location="cpu")
+        if "model" in ckpt:
+            ckpt = {k.replace("denoiser.", ""): v for k, v in ckpt["model"].items()
+                    if k.startswith("denoiser.") and not k.startswith("denoiser.loss_computer")}
+        self.load_state_dict(ckpt, strict=True)
+
+    # -- engine -------------------------------------------------------------------------------------------
+    def engine(self):
+        version = tuple(p._version for p in self.parameters())
+        if self._engine is None or version != self._engine_version:
+            c = self.cfg
+            self._engine = DitEngine(self.state_dict(), width=c.width, patch_size=c.patch_size, n_gaussians=c.n_gaussians,
+                                     dim_heads=c.dim_heads, num_layers=c.num_layers, in_channels=c.in_channels,
+                                     ray_pe_type=c.ray_pe_type, gaussians_sh_degree=c.gaussians_sh_degree, scene=self.SCENE,
+                                     range_near=c.range_setting_near, range_far=c.range_setting_far, device=self.device,
+                                     lib=self._lib)
+            self._engine_version = version
+        return self._engine
+
+    # -- reference surface ------------------------------------------------------------------------------------
+    def forward(self, input_batch, timesteps):   # denoiser.py:284-287
+        params, _ = self.image_to_gaussians(input_batch["image"], input_batch["ray_o"], input_batch["ray_d"], timesteps)
+        rendered = self.render_gaussians(params, input_batch["c2w"], input_batch["fxfycxcy"], input_batch["image"].shape[3],
+                                         input_batch["image"].shape[4])
+        return rendered, self.prepare_to_save(params)
+
+    def prepare_to_save(self, gaussians_parameters):   # denoiser.py:290-304
+        out = []
+        for b in range(gaussians_parameters.xyz.size(0)):
+            self.gs_renderer.gaussians_model.empty()
+            gm = copy.deepcopy(self.gs_renderer.gaussians_model)
+            out.append(gm.set_data(*(gaussians_parameters[k][b].detach().float()
+                                     for k in ("xyz", "features", "scaling", "rotation", "opacity"))))
+        return out
+
+    def image_to_gaussians(self, images, ray_o, ray_d, t, training=False):   # denoiser.py:306-416
+        out, aligned = self.engine().image_to_gaussians(images, ray_o, ray_d, t)
+        return AttrDict(out), aligned
+
+    def render_gaussians(self, gaussian_params, c2w, fxfycxcy, height, width):   # denoiser.py:420-434
+        return self.gs_renderer(gaussian_params.xyz, gaussian_params.features, gaussian_params.scaling,
+                                gaussian_params.rotation, gaussian_params.opacity, height, width, C2W=c2w, fxfycxcy=fxfycxcy)
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+
+@register("diffusion-gs-model-scene")
+class DGSDenoiserScene(DGSDenoiser):
+    SCENE = True

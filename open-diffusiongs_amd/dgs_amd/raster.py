@@ -112,6 +112,38 @@ class RasterBackend:
         num_rendered = int(a.num_rendered) if binning_capacity <= 0 else ndev
         return num_rendered, out_color, radii, holder["geom"], holder["binning"], holder["img"]
 
+    # -- Camera (gs_core.py:277-316), all views at once ------------------------------------
+    def cameras_from_c2w(self, c2w, fxfycxcy, height, width, znear=0.01, zfar=100.0):
+        """c2w [...,4,4], fxfycxcy [...,4] -> (viewmatrix [n,4,4], projmatrix [n,4,4], campos [n,3], tanfov [n,2])."""
+        device = c2w.device
+        c = _prep(c2w.reshape(-1, 4, 4), device)
+        k = _prep(fxfycxcy.reshape(-1, 4), device)
+        n = int(c.shape[0])
+        view = torch.empty((n, 4, 4), dtype=torch.float32, device=device)
+        proj = torch.empty((n, 4, 4), dtype=torch.float32, device=device)
+        campos = torch.empty((n, 3), dtype=torch.float32, device=device)
+        tanfov = torch.empty((n, 2), dtype=torch.float32, device=device)
+        rc = self.lib.dgs_cameras_from_c2w(n, _ptr(c), _ptr(k), int(height), int(width), float(znear), float(zfar),
+                                           _ptr(view), _ptr(proj), _ptr(campos), _ptr(tanfov), self._stream(device))
+        self._check(rc)
+        return view, proj, campos, tanfov
+
+    def render_views(self, xyz, features, scaling, rotation, opacity, height, width, c2w, fxfycxcy, bg=None):
+        """Forward-only batched render of RAW Gaussian parameters (what Renderer.forward / deferred_gaussian_render do
+        per (sample, view) in the reference, renderer.py:34-92, gs_core.py:874-1016): xyz [B,P,3], features [B,P,M,3],
+        scaling/rotation/opacity raw [B,P,3|4|1]; c2w [B,V,4,4]; fxfycxcy [B,V,4] -> [B,V,3,H,W] float32."""
+        device = xyz.device
+        B, V = int(c2w.shape[0]), int(c2w.shape[1])
+        view, proj, campos, tanfov = self.cameras_from_c2w(c2w, fxfycxcy, height, width)
+        if bg is None:
+            bg = torch.ones(3, dtype=torch.float32, device=device)    # render_opencv_cam default, gs_core.py:879
+        M = int(features.shape[2])
+        degree = int(round(M ** 0.5)) - 1
+        out = self.forward_views(bg, xyz, None, opacity.reshape(B, -1), scaling, rotation, 1.0, None, view, proj, campos,
+                                 tanfov, 0.0, 0.0, height, width, features, degree, False, False, views_per_set=V,
+                                 raw_activations=True)
+        return out[1].reshape(B, V, 3, int(height), int(width))
+
     # -- _C.mark_visible ------------------------------------------------------------------
     def mark_visible(self, means3D, viewmatrix, projmatrix):
         device = means3D.device

@@ -69,6 +69,21 @@ def init_state_dict(cfg, seed=0, dtype=torch.float32):
     return sd
 
 
+def parity_state_dict(cfg, seed=0):
+    """Seeded weights for parity tests: reference initialisers, then every bias / LayerNorm weight perturbed (the
+    reference initialises biases to 0, which would hide bias-path bugs) and every GEMM weight rounded to a
+    bf16-representable value (the HIP path stores GEMM weights in bf16; tolerances then only cover activation rounding).
+    Deterministic given (cfg, seed) on the same torch build -- golden fixtures store the seed, not the weights."""
+    sd = init_state_dict(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    for k in sorted(sd):
+        if k.endswith("bias") or k.endswith("layernorm.weight"):
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith("weight") and sd[k].dim() == 2:
+            sd[k] = sd[k].to(torch.bfloat16).float()
+    return sd
+
+
 def timestep_embedding(t, dim=256, max_period=10000):
     """denoiser.py:46-67"""
     half = dim // 2

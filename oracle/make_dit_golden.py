@@ -179,5 +179,44 @@ def main():
         print("wrote", path, {k: tuple(params[k].shape) for k in params})
 
 
+def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5):
+    """Fixture the gfx950 kernels can run (head_dim 64, width % 256 == 0): weights are NOT stored -- they are
+    dit_oracle.parity_state_dict(cfg, seed), loaded into the reference modules with load_state_dict."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import dit_oracle as D
+    obj, scene = install_stubs()
+    TransformInput = load_transform_input()
+    out = {}
+    for kind, modcls, extra in (("obj", obj.DGSDenoiser, dict(ray_pe_type="relative_plk")),
+                                ("scene", scene.DGSDenoiser, dict(ray_pe_type="plk", range_setting_near=0.0, range_setting_far=50.0))):
+        cfg = dict(width=width, in_channels=9, patch_size=8, n_gaussians=2, dim_heads=64, num_layers=layers,
+                   gaussians_sh_degree=0, hard_pixelalign=True, **extra)
+        model = modcls(cfg).float().eval()
+        ocfg = D.Cfg(width=width, num_layers=layers, ray_pe_type=extra["ray_pe_type"], scene=(kind == "scene"), range_far=50.0)
+        sd = D.parity_state_dict(ocfg, seed)
+        missing, unexpected = model.load_state_dict(sd, strict=True), None
+        g = torch.Generator().manual_seed(seed + 1)
+        images = torch.rand(b, v, 3, res, res, generator=g)
+        c2w = torch.tensor(np.stack([ring_c2w(v, phase=17.0 * i) for i in range(b)]))
+        f = 1422.222 / 1024 * res
+        fxfycxcy = torch.tensor([f, f, res / 2, res / 2], dtype=torch.float32).expand(b, v, 4).contiguous()
+        ray_o, ray_d = TransformInput(images, c2w, fxfycxcy)
+        t = torch.tensor([17, 801])[:b]
+        with torch.no_grad():
+            params, aligned = model.image_to_gaussians(images, ray_o, ray_d, t)
+        pre = kind + "_"
+        out.update({pre + "in_images": images.numpy(), pre + "in_c2w": c2w.numpy(), pre + "in_fxfycxcy": fxfycxcy.numpy(),
+                    pre + "in_t": t.numpy(), pre + "out_aligned": aligned.numpy()})
+        for k in ("xyz", "features", "scaling", "rotation", "opacity"):
+            out[pre + "out_" + k] = params[k].numpy()
+    out.update(width=np.array(width), layers=np.array(layers), res=np.array(res), seed=np.array(seed))
+    path = os.path.join(OUT, f"dit_golden_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--hip" in sys.argv:
+        main_hip()
+    else:
+        main()

@@ -28,3 +28,18 @@ def synth_inputs(cfg, B, V, res, seed=0):
 
 def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def golden_case(kind):
+    """(cfg, state_dict, inputs, reference outputs) of tests/golden/dit_golden_hip256.npz for kind in {'obj','scene'}."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_golden_hip256.npz"))
+    cfg = D.Cfg(width=int(z["width"]), num_layers=int(z["layers"]), scene=(kind == "scene"), range_far=50.0,
+                ray_pe_type="plk" if kind == "scene" else "relative_plk")
+    sd = D.parity_state_dict(cfg, int(z["seed"]))
+    t = lambda k: torch.tensor(z[kind + "_" + k])
+    res = int(z["res"])
+    ray_o, ray_d = D.transform_input_rays(t("in_c2w"), t("in_fxfycxcy"), res, res)
+    inp = dict(images=t("in_images"), ray_o=ray_o.contiguous(), ray_d=ray_d.contiguous(), t=t("in_t"))
+    ref = {k: t("out_" + k) for k in ("xyz", "features", "scaling", "rotation", "opacity", "aligned")}
+    return cfg, sd, inp, ref
