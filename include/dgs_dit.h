@@ -131,6 +131,14 @@ typedef struct DgsDitForwardArgs {
     float* opacity;            /* [B,P,1]   raw (o - 2.0)                                             */
     float* aligned_xyz;        /* optional [B,V,3,H,W]                                                */
     float* tokens;             /* optional [B,L,W] f32: tokens after the last block, reference order  */
+    /* optional measurement hook (bench.py roofline): hipEvent_t handles recorded on `stream` immediately before
+     * and after every launch of ONE kernel class -- 1: attention, 2: QKV GEMM, 3: gate+residual GEMMs (proj, fc2),
+     * 4: fc1 GEMM (+GELU), 5: LayerNorm+modulate.  prof_events holds 2 * prof_capacity handles, used in launch
+     * order (before, after); *prof_count (host) receives the number of launches recorded.  NULL -> off.           */
+    void** prof_events;
+    int32_t prof_kind;
+    int32_t prof_capacity;
+    int32_t* prof_count;
 } DgsDitForwardArgs;
 
 int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream);

@@ -65,6 +65,16 @@ extern "C" size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32
 
 #define DGS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DGS_OK) return rc_; } while (0)
 
+namespace {
+// bench.py's roofline hook: HIP events around every launch of one kernel class, on the launch stream.
+struct Prof {
+    void** ev; int kind, cap, n; hipStream_t st;
+    void before(int k) { if (ev && k == kind && n < cap) hipEventRecord(static_cast<hipEvent_t>(ev[2 * n]), st); }
+    void after(int k) { if (ev && k == kind && n < cap) { hipEventRecord(static_cast<hipEvent_t>(ev[2 * n + 1]), st); ++n; } }
+};
+}  // namespace
+#define DGS_PROF(k, expr) do { prof.before(k); const int rc_ = (expr); prof.after(k); if (rc_ != DGS_OK) return rc_; } while (0)
+
 extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream) {
     if (!m || !a || a->B <= 0 || a->V <= 0 || a->H <= 0 || a->W <= 0) return DGS_ERR_INVALID_ARGUMENT;
     if (m->width % 256 || m->width != m->heads * 64 || m->layers <= 0 || m->patch <= 0 || a->H % m->patch || a->W % m->patch)
@@ -80,6 +90,7 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     DitWorkspace ws = DitWorkspace::carve(a->workspace, m, (size_t)B, (size_t)lpad, &need);
     if (a->workspace_bytes < need) return DGS_ERR_ALLOC;
     const int nmod = (6 * m->layers + 4) * W;
+    Prof prof{a->prof_events, a->prof_kind, a->prof_capacity, 0, st};
 
     // ---- conditioning: t -> sinusoid -> MLP -> cvec; all adaLN modulations in one GEMV (denoiser.py:26-72; DiTBlock :266-272) ----
     DGS_TRY(launch_timestep(a->t, ws.temb, B, st));
@@ -117,27 +128,28 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
         DgsDitLayerNormArgs l1{};
         l1.rows = M; l1.width = W; l1.x = ws.x; l1.shift = mod; l1.scale = mod + W; l1.mod_stride = nmod; l1.rows_per_batch = lpad;
         l1.eps = 1e-6f; l1.out = ws.xn;
-        DGS_TRY(launch_layernorm(&l1, st));
+        DGS_PROF(5, launch_layernorm(&l1, st));
         DgsDitGemmArgs q{};
         q.M = M; q.N = 3 * W; q.K = W; q.A = ws.xn; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_QKV;
         q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad;
-        DGS_TRY(dgs_dit_gemm(&q, stream));
-        DGS_TRY(dgs_dit_attention(&at, stream));
+        DGS_PROF(2, dgs_dit_gemm(&q, stream));
+        DGS_PROF(1, dgs_dit_attention(&at, stream));
         DgsDitGemmArgs pr{};
         pr.M = M; pr.N = W; pr.K = W; pr.A = ws.ao; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
         pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad;
-        DGS_TRY(dgs_dit_gemm(&pr, stream));
+        DGS_PROF(3, dgs_dit_gemm(&pr, stream));
         l1.shift = mod + 3 * W; l1.scale = mod + 4 * W;
-        DGS_TRY(launch_layernorm(&l1, st));
+        DGS_PROF(5, launch_layernorm(&l1, st));
         DgsDitGemmArgs f1{};
         f1.M = M; f1.N = 4 * W; f1.K = W; f1.A = ws.xn; f1.lda = W; f1.W = lw.fc1_w; f1.ldw = W; f1.bias = lw.fc1_b;
         f1.epilogue = DGS_EPI_GELU_BF16; f1.out = ws.h; f1.ldo = 4 * W;
-        DGS_TRY(dgs_dit_gemm(&f1, stream));
+        DGS_PROF(4, dgs_dit_gemm(&f1, stream));
         DgsDitGemmArgs f2{};
         f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = ws.h; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
         f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.out = ws.x; f2.ldo = W; f2.gate = mod + 5 * W; f2.gate_stride = nmod; f2.rows_per_batch = lpad;
-        DGS_TRY(dgs_dit_gemm(&f2, stream));
+        DGS_PROF(3, dgs_dit_gemm(&f2, stream));
     }
+    if (a->prof_count) *a->prof_count = prof.n;
     if (a->tokens) DGS_TRY(launch_gather_tokens(ws.x, a->tokens, B, lpad, L, ng, W, st));
 
     // ---- heads (denoiser.py:122-136,155-164): LN(weight)+modulate -> Linear ----

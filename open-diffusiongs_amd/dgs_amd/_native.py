@@ -168,7 +168,9 @@ class DgsDitForwardArgs(ctypes.Structure):
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
                 ("xyz", ctypes.c_void_p), ("features", ctypes.c_void_p), ("scaling", ctypes.c_void_p),
                 ("rotation", ctypes.c_void_p), ("opacity", ctypes.c_void_p), ("aligned_xyz", ctypes.c_void_p),
-                ("tokens", ctypes.c_void_p)]
+                ("tokens", ctypes.c_void_p),
+                ("prof_events", ctypes.POINTER(ctypes.c_void_p)), ("prof_kind", ctypes.c_int32),
+                ("prof_capacity", ctypes.c_int32), ("prof_count", ctypes.POINTER(ctypes.c_int32))]
 
 
 # every symbol include/dgs_dit.h declares (checked by tests/test_abi.py)

@@ -156,7 +156,7 @@ class DitEngine:
     def num_tokens(self, V, H, W):
         return self.ng + V * (H // self.patch) * (W // self.patch)
 
-    def image_to_gaussians(self, images, ray_o, ray_d, t, return_tokens=False):
+    def image_to_gaussians(self, images, ray_o, ray_d, t, return_tokens=False, prof=None):
         """images/ray_o/ray_d [B,V,>=3|3,H,W] f32, t [B] int64 -> (dict(xyz, features, scaling, rotation, opacity), aligned_xyz)."""
         dev = self.device
         B, V, _, H, W = images.shape
@@ -175,9 +175,17 @@ class DitEngine:
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
         a.xyz, a.features, a.scaling, a.rotation, a.opacity = (_p(out[k]) for k in ("xyz", "features", "scaling", "rotation", "opacity"))
         a.aligned_xyz, a.tokens = _p(aligned), _p(tokens)
+        if prof is not None:   # (kind, [torch.cuda.Event(enable_timing=True), ...]): HIP events around one kernel class
+            kind, events = prof
+            handles = (ctypes.c_void_p * len(events))(*[e.cuda_event for e in events])
+            count = ctypes.c_int32(0)
+            a.prof_events = ctypes.cast(handles, ctypes.POINTER(ctypes.c_void_p))
+            a.prof_kind, a.prof_capacity, a.prof_count = int(kind), len(events) // 2, ctypes.pointer(count)
         rc = self.lib.dgs_dit_forward(ctypes.byref(self.model), ctypes.byref(a), _stream(dev))
         if rc != 0:
             raise RuntimeError(f"dgs dit forward: {_native.status_string(self.lib, rc)} (status {rc})")
         if return_tokens:
             out["tokens"] = tokens
+        if prof is not None:
+            out["prof_count"] = int(count.value)
         return out, aligned
