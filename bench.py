@@ -70,15 +70,21 @@ def cpu_baseline(model, batch, t, res, V, hip_gaussians, hip_render):
     from oracle import dit_oracle as D
     from oracle import raster_oracle as RO
     RO.build()
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)           # more threads than this only adds oversubscription at L=4098
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    cfg = D.Cfg()
     cpu = {k: v[:1].cpu() for k, v in batch.items()}
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        g, _ = D.image_to_gaussians(sd, cfg, cpu["image"], cpu["ray_o"], cpu["ray_d"], t[:1].cpu())
-    t_dit = time.perf_counter() - t0
+    # bounded sample: 4 of the 24 (identical-cost) DiT blocks are timed and scaled by 6; tokenizer + heads are timed in
+    # full (they are inside both runs, so subtract the 0-block run)
+    def run(n_layers):
+        cfg = D.Cfg(num_layers=n_layers)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            g_, _ = D.image_to_gaussians(sd, cfg, cpu["image"], cpu["ray_o"], cpu["ray_d"], t[:1].cpu())
+        return time.perf_counter() - t0, g_
+    t_0, _ = run(0)
+    t_4, g = run(4)
+    t_dit = t_0 + (t_4 - t_0) * 6.0
     view, proj, campos, tanfov = D.camera_matrices(cpu["c2w"][0], cpu["fxfycxcy"][0], res, res)
     act = lambda gm: dict(xyz=gm["xyz"][0].numpy(), shs=gm["features"][0].numpy(),
                           op=torch.sigmoid(gm["opacity"][0]).numpy(), sc=torch.exp(gm["scaling"][0]).numpy(),
@@ -100,8 +106,9 @@ def cpu_baseline(model, batch, t, res, V, hip_gaussians, hip_render):
     mse = float(np.mean((ref.astype(np.float64) - mine) ** 2))
     psnr = 200.0 if mse == 0 else -10.0 * np.log10(mse)
     return dict(value=V / (t_dit + t_raster), unit="renders/s", cores=cores, kind="port",
-                sample=f"1 sample: 1 DiT step at L=4098 ({t_dit:.1f} s, torch-CPU fp32 oracle, {cores} threads) + {V} oracle "
-                       f"rasterizations at {res}^2 ({t_raster:.1f} s, C++ oracle, 1 thread)"), float(psnr)
+                sample=f"1 sample: DiT step at L=4098 extrapolated from 4 of 24 blocks ({t_4:.1f} s measured -> {t_dit:.1f} s, "
+                       f"torch-CPU fp32 oracle, {cores} threads) + {V} oracle rasterizations at {res}^2 ({t_raster:.1f} s "
+                       f"measured, C++ oracle, 1 thread)"), float(psnr)
 
 
 def main():

@@ -59,6 +59,9 @@ typedef struct DgsDitGemmArgs {
     int32_t gate_stride;
     int32_t rows_per_batch;
     uint16_t* vt;              /* DGS_EPI_QKV: V^T bf16 [batch, N/3, rows_per_batch]                   */
+    int32_t valid_rows;        /* 0 or rows_per_batch: every row is computed.  Otherwise rows [valid_rows, rows_per_batch)
+                                  of every sample are padding: 32-row blocks made only of padding are neither computed
+                                  nor stored (their output rows keep their previous contents).                       */
 } DgsDitGemmArgs;
 
 typedef struct DgsDitAttentionArgs {
@@ -120,7 +123,9 @@ typedef struct DgsDitForwardArgs {
     const float* ray_o;        /* [B,V,3,H,W]                                                         */
     const float* ray_d;        /* [B,V,3,H,W]                                                         */
     const int64_t* t;          /* [B] diffusion timestep                                              */
-    void* workspace;           /* dgs_dit_workspace_bytes(...) bytes, device                          */
+    void* workspace;           /* dgs_dit_workspace_bytes(...) bytes, device; must have been zero-filled once after
+                                  allocation and after every change of (B, V, H, W): padding rows are skipped and
+                                  have to hold finite values                                            */
     size_t workspace_bytes;
     /* outputs in the reference's Gaussian order: P = n_gaussians + V*H*W, index 0..n_g-1 = learned tokens,
      * then (v, hh, ww, ph, pw) as denoiser.py:371-379 */

@@ -22,7 +22,22 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
     return u >> 16;
 }
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+#ifdef HIPEMU
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+__device__ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
+__device__ __forceinline__ uint32_t f2bf_fast(float v) { return f2bf(v); }
+#else
+// one v_cvt_pk_bf16_f32 (round-to-nearest-even, same result as f2bf) instead of ~10 integer VALU ops per value
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ uint32_t f2bf_fast(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v); }
+// bare v_exp_f32 (no denormal-range fix-up): callers only pass x <= ~8, tiny results may flush to 0
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 
 // 16-byte global -> LDS DMA.  `lds_wave_base` must be wave-uniform: lane i's 16 bytes land at base + 16*i.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -44,6 +59,22 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+
+// Combine a value with the one held by lane ^ 32.  v_permlane32_swap exchanges the upper half of its first operand
+// with the lower half of its second (VALU, no LDS round trip like ds_bpermute / __shfl_xor).
+#ifdef HIPEMU
+__device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 32); }
+#else
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+#endif
 
 // XCD-aware remap of a linear workgroup id (cdna_hip_programming.md T1, bijective form): hardware places block b on
 // XCD b % 8; give every XCD a contiguous range of logical ids so neighbouring tiles share that XCD's L2.

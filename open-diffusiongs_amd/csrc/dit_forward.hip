@@ -1,6 +1,7 @@
 // dit_forward.hip -- host-side launch sequence of DGSDenoiser.image_to_gaussians (denoiser.py:306-416;
 // scene variant denoiser_scene.py) on one HIP stream: no host synchronisation, no allocation, every intermediate lives
-// in one caller-provided workspace.  Per DiT block: LN+modulate -> QKV GEMM (+V^T epilogue) -> flash attention ->
+// in one caller-provided workspace (which the caller zero-fills once: padding rows are skipped by the GEMMs and must
+// hold finite values).  Per DiT block: LN+modulate -> QKV GEMM (+V^T epilogue) -> flash attention ->
 // proj GEMM (+gate*y+residual) -> LN+modulate -> fc1 GEMM (+GELU) -> fc2 GEMM (+gate*y+residual): 7 launches, and the
 // adaLN modulation vectors of ALL blocks and both heads come from one weight-streaming GEMV up front (the
 // conditioning vector is the same for every block).
@@ -113,6 +114,7 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     DGS_TRY(launch_embed(ep, st));
     DgsDitGemmArgs g{};
     g.M = M; g.N = W; g.K = kin; g.A = ws.emb; g.lda = kin; g.W = m->tok_w; g.ldw = kin; g.epilogue = DGS_EPI_F32; g.out = ws.x; g.ldo = W;
+    g.rows_per_batch = lpad; g.valid_rows = L;
     DGS_TRY(dgs_dit_gemm(&g, stream));
     DGS_TRY(launch_pos_embed(m->pos_emb, ws.x, B, lpad, L, ng, W, st));
     DgsDitLayerNormArgs ln{};
@@ -131,22 +133,22 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
         DGS_PROF(5, launch_layernorm(&l1, st));
         DgsDitGemmArgs q{};
         q.M = M; q.N = 3 * W; q.K = W; q.A = ws.xn; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_QKV;
-        q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad;
+        q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad; q.valid_rows = L;
         DGS_PROF(2, dgs_dit_gemm(&q, stream));
         DGS_PROF(1, dgs_dit_attention(&at, stream));
         DgsDitGemmArgs pr{};
         pr.M = M; pr.N = W; pr.K = W; pr.A = ws.ao; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
-        pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad;
+        pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad; pr.valid_rows = L;
         DGS_PROF(3, dgs_dit_gemm(&pr, stream));
         l1.shift = mod + 3 * W; l1.scale = mod + 4 * W;
         DGS_PROF(5, launch_layernorm(&l1, st));
         DgsDitGemmArgs f1{};
         f1.M = M; f1.N = 4 * W; f1.K = W; f1.A = ws.xn; f1.lda = W; f1.W = lw.fc1_w; f1.ldw = W; f1.bias = lw.fc1_b;
-        f1.epilogue = DGS_EPI_GELU_BF16; f1.out = ws.h; f1.ldo = 4 * W;
+        f1.epilogue = DGS_EPI_GELU_BF16; f1.out = ws.h; f1.ldo = 4 * W; f1.rows_per_batch = lpad; f1.valid_rows = L;
         DGS_PROF(4, dgs_dit_gemm(&f1, stream));
         DgsDitGemmArgs f2{};
         f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = ws.h; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
-        f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.out = ws.x; f2.ldo = W; f2.gate = mod + 5 * W; f2.gate_stride = nmod; f2.rows_per_batch = lpad;
+        f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.out = ws.x; f2.ldo = W; f2.gate = mod + 5 * W; f2.gate_stride = nmod; f2.rows_per_batch = lpad; f2.valid_rows = L;
         DGS_PROF(3, dgs_dit_gemm(&f2, stream));
     }
     if (a->prof_count) *a->prof_count = prof.n;
@@ -160,7 +162,7 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     ld.rows_per_batch = lpad; ld.eps = 1e-5f; ld.out = ws.xn;
     DGS_TRY(launch_layernorm(&ld, st));
     DgsDitGemmArgs dg{};
-    dg.M = M; dg.N = pp * C; dg.K = W; dg.A = ws.xn; dg.lda = W; dg.W = m->dec_w; dg.ldw = W; dg.epilogue = DGS_EPI_F32; dg.out = ws.dec; dg.ldo = pp * C;
+    dg.M = M; dg.N = pp * C; dg.K = W; dg.A = ws.xn; dg.lda = W; dg.W = m->dec_w; dg.ldw = W; dg.epilogue = DGS_EPI_F32; dg.out = ws.dec; dg.ldo = pp * C; dg.rows_per_batch = lpad; dg.valid_rows = L;
     DGS_TRY(dgs_dit_gemm(&dg, stream));
     for (int b = 0; b < B; ++b) {
         DgsDitLayerNormArgs lu{};

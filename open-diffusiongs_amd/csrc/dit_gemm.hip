@@ -17,11 +17,11 @@
 
 namespace dgs {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand per stage
+constexpr int BM = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB: A tile of one stage (the W tile is BN/128 of that)
 
 struct GemmParams {
-    int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, tiles_n, ntiles;
+    int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles;
     const bf16_t* A;
     const bf16_t* W;
     const float* bias;
@@ -36,11 +36,12 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return x / (1.0f + __expf(-2.0f * u));
 }
 
-// Stage one [128][64] bf16 tile: 16 wave-instructions of 1 KiB (8 rows each); wave w issues instructions 4w..4w+3.
+// Stage one [ROWS][64] bf16 tile: ROWS/8 wave-instructions of 1 KiB (8 rows each); wave w issues pieces (ROWS/32) w ...
+template <int ROWS>
 __device__ __forceinline__ void stage_tile(const bf16_t* g, int ld, int row0, int k0, char* lds_tile, int wave, int lane) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int piece = wave * 4 + q;
+    for (int q = 0; q < ROWS / 32; ++q) {
+        const int piece = wave * (ROWS / 32) + q;
         const int row = piece * 8 + (lane >> 3);
         const int slot = lane & 7;
         const int chunk = slot ^ ((row >> 1) & 7);
@@ -49,62 +50,77 @@ __device__ __forceinline__ void stage_tile(const bf16_t* g, int ld, int row0, in
     }
 }
 
-template <int EPI>
+// BN = 128: waves 2(M) x 2(N), each 64 x 64 (2 x 2 accumulators).  BN = 64 (used when N / 128 tiles would not fill the
+// chip, e.g. the N = 1024 projections at batch 1): waves 2 x 2, each 64 x 32 (2 x 1 accumulators), half the LDS.
+template <int EPI, int BN>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];   // [stage][A,B] : 64 KiB
+    constexpr int NI = BN / 64;                              // 32-column accumulator blocks per wave
+    constexpr int STAGE_BYTES = TILE_BYTES + BN * BK * 2;
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];   // [stage][A | W] : 64 KiB (BN=128) / 48 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
     const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    // Padding rows (row-in-sample >= valid_rows) are never observed: a 32-row accumulator block made only of padding
+    // skips its MFMAs and its stores (its output rows keep the finite values they had), which makes the one
+    // mostly-padding M tile of every sample cost a fraction of a full tile.
+    const int mrow = m0 - (m0 / p.rows_per_batch) * p.rows_per_batch + wm * 64;
+    const bool live0 = mrow < p.valid_rows, live1 = mrow + 32 < p.valid_rows;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = p.K / BK;
-    stage_tile(p.A, p.lda, m0, 0, lds, wave, lane);
-    stage_tile(p.W, p.ldw, n0, 0, lds + TILE_BYTES, wave, lane);
+    stage_tile<BM>(p.A, p.lda, m0, 0, lds, wave, lane);
+    stage_tile<BN>(p.W, p.ldw, n0, 0, lds + TILE_BYTES, wave, lane);
     __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the tile
 
     // per-lane fragment addressing: row (lane & 31) of a 32-row block, k-chunk (lane >> 5) + 2*ks
     const int frow = lane & 31, fhalf = lane >> 5;
     const int swz = (frow >> 1) & 7;   // block row offsets are multiples of 32 -> do not change (row >> 1) & 7
     for (int t = 0; t < nk; ++t) {
-        char* cur = lds + (t & 1) * 2 * TILE_BYTES;
+        char* cur = lds + (t & 1) * STAGE_BYTES;
         if (t + 1 < nk) {
-            char* nxt = lds + ((t + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile(p.A, p.lda, m0, (t + 1) * BK, nxt, wave, lane);
-            stage_tile(p.W, p.ldw, n0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+            char* nxt = lds + ((t + 1) & 1) * STAGE_BYTES;
+            stage_tile<BM>(p.A, p.lda, m0, (t + 1) * BK, nxt, wave, lane);
+            stage_tile<BN>(p.W, p.ldw, n0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
         }
         const char* la = cur + (wm * 64 + frow) * 128;
-        const char* lb = cur + TILE_BYTES + (wn * 64 + frow) * 128;
+        const char* lb = cur + TILE_BYTES + (wn * (BN / 2) + frow) * 128;
+        if (live0) {   // wave-uniform
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int off = ((2 * ks + fhalf) ^ swz) << 4;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(la + off);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(la + 32 * 128 + off);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(lb + off);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(lb + 32 * 128 + off);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = ((2 * ks + fhalf) ^ swz) << 4;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(la + off);
+                bf16x8 b[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(lb + j * 32 * 128 + off);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[j], acc[0][j], 0, 0, 0);
+                if (live1) {
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(la + 32 * 128 + off);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[j], acc[1][j], 0, 0, 0);
+                }
+            }
         }
         __syncthreads();   // next tile landed; everyone is done reading `cur`
     }
 
     // ---- epilogue.  D fragment: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * (BN / 2) + ni * 32 + (lane & 31);
         const float bias = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
+            if (!(mi == 0 ? live0 : live1)) continue;
             const int mbase = m0 + wm * 64 + mi * 32 + 4 * fhalf;
             if (EPI == DGS_EPI_QKV && n >= (p.N / 3) * 2) {
                 // V^T: 4 consecutive tokens of one feature = one 8-byte store
@@ -127,8 +143,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                 const int m = mbase + (r & 3) + 8 * (r >> 2);
                 const float v = acc[mi][ni][r] + bias;
                 const size_t o = (size_t)m * p.ldo + n;
-                if (EPI == DGS_EPI_BF16 || EPI == DGS_EPI_QKV) reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf(v);
-                else if (EPI == DGS_EPI_GELU_BF16) reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf(gelu_tanh(v));
+                if (EPI == DGS_EPI_BF16 || EPI == DGS_EPI_QKV) reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(v);
+                else if (EPI == DGS_EPI_GELU_BF16) reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(gelu_tanh(v));
                 else if (EPI == DGS_EPI_GATE_RESIDUAL) { float* x = reinterpret_cast<float*>(p.out) + o; *x = *x + gate * v; }
                 else reinterpret_cast<float*>(p.out)[o] = v;
             }
@@ -140,25 +156,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
 using namespace dgs;
 
+template <int EPI>
+static void launch_gemm(const GemmParams& p0, int bn, hipStream_t st) {
+    GemmParams p = p0;
+    p.tiles_n = p.N / bn;
+    p.ntiles = p.tiles_n * (p.M / BM);
+    if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 128>), dim3(p.ntiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 64>), dim3(p.ntiles), dim3(256), 0, st, p);
+}
+
 extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
-    if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M % BM || a->N % BN || a->K % BK) return DGS_ERR_INVALID_ARGUMENT;
+    if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M % BM || a->N % 128 || a->K % BK) return DGS_ERR_INVALID_ARGUMENT;
     if (!a->A || !a->W || !a->out || a->lda < a->K || a->ldw < a->K || (a->lda & 7) || (a->ldw & 7)) return DGS_ERR_INVALID_ARGUMENT;
     if (a->epilogue == DGS_EPI_GATE_RESIDUAL && (!a->gate || a->rows_per_batch <= 0)) return DGS_ERR_INVALID_ARGUMENT;
-    if (a->epilogue == DGS_EPI_QKV && (!a->vt || a->rows_per_batch <= 0 || a->rows_per_batch % BM || a->N % 3 || (a->N / 3) % BN))
+    if (a->epilogue == DGS_EPI_QKV && (!a->vt || a->rows_per_batch <= 0 || a->rows_per_batch % BM || a->N % 3 || (a->N / 3) % 128))
         return DGS_ERR_INVALID_ARGUMENT;
+    if (a->rows_per_batch > 0 && (a->rows_per_batch % BM || a->M % a->rows_per_batch)) return DGS_ERR_INVALID_ARGUMENT;
     GemmParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo;
     p.gate_stride = a->gate_stride; p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
-    p.tiles_n = a->N / BN; p.ntiles = p.tiles_n * (a->M / BM);
+    p.valid_rows = (a->valid_rows > 0 && a->valid_rows < p.rows_per_batch) ? a->valid_rows : p.rows_per_batch;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt;
+    // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each
+    const int bn = ((a->M / BM) * (a->N / 128) < 512 && a->epilogue != DGS_EPI_QKV) ? 64 : 128;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(p.ntiles), block(256);
     switch (a->epilogue) {
-        case DGS_EPI_BF16: hipLaunchKernelGGL((gemm_bf16_kernel<DGS_EPI_BF16>), grid, block, 0, st, p); break;
-        case DGS_EPI_GELU_BF16: hipLaunchKernelGGL((gemm_bf16_kernel<DGS_EPI_GELU_BF16>), grid, block, 0, st, p); break;
-        case DGS_EPI_GATE_RESIDUAL: hipLaunchKernelGGL((gemm_bf16_kernel<DGS_EPI_GATE_RESIDUAL>), grid, block, 0, st, p); break;
-        case DGS_EPI_F32: hipLaunchKernelGGL((gemm_bf16_kernel<DGS_EPI_F32>), grid, block, 0, st, p); break;
-        case DGS_EPI_QKV: hipLaunchKernelGGL((gemm_bf16_kernel<DGS_EPI_QKV>), grid, block, 0, st, p); break;
+        case DGS_EPI_BF16: launch_gemm<DGS_EPI_BF16>(p, bn, st); break;
+        case DGS_EPI_GELU_BF16: launch_gemm<DGS_EPI_GELU_BF16>(p, bn, st); break;
+        case DGS_EPI_GATE_RESIDUAL: launch_gemm<DGS_EPI_GATE_RESIDUAL>(p, bn, st); break;
+        case DGS_EPI_F32: launch_gemm<DGS_EPI_F32>(p, bn, st); break;
+        case DGS_EPI_QKV: launch_gemm<DGS_EPI_QKV>(p, 128, st); break;
         default: return DGS_ERR_INVALID_ARGUMENT;
     }
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;

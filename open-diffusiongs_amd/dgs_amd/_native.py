@@ -124,7 +124,7 @@ class DgsDitGemmArgs(ctypes.Structure):
                 ("A", ctypes.c_void_p), ("lda", ctypes.c_int32), ("W", ctypes.c_void_p), ("ldw", ctypes.c_int32),
                 ("bias", ctypes.c_void_p), ("epilogue", ctypes.c_int32), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int32),
                 ("gate", ctypes.c_void_p), ("gate_stride", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32),
-                ("vt", ctypes.c_void_p)]
+                ("vt", ctypes.c_void_p), ("valid_rows", ctypes.c_int32)]
 
 
 class DgsDitAttentionArgs(ctypes.Structure):

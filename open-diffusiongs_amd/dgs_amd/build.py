@@ -19,7 +19,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE,
           "-Wno-unused-value", "-Wno-unused-result"]
 # Rasterizer: un-fused IEEE arithmetic is part of the parity contract.
 STRICT_FP = ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
-FLAGS = {"raster_forward.hip": STRICT_FP, "raster_backward.hip": STRICT_FP}
+# DiT attention: fmaxf on MFMA outputs must not be preceded by canonicalising v_max (cdna_hip_programming.md appendix B);
+# masked scores use -inf, so infinities stay honoured.
+FLAGS = {"raster_forward.hip": STRICT_FP, "raster_backward.hip": STRICT_FP, "dit_attention.hip": ["-fno-honor-nans"]}
 
 
 def sources():

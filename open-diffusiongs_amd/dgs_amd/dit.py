@@ -34,7 +34,7 @@ class DitOps:
         if rc != 0:
             raise RuntimeError(f"dgs dit: {_native.status_string(self.lib, rc)} (status {rc})")
 
-    def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None):
+    def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None, valid_rows=0):
         """A bf16 [M,K], W bf16 [N,K] -> per epilogue (see dgs_dit.h).  `out` is required for GATE_RESIDUAL (in-place)."""
         M, K = A.shape
         N = W.shape[0]
@@ -58,6 +58,7 @@ class DitOps:
         a.A, a.lda, a.W, a.ldw = _p(A), A.stride(0), _p(W), W.stride(0)
         a.bias, a.epilogue, a.out, a.ldo = _p(bias), epilogue, _p(out), ldo
         a.gate, a.gate_stride, a.rows_per_batch, a.vt = _p(gate), (gate.stride(0) if gate is not None else 0), rows_per_batch, _p(vt)
+        a.valid_rows = valid_rows
         self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))
         return (out, vt) if epilogue == _native.EPI_QKV else out
 
@@ -143,14 +144,18 @@ class DitEngine:
             setattr(m, k, keep[k].data_ptr())
         m.layer = ctypes.cast(self._layers, ctypes.POINTER(DgsDitLayerWeights))
         self.model = m
-        self._ws = None
+        self._ws, self._ws_shape = None, None
 
     def _workspace(self, B, V, H, W):
         need = int(self.lib.dgs_dit_workspace_bytes(ctypes.byref(self.model), B, V, H, W))
         if need == 0:
             raise RuntimeError("dgs dit: invalid shape for workspace")
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            self._ws_shape = (B, V, H, W)
+        elif self._ws_shape != (B, V, H, W):     # different carving: padding rows must be finite again
+            self._ws.zero_()
+            self._ws_shape = (B, V, H, W)
         return self._ws
 
     def num_tokens(self, V, H, W):

@@ -44,6 +44,24 @@ def test_gemm_epilogues(ops):
     assert torch.allclose(x, want, atol=2e-3, rtol=1e-4)
 
 
+def test_gemm_padding_blocks_are_skipped(ops):
+    g = torch.Generator().manual_seed(7)
+    rows, B, N, K = 256, 2, 128, 64
+    A = _bf(torch.randn(B * rows, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.1)
+    ref = A.float() @ W.float().t()
+    for valid in (130, 33, 256):
+        out = torch.full((B * rows, N), 7.0)
+        ops.gemm(A, W, None, _native.EPI_F32, out=out, rows_per_batch=rows, valid_rows=valid)
+        live = (valid + 31) // 32 * 32      # blocks with at least one valid row are computed completely
+        for b in range(B):
+            assert torch.allclose(out[b * rows: b * rows + live], ref[b * rows: b * rows + live], atol=1e-3, rtol=1e-4)
+            assert bool((out[b * rows + live: (b + 1) * rows] == 7.0).all())
+    # narrow-tile variant (chosen when 128 x 128 tiles would under-fill the chip) gives the same numbers
+    out = ops.gemm(A, W, None, _native.EPI_F32)
+    assert torch.allclose(out, ref, atol=1e-3, rtol=1e-4)
+
+
 def test_gemm_qkv_epilogue(ops):
     g = torch.Generator().manual_seed(2)
     lpad, B, Wd, K = 128, 2, 128, 64

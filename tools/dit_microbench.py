@@ -52,16 +52,16 @@ def main():
     rows = []
     t = timeit(lambda: ops.layernorm(x, None, mod[:, :W], mod[:, W:2 * W], rows_per_batch=lpad))
     rows.append(("layernorm+modulate", t, M * W * 6 / t / 1e9, "GB/s"))
-    t = timeit(lambda: ops.gemm(xn, ws["qkv"], bias["qkv"], _native.EPI_QKV, out=qk, vt=vt, rows_per_batch=lpad))
+    t = timeit(lambda: ops.gemm(xn, ws["qkv"], bias["qkv"], _native.EPI_QKV, out=qk, vt=vt, rows_per_batch=lpad, valid_rows=L))
     rows.append(("gemm qkv  [M,1024]x[3072,1024]", t, 2 * M * 3 * W * W / t / 1e12, "TFLOP/s"))
     qkr = bf(rnd(M, 2 * W)); vtr = bf(rnd(a.batch, W, lpad))
     t = timeit(lambda: ops.attention(qkr, vtr, L, heads))
     rows.append((f"attention L={L}", t, 4 * L * L * W * a.batch / t / 1e12, "TFLOP/s"))
-    t = timeit(lambda: ops.gemm(xn, ws["proj"], bias["proj"], _native.EPI_GATE_RESIDUAL, out=x, gate=mod[:, 2 * W:3 * W], rows_per_batch=lpad))
+    t = timeit(lambda: ops.gemm(xn, ws["proj"], bias["proj"], _native.EPI_GATE_RESIDUAL, out=x, gate=mod[:, 2 * W:3 * W], rows_per_batch=lpad, valid_rows=L))
     rows.append(("gemm proj [M,1024]x[1024,1024] +gate+res", t, 2 * M * W * W / t / 1e12, "TFLOP/s"))
-    t = timeit(lambda: ops.gemm(xn, ws["fc1"], bias["fc1"], _native.EPI_GELU_BF16, out=ob))
+    t = timeit(lambda: ops.gemm(xn, ws["fc1"], bias["fc1"], _native.EPI_GELU_BF16, out=ob, rows_per_batch=lpad, valid_rows=L))
     rows.append(("gemm fc1  [M,1024]x[4096,1024] +gelu", t, 2 * M * 4 * W * W / t / 1e12, "TFLOP/s"))
-    t = timeit(lambda: ops.gemm(h, ws["fc2"], bias["fc2"], _native.EPI_GATE_RESIDUAL, out=x, gate=mod[:, 2 * W:3 * W], rows_per_batch=lpad))
+    t = timeit(lambda: ops.gemm(h, ws["fc2"], bias["fc2"], _native.EPI_GATE_RESIDUAL, out=x, gate=mod[:, 2 * W:3 * W], rows_per_batch=lpad, valid_rows=L))
     rows.append(("gemm fc2  [M,4096]x[1024,4096] +gate+res", t, 2 * M * 4 * W * W / t / 1e12, "TFLOP/s"))
     cvec = rnd(a.batch, W); adaw = bf(rnd(148 * W, W) * 0.02)
     t = timeit(lambda: ops.rowlinear(cvec, adaw, None, silu_input=True))
