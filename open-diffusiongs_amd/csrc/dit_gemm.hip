@@ -50,6 +50,51 @@ __device__ __forceinline__ void stage_tile(const bf16_t* g, int ld, int row0, in
     }
 }
 
+// One BK = 64 slab of a wave's accumulators: MI live 32-row blocks x NI 32-column blocks.
+template <int NI, int MI>
+__device__ __forceinline__ void mma_tile(const char* la, const char* lb, int fhalf, int swz, f32x16 (&acc)[2][NI]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int off = ((2 * ks + fhalf) ^ swz) << 4;
+        bf16x8 a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(la + i * 32 * 128 + off);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(lb + j * 32 * 128 + off);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int BN, int NI, int MI>
+__device__ __forceinline__ void main_loop(const GemmParams& p, char* lds, int m0, int n0, int wave, int lane, int wm, int wn,
+                                          f32x16 (&acc)[2][NI]) {
+    constexpr int STAGE_BYTES = TILE_BYTES + BN * BK * 2;
+    const int nk = p.K / BK;
+    stage_tile<BM>(p.A, p.lda, m0, 0, lds, wave, lane);
+    stage_tile<BN>(p.W, p.ldw, n0, 0, lds + TILE_BYTES, wave, lane);
+    __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the tile
+    // per-lane fragment addressing: row (lane & 31) of a 32-row block, k-chunk (lane >> 5) + 2*ks
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int swz = (frow >> 1) & 7;   // block row offsets are multiples of 32 -> do not change (row >> 1) & 7
+    for (int t = 0; t < nk; ++t) {
+        char* cur = lds + (t & 1) * STAGE_BYTES;
+        if (t + 1 < nk) {
+            char* nxt = lds + ((t + 1) & 1) * STAGE_BYTES;
+            stage_tile<BM>(p.A, p.lda, m0, (t + 1) * BK, nxt, wave, lane);
+            stage_tile<BN>(p.W, p.ldw, n0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+        }
+        if (MI > 0) {
+            const char* la = cur + (wm * 64 + frow) * 128;
+            const char* lb = cur + TILE_BYTES + (wn * (BN / 2) + frow) * 128;
+            mma_tile<NI, (MI > 0 ? MI : 1)>(la, lb, fhalf, swz, acc);
+        }
+        __syncthreads();   // next tile landed; everyone is done reading `cur`
+    }
+}
+
 // BN = 128: waves 2(M) x 2(N), each 64 x 64 (2 x 2 accumulators).  BN = 64 (used when N / 128 tiles would not fill the
 // chip, e.g. the N = 1024 projections at batch 1): waves 2 x 2, each 64 x 32 (2 x 1 accumulators), half the LDS.
 template <int EPI, int BN>
@@ -57,7 +102,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NI = BN / 64;                              // 32-column accumulator blocks per wave
     constexpr int STAGE_BYTES = TILE_BYTES + BN * BK * 2;
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];   // [stage][A | W] : 64 KiB (BN=128) / 48 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: live0/live1 become scalar branches
     const int wm = wave >> 1, wn = wave & 1;
     const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
     const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
@@ -76,42 +122,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = p.K / BK;
-    stage_tile<BM>(p.A, p.lda, m0, 0, lds, wave, lane);
-    stage_tile<BN>(p.W, p.ldw, n0, 0, lds + TILE_BYTES, wave, lane);
-    __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the tile
-
-    // per-lane fragment addressing: row (lane & 31) of a 32-row block, k-chunk (lane >> 5) + 2*ks
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const int swz = (frow >> 1) & 7;   // block row offsets are multiples of 32 -> do not change (row >> 1) & 7
-    for (int t = 0; t < nk; ++t) {
-        char* cur = lds + (t & 1) * STAGE_BYTES;
-        if (t + 1 < nk) {
-            char* nxt = lds + ((t + 1) & 1) * STAGE_BYTES;
-            stage_tile<BM>(p.A, p.lda, m0, (t + 1) * BK, nxt, wave, lane);
-            stage_tile<BN>(p.W, p.ldw, n0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
-        }
-        const char* la = cur + (wm * 64 + frow) * 128;
-        const char* lb = cur + TILE_BYTES + (wn * (BN / 2) + frow) * 128;
-        if (live0) {   // wave-uniform
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = ((2 * ks + fhalf) ^ swz) << 4;
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(la + off);
-                bf16x8 b[NI];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(lb + j * 32 * 128 + off);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[j], acc[0][j], 0, 0, 0);
-                if (live1) {
-                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(la + 32 * 128 + off);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[j], acc[1][j], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();   // next tile landed; everyone is done reading `cur`
-    }
+    // The K loop exists in three branch-free copies selected per wave (2 / 1 / 0 live 32-row blocks); every copy
+    // stages and synchronises identically.  A branch INSIDE the loop makes hipcc carry the accumulators in VGPRs and copy
+    // them to AGPRs and back around every slab.
+    if (live1) main_loop<BN, NI, 2>(p, lds, m0, n0, wave, lane, wm, wn, acc);
+    else if (live0) main_loop<BN, NI, 1>(p, lds, m0, n0, wave, lane, wm, wn, acc);
+    else main_loop<BN, NI, 0>(p, lds, m0, n0, wave, lane, wm, wn, acc);
+    const int fhalf = lane >> 5;
 
     // ---- epilogue.  D fragment: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
 #pragma unroll
