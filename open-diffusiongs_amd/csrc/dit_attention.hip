@@ -30,7 +30,7 @@ constexpr int KV_TILE_BYTES = KB * 64 * 2;   // 8 KiB
 constexpr float RESCALE_THR = 6.0f;          // deferred-max threshold in exp2 units: P <= 64
 
 struct AttnParams {
-    int B, heads, L, lpad, ld_qk, nqb_full, nqb;
+    int B, heads, L, lpad, ld_qk, nqb, extra_unit;
     const bf16_t* qk;
     const bf16_t* vt;
     bf16_t* out;
@@ -51,6 +51,15 @@ __device__ __forceinline__ void qk_tile(const char* kb, const bf16x8 (&qf)[4], i
     }
 }
 
+__device__ __forceinline__ float row_max(const f32x16& s0, const f32x16& s1) {
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    return xor32_max(mx);
+}
+
+template <int V> struct Mode { static constexpr int value = V; };
+
 __device__ __forceinline__ void mask_tile(f32x16& s0, f32x16& s1, int key0, int half, int L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -60,27 +69,29 @@ __device__ __forceinline__ void mask_tile(f32x16& s0, f32x16& s1, int key0, int 
     }
 }
 
-// Workgroup = 256 queries of one (sample, head): 8 waves x 32 queries, two waves per SIMD.  The grid is 1-D and ordered so
-// that (a) head = id % heads, i.e. all query blocks of a head run on the same XCD (dispatch places block b on XCD b % 8)
-// and re-read its K / V^T (1 MiB) from that XCD's L2, and (b) the mostly-padding last query block of every (sample,
-// head) comes LAST, so that at batch 1 the 256 full blocks are exactly one workgroup per CU.
+// Workgroup = 256 queries of one (sample, head): 8 waves x 32 queries, two waves per SIMD, one workgroup per CU.  The
+// kernel is latency-bound per wave (a wave needs ~the same time for its 65 tiles whether or not the CU is shared), so the
+// work decomposition must come out in ONE round of the 256 CUs: L = 4098 = 16 * 256 + 2, and a 17th query block per head
+// for the two learned-token queries would cost a whole second round.  Instead the launch uses 9-wave workgroups and the
+// 9th wave of a head's last block takes the odd 32-query unit (`extra_unit`); everywhere else it exits at once.
+// The grid is 1-D with head = id % heads: all query blocks of a head run on one XCD (dispatch places block b on XCD
+// b % 8) and re-read that head's K / V^T (1 MiB) from its L2.
 // Software pipeline (T15): while the VALU works through the softmax of tile t, the matrix pipe already runs
 // S(t+1) = K(t+1) Q^T; K and V^T therefore live in two 2-deep rings that are one tile out of phase.
-__global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(576) void attention_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[4 * KV_TILE_BYTES];   // K ring [2] | V^T ring [2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     // ---- block -> (sample, head, query block) ----
-    int id = blockIdx.x, b, head, qblk;
-    const int nfull_blocks = p.B * p.heads * p.nqb_full;
-    if (id < nfull_blocks) {
-        head = id % p.heads; id /= p.heads;
-        qblk = id % p.nqb_full; b = id / p.nqb_full;
-    } else {                       // ragged last query block (only exists when nqb > nqb_full)
-        id -= nfull_blocks;
-        head = id % p.heads; b = id / p.heads;
-        qblk = p.nqb_full;
+    int id = blockIdx.x;
+    const int head = id % p.heads; id /= p.heads;
+    const int qblk = id % p.nqb, b = id / p.nqb;
+    // 32-query unit of this wave; wave 8 exists only to take the odd unit behind the last full block
+    int unit = qblk * NW + wave;
+    if (wave == NW) {
+        if (!(p.extra_unit && qblk == p.nqb - 1)) return;   // leaves before the first barrier
+        unit = p.nqb * NW;
     }
     const size_t row0 = (size_t)b * p.lpad;
     const bf16_t* Qg = p.qk + row0 * p.ld_qk + head * 64;
@@ -88,13 +99,13 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
     const bf16_t* Vg = p.vt + ((size_t)b * p.heads + head) * 64 * p.lpad;
 
     // Q fragments (B operand): query = lane & 31, d-chunk = 2 ks + half.  Rows >= lpad do not exist: clamp (never stored).
-    const int q = qblk * QB + wave * 32 + l31;
+    const int q = unit * 32 + l31;
     const int qld = q < p.lpad ? q : p.lpad - 1;
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qld * p.ld_qk + (2 * ks + half) * 8);
     // a wave whose 32 queries are all padding rows only helps with staging and barriers
-    const bool wave_live = qblk * QB + wave * 32 < p.L;
+    const bool wave_live = unit * 32 < p.L;
 
     f32x16 oacc[2];
 #pragma unroll
@@ -122,56 +133,49 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
     const int kswz = (l31 >> 1) & 7;
 
     // ---- prologue: K(0), V(0) -> LDS; K(1) -> LDS; S_cur = QK(0) ----
-    kreg = *reinterpret_cast<const uint4*>(kptr);
-    vreg = *reinterpret_cast<const uint4*>(vptr);
-    *reinterpret_cast<uint4*>(kring + koff) = kreg;
-    *reinterpret_cast<uint2*>(vring + voff0) = make_uint2(vreg.x, vreg.y);
-    *reinterpret_cast<uint2*>(vring + voff1) = make_uint2(vreg.z, vreg.w);
-    if (ntiles > 1) {
-        kreg = *reinterpret_cast<const uint4*>(kptr + (size_t)KB * p.ld_qk);
-        *reinterpret_cast<uint4*>(kring + KV_TILE_BYTES + koff) = kreg;
+    const bool stager = wave < NW;        // the 512 threads of waves 0..7 move the tiles
+    if (stager) {
+        kreg = *reinterpret_cast<const uint4*>(kptr);
+        vreg = *reinterpret_cast<const uint4*>(vptr);
+        *reinterpret_cast<uint4*>(kring + koff) = kreg;
+        *reinterpret_cast<uint2*>(vring + voff0) = make_uint2(vreg.x, vreg.y);
+        *reinterpret_cast<uint2*>(vring + voff1) = make_uint2(vreg.z, vreg.w);
+        if (ntiles > 1) {
+            kreg = *reinterpret_cast<const uint4*>(kptr + (size_t)KB * p.ld_qk);
+            *reinterpret_cast<uint4*>(kring + KV_TILE_BYTES + koff) = kreg;
+        }
     }
     // Retire every outstanding global load (incl. the Q fragments) HERE: left pending, hipcc's in-order vmcnt
     // bookkeeping makes each tile's first MFMAs wait for that tile's just-issued prefetch.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
+    // ---- first tile: S(0), its row max, and the initial running max ----
     f32x16 s0, s1;
+    float mx = -1.0e30f;
     if (wave_live) {
         qk_tile(kring, qf, l31, half, kswz, s0, s1);
         if (mask_from == 0) mask_tile(s0, s1, 0, half, p.L);
+        mx = row_max(s0, s1);
+        m_run = mx;                          // first tile always "rescales" (O and l are still zero)
     }
     __syncthreads();   // K(0) is overwritten by K(2) at the end of iteration 0: every wave must be done reading it
 
-    for (int t = 0; t < ntiles; ++t) {
-        // prefetch K(t+2) and V(t+1) into registers
-        const bool pk = t + 2 < ntiles, pv = t + 1 < ntiles;
+    // One iteration = one 64-key tile t, in two MFMA||VALU phases that live in ONE basic block each:
+    //   phase A   matrix pipe: S(t+1) = K(t+1) Q^T        VALU: P(t) = exp2(S(t) c - m c), row sums, bf16 packing
+    //   phase B   matrix pipe: O^T += V^T(t) P^T(t)       VALU: row max of S(t+1)
+    // then the (rare, wave-uniform) deferred rescale for tile t+1 -- after ALL of P(t) V(t) has been issued (T13 hazard) --
+    // and the staging writes + barrier.  MODE 0: steady state, 1: S(t+1) is the ragged last tile (masked), 2: last tile
+    // (no S(t+1)).  Three straight-line copies instead of in-loop branches keep every phase a single scheduling region.
+    auto iteration = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const bool pk = stager && t + 2 < ntiles, pvs = stager && MODE != 2;
         if (pk) kreg = *reinterpret_cast<const uint4*>(kptr + (size_t)(t + 2) * KB * p.ld_qk);
-        if (pv) vreg = *reinterpret_cast<const uint4*>(vptr + (size_t)(t + 1) * KB);
-        f32x16 n0, n1;
+        if (pvs) vreg = *reinterpret_cast<const uint4*>(vptr + (size_t)(t + 1) * KB);
         if (wave_live) {
-            // ---- matrix pipe: S(t+1) ----
-            if (pv) {
-                qk_tile(kring + ((t + 1) & 1) * KV_TILE_BYTES, qf, l31, half, kswz, n0, n1);
-                if (t + 1 >= mask_from) mask_tile(n0, n1, (t + 1) * KB, half, p.L);
-            }
-            // ---- VALU: online softmax of S(t), per-lane query.  Deferred rescale (T13): the running max only moves when
-            //      some query of the wave outgrew it by more than RESCALE_THR (exp2 units), so P <= 2^THR and the O / l
-            //      rescale is skipped on almost every tile.
-            float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-            mx = xor32_max(mx);
-            if (__any((mx - m_run) * p.scale_log2e > RESCALE_THR)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = fast_exp2((m_run - m_new) * p.scale_log2e);
-                l_run *= alpha;
-                m_run = m_new;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-            }
+            f32x16 n0, n1;
             const float mb = m_run * p.scale_log2e;
+            // ---------------- phase A ----------------
+            if (MODE != 2) qk_tile(kring + ((t + 1) & 1) * KV_TILE_BYTES, qf, l31, half, kswz, n0, n1);
             float psum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -180,32 +184,74 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
                 psum += s0[r] + s1[r];
             }
             l_run += psum;
-            // ---- matrix pipe: O^T += V^T(t) . P^T ; k-step ks covers keys 16 ks .. 16 ks + 15 of the tile ----
+            union { bf16x8 v; uint32_t u[4]; } pf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 8 * (ks & 1) + 2 * j;
+                    pf[ks].u[j] = (ks < 2) ? pack_bf2(s0[r], s0[r + 1]) : pack_bf2(s1[r], s1[r + 1]);
+                }
+#ifndef HIPEMU
+            if (MODE != 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {          // 8 x { 1 LDS read, 1 MFMA, 14 VALU }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+                }
+            }
+#endif
+            if (MODE == 1) mask_tile(n0, n1, (t + 1) * KB, half, p.L);
+            // ---------------- phase B ----------------
             const char* vb = vring + (t & 1) * KV_TILE_BYTES + l31 * 128;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int r0 = 8 * (ks & 1);
-                union { bf16x8 v; uint32_t u[4]; } pf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    pf.u[j] = (ks < 2) ? pack_bf2(s0[r0 + 2 * j], s0[r0 + 2 * j + 1]) : pack_bf2(s1[r0 + 2 * j], s1[r0 + 2 * j + 1]);
                 const int off = ((2 * ks + half) ^ kswz) << 4;
                 const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vb + off);
                 const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(vb + 32 * 128 + off);
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf.v, oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf.v, oacc[1], 0, 0, 0);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[ks].v, oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[ks].v, oacc[1], 0, 0, 0);
             }
-            s0 = n0; s1 = n1;
+            if (MODE != 2) {
+                mx = row_max(n0, n1);
+#ifndef HIPEMU
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {          // 8 x { 1 LDS read, 1 MFMA, 3 VALU }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
+                }
+#endif
+                // deferred rescale (T13) for tile t+1: the running max only moves when some query of the wave outgrew it by
+                // more than RESCALE_THR (exp2 units), so P <= 2^THR and the O / l rescale is skipped on almost every tile
+                if (__any((mx - m_run) * p.scale_log2e > RESCALE_THR)) {
+                    const float m_new = fmaxf(m_run, mx);
+                    const float alpha = fast_exp2((m_run - m_new) * p.scale_log2e);
+                    l_run *= alpha;
+                    m_run = m_new;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                }
+                s0 = n0; s1 = n1;
+            }
         }
         // ---- publish K(t+2) (overwrites K(t), last read one iteration ago) and V(t+1) (overwrites V(t-1)) ----
         if (pk) *reinterpret_cast<uint4*>(kring + (t & 1) * KV_TILE_BYTES + koff) = kreg;
-        if (pv) {
+        if (pvs) {
             char* vdst = vring + ((t + 1) & 1) * KV_TILE_BYTES;
             *reinterpret_cast<uint2*>(vdst + voff0) = make_uint2(vreg.x, vreg.y);
             *reinterpret_cast<uint2*>(vdst + voff1) = make_uint2(vreg.z, vreg.w);
         }
-        __syncthreads();
-    }
+        if (MODE != 2) __syncthreads();
+    };
+    const bool ragged = mask_from < ntiles && ntiles > 1;       // the last tile holds keys >= L
+    const int steady_end = ragged ? ntiles - 2 : ntiles - 1;    // iterations [0, steady_end) use MODE 0
+    for (int t = 0; t < steady_end; ++t) iteration(t, Mode<0>{});
+    if (ragged) iteration(ntiles - 2, Mode<1>{});
+    iteration(ntiles - 1, Mode<2>{});
 
     // ---- finish: O[q, d] = O^T / l ; lane owns query q, d = db*32 + 8 (r >> 2) + 4 half + (r & 3) ----
     if (!wave_live || q >= p.lpad) return;
@@ -232,11 +278,12 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
         return DGS_ERR_INVALID_ARGUMENT;
     AttnParams p;
     p.B = a->B; p.heads = a->heads; p.L = a->L; p.lpad = a->lpad; p.ld_qk = 2 * a->heads * 64;
-    p.nqb_full = a->L / QB;                    // query blocks made only of valid rows
-    p.nqb = (a->L + QB - 1) / QB;
+    const int units = (a->L + 31) / 32;        // 32-query wave units
+    p.extra_unit = (units % NW == 1 && units > 1) ? 1 : 0;
+    p.nqb = p.extra_unit ? units / NW : (units + NW - 1) / NW;
     p.qk = a->qk; p.vt = a->vt; p.out = a->out;
     p.scale_log2e = a->scale * 1.44269504088896341f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(a->B * a->heads * p.nqb), dim3(512), 0, st, p);
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(a->B * a->heads * p.nqb), dim3(576), 0, st, p);
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }

@@ -75,7 +75,7 @@ def test_gemm_qkv_epilogue(ops):
     assert torch.allclose(vt.float(), v, atol=2e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("L", [128, 130, 67])
+@pytest.mark.parametrize("L", [128, 130, 67, 258, 520])
 def test_attention(ops, L):
     g = torch.Generator().manual_seed(3)
     B, heads = 2, 2
