@@ -103,7 +103,7 @@ typedef struct DgsRasterBackwardArgs {
     const float* means3D;
     const float* shs;
     const float* colors_precomp;
-    const float* opacities;      /* only read when raw_activations=1                    */
+    const float* opacities;      /* [S,P] raw opacities; only read when raw_activations=1 */
     const float* scales;
     const float* rotations;
     const float* cov3D_precomp;
@@ -124,7 +124,8 @@ typedef struct DgsRasterBackwardArgs {
      * With V > 1 gradients of the views of one set are SUMMED into that set's slot.   */
     float* dL_dmeans2D;   /* [V,P,3]  (per view, like the reference's per-call tensor)   */
     float* dL_dconic;     /* [V,P,4]  scratch ([P,2,2] in the reference), never returned to Python */
-    float* dL_dcolors;    /* [V,P,3]  scratch when SH are used, else summed per set into [S,P,3] by the caller */
+    float* dL_dcolors;    /* SH given: [V,P,3] per-view scratch (consumed by the SH backward); colours precomputed: [S,P,3],
+                             summed over the views of each set (this IS the gradient returned to Python)             */
     float* dL_dcov3D;     /* [V,P,6]  */
     float* dL_dopacity;   /* [S,P]    */
     float* dL_dmeans3D;   /* [S,P,3]  */

@@ -1,0 +1,427 @@
+// raster_backward.hip -- backward pass of the MI355X-native 3D-Gaussian rasterizer (gfx950, wave64).
+//
+// What it computes is fixed by the reference (cuda_rasterizer/backward.cu, rasterizer_impl.cu:340-434); HOW is
+// redesigned for CDNA4:
+//
+//   reference (CUDA)                                         this file
+//   -------------------------------------------------------  ---------------------------------------------------------
+//   renderCUDA backward  backward.cu:399-557                 blend_backward_kernel: same back-to-front replay per 16x16
+//     9-10 global atomicAdd per contributing (pixel,           tile, but the nine per-Gaussian partial sums are first
+//     Gaussian) pair                                           reduced across the 64 lanes of a wave with DPP adds and
+//                                                              only lane 63 issues atomics (<= 4 per value per Gaussian per
+//                                                              tile instead of <= 256); waves in which no pixel takes a
+//                                                              Gaussian skip it after one ballot; the replay starts at the
+//                                                              tile's deepest contributor instead of the end of the list
+//   computeCov2DCUDA     backward.cu:144-274                 preprocess_backward_kernel: ONE thread per (set, Gaussian)
+//   preprocessCUDA bwd   backward.cu:346-396 (+ SH :20-139,    walks the views of its set, so gradients of the views of a
+//     computeCov3D :278-341)                                   set are summed in registers in a fixed order -- no atomics,
+//   torch autograd of exp / normalize / sigmoid                deterministic -- and the activation Jacobians are applied in
+//     (gs_core.py:330-334) when raw_activations = 1            the same pass
+#include "raster_common.h"
+
+namespace dgs {
+
+struct BwdParams {
+    int P, D, M, W, H, V, vps, gx, gy, T, raw_act;
+    const float *bg, *means3D, *shs, *colors_pre, *opac, *scales, *rots, *cov_pre, *viewm, *projm, *campos, *tanfov;
+    float tanfovx, tanfovy, scale_mod;
+    const int* radii;
+    const float* dL_dpix;
+    GeomState g;
+    ImageState im;
+    BinningState bn;
+    float *dL_dmean2D, *dL_dconic, *dL_dcolors, *dL_dcov3D, *dL_dopacity, *dL_dmeans3D, *dL_dsh, *dL_dscales, *dL_drots;
+};
+
+// grid (gx, gy, V), block 16x16 = 4 wave64 (each a 16x4 pixel strip).  backward.cu:399-557.
+__global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
+    __shared__ uint32_t s_id[256];
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float4 s_rgb[256];
+    __shared__ uint32_t s_max[4];
+    const int v = blockIdx.z, s = v / p.vps;
+    const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pxi = blockIdx.x * kTile + threadIdx.x, pyi = blockIdx.y * kTile + threadIdx.y;
+    const bool inside = pxi < p.W && pyi < p.H;
+    const float pfx = (float)pxi, pfy = (float)pyi;
+    const size_t HW = (size_t)p.H * p.W, pid = (size_t)p.W * pyi + pxi;
+    const uint2 rg = p.im.ranges[(size_t)v * p.T + blockIdx.y * p.gx + blockIdx.x];
+    const size_t vo = (size_t)v * p.P;
+
+    const float T_final = inside ? p.im.final_T[(size_t)v * HW + pid] : 0.0f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? p.im.n_contrib[(size_t)v * HW + pid] : 0u;
+    float dpix[3] = {0.f, 0.f, 0.f};
+    if (inside) {
+        const float* g = p.dL_dpix + (size_t)v * 3 * HW;
+        dpix[0] = g[pid]; dpix[1] = g[HW + pid]; dpix[2] = g[2 * HW + pid];
+    }
+    float bg_dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bg_dot += p.bg[c] * dpix[c];
+    float accum_rec[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f}, last_alpha = 0.f;
+    const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
+
+    // the deepest contributor of the tile: everything behind it in the list contributes to no pixel
+    uint32_t mc = last_contributor;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
+    if (lane == 0) s_max[wave] = mc;
+    __syncthreads();
+    const uint32_t todo = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));   // <= rg.y - rg.x
+    const int rounds = (int)((todo + 255u) / 256u);
+    uint32_t contributor = todo;       // 1-based index of the entry about to be processed
+    const bool colors_per_set = p.colors_pre != nullptr;
+    for (int i = 0; i < rounds; ++i) {
+        __syncthreads();
+        // entries contributor .. contributor-255 (1-based), i.e. list positions rg.x + contributor - 1 - tid
+        const int idx = (int)todo - 1 - (i * 256 + tid);
+        if (idx >= 0) {
+            const uint32_t id = p.bn.point_list[rg.x + (uint32_t)idx];
+            s_id[tid] = id;
+            s_xy[tid] = p.g.means2D[vo + id];
+            s_co[tid] = p.g.conic_opacity[vo + id];
+            if (colors_per_set) {
+                const float* c = p.colors_pre + 3 * ((size_t)s * p.P + id);
+                s_rgb[tid] = make_float4(c[0], c[1], c[2], 0.f);
+            } else {
+                s_rgb[tid] = p.g.rgb_cut[vo + id];
+            }
+        }
+        __syncthreads();
+        const int nb = min(256, (int)todo - i * 256);
+        for (int j = 0; j < nb; ++j, --contributor) {
+            // contributor = 1-based index of this entry; pixel took part iff index <= last_contributor (backward.cu:463-468)
+            bool take = inside && contributor <= last_contributor;
+            float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
+            float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (take) {
+                const float2 xy = s_xy[j];
+                dx = xy.x - pfx; dy = xy.y - pfy;
+                co = s_co[j];
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                take = !(power > 0.0f);
+                if (take) {
+                    G = det_expf(power);
+                    alpha = fminf(0.99f, co.w * G);
+                    take = !(alpha < 1.0f / 255.0f);
+                }
+            }
+            if (!__any(take)) continue;      // wave-uniform: nobody in this 16x4 strip touches the Gaussian
+            float c9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (take) {
+                T = T / (1.f - alpha);
+                const float dchannel_dcolor = alpha * T;
+                const float4 rgb = s_rgb[j];
+                const float col[3] = {rgb.x, rgb.y, rgb.z};
+                float dL_dalpha = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                    last_color[ch] = col[ch];
+                    dL_dalpha += (col[ch] - accum_rec[ch]) * dpix[ch];
+                    c9[ch] = dchannel_dcolor * dpix[ch];
+                }
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                const float dG_ddely = -gdy * co.z - gdx * co.y;
+                c9[3] = dL_dG * dG_ddelx * ddelx_dx;
+                c9[4] = dL_dG * dG_ddely * ddely_dy;
+                c9[5] = -0.5f * gdx * dx * dL_dG;
+                c9[6] = -0.5f * gdx * dy * dL_dG;
+                c9[7] = -0.5f * gdy * dy * dL_dG;
+                c9[8] = G * dL_dalpha;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) c9[k] = wave_sum_to_lane63(c9[k]);
+            if (lane == 63) {
+                const uint32_t id = s_id[j];
+                const size_t gv = vo + id, gs = (size_t)s * p.P + id;
+                float* dc = p.dL_dcolors + 3 * (colors_per_set ? gs : gv);
+                atomicAdd(dc, c9[0]); atomicAdd(dc + 1, c9[1]); atomicAdd(dc + 2, c9[2]);
+                atomicAdd(p.dL_dmean2D + 3 * gv, c9[3]); atomicAdd(p.dL_dmean2D + 3 * gv + 1, c9[4]);
+                atomicAdd(p.dL_dconic + 4 * gv, c9[5]); atomicAdd(p.dL_dconic + 4 * gv + 1, c9[6]); atomicAdd(p.dL_dconic + 4 * gv + 3, c9[7]);
+                atomicAdd(p.dL_dopacity + gs, c9[8]);
+            }
+        }
+    }
+}
+
+// backward.cu:20-139 for one Gaussian of one view.  dRGB already has the clamp mask applied.  Adds into dsh[M][3] and dmean.
+__device__ __forceinline__ void sh_backward(int deg, const float* sh, float ox, float oy, float oz, const float* dRGB, float* dsh,
+                                            float* dmean) {
+    const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox / len, y = oy / len, z = oz / len;
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+#define SHV(k, c) sh[3 * (k) + (c)]
+#define OUT(k, w)                                          \
+    do {                                                   \
+        dsh[3 * (k)] += (w) * dRGB[0];                     \
+        dsh[3 * (k) + 1] += (w) * dRGB[1];                 \
+        dsh[3 * (k) + 2] += (w) * dRGB[2];                 \
+    } while (0)
+    OUT(0, C0);
+    if (deg > 0) {
+        OUT(1, -C1 * y); OUT(2, C1 * z); OUT(3, -C1 * x);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { dx[c] = -C1 * SHV(3, c); dy[c] = -C1 * SHV(1, c); dz[c] = C1 * SHV(2, c); }
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            OUT(4, C2[0] * xy); OUT(5, C2[1] * yz); OUT(6, C2[2] * (2.f * zz - xx - yy)); OUT(7, C2[3] * xz); OUT(8, C2[4] * (xx - yy));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dx[c] += C2[0] * y * SHV(4, c) + C2[2] * 2.f * -x * SHV(6, c) + C2[3] * z * SHV(7, c) + C2[4] * 2.f * x * SHV(8, c);
+                dy[c] += C2[0] * x * SHV(4, c) + C2[1] * z * SHV(5, c) + C2[2] * 2.f * -y * SHV(6, c) + C2[4] * 2.f * -y * SHV(8, c);
+                dz[c] += C2[1] * y * SHV(5, c) + C2[2] * 2.f * 2.f * z * SHV(6, c) + C2[3] * x * SHV(7, c);
+            }
+            if (deg > 2) {
+                OUT(9, C3[0] * y * (3.f * xx - yy)); OUT(10, C3[1] * xy * z); OUT(11, C3[2] * y * (4.f * zz - xx - yy));
+                OUT(12, C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)); OUT(13, C3[4] * x * (4.f * zz - xx - yy));
+                OUT(14, C3[5] * z * (xx - yy)); OUT(15, C3[6] * x * (xx - 3.f * yy));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    dx[c] += C3[0] * SHV(9, c) * 3.f * 2.f * xy + C3[1] * SHV(10, c) * yz + C3[2] * SHV(11, c) * -2.f * xy +
+                             C3[3] * SHV(12, c) * -3.f * 2.f * xz + C3[4] * SHV(13, c) * (-3.f * xx + 4.f * zz - yy) +
+                             C3[5] * SHV(14, c) * 2.f * xz + C3[6] * SHV(15, c) * 3.f * (xx - yy);
+                    dy[c] += C3[0] * SHV(9, c) * 3.f * (xx - yy) + C3[1] * SHV(10, c) * xz + C3[2] * SHV(11, c) * (-3.f * yy + 4.f * zz - xx) +
+                             C3[3] * SHV(12, c) * -3.f * 2.f * yz + C3[4] * SHV(13, c) * -2.f * xy + C3[5] * SHV(14, c) * -2.f * yz +
+                             C3[6] * SHV(15, c) * -3.f * 2.f * xy;
+                    dz[c] += C3[1] * SHV(10, c) * xy + C3[2] * SHV(11, c) * 4.f * 2.f * yz + C3[3] * SHV(12, c) * 3.f * (2.f * zz - xx - yy) +
+                             C3[4] * SHV(13, c) * 4.f * 2.f * xz + C3[5] * SHV(14, c) * (xx - yy);
+                }
+            }
+        }
+    }
+#undef OUT
+#undef SHV
+    const float ddx = dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2];
+    const float ddy = dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2];
+    const float ddz = dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2];
+    // dnormvdv, auxiliary.h:107-117
+    const float sum2 = ox * ox + oy * oy + oz * oz;
+    const float inv = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dmean[0] += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * inv;
+    dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * inv;
+    dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * inv;
+}
+
+// grid ceil(S*P / 256).  One thread per (set, Gaussian); loops over the views of the set.
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, int S) {
+    const size_t si = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (si >= (size_t)S * p.P) return;
+    const int s = (int)(si / p.P), idx = (int)(si % p.P);
+    const float mx = p.means3D[3 * si], my = p.means3D[3 * si + 1], mz = p.means3D[3 * si + 2];
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov_sum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dsh[48];
+    const int nsh = p.shs ? 3 * p.M : 0;
+    for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
+    const int v0 = s * p.vps, v1 = min(p.V, v0 + p.vps);
+    for (int v = v0; v < v1; ++v) {
+        const size_t gi = (size_t)v * p.P + idx;
+        if (!(p.radii[gi] > 0)) continue;
+        const float* vm = p.viewm + 16 * v;
+        const float* proj = p.projm + 16 * v;
+        float tanx, tany;
+        if (p.tanfov) { tanx = p.tanfov[2 * v]; tany = p.tanfov[2 * v + 1]; } else { tanx = p.tanfovx; tany = p.tanfovy; }
+        const float focal_y = p.H / (2.0f * tany), focal_x = p.W / (2.0f * tanx);
+        // ---- computeCov2DCUDA, backward.cu:144-274 ----
+        float c6[6];
+        if (p.cov_pre) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = p.cov_pre[6 * si + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = p.g.cov3D[6 * gi + k];
+        }
+        float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+        float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+        const float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+        const float limx = 1.3f * tanx, limy = 1.3f * tany;
+        const float txtz = tx / tz, tytz = ty / tz;
+        tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const float xgm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float ygm = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const M3 J = m3_cols(focal_x / tz, 0.0f, -(focal_x * tx) / (tz * tz), 0.0f, focal_y / tz, -(focal_y * ty) / (tz * tz), 0, 0, 0);
+        const M3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+        const M3 Tm = m3_mul(Wm, J);
+        const M3 Vrk = m3_cols(c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]);
+        const M3 cov = m3_mul(m3_mul(m3_t(Tm), m3_t(Vrk)), Tm);
+        const float a = cov.c[0][0] + 0.3f, b = cov.c[0][1], c = cov.c[1][1] + 0.3f;
+        const float denom = a * c - b * b;
+        const float dcx = p.dL_dconic[4 * gi], dcy = p.dL_dconic[4 * gi + 1], dcz = p.dL_dconic[4 * gi + 3];
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float (*T)[3] = Tm.c;
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
+            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
+            dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+            dcov[0] = (T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc);
+            dcov[3] = (T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc);
+            dcov[5] = (T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc);
+            dcov[1] = 2 * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][1] * dL_dc;
+            dcov[2] = 2 * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][2] * dL_dc;
+            dcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2 * T[1][1] * T[1][2] * dL_dc;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { p.dL_dcov3D[6 * gi + k] = dcov[k]; dcov_sum[k] += dcov[k]; }
+        const float (*Vm)[3] = Vrk.c;
+        const float dT00 = 2 * (T[0][0] * Vm[0][0] + T[0][1] * Vm[0][1] + T[0][2] * Vm[0][2]) * dL_da + (T[1][0] * Vm[0][0] + T[1][1] * Vm[0][1] + T[1][2] * Vm[0][2]) * dL_db;
+        const float dT01 = 2 * (T[0][0] * Vm[1][0] + T[0][1] * Vm[1][1] + T[0][2] * Vm[1][2]) * dL_da + (T[1][0] * Vm[1][0] + T[1][1] * Vm[1][1] + T[1][2] * Vm[1][2]) * dL_db;
+        const float dT02 = 2 * (T[0][0] * Vm[2][0] + T[0][1] * Vm[2][1] + T[0][2] * Vm[2][2]) * dL_da + (T[1][0] * Vm[2][0] + T[1][1] * Vm[2][1] + T[1][2] * Vm[2][2]) * dL_db;
+        const float dT10 = 2 * (T[1][0] * Vm[0][0] + T[1][1] * Vm[0][1] + T[1][2] * Vm[0][2]) * dL_dc + (T[0][0] * Vm[0][0] + T[0][1] * Vm[0][1] + T[0][2] * Vm[0][2]) * dL_db;
+        const float dT11 = 2 * (T[1][0] * Vm[1][0] + T[1][1] * Vm[1][1] + T[1][2] * Vm[1][2]) * dL_dc + (T[0][0] * Vm[1][0] + T[0][1] * Vm[1][1] + T[0][2] * Vm[1][2]) * dL_db;
+        const float dT12 = 2 * (T[1][0] * Vm[2][0] + T[1][1] * Vm[2][1] + T[1][2] * Vm[2][2]) * dL_dc + (T[0][0] * Vm[2][0] + T[0][1] * Vm[2][1] + T[0][2] * Vm[2][2]) * dL_db;
+        const float dJ00 = Wm.c[0][0] * dT00 + Wm.c[0][1] * dT01 + Wm.c[0][2] * dT02;
+        const float dJ02 = Wm.c[2][0] * dT00 + Wm.c[2][1] * dT01 + Wm.c[2][2] * dT02;
+        const float dJ11 = Wm.c[1][0] * dT10 + Wm.c[1][1] * dT11 + Wm.c[1][2] * dT12;
+        const float dJ12 = Wm.c[2][0] * dT10 + Wm.c[2][1] * dT11 + Wm.c[2][2] * dT12;
+        const float itz = 1.f / tz, tz2 = itz * itz, tz3 = tz2 * itz;
+        const float dtx = xgm * -focal_x * tz2 * dJ02;
+        const float dty = ygm * -focal_y * tz2 * dJ12;
+        const float dtz = -focal_x * tz2 * dJ00 - focal_y * tz2 * dJ11 + (2 * focal_x * tx) * tz3 * dJ02 + (2 * focal_y * ty) * tz3 * dJ12;
+        // transformVec4x3Transpose, auxiliary.h:97-105
+        float dmv[3];
+        dmv[0] = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;
+        dmv[1] = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
+        dmv[2] = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+        // ---- preprocessCUDA backward, backward.cu:346-396 ----
+        const float hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+        const float d2x = p.dL_dmean2D[3 * gi], d2y = p.dL_dmean2D[3 * gi + 1];
+        dmv[0] += (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
+        dmv[1] += (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
+        dmv[2] += (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
+        if (p.shs) {
+            const unsigned cb = p.g.clamped[gi];
+            const float dRGB[3] = {(cb & 1u) ? 0.f : p.dL_dcolors[3 * gi], (cb & 2u) ? 0.f : p.dL_dcolors[3 * gi + 1],
+                                   (cb & 4u) ? 0.f : p.dL_dcolors[3 * gi + 2]};
+            const float* cam = p.campos + 3 * v;
+            sh_backward(p.D, p.shs + 3 * (size_t)p.M * si, mx - cam[0], my - cam[1], mz - cam[2], dRGB, dsh, dmv);
+        }
+        dmean[0] += dmv[0]; dmean[1] += dmv[1]; dmean[2] += dmv[2];
+    }
+    p.dL_dmeans3D[3 * si] = dmean[0]; p.dL_dmeans3D[3 * si + 1] = dmean[1]; p.dL_dmeans3D[3 * si + 2] = dmean[2];
+    if (p.dL_dsh)
+        for (int k = 0; k < nsh; ++k) p.dL_dsh[(size_t)nsh * si + k] = dsh[k];
+    if (p.raw_act) {   // d sigmoid, gs_core.py:334
+        const float op = 1.0f / (1.0f + det_expf(-p.opac[si]));
+        p.dL_dopacity[si] = p.dL_dopacity[si] * (op * (1.0f - op));
+    }
+    if (!p.cov_pre && p.dL_dscales && p.dL_drots) {
+        // ---- computeCov3D backward, backward.cu:278-341, on the view-summed dL/dSigma ----
+        float sx = p.scales[3 * si], sy = p.scales[3 * si + 1], sz = p.scales[3 * si + 2];
+        float qr = p.rots[4 * si], qx = p.rots[4 * si + 1], qy = p.rots[4 * si + 2], qz = p.rots[4 * si + 3];
+        const float raw_q[4] = {qr, qx, qy, qz};
+        float nrm = 1.0f;
+        if (p.raw_act) {
+            sx = det_expf(sx); sy = det_expf(sy); sz = det_expf(sz);
+            nrm = fmaxf(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
+            qr = qr / nrm; qx = qx / nrm; qy = qy / nrm; qz = qz / nrm;
+        }
+        const float r = qr, x = qx, y = qy, z = qz;
+        const M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                             2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                             2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+        M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
+        const float s3[3] = {p.scale_mod * sx, p.scale_mod * sy, p.scale_mod * sz};
+        S.c[0][0] = s3[0]; S.c[1][1] = s3[1]; S.c[2][2] = s3[2];
+        const M3 Mm = m3_mul(S, R);
+        const float* d6 = dcov_sum;
+        const M3 dSig = m3_cols(d6[0], 0.5f * d6[1], 0.5f * d6[2], 0.5f * d6[1], d6[3], 0.5f * d6[4], 0.5f * d6[2], 0.5f * d6[4], d6[5]);
+        M3 M2;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) M2.c[cc][rr] = Mm.c[cc][rr] * 2.0f;
+        const M3 dM = m3_mul(M2, dSig);
+        const M3 Rt = m3_t(R);
+        M3 dMt = m3_t(dM);
+        float gs[3];
+        gs[0] = Rt.c[0][0] * dMt.c[0][0] + Rt.c[0][1] * dMt.c[0][1] + Rt.c[0][2] * dMt.c[0][2];
+        gs[1] = Rt.c[1][0] * dMt.c[1][0] + Rt.c[1][1] * dMt.c[1][1] + Rt.c[1][2] * dMt.c[1][2];
+        gs[2] = Rt.c[2][0] * dMt.c[2][0] + Rt.c[2][1] * dMt.c[2][1] + Rt.c[2][2] * dMt.c[2][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dMt.c[0][k] *= s3[0]; dMt.c[1][k] *= s3[1]; dMt.c[2][k] *= s3[2]; }
+        float gq[4];
+        gq[0] = 2 * z * (dMt.c[0][1] - dMt.c[1][0]) + 2 * y * (dMt.c[2][0] - dMt.c[0][2]) + 2 * x * (dMt.c[1][2] - dMt.c[2][1]);
+        gq[1] = 2 * y * (dMt.c[1][0] + dMt.c[0][1]) + 2 * z * (dMt.c[2][0] + dMt.c[0][2]) + 2 * r * (dMt.c[1][2] - dMt.c[2][1]) - 4 * x * (dMt.c[2][2] + dMt.c[1][1]);
+        gq[2] = 2 * x * (dMt.c[1][0] + dMt.c[0][1]) + 2 * r * (dMt.c[2][0] - dMt.c[0][2]) + 2 * z * (dMt.c[1][2] + dMt.c[2][1]) - 4 * y * (dMt.c[2][2] + dMt.c[0][0]);
+        gq[3] = 2 * r * (dMt.c[0][1] - dMt.c[1][0]) + 2 * x * (dMt.c[2][0] + dMt.c[0][2]) + 2 * y * (dMt.c[1][2] + dMt.c[2][1]) - 4 * z * (dMt.c[1][1] + dMt.c[0][0]);
+        if (p.raw_act) {
+            // gs is d/d(scale_mod * s) per component (backward.cu:329-331 writes it as dL_dscale): chain d exp = s
+            gs[0] *= sx; gs[1] *= sy; gs[2] *= sz;
+            // F.normalize backward (q = raw / max(|raw|, eps)): (g - q (q . g)) / |raw|
+            const float qg = qr * gq[0] + qx * gq[1] + qy * gq[2] + qz * gq[3];
+            const float qn[4] = {qr, qx, qy, qz};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gq[k] = (gq[k] - qn[k] * qg) / nrm;
+            (void)raw_q;
+        }
+        p.dL_dscales[3 * si] = gs[0]; p.dL_dscales[3 * si + 1] = gs[1]; p.dL_dscales[3 * si + 2] = gs[2];
+        p.dL_drots[4 * si] = gq[0]; p.dL_drots[4 * si + 1] = gq[1]; p.dL_drots[4 * si + 2] = gq[2]; p.dL_drots[4 * si + 3] = gq[3];
+    }
+}
+
+}  // namespace dgs
+
+using namespace dgs;
+
+extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!a || a->P < 0 || a->width <= 0 || a->height <= 0 || a->V < 1 || a->views_per_set < 1) return DGS_ERR_INVALID_ARGUMENT;
+    const int P = a->P, V = a->V, W = a->width, H = a->height;
+    const int S = (V + a->views_per_set - 1) / a->views_per_set;
+    if (P == 0) return DGS_OK;
+    if (!a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos || !a->background || !a->radii || !a->dL_dpix ||
+        !a->geom_buffer || !a->binning_buffer || !a->img_buffer)
+        return DGS_ERR_INVALID_ARGUMENT;
+    if (!a->dL_dmeans2D || !a->dL_dconic || !a->dL_dcolors || !a->dL_dcov3D || !a->dL_dopacity || !a->dL_dmeans3D)
+        return DGS_ERR_INVALID_ARGUMENT;
+    if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) return DGS_ERR_NEED_COLORS;
+    if (a->cov3D_precomp ? (a->scales || a->rotations) : !(a->scales && a->rotations)) return DGS_ERR_NEED_COVARIANCE;
+    if (a->shs && (!a->dL_dsh || a->M < 1 || a->M > 16)) return DGS_ERR_INVALID_ARGUMENT;
+    if (!a->cov3D_precomp && (!a->dL_dscales || !a->dL_drotations)) return DGS_ERR_INVALID_ARGUMENT;
+    if (a->raw_activations && !a->opacities) return DGS_ERR_INVALID_ARGUMENT;
+
+    BwdParams p{};
+    p.P = P; p.D = a->D; p.M = a->M; p.W = W; p.H = H; p.V = V; p.vps = a->views_per_set;
+    p.gx = (W + kTile - 1) / kTile; p.gy = (H + kTile - 1) / kTile; p.T = p.gx * p.gy; p.raw_act = a->raw_activations;
+    p.bg = a->background; p.means3D = a->means3D; p.shs = a->shs; p.colors_pre = a->colors_precomp; p.opac = a->opacities;
+    p.scales = a->scales; p.rots = a->rotations; p.cov_pre = a->cov3D_precomp; p.viewm = a->viewmatrix; p.projm = a->projmatrix;
+    p.campos = a->campos; p.tanfov = a->tanfov; p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.scale_mod = a->scale_modifier;
+    p.radii = a->radii; p.dL_dpix = a->dL_dpix;
+    p.g = GeomState::carve(const_cast<void*>(a->geom_buffer), (size_t)P, (size_t)V, nullptr);
+    p.im = ImageState::carve(const_cast<void*>(a->img_buffer), (size_t)W, (size_t)H, (size_t)V, nullptr);
+    p.bn = BinningState::carve(const_cast<void*>(a->binning_buffer), (size_t)(a->num_rendered < 1 ? 1 : a->num_rendered), nullptr);
+    p.dL_dmean2D = a->dL_dmeans2D; p.dL_dconic = a->dL_dconic; p.dL_dcolors = a->dL_dcolors; p.dL_dcov3D = a->dL_dcov3D;
+    p.dL_dopacity = a->dL_dopacity; p.dL_dmeans3D = a->dL_dmeans3D; p.dL_dsh = a->dL_dsh; p.dL_dscales = a->dL_dscales;
+    p.dL_drots = a->dL_drotations;
+
+    const size_t nv = (size_t)V * P, ns = (size_t)S * P;
+    hipMemsetAsync(p.dL_dmean2D, 0, nv * 3 * sizeof(float), st);
+    hipMemsetAsync(p.dL_dconic, 0, nv * 4 * sizeof(float), st);
+    hipMemsetAsync(p.dL_dcolors, 0, (a->colors_precomp ? ns : nv) * 3 * sizeof(float), st);
+    hipMemsetAsync(p.dL_dcov3D, 0, nv * 6 * sizeof(float), st);
+    hipMemsetAsync(p.dL_dopacity, 0, ns * sizeof(float), st);
+    if (a->num_rendered != 0)
+        hipLaunchKernelGGL(blend_backward_kernel, dim3(p.gx, p.gy, V), dim3(kTile, kTile), 0, st, p);
+    if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
+    if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}

@@ -1,0 +1,61 @@
+// raster_common.h -- helpers shared by the forward and backward rasterizer translation units.
+#pragma once
+#include "dgs_device.h"
+#include "raster_state.h"
+#include "dgs_raster.h"
+
+namespace dgs {
+
+// ---- small column-major 3x3 helper with glm's product order (type_mat3x3.inl:486-519) ----
+struct M3 { float c[3][3]; };
+__device__ __forceinline__ M3 m3_cols(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
+    M3 m;
+    m.c[0][0] = a0; m.c[0][1] = a1; m.c[0][2] = a2;
+    m.c[1][0] = a3; m.c[1][1] = a4; m.c[1][2] = a5;
+    m.c[2][0] = a6; m.c[2][1] = a7; m.c[2][2] = a8;
+    return m;
+}
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            R.c[j][i] = A.c[0][i] * B.c[j][0] + A.c[1][i] * B.c[j][1] + A.c[2][i] * B.c[j][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3& A) {
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) R.c[j][i] = A.c[i][j];
+    return R;
+}
+
+
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 only.  Six v_add_f32_dpp (row shifts inside the 16-lane
+// rows, then row broadcasts) instead of six ds_bpermute round trips.
+#ifdef HIPEMU
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+#else
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v += dpp_mov<0x111>(v);   // row_shr:1
+    v += dpp_mov<0x112>(v);   // row_shr:2
+    v += dpp_mov<0x114>(v);   // row_shr:4
+    v += dpp_mov<0x118>(v);   // row_shr:8    -> lane 15 of every 16-lane row holds the row sum
+    v += dpp_mov<0x142>(v);   // row_bcast:15 -> lanes 31 / 63 hold the sum of their row pair
+    v += dpp_mov<0x143>(v);   // row_bcast:31 -> lane 63 holds the wave sum
+    return v;
+}
+#endif
+
+}  // namespace dgs

@@ -20,9 +20,7 @@
 // All V views of a call are processed by the same launches (grid.y / grid.z = view).
 #include <string.h>
 
-#include "dgs_device.h"
-#include "raster_state.h"
-#include "dgs_raster.h"
+#include "raster_common.h"
 
 namespace dgs {
 
@@ -37,33 +35,6 @@ struct FwdParams {
     ImageState im;
     BinningState bn;
 };
-
-// ---- small column-major 3x3 helper with glm's product order (type_mat3x3.inl:486-519) ----
-struct M3 { float c[3][3]; };
-__device__ __forceinline__ M3 m3_cols(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
-    M3 m;
-    m.c[0][0] = a0; m.c[0][1] = a1; m.c[0][2] = a2;
-    m.c[1][0] = a3; m.c[1][1] = a4; m.c[1][2] = a5;
-    m.c[2][0] = a6; m.c[2][1] = a7; m.c[2][2] = a8;
-    return m;
-}
-__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
-    M3 R;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            R.c[j][i] = A.c[0][i] * B.c[j][0] + A.c[1][i] * B.c[j][1] + A.c[2][i] * B.c[j][2];
-    return R;
-}
-__device__ __forceinline__ M3 m3_t(const M3& A) {
-    M3 R;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) R.c[j][i] = A.c[i][j];
-    return R;
-}
 
 __device__ __forceinline__ void view_tanfov(const FwdParams& p, int v, float* tx, float* ty) {
     if (p.tanfov) { *tx = p.tanfov[2 * v]; *ty = p.tanfov[2 * v + 1]; }
@@ -408,7 +379,6 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
     const uint2 rg = p.im.ranges[(size_t)v * p.T + t];
     if (rg.x == rg.y) return;
     const uint32_t* order = p.g.vals[0] + (size_t)v * p.P;   // rank -> Gaussian index (after 4 passes the result is in buffer 0)
-    const int wpt = wwords / 256;                            // words per thread
     uint32_t emitted = rg.x;
     for (uint32_t w0 = 0; w0 < (uint32_t)p.P; w0 += (uint32_t)wwords * 32u) {
         for (int i = tid; i < wwords; i += 256) bm[i] = 0;
@@ -418,19 +388,33 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
             if (r < (uint32_t)wwords * 32u) atomicOr(&bm[r >> 5], 1u << (r & 31u));
         }
         __syncthreads();
+        // Emission is wave-cooperative so that stores (and the rank -> index gathers) are coalesced: every wave owns a
+        // contiguous quarter of the window's words and expands them 64 bits (two words) per step -- lane l tests bit l & 31
+        // of word (l >> 5), a ballot + popcount prefix gives each set lane its output slot.  (One thread walking its own
+        // words writes 64 scattered cache lines per store instruction: 34x write amplification on long tile lists.)
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wpw = wwords / 4;                       // words per wave (wwords is a multiple of 256)
         uint32_t cnt = 0;
-        for (int k = 0; k < wpt; ++k) cnt += (uint32_t)__popc(bm[tid * wpt + k]);
-        uint32_t total;
-        uint32_t off = emitted + block_exclusive_scan<256>(cnt, scratch, &total);
-        if (cnt)
-            for (int k = 0; k < wpt; ++k) {
-                uint32_t word = bm[tid * wpt + k];
-                while (word) {
-                    const int bit = __ffs((int)word) - 1;
-                    word &= word - 1;
-                    p.bn.point_list[off++] = order[w0 + (uint32_t)(tid * wpt + k) * 32u + (uint32_t)bit];
-                }
-            }
+        for (int k = lane; k < wpw; k += 64) cnt += (uint32_t)__popc(bm[wave * wpw + k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) scratch[wave] = cnt;
+        __syncthreads();
+        uint32_t off = emitted, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = scratch[w];
+            if (w < wave) off += c;
+            total += c;
+        }
+        const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        for (int k = 0; k < wpw; k += 2) {
+            const uint32_t word = bm[wave * wpw + k + (lane >> 5)];
+            const bool set = (word >> (lane & 31)) & 1u;
+            const unsigned long long m = __ballot(set);
+            if (set) p.bn.point_list[off + (uint32_t)__popcll(m & lt_mask)] = order[w0 + (uint32_t)(wave * wpw + k) * 32u + (uint32_t)lane];
+            off += (uint32_t)__popcll(m);
+        }
         emitted += total;
         __syncthreads();
     }

@@ -96,6 +96,10 @@ class Renderer(nn.Module):
     def forward(self, xyz, features, scaling, rotation, opacity, height, width, C2W, fxfycxcy, deferred=True):
         f = lambda t: t.float()      # custom_fwd(cast_inputs=float32), renderer.py:34
         backend = self._backend if self._backend is not None else default_backend()
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (xyz, features, scaling, rotation, opacity)):
+            from .raster import render_views_autograd      # training: DeferredGaussianRender's role, gs_core.py:949-1064
+            return render_views_autograd(backend, f(xyz), f(features), f(scaling), f(rotation), f(opacity), height, width,
+                                         f(C2W), f(fxfycxcy))
         return backend.render_views(f(xyz), f(features), f(scaling), f(rotation), f(opacity), height, width,
                                               f(C2W), f(fxfycxcy))
 

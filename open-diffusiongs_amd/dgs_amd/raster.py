@@ -112,6 +112,65 @@ class RasterBackend:
         num_rendered = int(a.num_rendered) if binning_capacity <= 0 else ndev
         return num_rendered, out_color, radii, holder["geom"], holder["binning"], holder["img"]
 
+    # -- _C.rasterize_gaussians_backward ----------------------------------------------------
+    def rasterize_gaussians_backward(self, background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, dL_dout_color, sh, degree,
+                                     campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+        """rasterize_points.cu:117-196: -> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3],
+        dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])."""
+        H, W = int(dL_dout_color.shape[-2]), int(dL_dout_color.shape[-1])
+        g = self.backward_views(background, means3D[None], radii[None], colors, None, scales, rotations, scale_modifier,
+                                cov3D_precomp, viewmatrix.reshape(1, 4, 4), projmatrix.reshape(1, 4, 4), campos.reshape(1, 3),
+                                None, float(tanfovx), float(tanfovy), dL_dout_color.reshape(1, 3, H, W), sh, degree,
+                                geomBuffer, R, binningBuffer, imageBuffer, debug, views_per_set=1)
+        P = int(means3D.shape[0])
+        M = int(sh.shape[-2]) if sh is not None and sh.numel() else 0
+        return (g["means2D"][0], g["colors"].reshape(-1, 3)[:P], g["opacity"].reshape(P, 1), g["means3D"][0], g["cov3D"][0],
+                g["sh"].reshape(P, M, 3), g["scales"].reshape(-1, 3)[:P] if g["scales"] is not None else torch.zeros((P, 3), device=means3D.device),
+                g["rotations"].reshape(-1, 4)[:P] if g["rotations"] is not None else torch.zeros((P, 4), device=means3D.device))
+
+    def backward_views(self, background, means3D, radii, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                       viewmatrix, projmatrix, campos, tanfov, tanfovx, tanfovy, dL_dpix, sh, degree, geom, num_rendered,
+                       binning, img, debug, views_per_set=1, raw_activations=False):
+        """Batched backward: means3D [S,P,3], radii [V,P], dL_dpix [V,3,H,W] -> dict of gradients
+        (means2D [V,P,3], cov3D [V,P,6] per view; means3D, opacity, scales, rotations, sh (and colors when precomputed)
+        summed over the views of each set)."""
+        device = means3D.device
+        S, P = int(means3D.shape[0]), int(means3D.shape[1])
+        V = int(viewmatrix.shape[0])
+        H, W = int(dL_dpix.shape[-2]), int(dL_dpix.shape[-1])
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+        keep = dict(bg=_prep(background, device), means=_prep(means3D, device), colors=_prep(colors, device),
+                    op=_prep(opacity, device), scales=_prep(scales, device), rots=_prep(rotations, device),
+                    cov=_prep(cov3D_precomp, device), vm=_prep(viewmatrix, device), pm=_prep(projmatrix, device),
+                    cam=_prep(campos, device), sh=_prep(sh, device), tanfov=_prep(tanfov, device), g=_prep(dL_dpix, device))
+        M = int(keep["sh"].shape[-2]) if keep["sh"] is not None else 0
+        use_sr = keep["cov"] is None
+        out = dict(means2D=z(V, P, 3), conic=z(V, P, 4), cov3D=z(V, P, 6), opacity=z(S, P), means3D=z(S, P, 3),
+                   colors=z(S, P, 3) if keep["colors"] is not None else z(V, P, 3), sh=z(S, P, max(M, 0), 3),
+                   scales=z(S, P, 3) if use_sr else None, rotations=z(S, P, 4) if use_sr else None)
+        if P == 0:
+            return out
+        a = _native.DgsRasterBackwardArgs()
+        a.P, a.D, a.M, a.width, a.height, a.V, a.views_per_set = P, int(degree), M, W, H, V, int(views_per_set)
+        a.num_rendered = int(num_rendered)
+        a.background = _ptr(keep["bg"]); a.means3D = _ptr(keep["means"]); a.shs = _ptr(keep["sh"])
+        a.colors_precomp = _ptr(keep["colors"]); a.opacities = _ptr(keep["op"]); a.scales = _ptr(keep["scales"])
+        a.rotations = _ptr(keep["rots"]); a.cov3D_precomp = _ptr(keep["cov"]); a.viewmatrix = _ptr(keep["vm"])
+        a.projmatrix = _ptr(keep["pm"]); a.campos = _ptr(keep["cam"]); a.tanfov = _ptr(keep["tanfov"])
+        a.tanfovx, a.tanfovy, a.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
+        a.debug, a.raw_activations = int(bool(debug)), int(bool(raw_activations))
+        radii = radii.to(device=device, dtype=torch.int32).contiguous()
+        a.radii = ctypes.c_void_p(radii.data_ptr()); a.dL_dpix = _ptr(keep["g"])
+        a.geom_buffer, a.binning_buffer, a.img_buffer = _ptr(geom), _ptr(binning), _ptr(img)
+        a.dL_dmeans2D, a.dL_dconic, a.dL_dcolors, a.dL_dcov3D = (_ptr(out[k]) for k in ("means2D", "conic", "colors", "cov3D"))
+        a.dL_dopacity, a.dL_dmeans3D = _ptr(out["opacity"]), _ptr(out["means3D"])
+        a.dL_dsh = _ptr(out["sh"]) if M else None
+        a.dL_dscales, a.dL_drotations = (_ptr(out["scales"]), _ptr(out["rotations"])) if use_sr else (None, None)
+        rc = self.lib.dgs_raster_backward(ctypes.byref(a), self._stream(device))
+        self._check(rc)
+        return out
+
     # -- Camera (gs_core.py:277-316), all views at once ------------------------------------
     def cameras_from_c2w(self, c2w, fxfycxcy, height, width, znear=0.01, zfar=100.0):
         """c2w [...,4,4], fxfycxcy [...,4] -> (viewmatrix [n,4,4], projmatrix [n,4,4], campos [n,3], tanfov [n,2])."""
@@ -166,6 +225,45 @@ class RasterBackend:
         if n < 0:
             self._check(int(n))
         return dst[: int(n) // dst.element_size()]
+
+
+class _RenderViews(torch.autograd.Function):
+    """Differentiable batched render of raw Gaussian parameters: what DeferredGaussianRender (gs_core.py:949-1064) does with
+    b*v per-view calls and a recompute in backward, as ONE forward and ONE backward launch sequence.  The forward state
+    buffers are kept for backward (no second forward pass: MI355X has the HBM for it)."""
+
+    @staticmethod
+    def forward(ctx, backend, xyz, features, scaling, rotation, opacity, c2w, fxfycxcy, height, width, bg):
+        device = xyz.device
+        B, V = int(c2w.shape[0]), int(c2w.shape[1])
+        view, proj, campos, tanfov = backend.cameras_from_c2w(c2w, fxfycxcy, height, width)
+        M = int(features.shape[2])
+        degree = int(round(M ** 0.5)) - 1
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        xyz_, sh_, sc_, ro_, op_ = f(xyz), f(features), f(scaling), f(rotation), f(opacity).reshape(B, -1)
+        n, color, radii, geom, binning, img = backend.forward_views(
+            bg, xyz_, None, op_, sc_, ro_, 1.0, None, view, proj, campos, tanfov, 0.0, 0.0, height, width, sh_, degree,
+            False, False, views_per_set=V, raw_activations=True)
+        ctx.backend, ctx.meta = backend, (B, V, int(height), int(width), degree, n)
+        ctx.save_for_backward(bg, xyz_, sh_, sc_, ro_, op_, view, proj, campos, tanfov, radii, geom, binning, img)
+        return color.reshape(B, V, 3, int(height), int(width))
+
+    @staticmethod
+    def backward(ctx, grad):
+        bg, xyz_, sh_, sc_, ro_, op_, view, proj, campos, tanfov, radii, geom, binning, img = ctx.saved_tensors
+        B, V, H, W, degree, n = ctx.meta
+        g = ctx.backend.backward_views(bg, xyz_, radii, None, op_, sc_, ro_, 1.0, None, view, proj, campos, tanfov, 0.0, 0.0,
+                                       grad.reshape(B * V, 3, H, W), sh_, degree, geom, n, binning, img, False,
+                                       views_per_set=V, raw_activations=True)
+        return (None, g["means3D"], g["sh"], g["scales"], g["rotations"], g["opacity"].reshape(B, -1, 1), None, None, None,
+                None, None)
+
+
+def render_views_autograd(backend, xyz, features, scaling, rotation, opacity, height, width, c2w, fxfycxcy, bg=None):
+    """[B,P,..] raw Gaussian parameters -> [B,V,3,H,W]; differentiable w.r.t. the five parameter tensors."""
+    if bg is None:
+        bg = torch.ones(3, dtype=torch.float32, device=xyz.device)
+    return _RenderViews.apply(backend, xyz, features, scaling, rotation, opacity, c2w.float(), fxfycxcy.float(), height, width, bg)
 
 
 _default = None

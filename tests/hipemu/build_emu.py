@@ -26,7 +26,7 @@ def build(force=False):
         return LIB
     objs = []
     common = ["-std=c++17", "-O2", "-g", "-fPIC", "-ffp-contract=off", "-mfma", "-I" + HERE, "-I" + INCLUDE, "-I" + CSRC,
-              "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
+              "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-psabi"]
     for s in srcs + [os.path.join(HERE, "hipemu_runtime.cpp")]:
         o = os.path.join(OUT_DIR, os.path.basename(s) + ".o")
         subprocess.check_call([CLANG, "-x", "c++"] + common + ["-c", s, "-o", o])

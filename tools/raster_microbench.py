@@ -56,5 +56,41 @@ def main():
               f"-> {a.views / (e0.elapsed_time(e1) / a.iters) * 1e3:.0f} views/s")
 
 
+def bench_backward(a):
+    """forward + backward through the batched autograd entry (raw parameters), views/s."""
+    from dgs_amd import cameras
+    from dgs_amd.raster import render_views_autograd
+    dev = torch.device("cuda:0")
+    be = default_backend()
+    sc = synth.gaussian_scene(a.res, regime=a.regime, seed=0, activated=False)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
+    leaves = [t(sc[k])[None].requires_grad_(True) for k in ("xyz", "shs", "scales", "rotations", "opacities")]
+    c2w = t(cameras.ring_cameras(a.views, phase_deg=10))[None]
+    k = t(cameras.default_fxfycxcy(a.res)).expand(1, a.views, 4).contiguous()
+    w = torch.randn(1, a.views, 3, a.res, a.res, device=dev) / (3 * a.res * a.res)
+
+    def step():
+        for x in leaves:
+            x.grad = None
+        img = render_views_autograd(be, *leaves, a.res, a.res, c2w, k)
+        img.backward(w)
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    print(f"  forward+backward (batched autograd entry): {ms:.3f} ms/call -> {a.views / ms * 1e3:.0f} views/s")
+
+
 if __name__ == "__main__":
     main()
+    import argparse as _ap
+    _p = _ap.ArgumentParser(); _p.add_argument("--res", type=int, default=256); _p.add_argument("--views", type=int, default=4)
+    _p.add_argument("--regime", default="trained"); _p.add_argument("--iters", type=int, default=20)
+    bench_backward(_p.parse_args())
