@@ -41,8 +41,11 @@ typedef enum DgsGemmEpilogue {
     DGS_EPI_GELU_BF16 = 1,     /* out_bf16[m,n] = gelu_tanh(acc + bias[n])                            */
     DGS_EPI_GATE_RESIDUAL = 2, /* out_f32[m,n] += gate[m / rows_per_batch, n] * (acc + bias[n])       */
     DGS_EPI_F32 = 3,           /* out_f32[m,n]  = acc + bias[n]                                       */
-    DGS_EPI_QKV = 4            /* n < 2N/3: out_bf16[m,n] (ldo = 2N/3);  n >= 2N/3: V^T: vt[(b*N/3 + n-2N/3)*lpad + t],
+    DGS_EPI_QKV = 4,           /* n < 2N/3: out_bf16[m,n] (ldo = 2N/3);  n >= 2N/3: V^T: vt[(b*N/3 + n-2N/3)*lpad + t],
                                   b = m / lpad, t = m % lpad  (rows_per_batch = lpad)                 */
+    DGS_EPI_DGELU_BF16 = 5     /* out_bf16[m,n] = (acc + bias[n]) * gelu_tanh'(aux_bf16[m,n])   (MLP backward) */
+    /* BF16 / GELU_BF16 / DGELU_BF16 additionally write a transposed bf16 copy [batch, N, rows_per_batch] when `vt` is set;
+     * GELU_BF16 / GATE_RESIDUAL additionally write the pre-activation / pre-gate value to `aux` (bf16 [M, ldo]) when set. */
 } DgsGemmEpilogue;
 
 typedef struct DgsDitGemmArgs {
@@ -59,6 +62,12 @@ typedef struct DgsDitGemmArgs {
     int32_t gate_stride;
     int32_t rows_per_batch;
     uint16_t* vt;              /* DGS_EPI_QKV: V^T bf16 [batch, N/3, rows_per_batch]                   */
+    const float* resid;        /* DGS_EPI_GATE_RESIDUAL: residual input [M, ldo] f32; NULL -> `out` (in place)             */
+    void* aux;                 /* bf16 [M, ldo]: see DgsGemmEpilogue                                                  */
+    int32_t k_per_batch;       /* 0 -> K.  Otherwise the reduction runs over K / k_per_batch samples whose operand rows
+                                  are a_batch_stride / w_batch_stride elements apart (weight gradients: reduction over the
+                                  tokens of [batch, features, lpad] transposed activations)                          */
+    int64_t a_batch_stride, w_batch_stride;
     int32_t valid_rows;        /* 0 or rows_per_batch: every row is computed.  Otherwise rows [valid_rows, rows_per_batch)
                                   of every sample are padding: 32-row blocks made only of padding are neither computed
                                   nor stored (their output rows keep their previous contents).                       */
@@ -70,7 +79,25 @@ typedef struct DgsDitAttentionArgs {
     const uint16_t* vt;        /* bf16 [B, heads*64, lpad]                                            */
     uint16_t* out;             /* bf16 [B*lpad, heads*64]                                             */
     float scale;               /* 1/sqrt(64)                                                          */
+    /* optional generalisations (training keeps q|k|v in ONE [B*lpad, 3W] tensor and its transposed copy):         */
+    int32_t ld_qk;             /* row stride of `qk` in elements; 0 -> 2*heads*64                                  */
+    int32_t k_offset;          /* elements from a row's q features to its k features; 0 -> heads*64                */
+    int64_t vt_batch_stride;   /* elements between samples of `vt`; 0 -> heads*64*lpad                             */
+    float* lse2;               /* optional out [B, heads, lpad]: log2-domain log-sum-exp per query (for backward)  */
 } DgsDitAttentionArgs;
+
+typedef struct DgsDitAttentionBackwardArgs {
+    int32_t B, heads, L, lpad;
+    const uint16_t* qkv;       /* bf16 [B*lpad, 3W] row-major: q | k | v                                           */
+    const uint16_t* qkvT;      /* bf16 [B, 3W, lpad] token-contiguous copy                                         */
+    const uint16_t* o;         /* bf16 [B*lpad, W] attention output of the forward                                 */
+    const uint16_t* dO;        /* bf16 [B*lpad, W] its gradient                                                    */
+    const uint16_t* dOT;       /* bf16 [B, W, lpad] token-contiguous copy of dO                                    */
+    const float* lse2;         /* [B, heads, lpad] from the forward                                                */
+    float* D;                  /* [B, heads, lpad] scratch: rowsum(dO o O)                                         */
+    uint16_t* dqkv;            /* out bf16 [B*lpad, 3W]: dq | dk | dv                                              */
+    float scale;
+} DgsDitAttentionBackwardArgs;
 
 typedef struct DgsDitLayerNormArgs {
     int32_t rows, width;       /* width == 1024 (one wave per row, 16 elements per lane) or any multiple of 64 <= 2048 */
@@ -148,6 +175,7 @@ typedef struct DgsDitForwardArgs {
 
 int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream);
 int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream);
+int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, dgs_stream_t stream);
 int dgs_dit_layernorm(const DgsDitLayerNormArgs* a, dgs_stream_t stream);
 int dgs_dit_rowlinear(const DgsDitRowLinearArgs* a, dgs_stream_t stream);
 

@@ -30,7 +30,9 @@ constexpr int KV_TILE_BYTES = KB * 64 * 2;   // 8 KiB
 constexpr float RESCALE_THR = 6.0f;          // deferred-max threshold in exp2 units: P <= 64
 
 struct AttnParams {
-    int B, heads, L, lpad, ld_qk, nqb, extra_unit;
+    int B, heads, L, lpad, ld_qk, k_offset, nqb, extra_unit;
+    long long vt_batch_stride;
+    float* lse2;
     const bf16_t* qk;
     const bf16_t* vt;
     bf16_t* out;
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(576) void attention_fwd_kernel(AttnParams p) {
     }
     const size_t row0 = (size_t)b * p.lpad;
     const bf16_t* Qg = p.qk + row0 * p.ld_qk + head * 64;
-    const bf16_t* Kg = Qg + p.heads * 64;
-    const bf16_t* Vg = p.vt + ((size_t)b * p.heads + head) * 64 * p.lpad;
+    const bf16_t* Kg = Qg + p.k_offset;
+    const bf16_t* Vg = p.vt + (size_t)b * p.vt_batch_stride + (size_t)head * 64 * p.lpad;
 
     // Q fragments (B operand): query = lane & 31, d-chunk = 2 ks + half.  Rows >= lpad do not exist: clamp (never stored).
     const int q = unit * 32 + l31;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(576) void attention_fwd_kernel(AttnParams p) {
     if (!wave_live || q >= p.lpad) return;
     const float l_tot = xor32_sum(l_run);
     const float inv = 1.0f / l_tot;
+    if (p.lse2 && half == 0) p.lse2[((size_t)b * p.heads + head) * p.lpad + q] = m_run * p.scale_log2e + log2f(l_tot);
     bf16_t* orow = p.out + (row0 + q) * (size_t)(p.heads * 64) + head * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -277,7 +280,11 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     if (!a || a->B <= 0 || a->heads <= 0 || a->L <= 0 || a->lpad < a->L || a->lpad % 128 || !a->qk || !a->vt || !a->out)
         return DGS_ERR_INVALID_ARGUMENT;
     AttnParams p;
-    p.B = a->B; p.heads = a->heads; p.L = a->L; p.lpad = a->lpad; p.ld_qk = 2 * a->heads * 64;
+    p.B = a->B; p.heads = a->heads; p.L = a->L; p.lpad = a->lpad;
+    p.ld_qk = a->ld_qk > 0 ? a->ld_qk : 2 * a->heads * 64;
+    p.k_offset = a->k_offset > 0 ? a->k_offset : a->heads * 64;
+    p.vt_batch_stride = a->vt_batch_stride > 0 ? a->vt_batch_stride : (long long)a->heads * 64 * a->lpad;
+    p.lse2 = a->lse2;
     const int units = (a->L + 31) / 32;        // 32-query wave units
     p.extra_unit = (units % NW == 1 && units > 1) ? 1 : 0;
     p.nqb = p.extra_unit ? units / NW : (units + NW - 1) / NW;

@@ -1,0 +1,325 @@
+// dit_backward_elementwise.hip -- the HBM-bound kernels of the DiT backward pass (gfx950, wave64).
+//
+// The reference gets these from torch autograd (LayerNorm / modulate / gated residual / Linear bias / SiLU-Linear
+// backward nodes of DiTBlock, utils_transformer.py:271-290, and of the heads, denoiser.py:122-164); here each is one pass
+// over its operands:
+//   transpose_kernel            bf16 [B*lpad, F] -> [B, F, lpad]: token-contiguous operands for the weight-gradient GEMMs
+//   gate_mul_kernel             dy = gate * dx (bf16, row-major + transposed)  and  dgate += sum_t dx * y
+//   layernorm_backward_kernel   dx += LN'(dh (1+scale) w);  dshift += sum_t dh;  dscale += sum_t dh * n w;  dw += sum dh (1+scale) n
+//   colsum_kernel               bias gradients  db[n] = sum_m dY[m, n]
+//   rowlinear_backward_kernel   Linear on <= 16 rows (adaLN, TimestepEmbedder, upsampler): dW (outer products), db, dx
+//   gaussians_backward_kernel   to_gs + hard pixel alignment (denoiser.py:103-120,370-413) -> d(decoder output), d(upsampler output)
+// Column sums over tokens are accumulated per workgroup in registers and flushed with one fp32 atomic per column per
+// workgroup (summation order across workgroups is not fixed, like the reference's atomics-based reductions in torch).
+#include "dit_kernels.h"
+
+namespace dgs {
+
+// ------------------------------------------------------------------------------------------------
+// bf16 [B*rows, F] (row stride ld) -> [B, F, rows].  64 x 64 tiles through LDS; 256 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, int ld, bf16_t* out, int rows, int F) {
+    __shared__ bf16_t tile[64][66];
+    const int b = blockIdx.z, t0 = blockIdx.y * 64, f0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const bf16_t* src = in + ((size_t)b * rows + t0) * ld + f0;
+#pragma unroll
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = src[(size_t)r * ld + tx];
+    __syncthreads();
+    bf16_t* dst = out + ((size_t)b * F + f0) * rows + t0;
+#pragma unroll
+    for (int r = ty; r < 64; r += 4) dst[(size_t)r * rows + tx] = tile[tx][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// dy[m, n] = gate[b, n] * dx[m, n]  (bf16 row-major + transposed [B, W, rows]);  dgate[b, n] += sum_t dx[m, n] * y[m, n].
+// One workgroup = 64 tokens x 64 features of one sample.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_mul_kernel(const float* dx, const bf16_t* y, const float* gate, int gate_stride,
+                                                      bf16_t* dy, bf16_t* dyT, float* dgate, int rows, int W) {
+    __shared__ bf16_t tile[64][66];
+    const int b = blockIdx.z, t0 = blockIdx.y * 64, f0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t base = ((size_t)b * rows + t0) * W + f0;
+    const float gt = gate[(size_t)b * gate_stride + f0 + tx];
+    float acc = 0.f;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const size_t o = base + (size_t)r * W + tx;
+        const float d = dx[o];
+        const bf16_t v = (bf16_t)f2bf_fast(gt * d);
+        dy[o] = v;
+        tile[r][tx] = v;
+        acc += d * bf2f(y[o]);
+    }
+    atomicAdd(&dgate[(size_t)b * gate_stride + f0 + tx], acc);
+    __syncthreads();
+    bf16_t* dst = dyT + ((size_t)b * W + f0) * rows + t0;
+#pragma unroll
+    for (int r = ty; r < 64; r += 4) dst[(size_t)r * rows + tx] = tile[tx][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm(+weight)+modulate backward.  h = LN(x) * w * (1 + scale) + shift.  One wave per row; a workgroup of 4 waves
+// walks `rows_per_block` consecutive rows of ONE sample so the per-column sums stay in registers until the end.
+// ------------------------------------------------------------------------------------------------
+
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_backward_kernel(LnBwdParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * p.rows_per_block;
+    const int b = row0 / p.rows_per_batch;
+    float4 a_shift[VPL], a_scale[VPL], a_w[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) a_shift[i] = a_scale[i] = a_w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv_w = 1.0f / (float)p.width;
+    for (int r = wave; r < p.rows_per_block; r += 4) {
+        const int row = row0 + r;
+        if (row >= p.rows) break;
+        const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)row * p.width);
+        float4 n[VPL], dn[VPL];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { n[i] = xr[i * 64 + lane]; sum += (n[i].x + n[i].y) + (n[i].z + n[i].w); }
+        const float mean = wave_sum(sum) * inv_w;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            n[i].x -= mean; n[i].y -= mean; n[i].z -= mean; n[i].w -= mean;
+            sq += (n[i].x * n[i].x + n[i].y * n[i].y) + (n[i].z * n[i].z + n[i].w * n[i].w);
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * inv_w + p.eps);
+        float s1 = 0.f, s2 = 0.f;     // sum(dn), sum(dn * n)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c4 = i * 64 + lane;
+            n[i].x *= rstd; n[i].y *= rstd; n[i].z *= rstd; n[i].w *= rstd;
+            float4 g;
+            if (p.dh_f32) g = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dh) + (size_t)row * p.width)[c4];
+            else {
+                const uint2 u = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.dh) + (size_t)row * p.width)[c4];
+                g = make_float4(bf2f(u.x & 0xffffu), bf2f(u.x >> 16), bf2f(u.y & 0xffffu), bf2f(u.y >> 16));
+            }
+            float4 w = make_float4(1.f, 1.f, 1.f, 1.f), m1 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.weight) w = reinterpret_cast<const float4*>(p.weight)[c4];
+            if (p.scale) {
+                const float4 sc = reinterpret_cast<const float4*>(p.scale + (size_t)b * p.mod_stride)[c4];
+                m1 = make_float4(1.f + sc.x, 1.f + sc.y, 1.f + sc.z, 1.f + sc.w);
+            }
+            a_shift[i].x += g.x; a_shift[i].y += g.y; a_shift[i].z += g.z; a_shift[i].w += g.w;
+            a_scale[i].x += g.x * n[i].x * w.x; a_scale[i].y += g.y * n[i].y * w.y; a_scale[i].z += g.z * n[i].z * w.z; a_scale[i].w += g.w * n[i].w * w.w;
+            a_w[i].x += g.x * m1.x * n[i].x; a_w[i].y += g.y * m1.y * n[i].y; a_w[i].z += g.z * m1.z * n[i].z; a_w[i].w += g.w * m1.w * n[i].w;
+            dn[i] = make_float4(g.x * m1.x * w.x, g.y * m1.y * w.y, g.z * m1.z * w.z, g.w * m1.w * w.w);
+            s1 += (dn[i].x + dn[i].y) + (dn[i].z + dn[i].w);
+            s2 += (dn[i].x * n[i].x + dn[i].y * n[i].y) + (dn[i].z * n[i].z + dn[i].w * n[i].w);
+        }
+        const float m1s = wave_sum(s1) * inv_w, m2s = wave_sum(s2) * inv_w;
+        float4* out = reinterpret_cast<float4*>(p.dx_out + (size_t)row * p.width);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c4 = i * 64 + lane;
+            float4 d = make_float4(rstd * (dn[i].x - m1s - n[i].x * m2s), rstd * (dn[i].y - m1s - n[i].y * m2s),
+                                   rstd * (dn[i].z - m1s - n[i].z * m2s), rstd * (dn[i].w - m1s - n[i].w * m2s));
+            if (p.dx_in) {
+                const float4 r0 = reinterpret_cast<const float4*>(p.dx_in + (size_t)row * p.width)[c4];
+                d.x += r0.x; d.y += r0.y; d.z += r0.z; d.w += r0.w;
+            }
+            out[c4] = d;
+        }
+    }
+    // flush the column sums of this workgroup (each wave owns all columns of its rows)
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (p.dshift) {
+            float* d = p.dshift + (size_t)b * p.mod_stride + c;
+            atomicAdd(d, a_shift[i].x); atomicAdd(d + 1, a_shift[i].y); atomicAdd(d + 2, a_shift[i].z); atomicAdd(d + 3, a_shift[i].w);
+        }
+        if (p.dscale) {
+            float* d = p.dscale + (size_t)b * p.mod_stride + c;
+            atomicAdd(d, a_scale[i].x); atomicAdd(d + 1, a_scale[i].y); atomicAdd(d + 2, a_scale[i].z); atomicAdd(d + 3, a_scale[i].w);
+        }
+        if (p.dweight) {
+            float* d = p.dweight + c;
+            atomicAdd(d, a_w[i].x); atomicAdd(d + 1, a_w[i].y); atomicAdd(d + 2, a_w[i].z); atomicAdd(d + 3, a_w[i].w);
+        }
+    }
+}
+
+// db[n] += sum_m dY[m, n]   (bf16 [M, ld]); workgroup = 256 rows x 64 columns
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, int ld, int M, float* db) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx, m0 = blockIdx.y * 256;
+    float acc = 0.f;
+    for (int r = ty; r < 256 && m0 + r < M; r += 4) acc += bf2f(dy[(size_t)(m0 + r) * ld + n]);
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0) atomicAdd(&db[n], (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of  y[m, n] = sum_k act(x[m, k]) W[n, k] + b[n]  on M <= 16 rows (weight-streaming, one wave per output row n):
+//   dW[n, :] = sum_m dy[m, n] act(x[m, :])        (written, not accumulated)
+//   db[n]    = sum_m dy[m, n]
+//   dx[m, k] += act'(x[m, k]) sum_n dy[m, n] W[n, k]      (atomics; dx must be zeroed by the caller)
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float dsilu_f(float v) { const float s = 1.0f / (1.0f + __expf(-v)); return s * (1.0f + v * (1.0f - s)); }
+
+template <int MR>
+__global__ __launch_bounds__(256) void rowlinear_backward_kernel(RowLinBwdParams p, int rows_per_block) {
+    DGS_DYNAMIC_LDS(smem);
+    float* xs = reinterpret_cast<float*>(smem);           // [MR][K] activated input
+    float* dxs = xs + (size_t)MR * p.K;                   // [MR][K] partial dx of this workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < MR * p.K; i += 256) {
+        const int m = i / p.K;
+        float v = (m < p.M) ? p.x[i] : 0.0f;
+        xs[i] = p.silu_in ? silu_f(v) : v;
+        dxs[i] = 0.f;
+    }
+    __syncthreads();
+    const int n0 = blockIdx.x * rows_per_block;
+    for (int n = n0 + wave; n < n0 + rows_per_block && n < p.N; n += 4) {
+        float dyv[MR];
+        float bsum = 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) { dyv[m] = (m < p.M) ? p.dy[(size_t)m * p.N + n] : 0.f; bsum += dyv[m]; }
+        if (p.db && lane == 0) p.db[n] = bsum;
+        const bf16_t* wr = p.W + (size_t)n * p.K;
+        for (int k = lane; k < p.K; k += 64) {
+            float g = 0.f;
+            const float w = bf2f(wr[k]);
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                g += dyv[m] * xs[m * p.K + k];
+                if (p.dx) atomicAdd(&dxs[m * p.K + k], dyv[m] * w);   // LDS atomic: 4 waves share dxs
+            }
+            if (p.dW) p.dW[(size_t)n * p.K + k] = g;
+        }
+    }
+    __syncthreads();
+    if (p.dx)
+        for (int i = threadIdx.x; i < p.M * p.K; i += 256) {
+            float g = dxs[i];
+            if (p.silu_in) g *= dsilu_f(p.x[i]);
+            if (g != 0.f) atomicAdd(&p.dx[i], g);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of gaussians_kernel (to_gs + pixel alignment).  One thread per Gaussian; writes the gradient of the decoder
+// GEMM output as bf16 [B*lpad, ps*ps*C] (row-major; rows of learned tokens / padding stay zero) and of the upsampler
+// output as f32 [B*ng, C].
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void gaussians_backward_kernel(GsBwdParams p) {
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t P = (size_t)p.ng + (size_t)p.V * HW;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)p.B * P) return;
+    const int b = (int)(gid / P);
+    const size_t i = gid % P;
+    float d[14];
+    const float gx = p.dxyz[gid * 3], gy = p.dxyz[gid * 3 + 1], gz = p.dxyz[gid * 3 + 2];
+    d[3] = p.dfeatures[gid * 3]; d[4] = p.dfeatures[gid * 3 + 1]; d[5] = p.dfeatures[gid * 3 + 2];
+    d[9] = p.drotation[gid * 4]; d[10] = p.drotation[gid * 4 + 1]; d[11] = p.drotation[gid * 4 + 2]; d[12] = p.drotation[gid * 4 + 3];
+    d[13] = p.dopacity[gid];
+    if (i < (size_t)p.ng) {
+        const float* src = p.up + ((size_t)b * p.ng + i) * p.C;
+        d[0] = gx; d[1] = gy; d[2] = gz;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[6 + k] = (src[6 + k] - 2.3f < -1.2f) ? p.dscaling[gid * 3 + k] : 0.f;   // clamp(max=-1.2)
+        float* dst = p.dup + ((size_t)b * p.ng + i) * p.C;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) dst[k] = d[k];
+        return;
+    }
+    const size_t j = i - p.ng;
+    const int pp = p.ps * p.ps;
+    const size_t tok = j / pp;
+    const int pi = (int)(j % pp);
+    const size_t off = ((size_t)b * p.lpad + tok) * (size_t)(pp * p.C) + (size_t)pi * p.C;
+    const float* src = p.dec + off;
+    const int np_w = p.W / p.ps, np = (p.H / p.ps) * np_w;
+    const int v = (int)(tok / np), hh = (int)((tok % np) / np_w), ww = (int)(tok % np_w);
+    const int h = hh * p.ps + pi / p.ps, w = ww * p.ps + pi % p.ps;
+    const size_t base = ((size_t)b * p.V + v) * 3 * HW + (size_t)h * p.W + w;
+    const float dx = p.ray_d[base], dy = p.ray_d[base + HW], dz = p.ray_d[base + 2 * HW];
+    const float mean = (src[0] + src[1] + src[2]) / 3.0f;
+    const float sg = 1.0f / (1.0f + __expf(-mean));
+    float ddepth = gx * dx + gy * dy + gz * dz;                     // xyz = ray_o + depth * ray_d
+    float k = sg * (1.0f - sg);
+    if (p.scene) k *= (p.range_far - p.range_near);
+    else if (p.relative_plk) k *= 2.0f * 1.8f;
+    ddepth = ddepth * k / 3.0f;
+    d[0] = d[1] = d[2] = ddepth;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) d[6 + q] = (src[6 + q] - 2.3f < -1.2f) ? p.dscaling[gid * 3 + q] : 0.f;
+    bf16_t* dst = p.ddec + off;
+#pragma unroll
+    for (int q = 0; q < 14; ++q) dst[q] = (bf16_t)f2bf_fast(d[q]);
+}
+
+static int ok() { return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE; }
+
+int launch_transpose(const bf16_t* in, int ld, bf16_t* out, int B, int rows, int F, hipStream_t st) {
+    if (rows % 64 || F % 64) return DGS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(transpose_kernel, dim3(F / 64, rows / 64, B), dim3(256), 0, st, in, ld, out, rows, F);
+    return ok();
+}
+
+int launch_gate_mul(const float* dx, const bf16_t* y, const float* gate, int gate_stride, bf16_t* dy, bf16_t* dyT, float* dgate, int B,
+                    int rows, int W, hipStream_t st) {
+    if (rows % 64 || W % 64) return DGS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(gate_mul_kernel, dim3(W / 64, rows / 64, B), dim3(256), 0, st, dx, y, gate, gate_stride, dy, dyT, dgate, rows, W);
+    return ok();
+}
+
+int launch_layernorm_backward(const LnBwdParams& p0, hipStream_t st) {
+    LnBwdParams p = p0;
+    if (p.rows <= 0 || p.width % 256 || p.width > 2048) return DGS_ERR_INVALID_ARGUMENT;
+    if (p.rows_per_batch <= 0) p.rows_per_batch = p.rows;
+    p.rows_per_block = p.rows_per_batch % 32 == 0 ? 32 : p.rows_per_batch;   // never straddles samples
+    const dim3 grid((p.rows + p.rows_per_block - 1) / p.rows_per_block), block(256);
+    switch (p.width / 256) {
+        case 1: hipLaunchKernelGGL((layernorm_backward_kernel<1>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((layernorm_backward_kernel<2>), grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((layernorm_backward_kernel<4>), grid, block, 0, st, p); break;
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
+    return ok();
+}
+
+int launch_colsum(const bf16_t* dy, int ld, int M, int N, float* db, hipStream_t st) {
+    if (N % 64) return DGS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(colsum_kernel, dim3(N / 64, (M + 255) / 256), dim3(256), 0, st, dy, ld, M, db);
+    return ok();
+}
+
+int launch_rowlinear_backward(const RowLinBwdParams& p, hipStream_t st) {
+    if (p.M <= 0 || p.M > 16 || p.N <= 0 || p.K <= 0) return DGS_ERR_INVALID_ARGUMENT;
+    const int rpb = 64;
+    const dim3 grid((p.N + rpb - 1) / rpb), block(256);
+    const int mr = p.M <= 1 ? 1 : p.M <= 2 ? 2 : p.M <= 4 ? 4 : p.M <= 8 ? 8 : 16;
+    const size_t lds = (size_t)2 * mr * p.K * sizeof(float);
+    if (lds > 65536) return DGS_ERR_INVALID_ARGUMENT;
+    switch (mr) {
+        case 1: hipLaunchKernelGGL((rowlinear_backward_kernel<1>), grid, block, lds, st, p, rpb); break;
+        case 2: hipLaunchKernelGGL((rowlinear_backward_kernel<2>), grid, block, lds, st, p, rpb); break;
+        case 4: hipLaunchKernelGGL((rowlinear_backward_kernel<4>), grid, block, lds, st, p, rpb); break;
+        case 8: hipLaunchKernelGGL((rowlinear_backward_kernel<8>), grid, block, lds, st, p, rpb); break;
+        default: hipLaunchKernelGGL((rowlinear_backward_kernel<16>), grid, block, lds, st, p, rpb); break;
+    }
+    return ok();
+}
+
+int launch_gaussians_backward(const GsBwdParams& p, hipStream_t st) {
+    const size_t n = (size_t)p.B * ((size_t)p.ng + (size_t)p.V * p.H * p.W);
+    hipLaunchKernelGGL(gaussians_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    return ok();
+}
+
+}  // namespace dgs

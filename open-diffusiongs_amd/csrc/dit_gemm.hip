@@ -22,18 +22,29 @@ constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB: A tile of one stage (the W 
 
 struct GemmParams {
     int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles;
+    int k_per_batch;                 // reduction elements per sample (K when the reduction dimension is not batched)
+    long long a_batch_stride, w_batch_stride;   // element stride between samples along the reduction (weight-gradient GEMMs)
     const bf16_t* A;
     const bf16_t* W;
     const float* bias;
     void* out;
     const float* gate;
-    bf16_t* vt;
+    const float* resid;              // GATE_RESIDUAL input stream (== out for the in-place inference form)
+    bf16_t* vt;                      // transposed bf16 copy [batch, N, rows_per_batch] (QKV: V only)
+    void* aux;                       // GELU: u out; GATE_RESIDUAL: y out; DGELU: u in   (bf16 [M, ldo])
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) == x * sigmoid(2u)
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     return x / (1.0f + __expf(-2.0f * u));
+}
+
+// d/dx of gelu_tanh: with s = sigmoid(2u), u = c (x + a x^3):  s + x s (1 - s) 2 c (1 + 3 a x^2)
+__device__ __forceinline__ float dgelu_tanh(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float sg = 1.0f / (1.0f + __expf(-2.0f * u));
+    return sg + x * sg * (1.0f - sg) * (2.0f * 0.7978845608028654f) * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
 // Stage one [ROWS][64] bf16 tile: ROWS/8 wave-instructions of 1 KiB (8 rows each); wave w issues pieces (ROWS/32) w ...
@@ -45,7 +56,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* g, int ld, int row0, in
         const int row = piece * 8 + (lane >> 3);
         const int slot = lane & 7;
         const int chunk = slot ^ ((row >> 1) & 7);
-        const bf16_t* src = g + (size_t)(row0 + row) * ld + k0 + chunk * 8;
+        const bf16_t* src = g + (size_t)(row0 + row) * ld + k0 + chunk * 8;   // k0 already carries the sample offset
         glds16(src, lds_tile + piece * 1024);
     }
 }
@@ -73,6 +84,7 @@ __device__ __forceinline__ void main_loop(const GemmParams& p, char* lds, int m0
                                           f32x16 (&acc)[2][NI]) {
     constexpr int STAGE_BYTES = TILE_BYTES + BN * BK * 2;
     const int nk = p.K / BK;
+    const int spb = p.k_per_batch / BK;                      // K slabs per sample
     stage_tile<BM>(p.A, p.lda, m0, 0, lds, wave, lane);
     stage_tile<BN>(p.W, p.ldw, n0, 0, lds + TILE_BYTES, wave, lane);
     __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the tile
@@ -83,8 +95,9 @@ __device__ __forceinline__ void main_loop(const GemmParams& p, char* lds, int m0
         char* cur = lds + (t & 1) * STAGE_BYTES;
         if (t + 1 < nk) {
             char* nxt = lds + ((t + 1) & 1) * STAGE_BYTES;
-            stage_tile<BM>(p.A, p.lda, m0, (t + 1) * BK, nxt, wave, lane);
-            stage_tile<BN>(p.W, p.ldw, n0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+            const int bb = (t + 1) / spb, kk = ((t + 1) - bb * spb) * BK;
+            stage_tile<BM>(p.A + bb * p.a_batch_stride, p.lda, m0, kk, nxt, wave, lane);
+            stage_tile<BN>(p.W + bb * p.w_batch_stride, p.ldw, n0, kk, nxt + TILE_BYTES, wave, lane);
         }
         if (MI > 0) {
             const char* la = cur + (wm * 64 + frow) * 128;
@@ -130,7 +143,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     else main_loop<BN, NI, 0>(p, lds, m0, n0, wave, lane, wm, wn, acc);
     const int fhalf = lane >> 5;
 
-    // ---- epilogue.  D fragment: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+    // ---- epilogue.  D fragment: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a lane holds, for ONE
+    //      output feature, four groups of four consecutive rows -> row-major stores are 2/4-byte per row, the optional
+    //      transposed copy ([batch, N, rows_per_batch], wanted by the attention and weight-gradient kernels) is one 8-byte
+    //      store per group.
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * (BN / 2) + ni * 32 + (lane & 31);
@@ -139,31 +155,45 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         for (int mi = 0; mi < 2; ++mi) {
             if (!(mi == 0 ? live0 : live1)) continue;
             const int mbase = m0 + wm * 64 + mi * 32 + 4 * fhalf;
-            if (EPI == DGS_EPI_QKV && n >= (p.N / 3) * 2) {
-                // V^T: 4 consecutive tokens of one feature = one 8-byte store
-                const int f = n - (p.N / 3) * 2;
-                const int b = mbase / p.rows_per_batch;      // a 32-row block never straddles samples (lpad % 128 == 0)
-                bf16_t* dst = p.vt + ((size_t)b * (p.N / 3) + f) * p.rows_per_batch + (mbase - b * p.rows_per_batch);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 v;
-                    v.x = pack_bf2(acc[mi][ni][4 * g] + bias, acc[mi][ni][4 * g + 1] + bias);
-                    v.y = pack_bf2(acc[mi][ni][4 * g + 2] + bias, acc[mi][ni][4 * g + 3] + bias);
-                    *reinterpret_cast<uint2*>(dst + 8 * g) = v;
-                }
-                continue;
+            const int b = mbase / p.rows_per_batch;          // a 32-row block never straddles samples (rows_per_batch % 128 == 0)
+            const bool qkv_v = EPI == DGS_EPI_QKV && n >= (p.N / 3) * 2;
+            bf16_t* tdst = nullptr;                           // transposed destination of this lane's feature
+            if (EPI == DGS_EPI_QKV) {
+                if (qkv_v) tdst = p.vt + ((size_t)b * (p.N / 3) + (n - (p.N / 3) * 2)) * p.rows_per_batch + (mbase - b * p.rows_per_batch);
+            } else if ((EPI == DGS_EPI_BF16 || EPI == DGS_EPI_GELU_BF16 || EPI == DGS_EPI_DGELU_BF16) && p.vt) {
+                tdst = p.vt + ((size_t)b * p.N + n) * p.rows_per_batch + (mbase - b * p.rows_per_batch);
             }
             float gate = 0.0f;
-            if (EPI == DGS_EPI_GATE_RESIDUAL) gate = p.gate[(size_t)(mbase / p.rows_per_batch) * p.gate_stride + n];
+            if (EPI == DGS_EPI_GATE_RESIDUAL) gate = p.gate[(size_t)b * p.gate_stride + n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                const float v = acc[mi][ni][r] + bias;
-                const size_t o = (size_t)m * p.ldo + n;
-                if (EPI == DGS_EPI_BF16 || EPI == DGS_EPI_QKV) reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(v);
-                else if (EPI == DGS_EPI_GELU_BF16) reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(gelu_tanh(v));
-                else if (EPI == DGS_EPI_GATE_RESIDUAL) { float* x = reinterpret_cast<float*>(p.out) + o; *x = *x + gate * v; }
-                else reinterpret_cast<float*>(p.out)[o] = v;
+            for (int g = 0; g < 4; ++g) {
+                float o4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mbase + q + 8 * g;
+                    const float v = acc[mi][ni][4 * g + q] + bias;
+                    const size_t o = (size_t)m * p.ldo + n;
+                    if (EPI == DGS_EPI_BF16) {
+                        o4[q] = v;
+                        reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(v);
+                    } else if (EPI == DGS_EPI_QKV) {
+                        o4[q] = v;
+                        if (!qkv_v) reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(v);
+                    } else if (EPI == DGS_EPI_GELU_BF16) {
+                        o4[q] = gelu_tanh(v);
+                        reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(o4[q]);
+                        if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = (bf16_t)f2bf_fast(v);
+                    } else if (EPI == DGS_EPI_DGELU_BF16) {
+                        o4[q] = v * dgelu_tanh(bf2f(reinterpret_cast<const bf16_t*>(p.aux)[o]));
+                        reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(o4[q]);
+                    } else if (EPI == DGS_EPI_GATE_RESIDUAL) {
+                        reinterpret_cast<float*>(p.out)[o] = p.resid[o] + gate * v;
+                        if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = (bf16_t)f2bf_fast(v);
+                    } else {
+                        reinterpret_cast<float*>(p.out)[o] = v;
+                    }
+                }
+                if (tdst) *reinterpret_cast<uint2*>(tdst + 8 * g) = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
             }
         }
     }
@@ -184,16 +214,21 @@ static void launch_gemm(const GemmParams& p0, int bn, hipStream_t st) {
 
 extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M % BM || a->N % 128 || a->K % BK) return DGS_ERR_INVALID_ARGUMENT;
-    if (!a->A || !a->W || !a->out || a->lda < a->K || a->ldw < a->K || (a->lda & 7) || (a->ldw & 7)) return DGS_ERR_INVALID_ARGUMENT;
+    if (!a->A || !a->W || !a->out || (a->lda & 7) || (a->ldw & 7)) return DGS_ERR_INVALID_ARGUMENT;
+    const int kpb = a->k_per_batch > 0 ? a->k_per_batch : a->K;
+    if (kpb % BK || a->K % kpb || a->lda < kpb || a->ldw < kpb) return DGS_ERR_INVALID_ARGUMENT;
     if (a->epilogue == DGS_EPI_GATE_RESIDUAL && (!a->gate || a->rows_per_batch <= 0)) return DGS_ERR_INVALID_ARGUMENT;
-    if (a->epilogue == DGS_EPI_QKV && (!a->vt || a->rows_per_batch <= 0 || a->rows_per_batch % BM || a->N % 3 || (a->N / 3) % 128))
-        return DGS_ERR_INVALID_ARGUMENT;
+    if (a->epilogue == DGS_EPI_QKV && (!a->vt || a->N % 3 || (a->N / 3) % 128)) return DGS_ERR_INVALID_ARGUMENT;
+    if (a->epilogue == DGS_EPI_DGELU_BF16 && !a->aux) return DGS_ERR_INVALID_ARGUMENT;
+    if ((a->vt || a->epilogue == DGS_EPI_QKV) && a->rows_per_batch <= 0) return DGS_ERR_INVALID_ARGUMENT;
     if (a->rows_per_batch > 0 && (a->rows_per_batch % BM || a->M % a->rows_per_batch)) return DGS_ERR_INVALID_ARGUMENT;
     GemmParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo;
     p.gate_stride = a->gate_stride; p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
     p.valid_rows = (a->valid_rows > 0 && a->valid_rows < p.rows_per_batch) ? a->valid_rows : p.rows_per_batch;
-    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt;
+    p.k_per_batch = kpb; p.a_batch_stride = a->a_batch_stride; p.w_batch_stride = a->w_batch_stride;
+    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
+    p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each
     const int bn = ((a->M / BM) * (a->N / 128) < 512 && a->epilogue != DGS_EPI_QKV) ? 64 : 128;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -203,6 +238,7 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
         case DGS_EPI_GATE_RESIDUAL: launch_gemm<DGS_EPI_GATE_RESIDUAL>(p, bn, st); break;
         case DGS_EPI_F32: launch_gemm<DGS_EPI_F32>(p, bn, st); break;
         case DGS_EPI_QKV: launch_gemm<DGS_EPI_QKV>(p, 128, st); break;
+        case DGS_EPI_DGELU_BF16: launch_gemm<DGS_EPI_DGELU_BF16>(p, bn, st); break;
         default: return DGS_ERR_INVALID_ARGUMENT;
     }
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;

@@ -41,4 +41,44 @@ int launch_pos_embed(const float* pe, float* x, int B, int lpad, int L, int ng, 
 int launch_gather_tokens(const float* x, float* out, int B, int lpad, int L, int ng, int width, hipStream_t st);
 int launch_gaussians(const GsParams& p, hipStream_t st);
 
+// ---- backward (dit_backward_elementwise.hip) ----
+struct LnBwdParams {
+    int rows, width, mod_stride, rows_per_batch, rows_per_block, dh_f32;
+    float eps;
+    const float* x;
+    const void* dh;          // bf16 (or f32) [rows, width]
+    const float *weight, *scale;
+    const float* dx_in;      // optional residual-path gradient added to the result
+    float* dx_out;
+    float *dshift, *dscale;  // [batch, mod_stride] accumulated (atomics), may be NULL
+    float* dweight;          // [width] accumulated, may be NULL
+};
+
+struct RowLinBwdParams {
+    int M, N, K, silu_in;
+    const float* x;       // [M, K] pre-activation input
+    const bf16_t* W;      // [N, K]
+    const float* dy;      // [M, N]
+    float* dW;            // [N, K] or NULL
+    float* db;            // [N] or NULL
+    float* dx;            // [M, K] or NULL
+};
+
+struct GsBwdParams {
+    int B, V, H, W, ps, lpad, ng, C, scene, relative_plk;
+    float range_near, range_far;
+    const float *dec, *up, *ray_d;                                   // forward values needed for the activation masks
+    const float *dxyz, *dfeatures, *dscaling, *drotation, *dopacity; // incoming gradients [B, P, ...]
+    bf16_t* ddec;
+    float* dup;
+};
+
+int launch_transpose(const bf16_t* in, int ld, bf16_t* out, int B, int rows, int F, hipStream_t st);
+int launch_gate_mul(const float* dx, const bf16_t* y, const float* gate, int gate_stride, bf16_t* dy, bf16_t* dyT, float* dgate, int B,
+                    int rows, int W, hipStream_t st);
+int launch_layernorm_backward(const LnBwdParams& p, hipStream_t st);
+int launch_colsum(const bf16_t* dy, int ld, int M, int N, float* db, hipStream_t st);
+int launch_rowlinear_backward(const RowLinBwdParams& p, hipStream_t st);
+int launch_gaussians_backward(const GsBwdParams& p, hipStream_t st);
+
 }  // namespace dgs

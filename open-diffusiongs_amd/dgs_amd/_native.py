@@ -116,7 +116,7 @@ def status_string(L, code):
 # ---------------------------------------------------------------------------------------------------
 # include/dgs_dit.h
 # ---------------------------------------------------------------------------------------------------
-EPI_BF16, EPI_GELU_BF16, EPI_GATE_RESIDUAL, EPI_F32, EPI_QKV = range(5)
+EPI_BF16, EPI_GELU_BF16, EPI_GATE_RESIDUAL, EPI_F32, EPI_QKV, EPI_DGELU_BF16 = range(6)
 
 
 class DgsDitGemmArgs(ctypes.Structure):
@@ -124,12 +124,22 @@ class DgsDitGemmArgs(ctypes.Structure):
                 ("A", ctypes.c_void_p), ("lda", ctypes.c_int32), ("W", ctypes.c_void_p), ("ldw", ctypes.c_int32),
                 ("bias", ctypes.c_void_p), ("epilogue", ctypes.c_int32), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int32),
                 ("gate", ctypes.c_void_p), ("gate_stride", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32),
-                ("vt", ctypes.c_void_p), ("valid_rows", ctypes.c_int32)]
+                ("vt", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("k_per_batch", ctypes.c_int32),
+                ("a_batch_stride", ctypes.c_int64), ("w_batch_stride", ctypes.c_int64), ("valid_rows", ctypes.c_int32)]
 
 
 class DgsDitAttentionArgs(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("heads", ctypes.c_int32), ("L", ctypes.c_int32), ("lpad", ctypes.c_int32),
-                ("qk", ctypes.c_void_p), ("vt", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_float)]
+                ("qk", ctypes.c_void_p), ("vt", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_float),
+                ("ld_qk", ctypes.c_int32), ("k_offset", ctypes.c_int32), ("vt_batch_stride", ctypes.c_int64),
+                ("lse2", ctypes.c_void_p)]
+
+
+class DgsDitAttentionBackwardArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("heads", ctypes.c_int32), ("L", ctypes.c_int32), ("lpad", ctypes.c_int32),
+                ("qkv", ctypes.c_void_p), ("qkvT", ctypes.c_void_p), ("o", ctypes.c_void_p), ("dO", ctypes.c_void_p),
+                ("dOT", ctypes.c_void_p), ("lse2", ctypes.c_void_p), ("D", ctypes.c_void_p), ("dqkv", ctypes.c_void_p),
+                ("scale", ctypes.c_float)]
 
 
 class DgsDitLayerNormArgs(ctypes.Structure):
@@ -174,12 +184,13 @@ class DgsDitForwardArgs(ctypes.Structure):
 
 
 # every symbol include/dgs_dit.h declares (checked by tests/test_abi.py)
-DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
+DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward"]
 
 
 def _declare_dit(L):
     for name, argt in (("dgs_dit_gemm", DgsDitGemmArgs), ("dgs_dit_attention", DgsDitAttentionArgs),
+                       ("dgs_dit_attention_backward", DgsDitAttentionBackwardArgs),
                        ("dgs_dit_layernorm", DgsDitLayerNormArgs), ("dgs_dit_rowlinear", DgsDitRowLinearArgs)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int

@@ -34,10 +34,14 @@ class DitOps:
         if rc != 0:
             raise RuntimeError(f"dgs dit: {_native.status_string(self.lib, rc)} (status {rc})")
 
-    def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None, valid_rows=0):
+    def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None, valid_rows=0,
+             resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None):
         """A bf16 [M,K], W bf16 [N,K] -> per epilogue (see dgs_dit.h).  `out` is required for GATE_RESIDUAL (in-place)."""
-        M, K = A.shape
-        N = W.shape[0]
+        if shape is not None:          # batched-reduction form (weight gradients): operands are [batch, rows, tokens]
+            M, N, K = shape
+        else:
+            M, K = A.shape
+            N = W.shape[0]
         dev = A.device
         if epilogue == _native.EPI_QKV:
             ldo = 2 * N // 3
@@ -45,7 +49,7 @@ class DitOps:
                 out = torch.empty((M, ldo), dtype=torch.bfloat16, device=dev)
             if vt is None:
                 vt = torch.empty((M // rows_per_batch, N // 3, rows_per_batch), dtype=torch.bfloat16, device=dev)
-        elif epilogue in (_native.EPI_BF16, _native.EPI_GELU_BF16):
+        elif epilogue in (_native.EPI_BF16, _native.EPI_GELU_BF16, _native.EPI_DGELU_BF16):
             ldo = N
             if out is None:
                 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
@@ -55,22 +59,42 @@ class DitOps:
                 out = torch.empty((M, N), dtype=torch.float32, device=dev)
         a = DgsDitGemmArgs()
         a.M, a.N, a.K = M, N, K
-        a.A, a.lda, a.W, a.ldw = _p(A), A.stride(0), _p(W), W.stride(0)
+        a.A, a.lda, a.W, a.ldw = _p(A), (lda if lda is not None else A.stride(0)), _p(W), (ldw if ldw is not None else W.stride(0))
+        a.resid, a.aux = _p(resid), _p(aux)
+        a.k_per_batch, a.a_batch_stride, a.w_batch_stride = k_per_batch, a_batch_stride, w_batch_stride
         a.bias, a.epilogue, a.out, a.ldo = _p(bias), epilogue, _p(out), ldo
         a.gate, a.gate_stride, a.rows_per_batch, a.vt = _p(gate), (gate.stride(0) if gate is not None else 0), rows_per_batch, _p(vt)
         a.valid_rows = valid_rows
         self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))
         return (out, vt) if epilogue == _native.EPI_QKV else out
 
-    def attention(self, qk, vt, L, heads):
-        """qk bf16 [B*lpad, 2*heads*64], vt bf16 [B, heads*64, lpad] -> bf16 [B*lpad, heads*64]."""
+    def attention(self, qk, vt, L, heads, qkv_layout=False, lse2=None):
+        """qk bf16 [B*lpad, 2*heads*64], vt bf16 [B, heads*64, lpad] -> bf16 [B*lpad, heads*64].
+        qkv_layout: `qk` is the training tensor [B*lpad, 3W] and `vt` its transposed copy [B, 3W, lpad]."""
         B, _, lpad = vt.shape
-        out = torch.zeros((B * lpad, heads * 64), dtype=torch.bfloat16, device=qk.device)
+        W = heads * 64
+        out = torch.zeros((B * lpad, W), dtype=torch.bfloat16, device=qk.device)
         a = DgsDitAttentionArgs()
         a.B, a.heads, a.L, a.lpad = B, heads, L, lpad
         a.qk, a.vt, a.out, a.scale = _p(qk), _p(vt), _p(out), 0.125
+        if qkv_layout:
+            a.ld_qk, a.k_offset, a.vt_batch_stride = 3 * W, W, 3 * W * lpad
+            a.vt = ctypes.c_void_p(vt.data_ptr() + 2 * W * lpad * 2)
+        a.lse2 = _p(lse2)
         self._check(self.lib.dgs_dit_attention(ctypes.byref(a), _stream(qk.device)))
         return out
+
+    def attention_backward(self, qkv, qkvT, o, dO, dOT, lse2, L, heads):
+        """-> dqkv bf16 [B*lpad, 3W] (dq | dk | dv)."""
+        B, _, lpad = qkvT.shape
+        dqkv = torch.zeros_like(qkv)
+        D = torch.zeros_like(lse2)
+        a = _native.DgsDitAttentionBackwardArgs()
+        a.B, a.heads, a.L, a.lpad = B, heads, L, lpad
+        a.qkv, a.qkvT, a.o, a.dO, a.dOT, a.lse2, a.D, a.dqkv = (_p(t) for t in (qkv, qkvT, o, dO, dOT, lse2, D, dqkv))
+        a.scale = 0.125
+        self._check(self.lib.dgs_dit_attention_backward(ctypes.byref(a), _stream(qkv.device)))
+        return dqkv
 
     def layernorm(self, x, weight=None, shift=None, scale=None, rows_per_batch=0, eps=1e-6, out_f32=False):
         rows, width = x.shape

@@ -122,3 +122,85 @@ def test_rowlinear(ops, M, K):
     assert torch.allclose(out, F.linear(F.silu(x), W.float(), b), atol=1e-4, rtol=1e-4)
     out = ops.rowlinear(x, W, None, silu_output=True)
     assert torch.allclose(out, F.silu(F.linear(x, W.float())), atol=1e-4, rtol=1e-4)
+
+
+def test_gemm_training_epilogues(ops):
+    g = torch.Generator().manual_seed(11)
+    rows, B, N, K = 128, 2, 128, 64
+    M = B * rows
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.2)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    tr = lambda t: t.reshape(B, rows, N).transpose(1, 2)
+    # bf16 + transposed copy
+    vt = torch.zeros(B, N, rows, dtype=torch.bfloat16)
+    out = ops.gemm(A, W, bias, _native.EPI_BF16, rows_per_batch=rows, vt=vt)
+    assert torch.allclose(out.float(), ref, atol=3e-2, rtol=1e-2) and torch.equal(vt, tr(out))
+    # GELU: pre-activation saved, transposed copy of the activation
+    aux = torch.zeros(M, N, dtype=torch.bfloat16)
+    out = ops.gemm(A, W, bias, _native.EPI_GELU_BF16, rows_per_batch=rows, vt=vt, aux=aux)
+    assert torch.allclose(aux.float(), ref, atol=3e-2, rtol=1e-2) and torch.equal(vt, tr(out))
+    # dGELU: out = acc * gelu'(u)
+    u = _bf(torch.randn(M, N, generator=g) * 2)
+    out = ops.gemm(A, W, None, _native.EPI_DGELU_BF16, rows_per_batch=rows, vt=vt, aux=u)
+    uu = u.float().requires_grad_(True)
+    F.gelu(uu, approximate="tanh").sum().backward()
+    assert torch.allclose(out.float(), (ref - bias) * uu.grad, atol=3e-2, rtol=2e-2) and torch.equal(vt, tr(out))
+    # out-of-place gated residual + saved pre-gate value
+    x0 = torch.randn(M, N, generator=g)
+    gate = torch.randn(B, N, generator=g)
+    x1 = torch.zeros(M, N)
+    y = torch.zeros(M, N, dtype=torch.bfloat16)
+    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x1, gate=gate, rows_per_batch=rows, resid=x0, aux=y)
+    assert torch.allclose(x1, x0 + gate.repeat_interleave(rows, 0) * ref, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(y.float(), ref, atol=3e-2, rtol=1e-2)
+
+
+def test_gemm_weight_gradient_batched_reduction(ops):
+    """dW[N,K] = sum over samples and tokens of dY^T X with both operands stored transposed [batch, features, tokens]."""
+    g = torch.Generator().manual_seed(12)
+    B, T, N, K = 3, 128, 128, 256
+    dyT = _bf(torch.randn(B, N, T, generator=g))
+    xT = _bf(torch.randn(B, K, T, generator=g))
+    ref = torch.einsum("bnt,bkt->nk", dyT.float(), xT.float())
+    out = ops.gemm(dyT, xT, None, _native.EPI_F32, shape=(N, K, B * T), k_per_batch=T, a_batch_stride=N * T, w_batch_stride=K * T,
+                   lda=T, ldw=T)
+    assert torch.allclose(out, ref, atol=2e-3, rtol=1e-4)
+
+
+def _attention_case(L, B, heads, seed):
+    """q, k, v (bf16-rounded) in the training layout + torch autograd reference."""
+    g = torch.Generator().manual_seed(seed)
+    lpad = (L + 127) // 128 * 128
+    W = heads * 64
+    qkv = _bf(torch.randn(B, lpad, 3 * W, generator=g))          # padding rows hold finite garbage, like in the model
+    dO = torch.zeros(B, lpad, W)
+    dO[:, :L] = torch.randn(B, L, W, generator=g)
+    dO = _bf(dO)
+    x = qkv.float()[:, :L].reshape(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
+    q, k, v = x[0], x[1], x[2]
+    o = ((q @ k.transpose(-1, -2)) * 0.125).softmax(-1) @ v                       # [B, heads, L, 64]
+    o.backward(dO.float()[:, :L].reshape(B, L, heads, 64).permute(0, 2, 1, 3))
+    dref = x.grad.permute(1, 3, 0, 2, 4).reshape(B, L, 3 * W)                    # [B, L, (q|k|v) W]
+    return lpad, W, qkv, dO, o.detach().permute(0, 2, 1, 3).reshape(B, L, W), dref
+
+
+@pytest.mark.parametrize("L,B", [(128, 1), (130, 2), (300, 1)])
+def test_attention_backward(ops, L, B):
+    heads = 2
+    lpad, W, qkv, dO, oref, dref = _attention_case(L, B, heads, seed=L)
+    qkv2 = qkv.reshape(B * lpad, 3 * W).contiguous()
+    qkvT = qkv.transpose(1, 2).contiguous()
+    lse2 = torch.zeros(B, heads, lpad)
+    o = ops.attention(qkv2, qkvT, L, heads, qkv_layout=True, lse2=lse2)
+    assert torch.allclose(o.float().reshape(B, lpad, W)[:, :L], oref, atol=2e-2, rtol=2e-2)
+    dOT = dO.transpose(1, 2).contiguous()
+    dqkv = ops.attention_backward(qkv2, qkvT, o, dO.reshape(B * lpad, W).contiguous(), dOT, lse2, L, heads)
+    got = dqkv.float().reshape(B, lpad, 3 * W)
+    for name, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+        a, r = got[:, :L, sl], dref[:, :, sl]
+        err = float((a - r).norm() / r.norm())
+        assert err < 2e-2, (name, err)
+    if L < lpad:
+        assert float(got[:, L:].abs().max()) == 0.0   # padding rows receive exactly zero gradient
