@@ -6,6 +6,8 @@
  *
  *   dgs_dit_forward        <- DGSDenoiser.image_to_gaussians     models/denoiser/denoiser.py:306-416
  *                             (scene variant                      models/denoiser/denoiser_scene.py:292-420)
+ *   dgs_dit_forward_train / dgs_dit_backward  <- the same function under torch autograd with per-block
+ *                             torch.utils.checkpoint (denoiser.py:348-354,441-447); here nothing is recomputed
  *   dgs_dit_gemm           <- nn.Linear inside timm Attention/Mlp models/transformers/utils_transformer.py:254-265
  *                             (+ gated residual :286-289, GELU-tanh :259, tokenizer denoiser.py:216-221,
  *                              decoder head denoiser.py:148-164)
@@ -112,6 +114,43 @@ typedef struct DgsDitLayerNormArgs {
     int32_t out_f32;
 } DgsDitLayerNormArgs;
 
+/* Backward of dgs_dit_layernorm: h = LN(x) * weight * (1 + scale) + shift.  dx_out = dx_in + dLN; column sums over the
+ * rows of each sample are ADDED to dshift / dscale ([batch, mod_stride]) and dweight ([width]) with fp32 atomics. */
+typedef struct DgsDitLayerNormBackwardArgs {
+    int32_t rows, width;
+    const float* x;            /* f32 [rows, width]: the forward's input                               */
+    const void* dh;            /* bf16 (dh_f32 = 0) or f32 [rows, width]                                */
+    int32_t dh_f32;
+    const float* weight;       /* [width] or NULL                                                     */
+    const float* scale;        /* [batch, mod_stride] or NULL                                         */
+    int32_t mod_stride, rows_per_batch;
+    float eps;
+    const float* dx_in;        /* optional f32 [rows, width] added to the result (residual path)      */
+    float* dx_out;             /* f32 [rows, width]                                                   */
+    float *dshift, *dscale, *dweight;   /* optional accumulators                                      */
+} DgsDitLayerNormBackwardArgs;
+
+/* Backward of dgs_dit_rowlinear (M <= 8): dW [N,K] and db [N] are WRITTEN; dx [M,K] is ACCUMULATED. */
+typedef struct DgsDitRowLinearBackwardArgs {
+    int32_t M, N, K;
+    const float* x;            /* f32 [M, K] forward input (before the optional SiLU)                  */
+    int32_t silu_input;
+    const uint16_t* W;         /* bf16 [N, K]                                                         */
+    const float* dy;           /* f32 [M, N]                                                          */
+    float *dW, *db, *dx;       /* each optional                                                       */
+} DgsDitRowLinearBackwardArgs;
+
+/* dy = gate * dx (bf16 [B*rows, W] and its token-contiguous copy [B, W, rows]); dgate[b, n] += sum_t dx[t, n] y[t, n]. */
+typedef struct DgsDitGateMulArgs {
+    int32_t B, rows, width;
+    const float* dx;           /* f32 [B*rows, width]                                                 */
+    const uint16_t* y;         /* bf16 [B*rows, width]: pre-gate branch output saved by the forward    */
+    const float* gate;         /* [B, gate_stride]                                                    */
+    int32_t gate_stride;
+    uint16_t *dy, *dyT;
+    float* dgate;              /* [B, gate_stride] accumulated                                        */
+} DgsDitGateMulArgs;
+
 typedef struct DgsDitRowLinearArgs {
     int32_t M, N, K;           /* M <= 16 rows; K % 512 == 0 or K == 256                              */
     const float* x;            /* f32 [M, K]                                                          */
@@ -173,10 +212,49 @@ typedef struct DgsDitForwardArgs {
     int32_t* prof_count;
 } DgsDitForwardArgs;
 
+/* ---- training: forward that saves activations, and the backward ------------------------------------------------ */
+typedef struct DgsDitLayerWeightsT {           /* K-contiguous copies for the input-gradient GEMMs: W^T */
+    const uint16_t *qkv_wT, *proj_wT, *fc1_wT, *fc2_wT;   /* bf16 [W,3W] [W,W] [W,4W] [4W,W]            */
+} DgsDitLayerWeightsT;
+
+typedef struct DgsDitModelT {
+    const DgsDitLayerWeightsT* layer;          /* HOST array [layers]                                    */
+    const uint16_t* dec_wT;                    /* bf16 [W, patch^2*gs_channels]                          */
+} DgsDitModelT;
+
+typedef struct DgsDitLayerGrads {
+    float *qkv_w, *proj_w, *fc1_w, *fc2_w, *qkv_b, *proj_b, *fc1_b, *fc2_b;
+} DgsDitLayerGrads;
+
+typedef struct DgsDitGrads {                   /* f32 gradient of every parameter, same shapes as the state dict; WRITTEN   */
+    float *t_w0, *t_b0, *t_w1, *t_b1, *tok_w, *pos_emb, *in_ln_w;
+    const DgsDitLayerGrads* layer;             /* HOST array [layers]                                    */
+    float *ada_w, *ada_b;                      /* stacked like DgsDitModel.ada_w / ada_b                 */
+    float *up_ln_w, *up_w, *dec_ln_w, *dec_w;
+} DgsDitGrads;
+
+typedef struct DgsDitBackwardArgs {
+    int32_t B, V, H, W;
+    const float* ray_d;                        /* [B,V,3,H,W]                                            */
+    void* saved;        size_t saved_bytes;    /* arena filled by dgs_dit_forward_train                  */
+    void* workspace;    size_t workspace_bytes;/* dgs_dit_backward_workspace_bytes, zero-filled once     */
+    const float *dxyz, *dfeatures, *dscaling, *drotation, *dopacity;   /* gradients of the five outputs  */
+} DgsDitBackwardArgs;
+
+size_t dgs_dit_saved_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W);
+size_t dgs_dit_backward_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W);
+/* same outputs as dgs_dit_forward (a->workspace is not used); B <= 4 */
+int dgs_dit_forward_train(const DgsDitModel* m, const DgsDitForwardArgs* a, void* saved, size_t saved_bytes, dgs_stream_t stream);
+int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, const DgsDitGrads* grads, const DgsDitBackwardArgs* a,
+                     dgs_stream_t stream);
+
 int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream);
 int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream);
 int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, dgs_stream_t stream);
 int dgs_dit_layernorm(const DgsDitLayerNormArgs* a, dgs_stream_t stream);
+int dgs_dit_layernorm_backward(const DgsDitLayerNormBackwardArgs* a, dgs_stream_t stream);
+int dgs_dit_rowlinear_backward(const DgsDitRowLinearBackwardArgs* a, dgs_stream_t stream);
+int dgs_dit_gate_mul(const DgsDitGateMulArgs* a, dgs_stream_t stream);
 int dgs_dit_rowlinear(const DgsDitRowLinearArgs* a, dgs_stream_t stream);
 
 int32_t dgs_dit_lpad(int32_t L);   /* padded rows per sample */

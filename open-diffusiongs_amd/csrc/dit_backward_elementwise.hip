@@ -323,3 +323,28 @@ int launch_gaussians_backward(const GsBwdParams& p, hipStream_t st) {
 }
 
 }  // namespace dgs
+
+using namespace dgs;
+
+extern "C" int dgs_dit_layernorm_backward(const DgsDitLayerNormBackwardArgs* a, dgs_stream_t stream) {
+    if (!a || !a->x || !a->dh || !a->dx_out) return DGS_ERR_INVALID_ARGUMENT;
+    LnBwdParams p{};
+    p.rows = a->rows; p.width = a->width; p.mod_stride = a->mod_stride; p.rows_per_batch = a->rows_per_batch; p.dh_f32 = a->dh_f32;
+    p.eps = a->eps; p.x = a->x; p.dh = a->dh; p.weight = a->weight; p.scale = a->scale; p.dx_in = a->dx_in; p.dx_out = a->dx_out;
+    p.dshift = a->dshift; p.dscale = a->dscale; p.dweight = a->dweight;
+    return launch_layernorm_backward(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dgs_dit_rowlinear_backward(const DgsDitRowLinearBackwardArgs* a, dgs_stream_t stream) {
+    if (!a || !a->x || !a->W || !a->dy) return DGS_ERR_INVALID_ARGUMENT;
+    RowLinBwdParams p{};
+    p.M = a->M; p.N = a->N; p.K = a->K; p.silu_in = a->silu_input; p.x = a->x; p.W = a->W; p.dy = a->dy;
+    p.dW = a->dW; p.db = a->db; p.dx = a->dx;
+    return launch_rowlinear_backward(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dgs_dit_gate_mul(const DgsDitGateMulArgs* a, dgs_stream_t stream) {
+    if (!a || !a->dx || !a->y || !a->gate || !a->dy || !a->dyT || !a->dgate) return DGS_ERR_INVALID_ARGUMENT;
+    return launch_gate_mul(a->dx, a->y, a->gate, a->gate_stride, a->dy, a->dyT, a->dgate, a->B, a->rows, a->width,
+                           static_cast<hipStream_t>(stream));
+}

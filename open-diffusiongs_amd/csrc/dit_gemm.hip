@@ -213,7 +213,7 @@ static void launch_gemm(const GemmParams& p0, int bn, hipStream_t st) {
 }
 
 extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
-    if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M % BM || a->N % 128 || a->K % BK) return DGS_ERR_INVALID_ARGUMENT;
+    if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M % BM || a->N % 64 || a->K % BK) return DGS_ERR_INVALID_ARGUMENT;
     if (!a->A || !a->W || !a->out || (a->lda & 7) || (a->ldw & 7)) return DGS_ERR_INVALID_ARGUMENT;
     const int kpb = a->k_per_batch > 0 ? a->k_per_batch : a->K;
     if (kpb % BK || a->K % kpb || a->lda < kpb || a->ldw < kpb) return DGS_ERR_INVALID_ARGUMENT;
@@ -230,7 +230,8 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each
-    const int bn = ((a->M / BM) * (a->N / 128) < 512 && a->epilogue != DGS_EPI_QKV) ? 64 : 128;
+    if (a->epilogue == DGS_EPI_QKV && a->N % 128) return DGS_ERR_INVALID_ARGUMENT;
+    const int bn = (a->N % 128 || ((a->M / BM) * (a->N / 128) < 512 && a->epilogue != DGS_EPI_QKV)) ? 64 : 128;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (a->epilogue) {
         case DGS_EPI_BF16: launch_gemm<DGS_EPI_BF16>(p, bn, st); break;

@@ -155,6 +155,26 @@ class DgsDitRowLinearArgs(ctypes.Structure):
                 ("silu_output", ctypes.c_int32), ("out", ctypes.c_void_p)]
 
 
+class DgsDitLayerNormBackwardArgs(ctypes.Structure):
+    _fields_ = [("rows", ctypes.c_int32), ("width", ctypes.c_int32), ("x", ctypes.c_void_p), ("dh", ctypes.c_void_p),
+                ("dh_f32", ctypes.c_int32), ("weight", ctypes.c_void_p), ("scale", ctypes.c_void_p),
+                ("mod_stride", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32), ("eps", ctypes.c_float),
+                ("dx_in", ctypes.c_void_p), ("dx_out", ctypes.c_void_p), ("dshift", ctypes.c_void_p),
+                ("dscale", ctypes.c_void_p), ("dweight", ctypes.c_void_p)]
+
+
+class DgsDitRowLinearBackwardArgs(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("x", ctypes.c_void_p),
+                ("silu_input", ctypes.c_int32), ("W", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dW", ctypes.c_void_p),
+                ("db", ctypes.c_void_p), ("dx", ctypes.c_void_p)]
+
+
+class DgsDitGateMulArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("rows", ctypes.c_int32), ("width", ctypes.c_int32), ("dx", ctypes.c_void_p),
+                ("y", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("gate_stride", ctypes.c_int32), ("dy", ctypes.c_void_p),
+                ("dyT", ctypes.c_void_p), ("dgate", ctypes.c_void_p)]
+
+
 class DgsDitLayerWeights(ctypes.Structure):
     _fields_ = [("qkv_w", ctypes.c_void_p), ("proj_w", ctypes.c_void_p), ("fc1_w", ctypes.c_void_p), ("fc2_w", ctypes.c_void_p),
                 ("qkv_b", ctypes.c_void_p), ("proj_b", ctypes.c_void_p), ("fc1_b", ctypes.c_void_p), ("fc2_b", ctypes.c_void_p)]
@@ -183,14 +203,44 @@ class DgsDitForwardArgs(ctypes.Structure):
                 ("prof_capacity", ctypes.c_int32), ("prof_count", ctypes.POINTER(ctypes.c_int32))]
 
 
+class DgsDitLayerWeightsT(ctypes.Structure):
+    _fields_ = [("qkv_wT", ctypes.c_void_p), ("proj_wT", ctypes.c_void_p), ("fc1_wT", ctypes.c_void_p), ("fc2_wT", ctypes.c_void_p)]
+
+
+class DgsDitModelT(ctypes.Structure):
+    _fields_ = [("layer", ctypes.POINTER(DgsDitLayerWeightsT)), ("dec_wT", ctypes.c_void_p)]
+
+
+class DgsDitLayerGrads(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b")]
+
+
+class DgsDitGrads(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("t_w0", "t_b0", "t_w1", "t_b1", "tok_w", "pos_emb", "in_ln_w")] + \
+               [("layer", ctypes.POINTER(DgsDitLayerGrads))] + \
+               [(k, ctypes.c_void_p) for k in ("ada_w", "ada_b", "up_ln_w", "up_w", "dec_ln_w", "dec_w")]
+
+
+class DgsDitBackwardArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("V", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("ray_d", ctypes.c_void_p), ("saved", ctypes.c_void_p), ("saved_bytes", ctypes.c_size_t),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("dxyz", ctypes.c_void_p), ("dfeatures", ctypes.c_void_p), ("dscaling", ctypes.c_void_p),
+                ("drotation", ctypes.c_void_p), ("dopacity", ctypes.c_void_p)]
+
+
 # every symbol include/dgs_dit.h declares (checked by tests/test_abi.py)
-DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
+DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward", "dgs_dit_layernorm_backward",
+               "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
+               "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward"]
 
 
 def _declare_dit(L):
     for name, argt in (("dgs_dit_gemm", DgsDitGemmArgs), ("dgs_dit_attention", DgsDitAttentionArgs),
                        ("dgs_dit_attention_backward", DgsDitAttentionBackwardArgs),
+                       ("dgs_dit_layernorm_backward", DgsDitLayerNormBackwardArgs),
+                       ("dgs_dit_rowlinear_backward", DgsDitRowLinearBackwardArgs), ("dgs_dit_gate_mul", DgsDitGateMulArgs),
                        ("dgs_dit_layernorm", DgsDitLayerNormArgs), ("dgs_dit_rowlinear", DgsDitRowLinearArgs)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
@@ -199,6 +249,15 @@ def _declare_dit(L):
     L.dgs_dit_lpad.argtypes = [ctypes.c_int32]
     L.dgs_dit_workspace_bytes.restype = ctypes.c_size_t
     L.dgs_dit_workspace_bytes.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    for fn in (L.dgs_dit_saved_bytes, L.dgs_dit_backward_workspace_bytes):
+        fn.restype = ctypes.c_size_t
+        fn.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.dgs_dit_forward_train.restype = ctypes.c_int
+    L.dgs_dit_forward_train.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitForwardArgs), ctypes.c_void_p,
+                                        ctypes.c_size_t, ctypes.c_void_p]
+    L.dgs_dit_backward.restype = ctypes.c_int
+    L.dgs_dit_backward.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitModelT), ctypes.POINTER(DgsDitGrads),
+                                   ctypes.POINTER(DgsDitBackwardArgs), ctypes.c_void_p]
     L.dgs_dit_forward.restype = ctypes.c_int
     L.dgs_dit_forward.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitForwardArgs), ctypes.c_void_p]
     return L

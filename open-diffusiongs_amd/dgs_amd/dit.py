@@ -169,6 +169,7 @@ class DitEngine:
         m.layer = ctypes.cast(self._layers, ctypes.POINTER(DgsDitLayerWeights))
         self.model = m
         self._ws, self._ws_shape = None, None
+        self._train = None           # lazily built: transposed weights, gradient buffer, arenas
 
     def _workspace(self, B, V, H, W):
         need = int(self.lib.dgs_dit_workspace_bytes(ctypes.byref(self.model), B, V, H, W))
@@ -218,3 +219,113 @@ class DitEngine:
         if prof is not None:
             out["prof_count"] = int(count.value)
         return out, aligned
+
+
+    # ------------------------------------------------------------------------------------------------------------
+    # training: forward that saves activations + backward (include/dgs_dit.h "training")
+    # ------------------------------------------------------------------------------------------------------------
+    def _train_state(self):
+        """Transposed bf16 weight copies (K-contiguous operands of the input-gradient GEMMs) and the flat fp32 gradient
+        buffer, laid out in backward-completion order (heads, block L-1 .. 0, embeddings) for bucketed all-reduce."""
+        if self._train is not None:
+            return self._train
+        from .parallel import FlatGrads
+        from ._native import DgsDitGrads, DgsDitLayerGrads, DgsDitLayerWeightsT, DgsDitModelT
+        k, W, L = self._keep, self.width, self.layers
+        tkeep = {}
+        layersT = (DgsDitLayerWeightsT * L)()
+        for i in range(L):
+            for short in ("qkv", "proj", "fc1", "fc2"):
+                tkeep[f"{i}.{short}"] = k[f"{i}.{short}_w"].t().contiguous()
+                setattr(layersT[i], short + "_wT", tkeep[f"{i}.{short}"].data_ptr())
+        tkeep["dec"] = k["dec_w"].t().contiguous()
+        mt = DgsDitModelT()
+        mt.layer = ctypes.cast(layersT, ctypes.POINTER(DgsDitLayerWeightsT))
+        mt.dec_wT = tkeep["dec"].data_ptr()
+        # flat gradient buffer: one slot per engine tensor (ada_w / ada_b are the stacked adaLN tensors)
+        shapes = [("dec_w", k["dec_w"].shape), ("dec_ln_w", (W,)), ("up_w", k["up_w"].shape), ("up_ln_w", (W,))]
+        for i in reversed(range(L)):
+            for short in ("fc2", "fc1", "proj", "qkv"):
+                shapes += [(f"{i}.{short}_w", k[f"{i}.{short}_w"].shape), (f"{i}.{short}_b", k[f"{i}.{short}_b"].shape)]
+        shapes += [("in_ln_w", (W,)), ("pos_emb", k["pos_emb"].shape), ("tok_w", k["tok_w"].shape), ("ada_w", k["ada_w"].shape),
+                   ("ada_b", k["ada_b"].shape), ("t_w1", k["t_w1"].shape), ("t_b1", (W,)), ("t_w0", k["t_w0"].shape), ("t_b0", (W,))]
+        fg = FlatGrads(shapes, self.device)
+        lgr = (DgsDitLayerGrads * L)()
+        for i in range(L):
+            for short in ("qkv", "proj", "fc1", "fc2"):
+                setattr(lgr[i], short + "_w", fg.view(f"{i}.{short}_w").data_ptr())
+                setattr(lgr[i], short + "_b", fg.view(f"{i}.{short}_b").data_ptr())
+        gr = DgsDitGrads()
+        for name in ("t_w0", "t_b0", "t_w1", "t_b1", "tok_w", "pos_emb", "in_ln_w", "ada_w", "ada_b", "up_ln_w", "up_w", "dec_ln_w", "dec_w"):
+            setattr(gr, name, fg.view(name).data_ptr())
+        gr.layer = ctypes.cast(lgr, ctypes.POINTER(DgsDitLayerGrads))
+        self._train = dict(tkeep=tkeep, layersT=layersT, mt=mt, fg=fg, lgr=lgr, gr=gr, saved=None, bws=None, shape=None)
+        return self._train
+
+    def grad_views(self):
+        """state-dict key -> fp32 gradient view inside the flat buffer (per-block adaLN keys are slices of the stack)."""
+        tr, W, L = self._train_state(), self.width, self.layers
+        fg, out = tr["fg"], {}
+        out["t_embedder.mlp.0.weight"], out["t_embedder.mlp.0.bias"] = fg.view("t_w0"), fg.view("t_b0")
+        out["t_embedder.mlp.2.weight"], out["t_embedder.mlp.2.bias"] = fg.view("t_w1"), fg.view("t_b1")
+        out["image_tokenizer.1.weight"] = fg.view("tok_w")
+        out["gaussians_pos_embedding"] = fg.view("pos_emb")
+        out["transformer_input_layernorm.weight"] = fg.view("in_ln_w")
+        aw, ab = fg.view("ada_w"), fg.view("ada_b")
+        for i in range(L):
+            p = f"transformer.{i}."
+            for short, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+                out[p + key + ".weight"], out[p + key + ".bias"] = fg.view(f"{i}.{short}_w"), fg.view(f"{i}.{short}_b")
+            out[p + "adaLN_modulation.1.weight"], out[p + "adaLN_modulation.1.bias"] = aw[6 * W * i:6 * W * (i + 1)], ab[6 * W * i:6 * W * (i + 1)]
+        o = 6 * W * L
+        for j, head in enumerate(("upsampler", "image_token_decoder")):
+            out[head + ".adaLN_modulation.1.weight"] = aw[o + 2 * W * j:o + 2 * W * (j + 1)]
+            out[head + ".adaLN_modulation.1.bias"] = ab[o + 2 * W * j:o + 2 * W * (j + 1)]
+        out["upsampler.layernorm.weight"], out["upsampler.linear.weight"] = fg.view("up_ln_w"), fg.view("up_w")
+        out["image_token_decoder.layernorm.weight"], out["image_token_decoder.linear.weight"] = fg.view("dec_ln_w"), fg.view("dec_w")
+        return out
+
+    def forward_train(self, images, ray_o, ray_d, t):
+        """image_to_gaussians that keeps what `backward` needs (no recomputation).  Returns (dict, aligned_xyz)."""
+        dev = self.device
+        tr = self._train_state()
+        B, V, _, H, W = images.shape
+        if tr["shape"] != (B, V, H, W):
+            m = ctypes.byref(self.model)
+            tr["saved"] = torch.zeros(int(self.lib.dgs_dit_saved_bytes(m, B, V, H, W)), dtype=torch.uint8, device=dev)
+            tr["bws"] = torch.zeros(int(self.lib.dgs_dit_backward_workspace_bytes(m, B, V, H, W)), dtype=torch.uint8, device=dev)
+            tr["shape"] = (B, V, H, W)
+        img = images[:, :, :3].to(dev, torch.float32).contiguous()
+        ro, rd = ray_o.to(dev, torch.float32).contiguous(), ray_d.to(dev, torch.float32).contiguous()
+        tt = t.to(dev, torch.int64).contiguous()
+        P = self.ng + V * H * W
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        out = dict(xyz=f(B, P, 3), features=f(B, P, 1, 3), scaling=f(B, P, 3), rotation=f(B, P, 4), opacity=f(B, P, 1))
+        aligned = f(B, V, 3, H, W)
+        a = DgsDitForwardArgs()
+        a.B, a.V, a.H, a.W = B, V, H, W
+        a.images, a.ray_o, a.ray_d, a.t = _p(img), _p(ro), _p(rd), _p(tt)
+        a.xyz, a.features, a.scaling, a.rotation, a.opacity = (_p(out[k]) for k in ("xyz", "features", "scaling", "rotation", "opacity"))
+        a.aligned_xyz = _p(aligned)
+        rc = self.lib.dgs_dit_forward_train(ctypes.byref(self.model), ctypes.byref(a), _p(tr["saved"]), tr["saved"].numel(), _stream(dev))
+        if rc != 0:
+            raise RuntimeError(f"dgs dit forward_train: {_native.status_string(self.lib, rc)} (status {rc})")
+        tr["ray_d"] = rd
+        return out, aligned
+
+    def backward(self, dxyz, dfeatures, dscaling, drotation, dopacity):
+        """Gradients of every parameter into the flat buffer (overwritten).  Must follow `forward_train`."""
+        tr = self._train_state()
+        B, V, H, W = tr["shape"]
+        dev = self.device
+        g = [x.to(dev, torch.float32).contiguous() for x in (dxyz, dfeatures, dscaling, drotation, dopacity)]
+        a = _native.DgsDitBackwardArgs()
+        a.B, a.V, a.H, a.W = B, V, H, W
+        a.ray_d = _p(tr["ray_d"])
+        a.saved, a.saved_bytes, a.workspace, a.workspace_bytes = _p(tr["saved"]), tr["saved"].numel(), _p(tr["bws"]), tr["bws"].numel()
+        a.dxyz, a.dfeatures, a.dscaling, a.drotation, a.dopacity = (_p(x) for x in g)
+        rc = self.lib.dgs_dit_backward(ctypes.byref(self.model), ctypes.byref(tr["mt"]), ctypes.byref(tr["gr"]), ctypes.byref(a),
+                                       _stream(dev))
+        if rc != 0:
+            raise RuntimeError(f"dgs dit backward: {_native.status_string(self.lib, rc)} (status {rc})")
+        return tr["fg"]

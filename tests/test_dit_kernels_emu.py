@@ -204,3 +204,72 @@ def test_attention_backward(ops, L, B):
         assert err < 2e-2, (name, err)
     if L < lpad:
         assert float(got[:, L:].abs().max()) == 0.0   # padding rows receive exactly zero gradient
+
+
+def _call(ops, fn, struct, **kw):
+    import ctypes
+    a = struct()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            setattr(a, k, v.data_ptr())
+        elif v is not None:
+            setattr(a, k, v)
+    rc = getattr(ops.lib, fn)(ctypes.byref(a), None)
+    assert rc == 0, rc
+
+
+def test_layernorm_backward(ops):
+    g = torch.Generator().manual_seed(21)
+    B, rows, Wd = 2, 64, 1024
+    x = (torch.randn(B * rows, Wd, generator=g) * 2 + 0.5).requires_grad_(True)
+    w = (1 + 0.2 * torch.randn(Wd, generator=g)).requires_grad_(True)
+    mod = torch.randn(B, 3 * Wd, generator=g)
+    shift = mod[:, :Wd].clone().requires_grad_(True)
+    scale = mod[:, Wd:2 * Wd].clone().requires_grad_(True)
+    dh = _bf(torch.randn(B * rows, Wd, generator=g))
+    dx_in = torch.randn(B * rows, Wd, generator=g)
+    h = F.layer_norm(x, (Wd,), w, None, 1e-6) * (1 + scale.repeat_interleave(rows, 0)) + shift.repeat_interleave(rows, 0)
+    h.backward(dh.float())
+    dmod = torch.zeros(B, 3 * Wd)
+    dw = torch.zeros(Wd)
+    dx = torch.zeros(B * rows, Wd)
+    _call(ops, "dgs_dit_layernorm_backward", _native.DgsDitLayerNormBackwardArgs, rows=B * rows, width=Wd, x=x.detach(), dh=dh,
+          dh_f32=0, weight=w.detach(), scale=mod[:, Wd:], mod_stride=3 * Wd, rows_per_batch=rows, eps=1e-6, dx_in=dx_in, dx_out=dx,
+          dshift=dmod, dscale=dmod[:, Wd:], dweight=dw)
+    assert torch.allclose(dx, x.grad + dx_in, atol=2e-4, rtol=1e-3)
+    assert torch.allclose(dmod[:, :Wd], shift.grad, atol=1e-3, rtol=1e-3)
+    assert torch.allclose(dmod[:, Wd:2 * Wd], scale.grad, atol=2e-3, rtol=1e-3)
+    assert torch.allclose(dw, w.grad, atol=2e-3, rtol=1e-3)
+    assert float(dmod[:, 2 * Wd:].abs().max()) == 0.0
+
+
+def test_rowlinear_backward_and_gate_mul(ops):
+    g = torch.Generator().manual_seed(22)
+    M, N, K = 3, 70, 256
+    x = torch.randn(M, K, generator=g).requires_grad_(True)
+    Wb = _bf(torch.randn(N, K, generator=g) * 0.1)
+    Wf = Wb.float().requires_grad_(True)
+    b = torch.zeros(N, requires_grad=True)
+    dy = torch.randn(M, N, generator=g)
+    F.linear(F.silu(x), Wf, b).backward(dy)
+    dW, db, dx = torch.zeros(N, K), torch.zeros(N), torch.zeros(M, K)
+    _call(ops, "dgs_dit_rowlinear_backward", _native.DgsDitRowLinearBackwardArgs, M=M, N=N, K=K, x=x.detach(), silu_input=1, W=Wb,
+          dy=dy, dW=dW, db=db, dx=dx)
+    assert torch.allclose(dW, Wf.grad, atol=1e-4, rtol=1e-4) and torch.allclose(db, b.grad, atol=1e-5)
+    assert torch.allclose(dx, x.grad, atol=1e-4, rtol=1e-4)
+    # gate_mul
+    B, rows, Wd = 2, 64, 128
+    dxr = torch.randn(B * rows, Wd, generator=g)
+    y = _bf(torch.randn(B * rows, Wd, generator=g))
+    gate = torch.randn(B, 2 * Wd, generator=g)
+    dyo = torch.zeros(B * rows, Wd, dtype=torch.bfloat16)
+    dyT = torch.zeros(B, Wd, rows, dtype=torch.bfloat16)
+    dgate = torch.zeros(B, 2 * Wd)
+    _call(ops, "dgs_dit_gate_mul", _native.DgsDitGateMulArgs, B=B, rows=rows, width=Wd, dx=dxr, y=y, gate=gate[:, Wd:], gate_stride=2 * Wd,
+          dy=dyo, dyT=dyT, dgate=dgate[:, Wd:])
+    want = gate[:, Wd:].repeat_interleave(rows, 0) * dxr
+    assert torch.allclose(dyo.float(), want, atol=3e-2, rtol=1e-2)
+    assert torch.equal(dyT, dyo.reshape(B, rows, Wd).transpose(1, 2))
+    assert torch.allclose(dgate[:, Wd:], (dxr * y.float()).reshape(B, rows, Wd).sum(1), atol=1e-3, rtol=1e-4)
