@@ -143,6 +143,32 @@ class _Head(nn.Module):
         self.adaLN_modulation = _seq(nn.Identity(), _Linear(w, 2 * w))
 
 
+class _DitFunction(torch.autograd.Function):
+    """image_to_gaussians under torch autograd: forward = dgs_dit_forward_train (activations saved in the engine's arena,
+    nothing recomputed -- the reference checkpoints every block, denoiser.py:348-354), backward = dgs_dit_backward.  The
+    parameter gradients are views into the engine's flat fp32 buffer (dgs_amd.parallel.FlatGrads), returned to autograd
+    in named_parameters() order."""
+
+    @staticmethod
+    def forward(ctx, module, names, images, ray_o, ray_d, t, *params):
+        eng = module.engine()
+        out, aligned = eng.forward_train(images, ray_o, ray_d, t)
+        ctx.engine, ctx.names, ctx.param_shapes = eng, names, [tuple(p.shape) for p in params]
+        ctx.mark_non_differentiable(aligned)
+        return out["xyz"], out["features"], out["scaling"], out["rotation"], out["opacity"], aligned
+
+    @staticmethod
+    def backward(ctx, dxyz, dfeat, dscal, drot, dopa, _daligned):
+        z = lambda g, like: g if g is not None else torch.zeros(like, device=ctx.engine.device)
+        eng = ctx.engine
+        B, V, H, W = eng._train["shape"]
+        P = eng.ng + V * H * W
+        eng.backward(z(dxyz, (B, P, 3)), z(dfeat, (B, P, 1, 3)), z(dscal, (B, P, 3)), z(drot, (B, P, 4)), z(dopa, (B, P, 1)))
+        views = eng.grad_views()
+        grads = tuple(views[n].reshape(shape) for n, shape in zip(ctx.names, ctx.param_shapes))
+        return (None, None, None, None, None, None) + grads
+
+
 @register("diffusion-gs-model")
 class DGSDenoiser(nn.Module):
     SCENE = False
@@ -250,6 +276,11 @@ class DGSDenoiser(nn.Module):
         return out
 
     def image_to_gaussians(self, images, ray_o, ray_d, t, training=False):   # denoiser.py:306-416
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            names = [n for n, _ in self.named_parameters()]
+            outs = _DitFunction.apply(self, names, images, ray_o, ray_d, t, *[p for _, p in self.named_parameters()])
+            out = dict(zip(("xyz", "features", "scaling", "rotation", "opacity"), outs[:5]))
+            return AttrDict(out), outs[5]
         out, aligned = self.engine().image_to_gaussians(images, ray_o, ray_d, t)
         return AttrDict(out), aligned
 

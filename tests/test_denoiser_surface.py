@@ -34,7 +34,8 @@ def test_forward_end_to_end_emulated():
     B, V, res = 1, 2, 16
     images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, B, V, res, seed=2)
     batch = dict(image=images, ray_o=ray_o, ray_d=ray_d, c2w=c2w, fxfycxcy=k)
-    rendered, gaussians = m(batch, t)
+    with torch.no_grad():            # the reference samples under no_grad (gaussian_diffusion.py p_sample_loop_progressive)
+        rendered, gaussians = m(batch, t)
     assert rendered.shape == (B, V, 3, res, res) and len(gaussians) == B
     sd = {k_: v.detach().clone() for k_, v in m.state_dict().items()}
     ref, _ = D.image_to_gaussians(sd, cfg, images, ray_o, ray_d, t)
@@ -51,3 +52,50 @@ def test_forward_end_to_end_emulated():
                   campos[v].numpy(), float(tanfov[v, 0]), float(tanfov[v, 1]), res, res, shs=g._features_dc.numpy(),
                   scales=g.get_scaling.numpy(), rotations=g.get_rotation.numpy(), exp_mode=1)
         np.testing.assert_allclose(rendered[0, v].numpy(), o.get("out_color"), atol=2e-4)
+
+
+def test_training_step_end_to_end_emulated():
+    """loss = MSE(DGSDenoiser.forward(batch, t) renders, target) -> .backward(): DiT backward + rasterizer backward kernels
+    under torch autograd must reproduce the gradients of the same loss computed with the fp32 oracle + the per-view drop-in
+    binding (reference call convention)."""
+    import dgs_amd.raster as R
+    R._default = emu_lib() and R.RasterBackend(emu_lib())
+    import diff_gaussian_rasterization as dgr
+    m = dn.DGSDenoiser(OBJ_CFG, device="cpu", lib=emu_lib())
+    m.reset_parameters(seed=6)
+    with torch.no_grad():
+        m.image_token_decoder.linear.weight.mul_(20.0)
+        for n_, p_ in m.named_parameters():          # bf16-representable GEMM weights: the oracle sees the same numbers
+            if p_.dim() == 2:
+                p_.copy_(p_.to(torch.bfloat16).float())
+    cfg = D.Cfg(width=256, num_layers=2)
+    B, V, res = 1, 2, 16
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, B, V, res, seed=3)
+    batch = dict(image=images, ray_o=ray_o, ray_d=ray_d, c2w=c2w, fxfycxcy=k)
+    target = torch.rand(B, V, 3, res, res, generator=torch.Generator().manual_seed(1))
+    rendered, _ = m(batch, t)
+    loss = ((rendered - target) ** 2).mean()
+    loss.backward()
+    # reference: oracle DiT (autograd) + torch activations + per-view binding
+    leaf = {n_: p_.detach().clone().requires_grad_(True) for n_, p_ in m.state_dict().items()}
+    g, _ = D.image_to_gaussians(leaf, cfg, images, ray_o, ray_d, t)
+    view, proj, campos, tanfov = D.camera_matrices(c2w, k, res, res)
+    imgs = []
+    for v in range(V):
+        rs = dgr.GaussianRasterizationSettings(res, res, float(tanfov[0, v, 0]), float(tanfov[0, v, 1]), torch.ones(3), 1.0,
+                                               view[0, v], proj[0, v], 0, campos[0, v], False, False)
+        color, _ = dgr.GaussianRasterizer(rs)(g["xyz"][0], torch.zeros_like(g["xyz"][0], requires_grad=True),
+                                              torch.sigmoid(g["opacity"][0]), shs=g["features"][0], scales=torch.exp(g["scaling"][0]),
+                                              rotations=torch.nn.functional.normalize(g["rotation"][0]))
+        imgs.append(color)
+    ref_loss = ((torch.stack(imgs)[None] - target) ** 2).mean()
+    ref_loss.backward()
+    print('LOSS', float(loss.detach()), float(ref_loss.detach()))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-2 * abs(float(ref_loss.detach())) + 1e-6
+    bad = []
+    for n_, p_ in m.named_parameters():
+        r = leaf[n_].grad
+        e = rel_l2(p_.grad, r)
+        if e > 0.1:
+            bad.append((n_, e))
+    assert not bad, bad[:5]
