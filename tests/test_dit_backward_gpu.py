@@ -70,8 +70,9 @@ def test_training_step_256_finite_and_descends():
     from dgs_amd import cameras, denoiser as dn
     import numpy as np
     cfg = D.Cfg()
-    m = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24), device=DEV).to(DEV)
+    m = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24), device=DEV)
     m.reset_parameters(seed=3)
+    m = m.to(DEV)
     images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 1, 4, 256, seed=8)
     rc2w = torch.tensor(np.stack([cameras.ring_cameras(10, phase_deg=5.0)])).to(DEV)
     rk = torch.tensor(cameras.default_fxfycxcy(256)).expand(1, 10, 4).contiguous().to(DEV)

@@ -54,3 +54,59 @@ def test_bucketed_allreduce_two_ranks():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert got == [(0, 2.0), (1, 2.0)]
+
+
+def _train_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "..", "open-diffusiongs_amd"), os.path.join(here, "..")):
+        sys.path.insert(0, os.path.abspath(p))
+    from dgs_amd import denoiser as dn
+    from dgs_amd.parallel import init_distributed
+    from dgs_amd.train import DataParallelTrainer
+    from dit_util import synth_inputs
+    from emu_util import emu_lib
+    from oracle import dit_oracle as D
+    init_distributed(backend="gloo")
+    cfg = D.Cfg(width=256, num_layers=1)
+    m = dn.DGSDenoiser(dict(width=256, in_channels=9, patch_size=8, num_layers=1), device="cpu", lib=emu_lib())
+    m.reset_parameters(seed=1)                                   # identical replicas
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 2, 2, 16, seed=9)      # global batch of 2; rank r takes sample r
+    sl = slice(rank, rank + 1) if world > 1 else slice(0, 2)
+    batch = dict(image=images[sl], ray_o=ray_o[sl], ray_d=ray_d[sl], c2w=c2w[sl], fxfycxcy=k[sl])
+    target = torch.rand(2, 2, 3, 16, 16, generator=torch.Generator().manual_seed(3))[sl]
+    tr = DataParallelTrainer(m, torch.optim.SGD(m.parameters(), lr=0.0), bucket_bytes=1 << 20)
+    loss = tr.step(batch, t[sl], target)
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    out.put((rank, float(loss), g.numpy()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_single_process_step():
+    """2 ranks x 1 sample, gradients averaged by the bucketed all-reduce == 1 process x 2 samples (mean loss)."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_train_worker, args=(0, 1, _free_port(), q1))
+    p1.start()
+    single = q1.get(timeout=240)
+    p1.join(60)
+    res.sort(key=lambda r: r[0])
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=0)            # ranks hold identical averaged gradients
+    np.testing.assert_allclose(0.5 * (res[0][1] + res[1][1]), single[1], rtol=1e-5)
+    denom = np.abs(single[2]).max()
+    assert np.abs(res[0][2] - single[2]).max() <= 2e-3 * denom
