@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(LnBwdParams p) 
     const float inv_w = 1.0f / (float)p.width;
     for (int r = wave; r < p.rows_per_block; r += 4) {
         const int row = row0 + r;
-        if (row >= p.rows) break;
+        if (row >= p.rows) break;       // (no barrier inside the loop)
         const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)row * p.width);
         float4 n[VPL], dn[VPL];
         float sum = 0.f;
@@ -127,22 +127,20 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(LnBwdParams p) 
             out[c4] = d;
         }
     }
-    // flush the column sums of this workgroup (each wave owns all columns of its rows)
+    // column sums: waves -> LDS -> one fp32 atomic per column per workgroup (128 rows)
+    __shared__ float red[3][4][VPL * 256];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * 64 + lane) * 4;
-        if (p.dshift) {
-            float* d = p.dshift + (size_t)b * p.mod_stride + c;
-            atomicAdd(d, a_shift[i].x); atomicAdd(d + 1, a_shift[i].y); atomicAdd(d + 2, a_shift[i].z); atomicAdd(d + 3, a_shift[i].w);
-        }
-        if (p.dscale) {
-            float* d = p.dscale + (size_t)b * p.mod_stride + c;
-            atomicAdd(d, a_scale[i].x); atomicAdd(d + 1, a_scale[i].y); atomicAdd(d + 2, a_scale[i].z); atomicAdd(d + 3, a_scale[i].w);
-        }
-        if (p.dweight) {
-            float* d = p.dweight + c;
-            atomicAdd(d, a_w[i].x); atomicAdd(d + 1, a_w[i].y); atomicAdd(d + 2, a_w[i].z); atomicAdd(d + 3, a_w[i].w);
-        }
+        *reinterpret_cast<float4*>(&red[0][wave][c]) = a_shift[i];
+        *reinterpret_cast<float4*>(&red[1][wave][c]) = a_scale[i];
+        *reinterpret_cast<float4*>(&red[2][wave][c]) = a_w[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.width; c += 256) {
+        if (p.dshift) atomicAdd(p.dshift + (size_t)b * p.mod_stride + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+        if (p.dscale) atomicAdd(p.dscale + (size_t)b * p.mod_stride + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+        if (p.dweight) atomicAdd(p.dweight + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
     }
 }
 
@@ -181,6 +179,15 @@ __global__ __launch_bounds__(256) void rowlinear_backward_kernel(RowLinBwdParams
         dxs[i] = 0.f;
     }
     __syncthreads();
+    // lane owns the 8-column chunks {lane, lane + 64, ...} (K <= 1024 -> at most 2 chunks): dx partials stay in registers
+    constexpr int MAXC = 2;
+    float dxr[MR][MAXC][8];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dxr[m][c][j] = 0.f;
     const int n0 = blockIdx.x * rows_per_block;
     for (int n = n0 + wave; n < n0 + rows_per_block && n < p.N; n += 4) {
         float dyv[MR];
@@ -189,24 +196,46 @@ __global__ __launch_bounds__(256) void rowlinear_backward_kernel(RowLinBwdParams
         for (int m = 0; m < MR; ++m) { dyv[m] = (m < p.M) ? p.dy[(size_t)m * p.N + n] : 0.f; bsum += dyv[m]; }
         if (p.db && lane == 0) p.db[n] = bsum;
         const bf16_t* wr = p.W + (size_t)n * p.K;
-        for (int k = lane; k < p.K; k += 64) {
-            float g = 0.f;
-            const float w = bf2f(wr[k]);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int k0 = (lane + 64 * c) * 8;
+            if (k0 >= p.K) continue;
+            const uint4 w = *reinterpret_cast<const uint4*>(wr + k0);
+            const float wf[8] = {bf2f(w.x & 0xffffu), bf2f(w.x >> 16), bf2f(w.y & 0xffffu), bf2f(w.y >> 16),
+                                 bf2f(w.z & 0xffffu), bf2f(w.z >> 16), bf2f(w.w & 0xffffu), bf2f(w.w >> 16)};
+            float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                g += dyv[m] * xs[m * p.K + k];
-                if (p.dx) atomicAdd(&dxs[m * p.K + k], dyv[m] * w);   // LDS atomic: 4 waves share dxs
+                const float4 xa = *reinterpret_cast<const float4*>(xs + m * p.K + k0);
+                const float4 xb = *reinterpret_cast<const float4*>(xs + m * p.K + k0 + 4);
+                const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { g[j] += dyv[m] * xv[j]; dxr[m][c][j] += dyv[m] * wf[j]; }
             }
-            if (p.dW) p.dW[(size_t)n * p.K + k] = g;
+            if (p.dW) {
+                float4* dst = reinterpret_cast<float4*>(p.dW + (size_t)n * p.K + k0);
+                dst[0] = make_float4(g[0], g[1], g[2], g[3]);
+                dst[1] = make_float4(g[4], g[5], g[6], g[7]);
+            }
         }
     }
-    __syncthreads();
-    if (p.dx)
+    if (p.dx) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int k0 = (lane + 64 * c) * 8;
+                if (k0 >= p.K) continue;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(&dxs[m * p.K + k0 + j], dxr[m][c][j]);   // 4 waves -> LDS
+            }
+        __syncthreads();
         for (int i = threadIdx.x; i < p.M * p.K; i += 256) {
             float g = dxs[i];
             if (p.silu_in) g *= dsilu_f(p.x[i]);
             if (g != 0.f) atomicAdd(&p.dx[i], g);
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -282,7 +311,7 @@ int launch_layernorm_backward(const LnBwdParams& p0, hipStream_t st) {
     LnBwdParams p = p0;
     if (p.rows <= 0 || p.width % 256 || p.width > 2048) return DGS_ERR_INVALID_ARGUMENT;
     if (p.rows_per_batch <= 0) p.rows_per_batch = p.rows;
-    p.rows_per_block = p.rows_per_batch % 32 == 0 ? 32 : p.rows_per_batch;   // never straddles samples
+    p.rows_per_block = p.rows_per_batch % 128 == 0 ? 128 : p.rows_per_batch;   // never straddles samples
     const dim3 grid((p.rows + p.rows_per_block - 1) / p.rows_per_block), block(256);
     switch (p.width / 256) {
         case 1: hipLaunchKernelGGL((layernorm_backward_kernel<1>), grid, block, 0, st, p); break;
@@ -300,18 +329,17 @@ int launch_colsum(const bf16_t* dy, int ld, int M, int N, float* db, hipStream_t
 }
 
 int launch_rowlinear_backward(const RowLinBwdParams& p, hipStream_t st) {
-    if (p.M <= 0 || p.M > 16 || p.N <= 0 || p.K <= 0) return DGS_ERR_INVALID_ARGUMENT;
-    const int rpb = 64;
+    if (p.M <= 0 || p.M > 8 || p.N <= 0 || p.K <= 0 || p.K % 8 || p.K > 1024) return DGS_ERR_INVALID_ARGUMENT;
+    const int rpb = 256;
     const dim3 grid((p.N + rpb - 1) / rpb), block(256);
-    const int mr = p.M <= 1 ? 1 : p.M <= 2 ? 2 : p.M <= 4 ? 4 : p.M <= 8 ? 8 : 16;
+    const int mr = p.M <= 1 ? 1 : p.M <= 2 ? 2 : p.M <= 4 ? 4 : 8;
     const size_t lds = (size_t)2 * mr * p.K * sizeof(float);
     if (lds > 65536) return DGS_ERR_INVALID_ARGUMENT;
     switch (mr) {
         case 1: hipLaunchKernelGGL((rowlinear_backward_kernel<1>), grid, block, lds, st, p, rpb); break;
         case 2: hipLaunchKernelGGL((rowlinear_backward_kernel<2>), grid, block, lds, st, p, rpb); break;
         case 4: hipLaunchKernelGGL((rowlinear_backward_kernel<4>), grid, block, lds, st, p, rpb); break;
-        case 8: hipLaunchKernelGGL((rowlinear_backward_kernel<8>), grid, block, lds, st, p, rpb); break;
-        default: hipLaunchKernelGGL((rowlinear_backward_kernel<16>), grid, block, lds, st, p, rpb); break;
+        default: hipLaunchKernelGGL((rowlinear_backward_kernel<8>), grid, block, lds, st, p, rpb); break;
     }
     return ok();
 }
