@@ -74,13 +74,13 @@ __device__ __forceinline__ void mask_tile(f32x16& s0, f32x16& s1, int key0, int 
 // Workgroup = 256 queries of one (sample, head): 8 waves x 32 queries, two waves per SIMD, one workgroup per CU.  The
 // kernel is latency-bound per wave (a wave needs ~the same time for its 65 tiles whether or not the CU is shared), so the
 // work decomposition must come out in ONE round of the 256 CUs: L = 4098 = 16 * 256 + 2, and a 17th query block per head
-// for the two learned-token queries would cost a whole second round.  That odd 32-query unit (`extra_unit`) is handled by
-// attention_tail_kernel instead, which splits the KEYS of the unit over eight waves (1/8 of the latency).
+// for the two learned-token queries would cost a whole second round.  Instead the launch uses 9-wave workgroups and the
+// 9th wave of a head's last block takes the odd 32-query unit (`extra_unit`); everywhere else it exits at once.
 // The grid is 1-D with head = id % heads: all query blocks of a head run on one XCD (dispatch places block b on XCD
 // b % 8) and re-read that head's K / V^T (1 MiB) from its L2.
 // Software pipeline (T15): while the VALU works through the softmax of tile t, the matrix pipe already runs
 // S(t+1) = K(t+1) Q^T; K and V^T therefore live in two 2-deep rings that are one tile out of phase.
-__global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(576) void attention_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[4 * KV_TILE_BYTES];   // K ring [2] | V^T ring [2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,7 +90,11 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
     const int head = id % p.heads; id /= p.heads;
     const int qblk = id % p.nqb, b = id / p.nqb;
     // 32-query unit of this wave; wave 8 exists only to take the odd unit behind the last full block
-    const int unit = qblk * NW + wave;
+    int unit = qblk * NW + wave;
+    if (wave == NW) {
+        if (!(p.extra_unit && qblk == p.nqb - 1)) return;   // leaves before the first barrier
+        unit = p.nqb * NW;
+    }
     const size_t row0 = (size_t)b * p.lpad;
     const bf16_t* Qg = p.qk + row0 * p.ld_qk + head * 64;
     const bf16_t* Kg = Qg + p.k_offset;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
     const int kswz = (l31 >> 1) & 7;
 
     // ---- prologue: K(0), V(0) -> LDS; K(1) -> LDS; S_cur = QK(0) ----
-    const bool stager = true;
+    const bool stager = wave < NW;        // the 512 threads of waves 0..7 move the tiles
     if (stager) {
         kreg = *reinterpret_cast<const uint4*>(kptr);
         vreg = *reinterpret_cast<const uint4*>(vptr);
@@ -172,36 +176,8 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
         if (wave_live) {
             f32x16 n0, n1;
             const float mb = m_run * p.scale_log2e;
-            // all 16 operand fragments of this iteration are requested from LDS up front (K(t+1): 8, V^T(t): 8) and pinned
-            // above the arithmetic: left to itself hipcc issues every ds_read right before the MFMA that consumes it and the
-            // LDS latency (~100+ cycles) is exposed sixteen times per tile
-            bf16x8 kfr[8], vfr[8];
-            {
-                const char* kb = kring + ((t + 1) & 1) * KV_TILE_BYTES + l31 * 128;
-                const char* vb0 = vring + (t & 1) * KV_TILE_BYTES + l31 * 128;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int off = ((2 * ks + half) ^ kswz) << 4;
-                    if (MODE != 2) {
-                        kfr[2 * ks] = *reinterpret_cast<const bf16x8*>(kb + off);
-                        kfr[2 * ks + 1] = *reinterpret_cast<const bf16x8*>(kb + 32 * 128 + off);
-                    }
-                    vfr[2 * ks] = *reinterpret_cast<const bf16x8*>(vb0 + off);
-                    vfr[2 * ks + 1] = *reinterpret_cast<const bf16x8*>(vb0 + 32 * 128 + off);
-                }
-            }
-#ifndef HIPEMU
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             // ---------------- phase A ----------------
-            if (MODE != 2) {
-                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[2 * ks], qf[ks], ks == 0 ? zero16 : n0, 0, 0, 0);
-                    n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[2 * ks + 1], qf[ks], ks == 0 ? zero16 : n1, 0, 0, 0);
-                }
-            }
+            if (MODE != 2) qk_tile(kring + ((t + 1) & 1) * KV_TILE_BYTES, qf, l31, half, kswz, n0, n1);
             float psum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -221,7 +197,8 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
 #ifndef HIPEMU
             if (MODE != 2) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {          // 8 x { 1 MFMA, 14 VALU }
+                for (int i = 0; i < 8; ++i) {          // 8 x { 1 LDS read, 1 MFMA, 14 VALU }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
                 }
@@ -229,16 +206,21 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
 #endif
             if (MODE == 1) mask_tile(n0, n1, (t + 1) * KB, half, p.L);
             // ---------------- phase B ----------------
+            const char* vb = vring + (t & 1) * KV_TILE_BYTES + l31 * 128;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[2 * ks], pf[ks].v, oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[2 * ks + 1], pf[ks].v, oacc[1], 0, 0, 0);
+                const int off = ((2 * ks + half) ^ kswz) << 4;
+                const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vb + off);
+                const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(vb + 32 * 128 + off);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[ks].v, oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[ks].v, oacc[1], 0, 0, 0);
             }
             if (MODE != 2) {
                 mx = row_max(n0, n1);
 #ifndef HIPEMU
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {          // 8 x { 1 MFMA, 3 VALU }
+                for (int i = 0; i < 8; ++i) {          // 8 x { 1 LDS read, 1 MFMA, 3 VALU }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
                     __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
                 }
@@ -290,106 +272,6 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(AttnParams p) {
         }
 }
 
-
-// The odd 32-query unit behind the last full 256-query block of every (sample, head) (L = 4098: the two learned-token
-// queries).  One workgroup per (sample, head); wave w walks key tiles w, w + 8, ... with operand fragments loaded straight
-// from global memory (nothing is shared between the waves, so no LDS staging and no barriers in the loop), then the eight
-// partial (m, l, O) states are merged pairwise through LDS.
-__global__ __launch_bounds__(512) void attention_tail_kernel(AttnParams p) {
-    __shared__ float xch[4][64][34];       // 4 partial states: 32 accumulator values + m + l per lane
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int head = blockIdx.x % p.heads, b = blockIdx.x / p.heads;
-    const size_t row0 = (size_t)b * p.lpad;
-    const bf16_t* Qg = p.qk + row0 * p.ld_qk + head * 64;
-    const bf16_t* Kg = Qg + p.k_offset;
-    const bf16_t* Vg = p.vt + (size_t)b * p.vt_batch_stride + (size_t)head * 64 * p.lpad;
-    const int q = p.nqb * QB + l31;                       // < lpad: the unit starts below L and lpad % 128 == 0
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)q * p.ld_qk + (2 * ks + half) * 8);
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -1.0e30f, l_run = 0.0f;
-    const int ntiles = (p.L + KB - 1) / KB;
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int t = wave; t < ntiles; t += NW) {
-        f32x16 s0, s1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kg + (size_t)(t * KB + l31) * p.ld_qk + (2 * ks + half) * 8);
-            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kg + (size_t)(t * KB + 32 + l31) * p.ld_qk + (2 * ks + half) * 8);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], ks == 0 ? zero16 : s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], ks == 0 ? zero16 : s1, 0, 0, 0);
-        }
-        if ((t + 1) * KB > p.L) mask_tile(s0, s1, t * KB, half, p.L);
-        const float mx = row_max(s0, s1);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2((m_run - m_new) * p.scale_log2e);
-        const float mb = m_new * p.scale_log2e;
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = fast_exp2(__builtin_fmaf(s0[r], p.scale_log2e, -mb));
-            s1[r] = fast_exp2(__builtin_fmaf(s1[r], p.scale_log2e, -mb));
-            psum += s0[r] + s1[r];
-            o0[r] *= alpha; o1[r] *= alpha;
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int r0 = 8 * (ks & 1);
-            union { bf16x8 v; uint32_t u[4]; } pf;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pf.u[j] = (ks < 2) ? pack_bf2(s0[r0 + 2 * j], s0[r0 + 2 * j + 1]) : pack_bf2(s1[r0 + 2 * j], s1[r0 + 2 * j + 1]);
-            // V^T fragment of feature row d: keys 16 ks + 4 half + {0..3} and 16 ks + 8 + 4 half + {0..3} of the tile
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const bf16_t* vrow = Vg + (size_t)(db * 32 + l31) * p.lpad + t * KB + 16 * ks + 4 * half;
-                union { bf16x8 v; uint2 h[2]; } vf;
-                vf.h[0] = *reinterpret_cast<const uint2*>(vrow);
-                vf.h[1] = *reinterpret_cast<const uint2*>(vrow + 8);
-                if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o0, 0, 0, 0);
-                else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o1, 0, 0, 0);
-            }
-        }
-    }
-    // ---- merge the 8 partial states: 8 -> 4 -> 2 -> 1 ----
-    for (int n = NW / 2; n >= 1; n >>= 1) {
-        if (wave >= n && wave < 2 * n) {
-            float* dst = xch[wave - n][lane];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dst[r] = o0[r]; dst[16 + r] = o1[r]; }
-            dst[32] = m_run; dst[33] = l_run;
-        }
-        __syncthreads();
-        if (wave < n) {
-            const float* src = xch[wave][lane];
-            const float m_b = src[32], l_b = src[33];
-            const float m_new = fmaxf(m_run, m_b);
-            const float fa = fast_exp2((m_run - m_new) * p.scale_log2e), fb = fast_exp2((m_b - m_new) * p.scale_log2e);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] = o0[r] * fa + src[r] * fb; o1[r] = o1[r] * fa + src[16 + r] * fb; }
-            l_run = l_run * fa + l_b * fb;
-            m_run = m_new;
-        }
-        __syncthreads();
-    }
-    if (wave != 0) return;
-    const float l_tot = xor32_sum(l_run);
-    const float inv = 1.0f / l_tot;
-    if (p.lse2 && half == 0) p.lse2[((size_t)b * p.heads + head) * p.lpad + q] = m_run * p.scale_log2e + log2f(l_tot);
-    bf16_t* orow = p.out + (row0 + q) * (size_t)(p.heads * 64) + head * 64;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = make_uint2(pack_bf2(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
-        *reinterpret_cast<uint2*>(orow + 32 + 8 * g + 4 * half) = make_uint2(pack_bf2(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
-    }
-}
-
 }  // namespace dgs
 
 using namespace dgs;
@@ -409,7 +291,6 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     p.qk = a->qk; p.vt = a->vt; p.out = a->out;
     p.scale_log2e = a->scale * 1.44269504088896341f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(a->B * a->heads * p.nqb), dim3(512), 0, st, p);
-    if (p.extra_unit) hipLaunchKernelGGL(attention_tail_kernel, dim3(a->B * a->heads), dim3(512), 0, st, p);
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(a->B * a->heads * p.nqb), dim3(576), 0, st, p);
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }
