@@ -12,6 +12,8 @@
 // [128 rows][128 B] images staged with 16-byte LDS-DMA (global_load_lds_dwordx4), double-buffered.  The LDS image is
 // lane-linear (DMA constraint), so the bank-conflict swizzle lives on the SOURCE address and on the ds_read_b128
 // address (rule 21): 16-byte chunk c of row r sits in slot c ^ ((r >> 1) & 7).
+#include <stdlib.h>
+
 #include "dit_common.h"
 #include "dgs_dit.h"
 
@@ -199,6 +201,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
+int deep_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);   // dit_gemm_deep.hip
+int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
+
 }  // namespace dgs
 
 using namespace dgs;
@@ -229,6 +234,12 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     p.k_per_batch = kpb; p.a_batch_stride = a->a_batch_stride; p.w_batch_stride = a->w_batch_stride;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
+    hipStream_t st0 = static_cast<hipStream_t>(stream);
+    static const bool force_simple = getenv("DGS_GEMM_SIMPLE") != nullptr;      // A/B switch for measurements
+    if (!force_simple) {
+        const int dbn = deep_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
+        if (dbn) return launch_deep_gemm(a, dbn, p.rows_per_batch, p.valid_rows, st0);
+    }
     // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each
     if (a->epilogue == DGS_EPI_QKV && a->N % 128) return DGS_ERR_INVALID_ARGUMENT;
     const int bn = (a->N % 128 || ((a->M / BM) * (a->N / 128) < 512 && a->epilogue != DGS_EPI_QKV)) ? 64 : 128;

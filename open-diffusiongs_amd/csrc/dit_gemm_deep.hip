@@ -1,0 +1,281 @@
+// dit_gemm_deep.hip -- deep-pipelined variant of the DiT GEMM (same contract and epilogues as dit_gemm.hip).
+//
+// Why a second kernel: rocprofv3 on the 128x128 / two-stage kernel shows ~3.5k cycles per K slab per workgroup against 512
+// cycles of MFMA issue -- every slab pays a full LDS-DMA round trip (L2 -> LDS, ~1.4 us under load) because only ONE slab
+// is in flight per workgroup and `__syncthreads()` drains it (vmcnt(0)) before anyone may continue.  Little's law: with
+// 64 KiB in flight per CU the chip streams ~12 TB/s into LDS, a third of what the L2 delivers.  This kernel
+//   * keeps NS-1 slabs in flight per workgroup (LDS ring of NS stages, 120-128 KiB, one 8-wave workgroup per CU),
+//     released by COUNTED `s_waitcnt vmcnt(N)` + a raw `s_barrier` (a `__syncthreads()` would drain the ring), one barrier
+//     per slab:   wait own DMAs of slab t -> barrier -> refill the stage read in iteration t-1 -> MFMAs on slab t;
+//   * uses 128 x BN tiles with BN = N / 8 where that makes the tile count a multiple of the CU count (batch 1:
+//     32 x 8 = 256 tiles for N = 1024 / 3072 / 4096), which also cuts the L2 -> LDS traffic per flop (128 x 384:
+//     96 flop/B, 128 x 512: 102, vs 64 for 128 x 128; the L2 needs 72 to keep the MFMAs fed);
+//   * gives the mostly-padding last M tile of a sample (L = 4098: two live rows) its own path: the eight waves split the BN
+//     columns and read fragments straight from L2 into registers -- no ring, no barriers -- because a tile that streams W
+//     through the ring costs a full tile's latency no matter how few rows are live.
+// Waves: 2 (M) x 4 (N); a wave owns 64 x BN/4 of the tile = 2 x (BN/128) accumulators of v_mfma_f32_32x32x16_bf16.
+#include "dit_common.h"
+#include "dgs_dit.h"
+
+namespace dgs {
+
+struct DeepParams {
+    int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles;
+    const bf16_t* A;
+    const bf16_t* W;
+    const float* bias;
+    void* out;
+    const float* gate;
+    const float* resid;
+    bf16_t* vt;
+    void* aux;
+};
+
+__device__ __forceinline__ float gelu_tanh_d(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+__device__ __forceinline__ float dgelu_tanh_d(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float sg = 1.0f / (1.0f + __expf(-2.0f * u));
+    return sg + x * sg * (1.0f - sg) * (2.0f * 0.7978845608028654f) * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+// ---- LDS image of a [rows][BK] bf16 slab: row-major, 16-byte chunk c of row r in slot
+//        BK = 64: c ^ ((r >> 1) & 7)   (128-byte rows)        BK = 32: c ^ ((r >> 2) & 3)   (64-byte rows)
+//      both conflict-free for ds_read_b128 when a 16-lane group reads 16 rows that are distinct mod 16.
+template <int BK>
+__device__ __forceinline__ int slab_off(int r, int c) {
+    return BK == 64 ? r * 128 + ((c ^ ((r >> 1) & 7)) << 4) : r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+}
+
+// DMA one [ROWS][BK] slab: wave-instructions of 1 KiB (1024 / (2 BK) rows each), spread over the 8 waves.
+template <int ROWS, int BK>
+__device__ __forceinline__ void stage_slab(const bf16_t* g, int ld, int row0, int k0, char* dst, int wave, int lane) {
+    constexpr int RPI = 1024 / (2 * BK);          // rows per instruction: 8 (BK 64) or 16 (BK 32)
+    constexpr int CPR = BK / 8;                   // 16-byte chunks per row
+    constexpr int NINST = ROWS / RPI;
+#pragma unroll
+    for (int q = 0; q < (NINST + 7) / 8; ++q) {
+        const int piece = wave + 8 * q;
+        if (NINST % 8 != 0 && piece >= NINST) break;
+        const int row = piece * RPI + lane / CPR;
+        const int slot = lane % CPR;
+        const int chunk = BK == 64 ? (slot ^ ((row >> 1) & 7)) : (slot ^ ((row >> 2) & 3));
+        glds16(g + (size_t)(row0 + row) * ld + k0 + chunk * 8, dst + piece * 1024);
+    }
+}
+
+template <int EPI, int NI>
+__device__ __forceinline__ void store_block(const DeepParams& p, const f32x16 (&acc)[NI], int mbase, int nbase, int lane) {
+    // D fragment: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); mbase already includes 4 * (lane >> 5)
+    const int b = mbase / p.rows_per_batch;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = nbase + ni * 32 + (lane & 31);
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+        const bool qkv_v = EPI == DGS_EPI_QKV && n >= (p.N / 3) * 2;
+        bf16_t* tdst = nullptr;
+        if (EPI == DGS_EPI_QKV) {
+            if (qkv_v) tdst = p.vt + ((size_t)b * (p.N / 3) + (n - (p.N / 3) * 2)) * p.rows_per_batch + (mbase - b * p.rows_per_batch);
+        } else if ((EPI == DGS_EPI_BF16 || EPI == DGS_EPI_GELU_BF16 || EPI == DGS_EPI_DGELU_BF16) && p.vt) {
+            tdst = p.vt + ((size_t)b * p.N + n) * p.rows_per_batch + (mbase - b * p.rows_per_batch);
+        }
+        float gate = 0.0f;
+        if (EPI == DGS_EPI_GATE_RESIDUAL) gate = p.gate[(size_t)b * p.gate_stride + n];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float o4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = mbase + q + 8 * g;
+                const float v = acc[ni][4 * g + q] + bias;
+                const size_t o = (size_t)m * p.ldo + n;
+                if (EPI == DGS_EPI_BF16) {
+                    o4[q] = v;
+                    reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(v);
+                } else if (EPI == DGS_EPI_QKV) {
+                    o4[q] = v;
+                    if (!qkv_v) reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(v);
+                } else if (EPI == DGS_EPI_GELU_BF16) {
+                    o4[q] = gelu_tanh_d(v);
+                    reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(o4[q]);
+                    if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = (bf16_t)f2bf_fast(v);
+                } else if (EPI == DGS_EPI_DGELU_BF16) {
+                    o4[q] = v * dgelu_tanh_d(bf2f(reinterpret_cast<const bf16_t*>(p.aux)[o]));
+                    reinterpret_cast<bf16_t*>(p.out)[o] = (bf16_t)f2bf_fast(o4[q]);
+                } else if (EPI == DGS_EPI_GATE_RESIDUAL) {
+                    reinterpret_cast<float*>(p.out)[o] = p.resid[o] + gate * v;
+                    if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = (bf16_t)f2bf_fast(v);
+                } else {
+                    reinterpret_cast<float*>(p.out)[o] = v;
+                }
+            }
+            if (tdst) *reinterpret_cast<uint2*>(tdst + 8 * g) = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
+        }
+    }
+}
+
+template <int EPI, int BN, int BK, int NS>
+__global__ __launch_bounds__(512, 2) void gemm_deep_kernel(DeepParams p) {
+    constexpr int NI = BN / 128;                                  // 32-column accumulator blocks per wave
+    constexpr int A_BYTES = 128 * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    static_assert((128 * 2 * BK / 1024) % 8 == 0 && (BN * 2 * BK / 1024) % 8 == 0, "every wave must issue the same number of DMAs per slab");
+    constexpr int G = (128 * 2 * BK / 1024) / 8 + (BN * 2 * BK / 1024) / 8;   // LDS-DMA instructions per wave per slab (vmcnt bookkeeping)
+    DGS_DYNAMIC_LDS(lds);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
+    const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
+    const int m0 = tm * 128, n0 = tn * BN;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int mrow_tile = m0 - (m0 / p.rows_per_batch) * p.rows_per_batch;
+    const int live_blocks = (p.valid_rows - mrow_tile + 31) / 32;            // 32-row blocks of this tile with live rows
+    const int nk = p.K / BK;
+
+    if (live_blocks <= 1) {
+        // ---- mostly-padding tile: at most one live 32-row block.  No ring, no barriers: the 8 waves split the BN / 32
+        //      column blocks, fragments come straight from global memory (L2). ----
+        if (live_blocks <= 0) return;
+        const bf16_t* arow = p.A + (size_t)(m0 + frow) * p.lda + fhalf * 8;
+        for (int cb = wave; cb < BN / 32; cb += 8) {
+            const bf16_t* wrow = p.W + (size_t)(n0 + cb * 32 + frow) * p.ldw + fhalf * 8;
+            f32x16 acc1[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < p.K; k += 16) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + k);
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(wrow + k);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc1[0], 0, 0, 0);
+            }
+            store_block<EPI, 1>(p, acc1, m0 + 4 * fhalf, n0 + cb * 32, lane);
+        }
+        return;
+    }
+
+    f32x16 acc[2][NI];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- prologue: NS - 1 slabs in flight ----
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+        if (s < nk) {
+            stage_slab<128, BK>(p.A, p.lda, m0, s * BK, lds + s * STAGE, wave, lane);
+            stage_slab<BN, BK>(p.W, p.ldw, n0, s * BK, lds + s * STAGE + A_BYTES, wave, lane);
+        }
+    }
+    for (int t = 0; t < nk; ++t) {
+        // slab t has landed once at most (slabs issued after it) * G of this wave's DMAs are still outstanding
+        const int after = min(nk - 1 - t, NS - 2);
+#ifndef HIPEMU
+        if (after >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ring is draining (last NS - 2 slabs)
+        __builtin_amdgcn_s_barrier();   // everybody's share of slab t landed; everybody finished reading slab t - 1
+#else
+        (void)after;
+        __syncthreads();
+#endif
+        if (t + NS - 1 < nk) {          // refill the stage that held slab t - 1
+            char* dst = lds + ((t + NS - 1) % NS) * STAGE;
+            stage_slab<128, BK>(p.A, p.lda, m0, (t + NS - 1) * BK, dst, wave, lane);
+            stage_slab<BN, BK>(p.W, p.ldw, n0, (t + NS - 1) * BK, dst + A_BYTES, wave, lane);
+        }
+        const char* cur = lds + (t % NS) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int c = 2 * ks + fhalf;
+            bf16x8 b[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(cur + A_BYTES + slab_off<BK>(wn * (BN / 4) + j * 32 + frow, c));
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(cur + slab_off<BK>(wm * 64 + frow, c));
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(cur + slab_off<BK>(wm * 64 + 32 + frow, c));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[j], acc[0][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[j], acc[1][j], 0, 0, 0);
+        }
+    }
+    // (a tile with >= 2 live blocks is computed and stored completely: rows that are padding hold finite values in the
+    // forward and exact zeros in the backward either way)
+    store_block<EPI, NI>(p, acc[0], m0 + wm * 64 + 4 * fhalf, n0 + wn * (BN / 4), lane);
+    store_block<EPI, NI>(p, acc[1], m0 + wm * 64 + 32 + 4 * fhalf, n0 + wn * (BN / 4), lane);
+}
+
+template <int EPI, int BN, int BK, int NS>
+static int launch_deep(DeepParams p, hipStream_t st) {
+    constexpr int STAGE = 128 * BK * 2 + BN * BK * 2;
+    constexpr int LDS = NS * STAGE;
+    static_assert(LDS <= 160 * 1024, "LDS ring too large");
+    p.tiles_n = p.N / BN;
+    p.ntiles = p.tiles_n * (p.M / 128);
+    auto kern = gemm_deep_kernel<EPI, BN, BK, NS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DGS_ERR_DEVICE;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(512), LDS, st, p);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+template <int EPI>
+static int dispatch_deep(const DeepParams& p, int bn, hipStream_t st) {
+    switch (bn) {
+        case 128: return launch_deep<EPI, 128, 64, 4>(p, st);      // stage 32 KiB, ring 128 KiB
+        case 256: return launch_deep<EPI, 256, 32, 5>(p, st);      // stage 24 KiB, ring 120 KiB
+        case 384: return launch_deep<EPI, 384, 32, 4>(p, st);      // stage 32 KiB, ring 128 KiB
+        case 512: return launch_deep<EPI, 512, 32, 3>(p, st);      // stage 40 KiB, ring 120 KiB
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
+}
+
+// Tile width for the deep kernel, or 0 when the shape is not eligible (then dit_gemm.hip's kernel runs).
+int deep_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows) {
+    if (k_per_batch != K || K % 64 || M % 128) return 0;     // batched-reduction (weight-gradient) GEMMs stay on the simple kernel
+    if (epilogue == DGS_EPI_QKV && N % 3) return 0;
+    // M tiles that run the ring (>= 2 live 32-row blocks); mostly-padding tiles take the cheap path and are not counted
+    const int tiles_per_sample = rows_per_batch / 128;
+    int full_per_sample = 0;
+    for (int i = 0; i < tiles_per_sample; ++i)
+        if (valid_rows - i * 128 > 32) ++full_per_sample;
+    const int mt = (M / rows_per_batch) * full_per_sample;
+    const int cand[4] = {512, 384, 256, 128};
+    int best = 0;
+    double best_cost = 1e30;
+    for (int i = 0; i < 4; ++i) {
+        const int bn = cand[i];
+        if (N % bn) continue;
+        const int tiles = mt * (N / bn);
+        const int rounds = (tiles + 255) / 256;
+        const double cost = (double)rounds * bn * (1.0 + 16.0 / bn);    // work per tile ~ bn; wider tiles move fewer L2 bytes per flop
+        if (cost < best_cost) { best_cost = cost; best = bn; }
+    }
+    return best;
+}
+
+int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st) {
+    DeepParams p;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
+    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows;
+    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
+    p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
+    switch (a->epilogue) {
+        case DGS_EPI_BF16: return dispatch_deep<DGS_EPI_BF16>(p, bn, st);
+        case DGS_EPI_GELU_BF16: return dispatch_deep<DGS_EPI_GELU_BF16>(p, bn, st);
+        case DGS_EPI_GATE_RESIDUAL: return dispatch_deep<DGS_EPI_GATE_RESIDUAL>(p, bn, st);
+        case DGS_EPI_F32: return dispatch_deep<DGS_EPI_F32>(p, bn, st);
+        case DGS_EPI_QKV: return dispatch_deep<DGS_EPI_QKV>(p, bn, st);
+        case DGS_EPI_DGELU_BF16: return dispatch_deep<DGS_EPI_DGELU_BF16>(p, bn, st);
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
+}
+
+}  // namespace dgs

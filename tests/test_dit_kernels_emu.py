@@ -50,13 +50,18 @@ def test_gemm_padding_blocks_are_skipped(ops):
     A = _bf(torch.randn(B * rows, K, generator=g))
     W = _bf(torch.randn(N, K, generator=g) * 0.1)
     ref = A.float() @ W.float().t()
-    for valid in (130, 33, 256):
+    for valid in (130, 33, 200, 256):
         out = torch.full((B * rows, N), 7.0)
         ops.gemm(A, W, None, _native.EPI_F32, out=out, rows_per_batch=rows, valid_rows=valid)
-        live = (valid + 31) // 32 * 32      # blocks with at least one valid row are computed completely
         for b in range(B):
-            assert torch.allclose(out[b * rows: b * rows + live], ref[b * rows: b * rows + live], atol=1e-3, rtol=1e-4)
-            assert bool((out[b * rows + live: (b + 1) * rows] == 7.0).all())
+            blk = out[b * rows:(b + 1) * rows]
+            rblk = ref[b * rows:(b + 1) * rows]
+            # every valid row is computed; a padding row is either computed (finite, correct) or left untouched
+            assert torch.allclose(blk[:valid], rblk[:valid], atol=1e-3, rtol=1e-4)
+            pad_ok = torch.isclose(blk[valid:], rblk[valid:], atol=1e-3, rtol=1e-4).all(1) | (blk[valid:] == 7.0).all(1)
+            assert bool(pad_ok.all())
+        if valid == 33:       # second 128-row tile of each sample holds one live block only: its other 96 rows are skipped
+            assert bool((out[128 + 32:256] == 7.0).all())
     # narrow-tile variant (chosen when 128 x 128 tiles would under-fill the chip) gives the same numbers
     out = ops.gemm(A, W, None, _native.EPI_F32)
     assert torch.allclose(out, ref, atol=1e-3, rtol=1e-4)
