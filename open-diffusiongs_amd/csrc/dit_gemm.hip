@@ -23,7 +23,7 @@ constexpr int BM = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB: A tile of one stage (the W tile is BN/128 of that)
 
 struct GemmParams {
-    int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles;
+    int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles, tiles_m, map_mode;
     int k_per_batch;                 // reduction elements per sample (K when the reduction dimension is not batched)
     long long a_batch_stride, w_batch_stride;   // element stride between samples along the reduction (weight-gradient GEMMs)
     const bf16_t* A;
@@ -121,7 +121,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: live0/live1 become scalar branches
     const int wm = wave >> 1, wn = wave & 1;
     const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
-    const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
+    // map_mode 0: an XCD's contiguous id range walks tn fastest (A row panels stay in that XCD's L2, W streams through);
+    // map_mode 1: tm fastest (a W column panel stays resident, A streams through)
+    const int tn = p.map_mode ? logical / p.tiles_m : logical % p.tiles_n;
+    const int tm = p.map_mode ? logical % p.tiles_m : logical / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     // Padding rows (row-in-sample >= valid_rows) are never observed: a 32-row accumulator block made only of padding
     // skips its MFMAs and its stores (its output rows keep the finite values they had), which makes the one
@@ -212,7 +215,10 @@ template <int EPI>
 static void launch_gemm(const GemmParams& p0, int bn, hipStream_t st) {
     GemmParams p = p0;
     p.tiles_n = p.N / bn;
-    p.ntiles = p.tiles_n * (p.M / BM);
+    p.tiles_m = p.M / BM;
+    p.ntiles = p.tiles_n * p.tiles_m;
+    static const int map_env = getenv("DGS_GEMM_MAP") ? atoi(getenv("DGS_GEMM_MAP")) : 0;
+    p.map_mode = map_env;
     if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 128>), dim3(p.ntiles), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 64>), dim3(p.ntiles), dim3(256), 0, st, p);
 }
@@ -235,8 +241,11 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     hipStream_t st0 = static_cast<hipStream_t>(stream);
-    static const bool force_simple = getenv("DGS_GEMM_SIMPLE") != nullptr;      // A/B switch for measurements
-    if (!force_simple) {
+    // The deep-pipelined kernel (dit_gemm_deep.hip) measured SLOWER than this one on MI355X at every DiT shape
+    // (profiles/r01_bench_kernel_stats_deep_gemm_experiment.txt: fc1 107 vs 62 us, qkv 77 vs 42 us): both move ~37 GB/s per
+    // CU into LDS, i.e. the GEMMs are bound by the L2/MALL -> LDS stream, not by its latency.  It stays opt-in.
+    static const bool use_deep = getenv("DGS_GEMM_DEEP") != nullptr;
+    if (use_deep) {
         const int dbn = deep_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
         if (dbn) return launch_deep_gemm(a, dbn, p.rows_per_batch, p.valid_rows, st0);
     }
