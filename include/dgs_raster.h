@@ -153,6 +153,11 @@ int dgs_cameras_from_c2w(int32_t n, const float* c2w, const float* fxfycxcy, int
                          float znear, float zfar, float* viewmatrix, float* projmatrix, float* campos, float* tanfov,
                          dgs_stream_t stream);
 
+/* Per-pixel rays of n cameras in one launch; replaces TransformInput (diffusionGS/systems/utils.py:621-684,751-757), the step
+ * immediately before the denoiser.  c2w [n,16], fxfycxcy [n,4] -> ray_o, ray_d [n,3,H,W] (ray_d unit length). */
+int dgs_rays_from_c2w(int32_t n, const float* c2w, const float* fxfycxcy, int32_t height, int32_t width, float* ray_o,
+                      float* ray_d, dgs_stream_t stream);
+
 /* Introspection for the parity tests: copies a named array of the forward state out of the
  * opaque buffers into `dst` (device pointer, `dst_bytes` capacity).  Names: "depths", "means2D",
  * "conic_opacity", "rgb", "tiles_touched", "clamped", "cov3D", "ranges", "n_contrib", "final_T",

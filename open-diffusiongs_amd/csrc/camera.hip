@@ -77,7 +77,41 @@ __global__ void cameras_kernel(int n, const float* c2w, const float* fxfycxcy, i
     tanfov[2 * i + 1] = (float)H / (2.0f * fy);
 }
 
+// Per-pixel rays of all (sample, view) cameras in one launch: TransformInput, diffusionGS/systems/utils.py:621-684,751-757
+// (the step immediately before image_to_gaussians; the reference builds them with a meshgrid, a bmm and two norms per call).
+// ray_d = normalize(R [ (x + .5 - cx) / fx, (y + .5 - cy) / fy, 1 ]),  ray_o = camera centre; outputs [n, 3, H, W] planar.
+__global__ __launch_bounds__(256) void rays_kernel(int n, const float* c2w, const float* fxfycxcy, int H, int W, float* ray_o, float* ray_d) {
+    const size_t HW = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * HW) return;
+    const int cam = (int)(i / HW);
+    const int px = (int)(i % W), py = (int)((i / W) % H);
+    const float* m = c2w + 16 * cam;
+    const float* k = fxfycxcy + 4 * cam;
+    const float x = ((float)px + 0.5f - k[2]) / k[0];
+    const float y = ((float)py + 0.5f - k[3]) / k[1];
+    float dx = x * m[0] + y * m[1] + m[2];
+    float dy = x * m[4] + y * m[5] + m[6];
+    float dz = x * m[8] + y * m[9] + m[10];
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx /= nrm; dy /= nrm; dz /= nrm;
+    const size_t o = (size_t)cam * 3 * HW + (size_t)py * W + px;
+    ray_d[o] = dx; ray_d[o + HW] = dy; ray_d[o + 2 * HW] = dz;
+    ray_o[o] = m[3]; ray_o[o + HW] = m[7]; ray_o[o + 2 * HW] = m[11];
+}
+
 }  // namespace dgs
+
+extern "C" int dgs_rays_from_c2w(int32_t n, const float* c2w, const float* fxfycxcy, int32_t height, int32_t width, float* ray_o,
+                                 float* ray_d, dgs_stream_t stream) {
+    if (n < 0 || height <= 0 || width <= 0) return DGS_ERR_INVALID_ARGUMENT;
+    if (n == 0) return DGS_OK;
+    if (!c2w || !fxfycxcy || !ray_o || !ray_d) return DGS_ERR_INVALID_ARGUMENT;
+    const size_t total = (size_t)n * height * width;
+    hipLaunchKernelGGL(dgs::rays_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, c2w,
+                       fxfycxcy, height, width, ray_o, ray_d);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
 
 extern "C" int dgs_cameras_from_c2w(int32_t n, const float* c2w, const float* fxfycxcy, int32_t height, int32_t width,
                                     float znear, float zfar, float* viewmatrix, float* projmatrix, float* campos,

@@ -55,7 +55,7 @@ class DgsRasterBackwardArgs(ctypes.Structure):
 # every symbol include/dgs_raster.h declares (checked by tests/test_abi.py)
 RASTER_SYMBOLS = ["dgs_abi_version", "dgs_status_string", "dgs_raster_geom_bytes", "dgs_raster_image_bytes",
                   "dgs_raster_binning_bytes", "dgs_raster_forward", "dgs_raster_backward", "dgs_mark_visible",
-                  "dgs_raster_state_read", "dgs_cameras_from_c2w"]
+                  "dgs_raster_state_read", "dgs_cameras_from_c2w", "dgs_rays_from_c2w"]
 
 
 def _declare(L):
@@ -80,6 +80,9 @@ def _declare(L):
     L.dgs_cameras_from_c2w.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]
+    L.dgs_rays_from_c2w.restype = ctypes.c_int
+    L.dgs_rays_from_c2w.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.dgs_raster_state_read.restype = ctypes.c_int64
     L.dgs_raster_state_read.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

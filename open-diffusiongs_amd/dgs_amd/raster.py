@@ -187,6 +187,20 @@ class RasterBackend:
         self._check(rc)
         return view, proj, campos, tanfov
 
+    def rays_from_c2w(self, c2w, fxfycxcy, height, width):
+        """TransformInput (systems/utils.py:621-757): c2w [b,v,4,4], fxfycxcy [b,v,4] -> ray_o, ray_d [b,v,3,H,W]."""
+        device = c2w.device
+        lead = tuple(c2w.shape[:-2])
+        c = _prep(c2w.reshape(-1, 4, 4), device)
+        k = _prep(fxfycxcy.reshape(-1, 4), device)
+        n = int(c.shape[0])
+        ray_o = torch.empty((n, 3, int(height), int(width)), dtype=torch.float32, device=device)
+        ray_d = torch.empty_like(ray_o)
+        rc = self.lib.dgs_rays_from_c2w(n, _ptr(c), _ptr(k), int(height), int(width), _ptr(ray_o), _ptr(ray_d), self._stream(device))
+        self._check(rc)
+        shape = lead + (3, int(height), int(width))
+        return ray_o.reshape(shape), ray_d.reshape(shape)
+
     def render_views(self, xyz, features, scaling, rotation, opacity, height, width, c2w, fxfycxcy, bg=None):
         """Forward-only batched render of RAW Gaussian parameters (what Renderer.forward / deferred_gaussian_render do
         per (sample, view) in the reference, renderer.py:34-92, gs_core.py:874-1016): xyz [B,P,3], features [B,P,M,3],

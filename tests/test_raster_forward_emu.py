@@ -64,3 +64,25 @@ def test_more_gaussians_than_one_bitmap_window():
     P = 16128 * 32 + 5000
     sc, cams = small_scene(P, W, H, seed=12, log_scale=-6.0, spread=0.8)
     assert_forward_parity(emu_backend(), sc, cams, H, W, CPU)
+
+
+def test_camera_and_ray_kernels_match_oracle():
+    """`Camera` (gs_core.py:277-316) and `TransformInput` (systems/utils.py:621-757) as single launches vs the oracle's
+    torch restatements (the ray restatement is itself pinned against the reference's own function in test_dit_oracle.py)."""
+    import torch
+    from dgs_amd import cameras
+    from oracle import dit_oracle as D
+    be = emu_backend()
+    B, V, H, W = 2, 3, 24, 40
+    c2w = torch.tensor(np.stack([cameras.ring_cameras(V, phase_deg=21.0 * b, radius=2.5 + b) for b in range(B)]))
+    k = torch.tensor(cameras.default_fxfycxcy(W, H)).expand(B, V, 4).contiguous() * torch.tensor([1.0, 1.1, 0.97, 1.02])
+    ro, rd = be.rays_from_c2w(c2w, k, H, W)
+    ro_ref, rd_ref = D.transform_input_rays(c2w, k, H, W)
+    np.testing.assert_allclose(ro.numpy(), ro_ref.numpy(), atol=1e-6)
+    np.testing.assert_allclose(rd.numpy(), rd_ref.numpy(), atol=2e-6)
+    view, proj, campos, tanfov = be.cameras_from_c2w(c2w, k, H, W)
+    v_ref, p_ref, c_ref, t_ref = D.camera_matrices(c2w.reshape(-1, 4, 4), k.reshape(-1, 4), H, W)
+    np.testing.assert_allclose(view.numpy(), v_ref.numpy(), atol=2e-6)
+    np.testing.assert_allclose(proj.numpy(), p_ref.numpy(), atol=2e-5)
+    np.testing.assert_allclose(campos.numpy(), c_ref.numpy(), atol=0)
+    np.testing.assert_allclose(tanfov.numpy(), t_ref.numpy(), rtol=1e-6)
