@@ -19,7 +19,7 @@
  *   dgs_dit_gaussians      <- GaussiansUpsampler.to_gs + hard pixel alignment   denoiser.py:103-120,370-413
  *
  * Plain C: raw device pointers + sizes + a HIP stream.  bf16 tensors are passed as uint16_t*.
- * Internal token layout ("padded rows"): every sample owns `lpad` consecutive rows (lpad % 128 == 0,
+ * Internal token layout ("padded rows"): every sample owns `lpad` consecutive rows (lpad % 256 == 0,
  * lpad >= L); rows [0, L-n_g) are the image tokens in the reference's (v, hh, ww) order, rows
  * [L-n_g, L) are the n_g learned Gaussian tokens (the reference puts them FIRST; every operator of the
  * block is permutation-equivariant over tokens, so only the final gather restores the order), rows

@@ -55,7 +55,8 @@ static int token_count(const DgsDitModel* m, int V, int H, int W) { return m->n_
 
 using namespace dgs;
 
-extern "C" int32_t dgs_dit_lpad(int32_t L) { return (L + 127) / 128 * 128; }
+// 256-row granularity: the 256 x 256 GEMM tiles must not straddle samples (the 128-wide kernels skip the extra dead tile)
+extern "C" int32_t dgs_dit_lpad(int32_t L) { return (L + 255) / 256 * 256; }
 
 extern "C" size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W) {
     if (!m || B <= 0 || V <= 0 || H <= 0 || W <= 0 || m->patch <= 0) return 0;

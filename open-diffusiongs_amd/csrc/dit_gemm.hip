@@ -123,8 +123,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
     // map_mode 0: an XCD's contiguous id range walks tn fastest (A row panels stay in that XCD's L2, W streams through);
     // map_mode 1: tm fastest (a W column panel stays resident, A streams through)
-    const int tn = p.map_mode ? logical / p.tiles_m : logical % p.tiles_n;
-    const int tm = p.map_mode ? logical % p.tiles_m : logical / p.tiles_n;
+    int tn, tm;
+    if (p.map_mode >= 2) {
+        // grouped order: ids walk GM = map_mode tile rows (tm fastest) before moving to the next tile column, so the ~64
+        // tiles an XCD runs at once form a compact GM x (64 / GM) block whose A and W panels fit that XCD's 4 MiB L2
+        const int gsz = p.map_mode * p.tiles_n, grp = logical / gsz, in = logical - grp * gsz;
+        const int first = grp * p.map_mode, gm = min(p.tiles_m - first, p.map_mode);
+        tm = first + in % gm;
+        tn = in / gm;
+    } else {
+        tn = p.map_mode ? logical / p.tiles_m : logical % p.tiles_n;
+        tm = p.map_mode ? logical % p.tiles_m : logical / p.tiles_n;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     // Padding rows (row-in-sample >= valid_rows) are never observed: a 32-row accumulator block made only of padding
     // skips its MFMAs and its stores (its output rows keep the finite values they had), which makes the one
@@ -206,6 +216,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
 int deep_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);   // dit_gemm_deep.hip
 int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
+bool big_gemm_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch);
+int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows, hipStream_t st);
 
 }  // namespace dgs
 
@@ -244,6 +256,9 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     // The deep-pipelined kernel (dit_gemm_deep.hip) measured SLOWER than this one on MI355X at every DiT shape
     // (profiles/r01_bench_kernel_stats_deep_gemm_experiment.txt: fc1 107 vs 62 us, qkv 77 vs 42 us): both move ~37 GB/s per
     // CU into LDS, i.e. the GEMMs are bound by the L2/MALL -> LDS stream, not by its latency.  It stays opt-in.
+    static const bool no_big = getenv("DGS_GEMM_NO_BIG") != nullptr;          // A/B switch
+    if (!no_big && big_gemm_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
+        return launch_big_gemm(a, p.rows_per_batch, p.valid_rows, st0);
     static const bool use_deep = getenv("DGS_GEMM_DEEP") != nullptr;
     if (use_deep) {
         const int dbn = deep_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);

@@ -209,6 +209,135 @@ __global__ __launch_bounds__(512, 2) void gemm_deep_kernel(DeepParams p) {
     store_block<EPI, NI>(p, acc[1], m0 + wm * 64 + 32 + 4 * fhalf, n0 + wn * (BN / 4), lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tiles, 8 waves (2 x 4, each 128 x 64 = 4 x 2 accumulators), two 64 KiB stages, plain __syncthreads().
+// Measurements on MI355X (profiles/): every variant of the 128-wide kernels moves ~37-40 GB/s per CU from L2 into LDS
+// (~10 TB/s chip-wide) whatever the ring depth or tile order -- the GEMMs are bound by that stream, so throughput is
+// proportional to the tile's flop per staged byte: 64 for 128 x 128, 128 for 256 x 256.  Used where 256-wide tiles still
+// cover the chip (N >= 3072: QKV, fc1 and the fc2 input-gradient GEMM); at batch 1, M = 4224 gives 16 full tile rows
+// (16 x 16 = 256 tiles for N = 4096) plus one mostly-padding row that takes the direct-from-L2 path.
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(DeepParams p) {
+    constexpr int BMB = 256, BNB = 256, BK = 64;
+    constexpr int OP_BYTES = BMB * BK * 2, STAGE = 2 * OP_BYTES;       // 32 KiB per operand, 64 KiB per stage
+    DGS_DYNAMIC_LDS(lds);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
+    const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
+    const int m0 = tm * BMB, n0 = tn * BNB;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int mrow_tile = m0 - (m0 / p.rows_per_batch) * p.rows_per_batch;
+    const int live_blocks = (p.valid_rows - mrow_tile + 31) / 32;
+    if (live_blocks <= 1) {            // mostly-padding tile: no staging, fragments straight from L2
+        if (live_blocks <= 0) return;
+        const bf16_t* arow = p.A + (size_t)(m0 + frow) * p.lda + fhalf * 8;
+        for (int cb = wave; cb < BNB / 32; cb += 8) {
+            const bf16_t* wrow = p.W + (size_t)(n0 + cb * 32 + frow) * p.ldw + fhalf * 8;
+            f32x16 acc1[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < p.K; k += 16)
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + k),
+                                                                  *reinterpret_cast<const bf16x8*>(wrow + k), acc1[0], 0, 0, 0);
+            store_block<EPI, 1>(p, acc1, m0 + 4 * fhalf, n0 + cb * 32, lane);
+        }
+        return;
+    }
+    // rows of this tile that exist in memory (the last tile row of a sample may reach past M): staging clamps, stores skip
+    const int rows_here = min(BMB, p.M - m0);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto stage = [&](int k0, char* dst) {
+        // A: 32 wave-instructions of 1 KiB (8 rows each), 4 per wave; rows past the end of A are clamped (never stored)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave + 8 * q;
+            const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            const int ar = row < rows_here ? row : rows_here - 1;
+            glds16(p.A + (size_t)(m0 + ar) * p.lda + k0 + chunk * 8, dst + piece * 1024);
+            glds16(p.W + (size_t)(n0 + row) * p.ldw + k0 + chunk * 8, dst + OP_BYTES + piece * 1024);
+        }
+    };
+    const int nk = p.K / BK;
+    stage(0, lds);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const char* cur = lds + (t & 1) * STAGE;
+        if (t + 1 < nk) stage((t + 1) * BK, lds + ((t + 1) & 1) * STAGE);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + fhalf;
+            bf16x8 b[2], a[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(cur + OP_BYTES + slab_off<64>(wn * 64 + j * 32 + frow, c));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cur + slab_off<64>(wm * 128 + i * 32 + frow, c));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mb = wm * 128 + i * 32;
+        if (mb < rows_here) store_block<EPI, 2>(p, acc[i], m0 + mb + 4 * fhalf, n0 + wn * 64, lane);
+    }
+}
+
+template <int EPI>
+static int launch_big(DeepParams p, hipStream_t st) {
+    constexpr int LDS = 2 * 2 * 256 * 64 * 2;      // 128 KiB
+    p.tiles_n = p.N / 256;
+    p.ntiles = p.tiles_n * ((p.M + 255) / 256);
+    auto kern = gemm_big_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DGS_ERR_DEVICE;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(512), LDS, st, p);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+// 256 x 256 tiles are used when they still give every CU work: N a multiple of 256 and >= 3072, plain (non-batched) reduction.
+bool big_gemm_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch) {
+    if (k_per_batch != K || K % 64 || N % 256 || N < 3072 || M < 2048) return false;
+    if (rows_per_batch % 128) return false;
+    if (epilogue == DGS_EPI_QKV && N % 3) return false;
+    // a 256-row tile must not straddle two samples' live rows in a way the padding logic cannot express: require that every
+    // sample starts on a tile boundary or that there is a single sample
+    return rows_per_batch % 256 == 0 || M == rows_per_batch;
+}
+
+int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows, hipStream_t st) {
+    DeepParams p;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
+    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows;
+    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
+    p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
+    switch (a->epilogue) {
+        case DGS_EPI_BF16: return launch_big<DGS_EPI_BF16>(p, st);
+        case DGS_EPI_GELU_BF16: return launch_big<DGS_EPI_GELU_BF16>(p, st);
+        case DGS_EPI_GATE_RESIDUAL: return launch_big<DGS_EPI_GATE_RESIDUAL>(p, st);
+        case DGS_EPI_F32: return launch_big<DGS_EPI_F32>(p, st);
+        case DGS_EPI_QKV: return launch_big<DGS_EPI_QKV>(p, st);
+        case DGS_EPI_DGELU_BF16: return launch_big<DGS_EPI_DGELU_BF16>(p, st);
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
+}
+
 template <int EPI, int BN, int BK, int NS>
 static int launch_deep(DeepParams p, hipStream_t st) {
     constexpr int STAGE = 128 * BK * 2 + BN * BK * 2;

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported():
             assert hasattr(lib, n), f"{n} declared in {header} but not exported"
         assert sorted(table) == names, (header, sorted(set(names) ^ set(table)))
     assert lib.dgs_abi_version() == 1
-    assert lib.dgs_dit_lpad(4098) == 4224
+    assert lib.dgs_dit_lpad(4098) == 4352
     assert lib.dgs_status_string(-1).decode().startswith("invalid argument")
 
 

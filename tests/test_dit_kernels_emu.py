@@ -278,3 +278,21 @@ def test_rowlinear_backward_and_gate_mul(ops):
     assert torch.allclose(dyo.float(), want, atol=3e-2, rtol=1e-2)
     assert torch.equal(dyT, dyo.reshape(B, rows, Wd).transpose(1, 2))
     assert torch.allclose(dgate[:, Wd:], (dxr * y.float()).reshape(B, rows, Wd).sum(1), atol=1e-3, rtol=1e-4)
+
+
+def test_gemm_256_tiles(ops):
+    """256 x 256 tile kernel (N >= 3072): ragged last tile row (rows past M are clamped on load, never stored), padding path."""
+    g = torch.Generator().manual_seed(31)
+    M, N, K = 2176, 3072, 64                       # 8.5 tile rows
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.2)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    out = ops.gemm(A, W, bias, _native.EPI_F32)
+    assert torch.allclose(out, ref, atol=2e-3, rtol=1e-4)
+    out = torch.full((M, N), 7.0)
+    ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=M, valid_rows=2050)      # last tile row: one live block
+    assert torch.allclose(out[:2080], ref[:2080], atol=2e-3, rtol=1e-4) and bool((out[2080:] == 7.0).all())
+    qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=M)
+    assert torch.allclose(qk.float(), ref[:, :2048], atol=3e-2, rtol=1e-2)
+    assert torch.allclose(vt.float()[0], ref[:, 2048:].t(), atol=3e-2, rtol=1e-2)

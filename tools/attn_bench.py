@@ -12,7 +12,7 @@ from dgs_amd.dit import DitOps
 
 DEV = "cuda:0"
 ops = DitOps()
-L, lpad, W, heads = 4098, 4224, 1024, 16
+L, lpad, W, heads = 4098, 4352, 1024, 16
 g = torch.Generator(device=DEV).manual_seed(0)
 bf = lambda *s: torch.randn(*s, generator=g, device=DEV).to(torch.bfloat16)
 qk, vt = bf(lpad, 2 * W), bf(1, W, lpad)

@@ -36,7 +36,7 @@ def main():
     ops = DitOps()
     W, heads = 1024, 16
     L = 2 + 4 * (a.res // 8) ** 2
-    lpad = (L + 127) // 128 * 128
+    lpad = (L + 255) // 256 * 256
     M = a.batch * lpad
     g = torch.Generator(device=DEV).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g, device=DEV)
