@@ -50,6 +50,13 @@ typedef enum DgsGemmEpilogue {
      * GELU_BF16 / GATE_RESIDUAL additionally write the pre-activation / pre-gate value to `aux` (bf16 [M, ldo]) when set. */
 } DgsGemmEpilogue;
 
+typedef enum DgsGemmAlgo {
+    DGS_GEMM_AUTO = 0,
+    DGS_GEMM_SIMPLE128 = 1,    /* 128 x 128|64 tiles, two LDS stages, 2 workgroups / CU (what AUTO picks)              */
+    DGS_GEMM_DEEP = 2,         /* 128 x N/8 tiles, NS-stage LDS-DMA ring, counted vmcnt + raw barrier                  */
+    DGS_GEMM_BIG256 = 3        /* 256 x 256 tiles, two stages (N >= 3072)                                              */
+} DgsGemmAlgo;
+
 typedef struct DgsDitGemmArgs {
     int32_t M, N, K;           /* M % 128 == 0, N % 128 == 0, K % 64 == 0                             */
     const uint16_t* A;         /* bf16 [M, lda]                                                       */
@@ -70,6 +77,7 @@ typedef struct DgsDitGemmArgs {
                                   are a_batch_stride / w_batch_stride elements apart (weight gradients: reduction over the
                                   tokens of [batch, features, lpad] transposed activations)                          */
     int64_t a_batch_stride, w_batch_stride;
+    int32_t algo;              /* DgsGemmAlgo; 0 = automatic                                                           */
     int32_t valid_rows;        /* 0 or rows_per_batch: every row is computed.  Otherwise rows [valid_rows, rows_per_batch)
                                   of every sample are padding: 32-row blocks made only of padding are neither computed
                                   nor stored (their output rows keep their previous contents).                       */

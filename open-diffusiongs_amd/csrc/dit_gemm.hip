@@ -253,14 +253,14 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     hipStream_t st0 = static_cast<hipStream_t>(stream);
-    // The deep-pipelined kernel (dit_gemm_deep.hip) measured SLOWER than this one on MI355X at every DiT shape
-    // (profiles/r01_bench_kernel_stats_deep_gemm_experiment.txt: fc1 107 vs 62 us, qkv 77 vs 42 us): both move ~37 GB/s per
-    // CU into LDS, i.e. the GEMMs are bound by the L2/MALL -> LDS stream, not by its latency.  It stays opt-in.
-    static const bool no_big = getenv("DGS_GEMM_NO_BIG") != nullptr;          // A/B switch
-    if (!no_big && big_gemm_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
+    // Kernel choice.  Measured on MI355X at the DiT shapes (profiles/r01_*gemm*): all three kernels stream ~12-40 GB/s per CU
+    // from L2 into LDS and none beats the 128-wide two-stage kernel by more than ~10 % on any shape, so AUTO = that kernel;
+    // the deep-ring (dit_gemm_deep.hip) and 256 x 256 kernels are selectable for experiments and are covered by the tests.
+    static const int env_algo = getenv("DGS_GEMM_ALGO") ? atoi(getenv("DGS_GEMM_ALGO")) : 0;
+    const int algo = a->algo ? a->algo : env_algo;
+    if (algo == DGS_GEMM_BIG256 && big_gemm_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
         return launch_big_gemm(a, p.rows_per_batch, p.valid_rows, st0);
-    static const bool use_deep = getenv("DGS_GEMM_DEEP") != nullptr;
-    if (use_deep) {
+    if (algo == DGS_GEMM_DEEP) {
         const int dbn = deep_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
         if (dbn) return launch_deep_gemm(a, dbn, p.rows_per_batch, p.valid_rows, st0);
     }

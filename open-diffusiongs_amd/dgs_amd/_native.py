@@ -120,6 +120,7 @@ def status_string(L, code):
 # include/dgs_dit.h
 # ---------------------------------------------------------------------------------------------------
 EPI_BF16, EPI_GELU_BF16, EPI_GATE_RESIDUAL, EPI_F32, EPI_QKV, EPI_DGELU_BF16 = range(6)
+GEMM_AUTO, GEMM_SIMPLE128, GEMM_DEEP, GEMM_BIG256 = range(4)
 
 
 class DgsDitGemmArgs(ctypes.Structure):
@@ -128,7 +129,8 @@ class DgsDitGemmArgs(ctypes.Structure):
                 ("bias", ctypes.c_void_p), ("epilogue", ctypes.c_int32), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int32),
                 ("gate", ctypes.c_void_p), ("gate_stride", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32),
                 ("vt", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("k_per_batch", ctypes.c_int32),
-                ("a_batch_stride", ctypes.c_int64), ("w_batch_stride", ctypes.c_int64), ("valid_rows", ctypes.c_int32)]
+                ("a_batch_stride", ctypes.c_int64), ("w_batch_stride", ctypes.c_int64), ("algo", ctypes.c_int32),
+                ("valid_rows", ctypes.c_int32)]
 
 
 class DgsDitAttentionArgs(ctypes.Structure):

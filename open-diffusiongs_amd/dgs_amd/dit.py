@@ -35,7 +35,7 @@ class DitOps:
             raise RuntimeError(f"dgs dit: {_native.status_string(self.lib, rc)} (status {rc})")
 
     def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None, valid_rows=0,
-             resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None):
+             resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None, algo=0):
         """A bf16 [M,K], W bf16 [N,K] -> per epilogue (see dgs_dit.h).  `out` is required for GATE_RESIDUAL (in-place)."""
         if shape is not None:          # batched-reduction form (weight gradients): operands are [batch, rows, tokens]
             M, N, K = shape
@@ -64,7 +64,7 @@ class DitOps:
         a.k_per_batch, a.a_batch_stride, a.w_batch_stride = k_per_batch, a_batch_stride, w_batch_stride
         a.bias, a.epilogue, a.out, a.ldo = _p(bias), epilogue, _p(out), ldo
         a.gate, a.gate_stride, a.rows_per_batch, a.vt = _p(gate), (gate.stride(0) if gate is not None else 0), rows_per_batch, _p(vt)
-        a.valid_rows = valid_rows
+        a.valid_rows, a.algo = valid_rows, algo
         self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))
         return (out, vt) if epilogue == _native.EPI_QKV else out
 

@@ -280,6 +280,23 @@ def test_rowlinear_backward_and_gate_mul(ops):
     assert torch.allclose(dgate[:, Wd:], (dxr * y.float()).reshape(B, rows, Wd).sum(1), atol=1e-3, rtol=1e-4)
 
 
+def test_gemm_deep_ring_kernel(ops):
+    """Opt-in deep-ring kernel: same results as the default kernel on every tile width it can pick."""
+    g = torch.Generator().manual_seed(32)
+    for (M, N, K) in ((256, 384, 192), (256, 512, 128), (384, 256, 128), (256, 128, 256)):
+        A = _bf(torch.randn(M, K, generator=g))
+        W = _bf(torch.randn(N, K, generator=g) * 0.2)
+        bias = torch.randn(N, generator=g)
+        ref = A.float() @ W.float().t() + bias
+        out = ops.gemm(A, W, bias, _native.EPI_F32, algo=_native.GEMM_DEEP)
+        assert torch.allclose(out, ref, atol=2e-3, rtol=1e-4), (M, N, K)
+    out = torch.full((256, 384), 7.0)
+    A = _bf(torch.randn(256, 64, generator=g)); W = _bf(torch.randn(384, 64, generator=g))
+    ops.gemm(A, W, None, _native.EPI_F32, out=out, rows_per_batch=256, valid_rows=130, algo=_native.GEMM_DEEP)
+    ref = A.float() @ W.float().t()
+    assert torch.allclose(out[:160], ref[:160], atol=2e-3, rtol=1e-4) and bool((out[160:] == 7.0).all())
+
+
 def test_gemm_256_tiles(ops):
     """256 x 256 tile kernel (N >= 3072): ragged last tile row (rows past M are clamped on load, never stored), padding path."""
     g = torch.Generator().manual_seed(31)
@@ -288,11 +305,12 @@ def test_gemm_256_tiles(ops):
     W = _bf(torch.randn(N, K, generator=g) * 0.2)
     bias = torch.randn(N, generator=g)
     ref = A.float() @ W.float().t() + bias
-    out = ops.gemm(A, W, bias, _native.EPI_F32)
+    big = _native.GEMM_BIG256
+    out = ops.gemm(A, W, bias, _native.EPI_F32, algo=big)
     assert torch.allclose(out, ref, atol=2e-3, rtol=1e-4)
     out = torch.full((M, N), 7.0)
-    ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=M, valid_rows=2050)      # last tile row: one live block
+    ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=M, valid_rows=2050, algo=big)   # last tile row: one live block
     assert torch.allclose(out[:2080], ref[:2080], atol=2e-3, rtol=1e-4) and bool((out[2080:] == 7.0).all())
-    qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=M)
+    qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=M, algo=big)
     assert torch.allclose(qk.float(), ref[:, :2048], atol=3e-2, rtol=1e-2)
     assert torch.allclose(vt.float()[0], ref[:, 2048:].t(), atol=3e-2, rtol=1e-2)
