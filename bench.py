@@ -47,6 +47,17 @@ def kernel_flops(kind, L, B, width=1024):
     return 2.0 * L * n * B
 
 
+def measured_traffic(kernel, batch):
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_pmc_traffic.json; collected
+    with tools/pmc_run.py exactly as MI355X_MICROARCH.md prescribes).  Only valid for the shape it was measured on (batch 1)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        v = d.get(kernel, {}).get("traffic_bytes_per_launch")
+        return int(v) if (v is not None and batch == 1) else None
+    except Exception:
+        return None
+
+
 def synth_batch(B, V, res, device, seed):
     """Synthetic inputs of the reference's shapes: U[0,1) images, ring cameras radius 3, G-Objaverse
     intrinsics; rays as TransformInput (systems/utils.py:621-757) computes them -- upstream of the timed step."""
@@ -192,7 +203,8 @@ def main():
                        "batch_per_gpu": B, "views": V, "resolution": res, "tokens": L, "gaussians": 2 + V * res * res,
                        "dit_tflop_per_sample": round(dit_flops(L) / 1e12, 3), "parallelism": f"dp{world}"},
             "roofline": {"kernel": a.roofline_kernel, "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_MFMA, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_MFMA, 4),
+                         "traffic": measured_traffic(a.roofline_kernel, B) if res == 256 and V == 4 else None,
                          "launches_timed": len(kern_ms), "avg_launch_us": round(avg_s * 1e6, 2)},
         }
         if world == 1 and not a.no_cpu_baseline:
