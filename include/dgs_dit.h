@@ -81,6 +81,9 @@ typedef struct DgsDitGemmArgs {
     int32_t valid_rows;        /* 0 or rows_per_batch: every row is computed.  Otherwise rows [valid_rows, rows_per_batch)
                                   of every sample are padding: 32-row blocks made only of padding are neither computed
                                   nor stored (their output rows keep their previous contents).                       */
+    float q_scale;             /* DGS_EPI_QKV: the q features (n < N/3) are multiplied by q_scale before the bf16 rounding
+                                  (0 -> 1).  The denoiser passes scale * log2(e) so that the attention kernel gets its
+                                  pre-scaled queries with a single rounding (DgsDitAttentionArgs.q_prescaled).        */
 } DgsDitGemmArgs;
 
 typedef struct DgsDitAttentionArgs {
@@ -94,6 +97,8 @@ typedef struct DgsDitAttentionArgs {
     int32_t k_offset;          /* elements from a row's q features to its k features; 0 -> heads*64                */
     int64_t vt_batch_stride;   /* elements between samples of `vt`; 0 -> heads*64*lpad                             */
     float* lse2;               /* optional out [B, heads, lpad]: log2-domain log-sum-exp per query (for backward)  */
+    int32_t q_prescaled;       /* nonzero: the q features already carry the factor scale * log2(e) (DgsDitGemmArgs.q_scale);
+                                  0: the kernel applies it to the bf16 queries itself (one extra bf16 rounding)       */
 } DgsDitAttentionArgs;
 
 typedef struct DgsDitAttentionBackwardArgs {

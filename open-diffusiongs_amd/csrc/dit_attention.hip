@@ -2,7 +2,7 @@
 //
 // Replaces F.scaled_dot_product_attention(q, k, v) as called by timm==0.9.16 Attention.forward (non-causal, no mask,
 // scale = head_dim^-1/2, head_dim = 64), used by DiTBlock (utils_transformer.py:254-256, 286).  The S = L x L score
-// matrix is never materialised: per 128-query workgroup (4 waves x 32 queries) the kernel walks 64-key tiles with an
+// matrix is never materialised: per 256-query workgroup (8 waves x 32 queries) the kernel walks 64-key tiles with an
 // online softmax (fp32 running max / sum, fp32 accumulators).
 //
 // Formulation (cdna_hip_programming.md appendix B, "swapped QK^T"): every MFMA is computed transposed,
@@ -14,10 +14,20 @@
 // as both operands agree, so the V^T fragment is simply read with the accumulator's row pattern).
 // V arrives already transposed ([B, heads*64, lpad]) from the QKV GEMM epilogue, so no transposing LDS access is needed.
 //
+// VALU diet (the loop is VALU-bound at head_dim 64: 32 scores per lane per tile against 16 MFMAs):
+//   * Q is multiplied by scale * log2(e) once, when its fragments are loaded, and the S accumulators START at -m (the
+//     running max, a per-lane scalar kept splatted in 16 registers as the MFMA's C operand) -- so the matrix pipe hands
+//     back S' - m and the softmax is a bare v_exp_f32 per score: no per-score multiply / subtract;
+//   * deferred rescale (T13): m only moves when a score outgrows it by more than 2^RESCALE_THR.
+//
 // LDS: K tile [64 keys][128 B] and V^T tile [64 d][128 B], both with the 16-byte slot swizzle s ^ ((row >> 1) & 7)
 // (conflict-free ds_read_b128); inside a V^T row every 16-key group is stored as [k0-3, k8-11 | k4-7, k12-15] so the 8
-// keys a lane contributes to one MFMA k-step are one 16-byte read.  Two stages, register-staged prefetch of the next
-// tile issued before the MFMAs of the current one (T14), one barrier per tile.
+// keys a lane contributes to one MFMA k-step are one 16-byte read.  K ring 3 deep, V^T ring 2 deep, register-staged
+// prefetch of the next tiles issued at the top of an iteration and written behind its MFMAs (T14), one barrier per tile.
+// Every operand fragment is read from LDS a whole phase before the MFMAs that consume it.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "dit_common.h"
 #include "dgs_dit.h"
 
@@ -30,28 +40,16 @@ constexpr int KV_TILE_BYTES = KB * 64 * 2;   // 8 KiB
 constexpr float RESCALE_THR = 6.0f;          // deferred-max threshold in exp2 units: P <= 64
 
 struct AttnParams {
-    int B, heads, L, lpad, ld_qk, k_offset, nqb, extra_unit;
+    int B, heads, L, lpad, ld_qk, k_offset, nqb, nfull, nmain, dbg, q_prescaled;
     long long vt_batch_stride;
     float* lse2;
+    float* tail_ws;          // [B * heads][chunks][L % 32][TAIL_REC] partial results of the tail workgroups
+    unsigned* tail_cnt;      // [B * heads] arrival counters (zero between launches)
     const bf16_t* qk;
     const bf16_t* vt;
     bf16_t* out;
     float scale_log2e;
 };
-
-// S^T block pair of one 64-key tile: A = K fragments from LDS, B = Q fragments (registers).
-__device__ __forceinline__ void qk_tile(const char* kb, const bf16x8 (&qf)[4], int l31, int half, int kswz, f32x16& s0, f32x16& s1) {
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const char* krow = kb + l31 * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int off = ((2 * ks + half) ^ kswz) << 4;
-        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(krow + off);
-        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(krow + 32 * 128 + off);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], ks == 0 ? zero16 : s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], ks == 0 ? zero16 : s1, 0, 0, 0);
-    }
-}
 
 __device__ __forceinline__ float row_max(const f32x16& s0, const f32x16& s1) {
     float mx = fmaxf(s0[0], s1[0]);
@@ -62,214 +60,491 @@ __device__ __forceinline__ float row_max(const f32x16& s0, const f32x16& s1) {
 
 template <int V> struct Mode { static constexpr int value = V; };
 
-__device__ __forceinline__ void mask_tile(f32x16& s0, f32x16& s1, int key0, int half, int L) {
+// bf16 query value times scale * log2(e), rounded back to bf16 (the B operand of S' = K (c Q)^T)
+__device__ __forceinline__ uint32_t scale_bf2(uint32_t two, float c) {
+    return pack_bf2(bf2f(two & 0xffffu) * c, bf2f(two >> 16) * c);
+}
+
+// The L % 32 queries behind the last full 32-query unit (the two learned tokens of the DiT: L = 32 k + 2) would cost a
+// whole extra wave per head on the matrix pipe.  Their attention is split over the KEY tiles instead: behind the main loop
+// of every workgroup of the head wave w takes key tile qblk + nqb * w (if it exists), computes exp2(S' - tile max), its sum and its P V for the tail queries with the same
+// MFMA formulation (fragments straight from global memory, no LDS) and parks one record {max, sum, O[64]} per tail
+// query in a library-owned workspace.  The last workgroup of the (sample, head) to finish merges the records.
+//
+// Cross-workgroup hand-off without fences: a release fence at agent scope writes back the whole L2 (~15 us behind 8 MB of
+// attention output); the records are written and read with agent-scope atomics instead (sc1: performed at the memory
+// side, coherent across XCDs), ordered by vmcnt(0) + barrier before the arrival counter is bumped.
+union PFrag { bf16x8 v; uint32_t u[4]; };
+
+constexpr int TAIL_REC = 66;          // floats per (key tile, query) record: max, sum, O[64]
+
+__device__ __forceinline__ void st_agent(float* ptr, float v) {
+#ifdef HIPEMU
+    *ptr = v;
+#else
+    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ float2 ld_agent2(const float2* ptr) {
+#ifdef HIPEMU
+    return *ptr;
+#else
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+#endif
+}
+
+__device__ __forceinline__ int pi16(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// one key tile of the tail queries, by one wave; rec = this tile's records [r][TAIL_REC]
+__device__ __forceinline__ void tail_tile(const AttnParams& p, int t, int r, const bf16_t* Qg, const bf16_t* Kg, const bf16_t* Vg, float* rec, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    // fragments: Q (B operand) of the tail unit, K rows pi-permuted like the LDS image, V^T rows as they are
+    const int qrow = p.nfull * 32 + l31, qld = qrow < p.lpad ? qrow : p.lpad - 1;
+    bf16x8 qf[4], kf[8], vf[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (key >= L) s0[r] = -__builtin_inff();
-        if (key + 32 >= L) s1[r] = -__builtin_inff();
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 raw = *reinterpret_cast<const uint4*>(Qg + (size_t)qld * p.ld_qk + (2 * ks + half) * 8);
+        if (!p.q_prescaled) {
+            raw.x = scale_bf2(raw.x, p.scale_log2e); raw.y = scale_bf2(raw.y, p.scale_log2e);
+            raw.z = scale_bf2(raw.z, p.scale_log2e); raw.w = scale_bf2(raw.w, p.scale_log2e);
+        }
+        qf[ks] = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int key = t * KB + pi16(l31 + 32 * blk);
+            kf[2 * ks + blk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)(key < p.L ? key : p.L - 1) * p.ld_qk + (2 * ks + half) * 8);
+            vf[2 * ks + blk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)(l31 + 32 * blk) * p.lpad + t * KB + 16 * ks + 8 * half);
+        }
+    }
+    f32x16 s0 = zero16, s1 = zero16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * ks], qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * ks + 1], qf[ks], s1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {          // keys >= L (only the last tile has any)
+        const int key = t * KB + (rr & 3) + 4 * ((rr >> 2) & 1) + 8 * half + 16 * (rr >> 3);
+        if (key >= p.L) s0[rr] = -__builtin_inff();
+        if (key + 32 >= p.L) s1[rr] = -__builtin_inff();
+    }
+    const float mx = row_max(s0, s1);          // finite: every tile holds a key < L
+    PFrag pf[4];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) { s0[rr] = fast_exp2(s0[rr] - mx); s1[rr] = fast_exp2(s1[rr] - mx); }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 8 * (ks & 1) + 2 * j;
+            pf[ks].u[j] = ks < 2 ? pack_bf2(s0[e], s0[e + 1]) : pack_bf2(s1[e], s1[e + 1]);
+        }
+    f32x16 o0 = zero16, o1 = zero16, la = zero16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2 * ks], pf[ks].v, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2 * ks + 1], pf[ks].v, o1, 0, 0, 0);
+        la = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[ks].v, la, 0, 0, 0);
+    }
+    if (l31 < r) {                             // lane owns query l31: d = db * 32 + 8 (rr >> 2) + 4 half + (rr & 3)
+        float* q = rec + l31 * TAIL_REC;
+        if (half == 0) { st_agent(q, mx); st_agent(q + 1, la[0]); }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int d = 8 * (rr >> 2) + 4 * half + (rr & 3);
+            st_agent(q + 2 + d, o0[rr]);
+            st_agent(q + 2 + 32 + d, o1[rr]);
+        }
     }
 }
 
-// Workgroup = 256 queries of one (sample, head): 8 waves x 32 queries, two waves per SIMD, one workgroup per CU.  The
-// kernel is latency-bound per wave (a wave needs ~the same time for its 65 tiles whether or not the CU is shared), so the
-// work decomposition must come out in ONE round of the 256 CUs: L = 4098 = 16 * 256 + 2, and a 17th query block per head
-// for the two learned-token queries would cost a whole second round.  Instead the launch uses 9-wave workgroups and the
-// 9th wave of a head's last block takes the odd 32-query unit (`extra_unit`); everywhere else it exits at once.
-// The grid is 1-D with head = id % heads: all query blocks of a head run on one XCD (dispatch places block b on XCD
-// b % 8) and re-read that head's K / V^T (1 MiB) from its L2.
-// Software pipeline (T15): while the VALU works through the softmax of tile t, the matrix pipe already runs
-// S(t+1) = K(t+1) Q^T; K and V^T therefore live in two 2-deep rings that are one tile out of phase.
-__global__ __launch_bounds__(576) void attention_fwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[4 * KV_TILE_BYTES];   // K ring [2] | V^T ring [2]
+// merge of the nrec per-tile records of one (sample, head), by the whole workgroup (512 threads)
+__device__ void tail_merge(const AttnParams& p, int bh, int nrec, int r, char* lds) {
+    const int tid = threadIdx.x, head = bh % p.heads, b = bh / p.heads;
+    // records of consecutive tiles are contiguous: pull them into LDS in batches (independent coalesced loads), then
+    // every thread folds the batch into the running {max, sum, O} of its (query, d) items
+    float* lbuf = reinterpret_cast<float*>(lds);
+    const float* const recs = p.tail_ws + (size_t)bh * nrec * r * TAIL_REC;
+    const int per_rec = r * TAIL_REC;
+    const int cb = 15360 / per_rec;                            // tiles per batch (60 KiB of LDS)
+    float Mr[4], lr[4], orr[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { Mr[it] = -3.0e38f; lr[it] = 0.0f; orr[it] = 0.0f; }
+    for (int c0 = 0; c0 < nrec; c0 += cb) {
+        const int n = nrec - c0 < cb ? nrec - c0 : cb;
+        __syncthreads();
+        const float2* src = reinterpret_cast<const float2*>(recs + (size_t)c0 * per_rec);       // 66 floats per record: 8-byte aligned
+        const int n2 = n * per_rec / 2;
+        for (int i0 = 0; i0 < n2; i0 += 10 * 512) {             // 10 independent loads in flight per thread
+            float2 v[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int i = i0 + u * 512 + tid;
+                v[u] = i < n2 ? ld_agent2(src + i) : make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int i = i0 + u * 512 + tid;
+                if (i < n2) reinterpret_cast<float2*>(lbuf)[i] = v[u];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + it * 512;
+            if (i >= r * 64) break;
+            const float* rec = lbuf + (i >> 6) * TAIL_REC;
+            float M = Mr[it];
+            for (int c = 0; c < n; ++c) M = fmaxf(M, rec[c * per_rec]);
+            const float w0 = fast_exp2(Mr[it] - M);
+            float l = lr[it] * w0, o = orr[it] * w0;
+            for (int c = 0; c < n; ++c) {
+                const float w = fast_exp2(rec[c * per_rec] - M);
+                l += w * rec[c * per_rec + 1];
+                o += w * rec[c * per_rec + 2 + (i & 63)];
+            }
+            Mr[it] = M; lr[it] = l; orr[it] = o;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = tid + it * 512;
+        if (i >= r * 64) break;
+        const int qq = i >> 6, d = i & 63, qrow = p.nfull * 32 + qq;
+        p.out[((size_t)b * p.lpad + qrow) * (size_t)(p.heads * 64) + head * 64 + d] = (bf16_t)f2bf_fast(orr[it] / lr[it]);
+        if (d == 0 && p.lse2) p.lse2[((size_t)b * p.heads + head) * p.lpad + qrow] = Mr[it] + log2f(lr[it]);
+    }
+}
+
+// Workgroup = 256 queries of one (sample, head): 8 waves x 32 queries, two waves per SIMD, one workgroup per CU.  At
+// L = 4098 that is 16 heads x 16 blocks = 256 workgroups = exactly one round of the 256 CUs (the L % 32 = 2
+// learned-token queries go to the tail workgroups above).  The grid is 1-D with head = id % heads: all query blocks of a
+// head run on one XCD (dispatch places block b on XCD b % 8) and re-read that head's K / V^T (1 MiB) from its L2.
+//
+// Staging is LDS-DMA (global_load_lds, 16 B per lane, no registers): K tile rows are stored PERMUTED -- LDS row R holds
+// key pi(R) = R with bits 2 and 3 swapped -- so that the 8 accumulator rows a lane owns inside a 16-row group are 8
+// CONSECUTIVE keys, and the matching V^T fragment is one plain 16-byte read of the token-contiguous V^T row; both tiles
+// use the 16-byte slot swizzle slot ^ ((row >> 1) & 7), applied on the DMA's source address and on the ds_read address.
+// Rings are 4 tiles deep; the DMA for K(t+4) / V(t+3) is issued at the top of iteration t and only has to have landed
+// by the end of iteration t+1 (counted vmcnt, raw s_barrier): more than a full iteration of flight time.
+//
+// Issue schedule (tools/ubench/issue_bench: on one SIMD a v_mfma_f32_32x32x16_bf16 occupies the matrix pipe for 32
+// cycles and hides ~6 plain VALU issued behind it; v_exp_f32 costs two issue slots, packed-f32 VALU stalls beside MFMAs).
+// The loop is VALU-issue bound at head_dim 64, so the goal is that no MFMA ever waits and no VALU slot is wasted: one
+// iteration is cut into 16 SLICES of { 1 MFMA, 1 LDS fragment read, 6 VALU }, fenced with sched_barrier so the order
+// below is the issue order.  Slices 0-7 carry S'(t+1) = K(t+1) (cQ)^T - m, slices 8-15 carry O^T += V^T(t) P^T(t); the
+// VALU list is the softmax of tile t (80 ops: exp2, row-sum add, bf16 pack; pf[g] is complete before the P V slice that
+// consumes it) followed by the row max of S'(t+1) (17 ops).
+constexpr int RING = 4;
+__device__ long long dgs_attn_dbg[4096 + 64];   // DGS_ATTN_DBG & 4: loop cycles (s_memtime) per wave of the first 512 workgroups; & 8: phases of wg 0
+
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
+}
+
+// flat VALU op list of the softmax of one tile: group g = K / 12 produces pf[g] from 8 scores as (exp2, exp2, pack) x 4
+// (the row sums are NOT formed on the VALU: a ones fragment rides through the matrix pipe beside V^T, see `lacc`)
+template <int K> __device__ __forceinline__ void softmax_step(f32x16& s0, f32x16& s1, PFrag (&pf)[4]) {
+    constexpr int g = K / 12, o = K % 12, j = o / 3, base = 8 * (g & 1);
+    f32x16& s = g < 2 ? s0 : s1;
+    if constexpr (o % 3 < 2) s[base + 2 * j + o % 3] = fast_exp2(s[base + 2 * j + o % 3]);
+    else pf[g].u[j] = pack_bf2(s[base + 2 * j], s[base + 2 * j + 1]);
+}
+// VALU steps per slice, balanced by issue cycles (tools/ubench/issue_bench: v_exp_f32 8, v_cvt_pk / v_max3 5, LDS read
+// ~5; at most 30 per slice incl. its LDS reads, next to the MFMA's 8): softmax steps in slices 0-15, row max in 15-18.
+__device__ constexpr int SLICE_END[20] = {2, 4, 8, 12, 14, 16, 20, 24, 28, 29, 30, 34, 38, 42, 46, 51, 56, 61, 64, 64};
+// row max of the next tile's scores, two per step (one v_max3_f32 each; hipcc fuses only every other pair on its own)
+template <int K> __device__ __forceinline__ void max_step(const f32x16& n0, const f32x16& n1, float& mx) {
+    const f32x16& n = K < 8 ? n0 : n1;
+    constexpr int e = 2 * (K & 7);
+    if constexpr (K == 0) mx = fmaxf(n[e], n[e + 1]);
+    else mx = __builtin_fmaxf(__builtin_fmaxf(mx, n[e]), n[e + 1]);
+}
+
+__global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
+    DGS_DYNAMIC_LDS(lds);                              // K ring [4] | V^T ring [4]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+#ifndef HIPEMU
+#define MAIN_STAMP(i) if ((p.dbg & 8) && blockIdx.x == 0 && tid == 0) dgs_attn_dbg[4096 + 16 + (i)] = clock64()
+#else
+#define MAIN_STAMP(i)
+#endif
+    MAIN_STAMP(0);
     // ---- block -> (sample, head, query block) ----
     int id = blockIdx.x;
     const int head = id % p.heads; id /= p.heads;
     const int qblk = id % p.nqb, b = id / p.nqb;
-    // 32-query unit of this wave; wave 8 exists only to take the odd unit behind the last full block
-    int unit = qblk * NW + wave;
-    if (wave == NW) {
-        if (!(p.extra_unit && qblk == p.nqb - 1)) return;   // leaves before the first barrier
-        unit = p.nqb * NW;
-    }
+    const int unit = qblk * NW + wave;                 // this wave's 32-query unit
+    const bool wave_live = unit < p.nfull;             // other waves only help with staging and barriers
     const size_t row0 = (size_t)b * p.lpad;
     const bf16_t* Qg = p.qk + row0 * p.ld_qk + head * 64;
     const bf16_t* Kg = Qg + p.k_offset;
     const bf16_t* Vg = p.vt + (size_t)b * p.vt_batch_stride + (size_t)head * 64 * p.lpad;
 
-    // Q fragments (B operand): query = lane & 31, d-chunk = 2 ks + half.  Rows >= lpad do not exist: clamp (never stored).
+    // Q fragments (B operand), pre-multiplied by scale * log2(e): query = lane & 31, d-chunk = 2 ks + half.
     const int q = unit * 32 + l31;
     const int qld = q < p.lpad ? q : p.lpad - 1;
     bf16x8 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qld * p.ld_qk + (2 * ks + half) * 8);
-    // a wave whose 32 queries are all padding rows only helps with staging and barriers
-    const bool wave_live = unit * 32 < p.L;
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 raw = *reinterpret_cast<const uint4*>(Qg + (size_t)qld * p.ld_qk + (2 * ks + half) * 8);
+        if (!p.q_prescaled) {
+            raw.x = scale_bf2(raw.x, p.scale_log2e); raw.y = scale_bf2(raw.y, p.scale_log2e);
+            raw.z = scale_bf2(raw.z, p.scale_log2e); raw.w = scale_bf2(raw.w, p.scale_log2e);
+        }
+        qf[ks] = __builtin_bit_cast(bf16x8, raw);
+    }
 
     f32x16 oacc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.0f;
-    float m_run = -1.0e30f, l_run = 0.0f;
+        for (int r = 0; r < 16; ++r) oacc[j][r] = 0.0f;
+    // Row sums l = sum_k P[q][k] come out of the matrix pipe: lacc^T = ones . P^T accumulates beside O^T (every row of the
+    // 32 x 32 block is the same sum, of the bf16-rounded P the numerator uses) -- 4 more MFMAs per tile instead of 32 adds.
+    f32x16 lacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.0f;
+    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    float m_run = 0.0f;                                   // log2 units (scores are pre-scaled)
 
     const int ntiles = (p.L + KB - 1) / KB;
     const int mask_from = p.L / KB;                       // first tile that contains keys >= L (== ntiles if none)
-    // staging: 512 16-byte chunks per tile, one K chunk and one V^T chunk per thread (row sr, column sc)
-    const int sr = tid >> 3, sc = tid & 7;
-    const bf16_t* kptr = Kg + (size_t)sr * p.ld_qk + sc * 8;
-    const bf16_t* vptr = Vg + (size_t)sr * p.lpad + sc * 8;
-    const int ksw = (sr >> 1) & 7;
-    const int koff = sr * 128 + ((sc ^ ksw) << 4);
-    // V^T row d: each 16-key group is stored as [k0-3, k8-11 | k4-7, k12-15] so that the 8 keys one lane needs for an
-    // MFMA k-step (accumulator rows 4h..4h+3 and 8+4h..8+4h+3) are ONE 16-byte slot: slot 2g + h of the row.
-    const int vslot = (sc >> 1) * 2;
-    const int voff0 = sr * 128 + (((vslot) ^ ksw) << 4) + 8 * (sc & 1);
-    const int voff1 = sr * 128 + (((vslot + 1) ^ ksw) << 4) + 8 * (sc & 1);
+    // ---- LDS-DMA staging: a tile is 8 pieces of 1 KiB (8 rows); wave w moves piece w of K and of V^T ----
     char* const kring = lds;
-    char* const vring = lds + 2 * KV_TILE_BYTES;
-    uint4 kreg, vreg;
+    char* const vring = lds + RING * KV_TILE_BYTES;
+    const int R = 8 * wave + (lane >> 3);                          // LDS row this lane fills
+    const int chunk = (lane & 7) ^ ((R >> 1) & 7);                 // 16-byte source chunk that belongs in LDS slot lane & 7
+    const bf16_t* const ksrc = Kg + (size_t)pi16(R) * p.ld_qk + chunk * 8;
+    const bf16_t* const vsrc = Vg + (size_t)R * p.lpad + chunk * 8;
+    auto stage_k = [&](int tile, int slot) { glds16(ksrc + (size_t)tile * KB * p.ld_qk, kring + slot * KV_TILE_BYTES + wave * 1024); };
+    auto stage_v = [&](int tile, int slot) { glds16(vsrc + (size_t)tile * KB, vring + slot * KV_TILE_BYTES + wave * 1024); };
+    // per-lane fragment address inside a tile: fragment i = 2 ks + blk -> row l31 + 32 blk, 16-byte slot (2 ks + half) ^ swizzle
     const int kswz = (l31 >> 1) & 7;
-
-    // ---- prologue: K(0), V(0) -> LDS; K(1) -> LDS; S_cur = QK(0) ----
-    const bool stager = wave < NW;        // the 512 threads of waves 0..7 move the tiles
-    if (stager) {
-        kreg = *reinterpret_cast<const uint4*>(kptr);
-        vreg = *reinterpret_cast<const uint4*>(vptr);
-        *reinterpret_cast<uint4*>(kring + koff) = kreg;
-        *reinterpret_cast<uint2*>(vring + voff0) = make_uint2(vreg.x, vreg.y);
-        *reinterpret_cast<uint2*>(vring + voff1) = make_uint2(vreg.z, vreg.w);
-        if (ntiles > 1) {
-            kreg = *reinterpret_cast<const uint4*>(kptr + (size_t)KB * p.ld_qk);
-            *reinterpret_cast<uint4*>(kring + KV_TILE_BYTES + koff) = kreg;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = l31 * 128 + (((2 * ks + half) ^ kswz) << 4);
+    auto frag = [&](const char* tile, int i) { return *reinterpret_cast<const bf16x8*>(tile + foff[i >> 1] + (i & 1) * 32 * 128); };
+    // key (inside the tile) of accumulator register r of key block kb: LDS row 32 kb + (r & 3) + 8 (r >> 2) + 4 half, un-permuted
+    auto mask_tile = [&](f32x16& s0, f32x16& s1, int key0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * half + 16 * (r >> 3);
+            if (key >= p.L) s0[r] = -__builtin_inff();
+            if (key + 32 >= p.L) s1[r] = -__builtin_inff();
         }
-    }
-    // Retire every outstanding global load (incl. the Q fragments) HERE: left pending, hipcc's in-order vmcnt
-    // bookkeeping makes each tile's first MFMAs wait for that tile's just-issued prefetch.
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    };
+
+    // ---- prologue: K(0..3), V(0..2) in flight; wait for all of it (and the Q fragments) ----
+#pragma unroll
+    for (int j = 0; j < RING; ++j)
+        if (j < ntiles) stage_k(j, j);
+#pragma unroll
+    for (int j = 0; j < RING - 1; ++j)
+        if (j < ntiles) stage_v(j, j);
+#ifndef HIPEMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
-    // ---- first tile: S(0), its row max, and the initial running max ----
-    f32x16 s0, s1;
-    float mx = -1.0e30f;
+    MAIN_STAMP(1);
+    // ---- first tile: S'(0), its row max = the initial running max; fragments of K(1) ----
+    f32x16 s0, s1, negm;
+    bf16x8 kf[8];
     if (wave_live) {
-        qk_tile(kring, qf, l31, half, kswz, s0, s1);
-        if (mask_from == 0) mask_tile(s0, s1, 0, half, p.L);
-        mx = row_max(s0, s1);
-        m_run = mx;                          // first tile always "rescales" (O and l are still zero)
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kf[i] = frag(kring, i);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * ks], qf[ks], ks == 0 ? zero16 : s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * ks + 1], qf[ks], ks == 0 ? zero16 : s1, 0, 0, 0);
+        }
+        if (mask_from == 0) mask_tile(s0, s1, 0);
+        m_run = row_max(s0, s1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] -= m_run; s1[r] -= m_run; negm[r] = -m_run; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kf[i] = frag(kring + KV_TILE_BYTES, i);     // K(1), first half; iteration 0 reads the rest
     }
-    __syncthreads();   // K(0) is overwritten by K(2) at the end of iteration 0: every wave must be done reading it
+    __syncthreads();   // K(0)'s slot is refilled with K(4) at the top of iteration 0: every wave must be done reading it
 
-    // One iteration = one 64-key tile t, in two MFMA||VALU phases that live in ONE basic block each:
-    //   phase A   matrix pipe: S(t+1) = K(t+1) Q^T        VALU: P(t) = exp2(S(t) c - m c), row sums, bf16 packing
-    //   phase B   matrix pipe: O^T += V^T(t) P^T(t)       VALU: row max of S(t+1)
-    // then the (rare, wave-uniform) deferred rescale for tile t+1 -- after ALL of P(t) V(t) has been issued (T13 hazard) --
-    // and the staging writes + barrier.  MODE 0: steady state, 1: S(t+1) is the ragged last tile (masked), 2: last tile
-    // (no S(t+1)).  Three straight-line copies instead of in-loop branches keep every phase a single scheduling region.
-    auto iteration = [&](int t, auto mode_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        const bool pk = stager && t + 2 < ntiles, pvs = stager && MODE != 2;
-        if (pk) kreg = *reinterpret_cast<const uint4*>(kptr + (size_t)(t + 2) * KB * p.ld_qk);
-        if (pvs) vreg = *reinterpret_cast<const uint4*>(vptr + (size_t)(t + 1) * KB);
+    // One iteration = one 64-key tile t.  MODE 0: steady state, 1: S(t+1) is the last tile (ragged: masked), 2: last tile
+    // (no S(t+1)).  Straight-line copies instead of in-loop branches.  `cs*` hold P(t) (in: S'(t) - m), `ns*` receive
+    // S'(t+1) - m: the caller alternates two register sets, so nothing is copied between iterations.
+    auto iteration = [&](int t, const int slot, auto mode_tag, f32x16& cs0, f32x16& cs1, f32x16& ns0, f32x16& ns1) {
+        constexpr int MODE = decltype(mode_tag)::value;     // slot == t % RING; a literal at the steady-state call sites
+        int issued = 0;
+        if (MODE == 0 && !(p.dbg & 1)) {
+            if (t + RING < ntiles) { stage_k(t + RING, slot); ++issued; }
+            if (t + RING - 1 < ntiles) { stage_v(t + RING - 1, (slot + RING - 1) & (RING - 1)); ++issued; }
+        }
         if (wave_live) {
-            f32x16 n0, n1;
-            const float mb = m_run * p.scale_log2e;
-            // ---------------- phase A ----------------
-            if (MODE != 2) qk_tile(kring + ((t + 1) & 1) * KV_TILE_BYTES, qf, l31, half, kswz, n0, n1);
-            float psum = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] = fast_exp2(__builtin_fmaf(s0[r], p.scale_log2e, -mb));
-                s1[r] = fast_exp2(__builtin_fmaf(s1[r], p.scale_log2e, -mb));
-                psum += s0[r] + s1[r];
-            }
-            l_run += psum;
-            union { bf16x8 v; uint32_t u[4]; } pf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 8 * (ks & 1) + 2 * j;
-                    pf[ks].u[j] = (ks < 2) ? pack_bf2(s0[r], s0[r + 1]) : pack_bf2(s1[r], s1[r + 1]);
+            bf16x8 vf[8];
+            PFrag pf[4];
+            float mx = 0.0f;
+            const char* const vtile = vring + slot * KV_TILE_BYTES;
+            const char* const ktile1 = kring + ((slot + 1) & (RING - 1)) * KV_TILE_BYTES;      // K(t+1)
+            const char* const ktile2 = kring + ((slot + 2) & (RING - 1)) * KV_TILE_BYTES;      // K(t+2)
+            static_for<0, 20>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                // ---- matrix pipe: slices 0-7 S'(t+1); slices 8-19 per k-step { O^T block 0, O^T block 1, row sums } ----
+                if constexpr (J < 8) {
+                    if constexpr (MODE != 2) {
+                        constexpr int ks = J >> 1;
+                        if constexpr ((J & 1) == 0) ns0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[J], qf[ks], ks == 0 ? negm : ns0, 0, 0, 0);
+                        else ns1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[J], qf[ks], ks == 0 ? negm : ns1, 0, 0, 0);
+                    }
+                } else {
+                    constexpr int ks = (J - 8) / 3, w = (J - 8) % 3;
+                    if constexpr (w < 2) oacc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2 * ks + w], pf[ks].v, oacc[w], 0, 0, 0);
+                    else lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[ks].v, lacc, 0, 0, 0);
                 }
+                // ---- LDS: three bursts -- slices 0-1: K(t+1) fragments 4-7 (used from slice 4); 4-5: V^T(t) fragments 0-3 (from
+                //      slice 8); 9-10: V^T(t) fragments 4-7 (from slice 14) and K(t+2) fragments 0-3 (next iteration).  hipcc waits
+                //      with lgkmcnt(0) at the first use of a burst, so no read may be in flight shortly before such a point. ----
+                if constexpr (J < 2 && MODE != 2) { kf[4 + 2 * J] = frag(ktile1, 4 + 2 * J); kf[5 + 2 * J] = frag(ktile1, 5 + 2 * J); }
+                if constexpr (J == 4 || J == 5) { vf[2 * J - 8] = frag(vtile, 2 * J - 8); vf[2 * J - 7] = frag(vtile, 2 * J - 7); }
+                if constexpr (J == 9 || J == 10) {
+                    vf[2 * J - 14] = frag(vtile, 2 * J - 14); vf[2 * J - 13] = frag(vtile, 2 * J - 13);
+                    if constexpr (MODE == 0) { kf[2 * J - 18] = frag(ktile2, 2 * J - 18); kf[2 * J - 17] = frag(ktile2, 2 * J - 17); }
+                }
+                // ---- VALU: [softmax(t) x 48 | row max of S'(t+1) x 16]; pf[ks] is complete 2+ slices before its P V ----
+                constexpr int K0 = J == 0 ? 0 : SLICE_END[J == 0 ? 0 : J - 1], K1 = SLICE_END[J];
+                static_for<K0, K1>([&](auto kc) {
+                    constexpr int K = decltype(kc)::value;
+                    if constexpr (K < 48) softmax_step<K>(cs0, cs1, pf);
+                    else if constexpr (MODE != 2) {
+                        if constexpr (MODE == 1 && K == 48) mask_tile(ns0, ns1, (t + 1) * KB);
+                        max_step<K - 48>(ns0, ns1, mx);
+                    }
+                });
 #ifndef HIPEMU
-            if (MODE != 2) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {          // 8 x { 1 LDS read, 1 MFMA, 14 VALU }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
-                }
-            }
+                __builtin_amdgcn_sched_barrier(0);
 #endif
-            if (MODE == 1) mask_tile(n0, n1, (t + 1) * KB, half, p.L);
-            // ---------------- phase B ----------------
-            const char* vb = vring + (t & 1) * KV_TILE_BYTES + l31 * 128;
+            });
+            if constexpr (MODE != 2) {
+                mx = xor32_max(mx);                     // relative to the running max
+                // deferred rescale (T13) for tile t+1 -- after ALL of P(t) V(t) has been issued: the running max only moves
+                // when some query of the wave outgrew it by more than RESCALE_THR (exp2 units), so P <= 2^THR and the
+                // O / l rescale is skipped on almost every tile
+                if (__any(mx > RESCALE_THR)) {
+                    const float d = fmaxf(mx, 0.0f);
+                    const float alpha = fast_exp2(-d);
+                    m_run += d;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = ((2 * ks + half) ^ kswz) << 4;
-                const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vb + off);
-                const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(vb + 32 * 128 + off);
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[ks].v, oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[ks].v, oacc[1], 0, 0, 0);
-            }
-            if (MODE != 2) {
-                mx = row_max(n0, n1);
-#ifndef HIPEMU
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {          // 8 x { 1 LDS read, 1 MFMA, 3 VALU }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
+                    for (int r = 0; r < 16; ++r) {
+                        oacc[0][r] *= alpha; oacc[1][r] *= alpha; lacc[r] *= alpha;
+                        ns0[r] -= d; ns1[r] -= d; negm[r] -= d;
+                    }
                 }
-#endif
-                // deferred rescale (T13) for tile t+1: the running max only moves when some query of the wave outgrew it by
-                // more than RESCALE_THR (exp2 units), so P <= 2^THR and the O / l rescale is skipped on almost every tile
-                if (__any((mx - m_run) * p.scale_log2e > RESCALE_THR)) {
-                    const float m_new = fmaxf(m_run, mx);
-                    const float alpha = fast_exp2((m_run - m_new) * p.scale_log2e);
-                    l_run *= alpha;
-                    m_run = m_new;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-                }
-                s0 = n0; s1 = n1;
             }
         }
-        // ---- publish K(t+2) (overwrites K(t), last read one iteration ago) and V(t+1) (overwrites V(t-1)) ----
-        if (pk) *reinterpret_cast<uint4*>(kring + (t & 1) * KV_TILE_BYTES + koff) = kreg;
-        if (pvs) {
-            char* vdst = vring + ((t + 1) & 1) * KV_TILE_BYTES;
-            *reinterpret_cast<uint2*>(vdst + voff0) = make_uint2(vreg.x, vreg.y);
-            *reinterpret_cast<uint2*>(vdst + voff1) = make_uint2(vreg.z, vreg.w);
+        if (MODE != 2) {
+            // everything issued BEFORE this iteration (K(t+3), V^T(t+2) and older) has landed once at most this
+            // iteration's own DMAs are outstanding; then everybody is also done reading K(t+2)'s and V^T(t)'s slots
+#ifndef HIPEMU
+            if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+#else
+            (void)issued;
+            __syncthreads();
+#endif
         }
-        if (MODE != 2) __syncthreads();
     };
     const bool ragged = mask_from < ntiles && ntiles > 1;       // the last tile holds keys >= L
     const int steady_end = ragged ? ntiles - 2 : ntiles - 1;    // iterations [0, steady_end) use MODE 0
-    for (int t = 0; t < steady_end; ++t) iteration(t, Mode<0>{});
-    if (ragged) iteration(ntiles - 2, Mode<1>{});
-    iteration(ntiles - 1, Mode<2>{});
+    MAIN_STAMP(2);
+    f32x16 u0, u1;                                              // second score register set
+    int t = 0;
+#ifndef HIPEMU
+    const long long dbg_t0 = (p.dbg & 4) ? clock64() : 0;
+#endif
+    // steady state, unrolled by the ring depth: ring slots are literals, every LDS address is register + immediate
+    for (; t + 3 < steady_end; t += 4) {
+        iteration(t, 0, Mode<0>{}, s0, s1, u0, u1);
+        iteration(t + 1, 1, Mode<0>{}, u0, u1, s0, s1);
+        iteration(t + 2, 2, Mode<0>{}, s0, s1, u0, u1);
+        iteration(t + 3, 3, Mode<0>{}, u0, u1, s0, s1);
+    }
+    if (t + 1 < steady_end) {
+        iteration(t, t & 3, Mode<0>{}, s0, s1, u0, u1);
+        iteration(t + 1, (t + 1) & 3, Mode<0>{}, u0, u1, s0, s1);
+        t += 2;
+    }
+    const int tl = ntiles - 1;
+    if (t < steady_end) {                                       // odd count: the current scores end up in u
+        iteration(t, t & 3, Mode<0>{}, s0, s1, u0, u1);
+        if (ragged) { iteration(tl - 1, (tl - 1) & 3, Mode<1>{}, u0, u1, s0, s1); iteration(tl, tl & 3, Mode<2>{}, s0, s1, u0, u1); }
+        else iteration(tl, tl & 3, Mode<2>{}, u0, u1, s0, s1);
+    } else {
+        if (ragged) { iteration(tl - 1, (tl - 1) & 3, Mode<1>{}, s0, s1, u0, u1); iteration(tl, tl & 3, Mode<2>{}, u0, u1, s0, s1); }
+        else iteration(tl, tl & 3, Mode<2>{}, s0, s1, u0, u1);
+    }
 
-    // ---- finish: O[q, d] = O^T / l ; lane owns query q, d = db*32 + 8 (r >> 2) + 4 half + (r & 3) ----
-    if (!wave_live || q >= p.lpad) return;
-    const float l_tot = xor32_sum(l_run);
-    const float inv = 1.0f / l_tot;
-    if (p.lse2 && half == 0) p.lse2[((size_t)b * p.heads + head) * p.lpad + q] = m_run * p.scale_log2e + log2f(l_tot);
-    bf16_t* orow = p.out + (row0 + q) * (size_t)(p.heads * 64) + head * 64;
+#ifndef HIPEMU
+    if ((p.dbg & 4) && lane == 0 && blockIdx.x < 512) dgs_attn_dbg[blockIdx.x * 8 + wave] = clock64() - dbg_t0;
+#endif
+    MAIN_STAMP(3);
+    // ---- finish: O[q, d] = O^T / l, packed to bf16 now (frees the accumulators), stored behind the tail tile ----
+    uint2 outv[8];
+    float lse_out = 0.0f;
+    if (wave_live) {
+        const float l_tot = lacc[0];                        // every row of the ones block holds the full row sum
+        const float inv = 1.0f / l_tot;
+        lse_out = m_run + log2f(l_tot);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 v;
-            v.x = pack_bf2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv);
-            v.y = pack_bf2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g + 4 * half) = v;
-        }
+            for (int g = 0; g < 4; ++g) {
+                outv[4 * db + g].x = pack_bf2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv);
+                outv[4 * db + g].y = pack_bf2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+            }
+    }
+    // ---- tail queries: wave w takes key tile qblk + nqb * w (K / V^T are L2-resident by now).  Its record stores are
+    //      issued BEFORE the output stores so that the counted wait below covers exactly them. ----
+    const int tail_r = p.L - p.nfull * 32, bh = b * p.heads + head;
+    if (tail_r)
+        for (int tt = qblk + p.nqb * wave; tt < ntiles; tt += p.nqb * NW)
+            tail_tile(p, tt, tail_r, Qg, Kg, Vg, p.tail_ws + ((size_t)bh * ntiles + tt) * tail_r * TAIL_REC, lane);
+    if (wave_live) {                                    // lane owns query q, d = db*32 + 8 g + 4 half + (0..3)
+        if (p.lse2 && half == 0) p.lse2[((size_t)b * p.heads + head) * p.lpad + q] = lse_out;
+        bf16_t* orow = p.out + (row0 + q) * (size_t)(p.heads * 64) + head * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(orow + (i >> 2) * 32 + 8 * (i & 3) + 4 * half) = outv[i];
+    }
+    MAIN_STAMP(4);
+    if (!tail_r) return;
+    // the last workgroup of this (sample, head) to get here merges the per-tile records
+#ifndef HIPEMU
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stores retire in order: all but the 8 output stores, i.e. every record
+                                                       // store of this wave, have been performed (sc1: at the memory side)
+#endif
+    int* flag = reinterpret_cast<int*>(lds);
+#ifndef HIPEMU
+    __builtin_amdgcn_s_barrier();                      // raw barriers: __syncthreads() would also drain the output stores
+#else
+    __syncthreads();
+#endif
+    if (tid == 0) {
+        const unsigned prev = atomicAdd(p.tail_cnt + bh, 1u);
+        *flag = prev + 1 == (unsigned)p.nqb;
+        if (*flag) p.tail_cnt[bh] = 0;                 // leave the counter ready for the next launch
+    }
+#ifndef HIPEMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#else
+    __syncthreads();
+#endif
+    if (*flag) tail_merge(p, bh, ntiles, tail_r, lds);
 }
 
 }  // namespace dgs
@@ -285,12 +560,58 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     p.k_offset = a->k_offset > 0 ? a->k_offset : a->heads * 64;
     p.vt_batch_stride = a->vt_batch_stride > 0 ? a->vt_batch_stride : (long long)a->heads * 64 * a->lpad;
     p.lse2 = a->lse2;
-    const int units = (a->L + 31) / 32;        // 32-query wave units
-    p.extra_unit = (units % NW == 1 && units > 1) ? 1 : 0;
-    p.nqb = p.extra_unit ? units / NW : (units + NW - 1) / NW;
-    p.qk = a->qk; p.vt = a->vt; p.out = a->out;
+    p.nfull = a->L / 32;                       // full 32-query wave units; the L % 32 rest goes to the tail workgroups
+    p.nqb = p.nfull ? (p.nfull + NW - 1) / NW : 1;        // L < 32: one workgroup per head, tail path only
+    p.nmain = a->B * a->heads * p.nqb;
+    static const int dbg = getenv("DGS_ATTN_DBG") ? atoi(getenv("DGS_ATTN_DBG")) : 0;
+    p.dbg = dbg;
+    const int r = a->L % 32, ntiles_h = (a->L + KB - 1) / KB;
+    p.tail_ws = nullptr; p.tail_cnt = nullptr;
+    if (r) {
+        // library-owned scratch of the tail records (a few hundred KiB), grown on demand, never shrunk
+        static float* ws = nullptr; static unsigned* cnt = nullptr; static size_t ws_floats = 0, cnt_n = 0;
+        const size_t need = (size_t)a->B * a->heads * ntiles_h * r * TAIL_REC, need_cnt = (size_t)a->B * a->heads;
+        if (need > ws_floats) {
+            if (ws) (void)hipFree(ws);
+            if (hipMalloc(&ws, need * sizeof(float)) != hipSuccess) { ws = nullptr; ws_floats = 0; return DGS_ERR_DEVICE; }
+            ws_floats = need;
+        }
+        if (need_cnt > cnt_n) {
+            if (cnt) (void)hipFree(cnt);
+            if (hipMalloc(&cnt, need_cnt * sizeof(unsigned)) != hipSuccess || hipMemset(cnt, 0, need_cnt * sizeof(unsigned)) != hipSuccess) {
+                cnt = nullptr; cnt_n = 0; return DGS_ERR_DEVICE;
+            }
+            cnt_n = need_cnt;
+        }
+        p.tail_ws = ws; p.tail_cnt = cnt;
+    }
+    p.qk = a->qk; p.vt = a->vt; p.out = a->out; p.q_prescaled = a->q_prescaled;
     p.scale_log2e = a->scale * 1.44269504088896341f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(a->B * a->heads * p.nqb), dim3(576), 0, st, p);
+    // 64 KiB of rings; DGS_ATTN_LDS_PAD (bytes) adds unused LDS to cap the workgroups per CU (measurement aid)
+    static const int lds_pad = getenv("DGS_ATTN_LDS_PAD") ? atoi(getenv("DGS_ATTN_LDS_PAD")) : 0;
+    const int lds_bytes = 2 * RING * KV_TILE_BYTES + lds_pad;
+    static int lds_attr = 0;
+    if (lds_attr != lds_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return DGS_ERR_DEVICE;
+        lds_attr = lds_bytes;
+    }
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(p.nmain), dim3(512), lds_bytes, st, p);
+#ifndef HIPEMU
+    if (dbg & 4) {
+        static long long host[4096 + 64];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(dgs_attn_dbg), sizeof(host));
+        const int n = (p.nmain < 512 ? p.nmain : 512) * 8;
+        long long mn = host[0], mx = host[0]; double sum = 0;
+        for (int i = 0; i < n; ++i) { mn = host[i] < mn ? host[i] : mn; mx = host[i] > mx ? host[i] : mx; sum += host[i]; }
+        const int ntiles = (a->L + KB - 1) / KB;
+        if (dbg & 8) fprintf(stderr, "[attn dbg] main wg0 stamps: prologue(load wait + tail tile) %lld, first tile %lld, loop %lld, epilogue stores %lld\n", host[4113] - host[4112],
+                             host[4114] - host[4113], host[4115] - host[4114], host[4116] - host[4115]);
+        fprintf(stderr, "[attn dbg] L=%d loop cycles per wave: min %lld avg %.0f max %lld  -> per tile %.0f / %.0f / %.0f\n", a->L, mn, sum / n, mx,
+                (double)mn / ntiles, sum / n / ntiles, (double)mx / ntiles);
+    }
+#endif
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }

@@ -124,7 +124,7 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
 
     // ---- 24 x DiTBlock (utils_transformer.py:271-290) ----
     DgsDitAttentionArgs at{};
-    at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = ws.qk; at.vt = ws.vt; at.out = ws.ao; at.scale = 0.125f;
+    at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = ws.qk; at.vt = ws.vt; at.out = ws.ao; at.scale = 0.125f; at.q_prescaled = 1;
     for (int i = 0; i < m->layers; ++i) {
         const DgsDitLayerWeights& lw = m->layer[i];
         const float* mod = ws.mod + (size_t)i * 6 * W;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -135,6 +135,7 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
         DgsDitGemmArgs q{};
         q.M = M; q.N = 3 * W; q.K = W; q.A = ws.xn; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_QKV;
         q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad; q.valid_rows = L;
+        q.q_scale = at.scale * 1.44269504088896341f;       // queries leave the GEMM pre-scaled for the exp2-domain softmax
         DGS_PROF(2, dgs_dit_gemm(&q, stream));
         DGS_PROF(1, dgs_dit_attention(&at, stream));
         DgsDitGemmArgs pr{};

@@ -34,6 +34,7 @@ struct GemmParams {
     const float* resid;              // GATE_RESIDUAL input stream (== out for the in-place inference form)
     bf16_t* vt;                      // transposed bf16 copy [batch, N, rows_per_batch] (QKV: V only)
     void* aux;                       // GELU: u out; GATE_RESIDUAL: y out; DGELU: u in   (bf16 [M, ldo])
+    float q_scale;                   // QKV: factor on the q features
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * (BN / 2) + ni * 32 + (lane & 31);
         const float bias = p.bias ? p.bias[n] : 0.0f;
+        const float qs = (EPI == DGS_EPI_QKV && n < p.N / 3) ? p.q_scale : 1.0f;      // pre-scaled queries
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             if (!(mi == 0 ? live0 : live1)) continue;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = mbase + q + 8 * g;
-                    const float v = acc[mi][ni][4 * g + q] + bias;
+                    const float v = EPI == DGS_EPI_QKV ? (acc[mi][ni][4 * g + q] + bias) * qs : acc[mi][ni][4 * g + q] + bias;
                     const size_t o = (size_t)m * p.ldo + n;
                     if (EPI == DGS_EPI_BF16) {
                         o4[q] = v;
@@ -251,6 +253,7 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     p.valid_rows = (a->valid_rows > 0 && a->valid_rows < p.rows_per_batch) ? a->valid_rows : p.rows_per_batch;
     p.k_per_batch = kpb; p.a_batch_stride = a->a_batch_stride; p.w_batch_stride = a->w_batch_stride;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
+    p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     hipStream_t st0 = static_cast<hipStream_t>(stream);
     // Kernel choice.  Measured on MI355X at the DiT shapes (profiles/r01_*gemm*): all three kernels stream ~12-40 GB/s per CU

@@ -29,6 +29,7 @@ struct DeepParams {
     const float* resid;
     bf16_t* vt;
     void* aux;
+    float q_scale;
 };
 
 __device__ __forceinline__ float gelu_tanh_d(float x) {
@@ -74,6 +75,7 @@ __device__ __forceinline__ void store_block(const DeepParams& p, const f32x16 (&
     for (int ni = 0; ni < NI; ++ni) {
         const int n = nbase + ni * 32 + (lane & 31);
         const float bias = p.bias ? p.bias[n] : 0.0f;
+        const float qs = (EPI == DGS_EPI_QKV && n < p.N / 3) ? p.q_scale : 1.0f;      // pre-scaled queries
         const bool qkv_v = EPI == DGS_EPI_QKV && n >= (p.N / 3) * 2;
         bf16_t* tdst = nullptr;
         if (EPI == DGS_EPI_QKV) {
@@ -89,7 +91,7 @@ __device__ __forceinline__ void store_block(const DeepParams& p, const f32x16 (&
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = mbase + q + 8 * g;
-                const float v = acc[ni][4 * g + q] + bias;
+                const float v = EPI == DGS_EPI_QKV ? (acc[ni][4 * g + q] + bias) * qs : acc[ni][4 * g + q] + bias;
                 const size_t o = (size_t)m * p.ldo + n;
                 if (EPI == DGS_EPI_BF16) {
                     o4[q] = v;
@@ -326,6 +328,7 @@ int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows,
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
     p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
+    p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     switch (a->epilogue) {
         case DGS_EPI_BF16: return launch_big<DGS_EPI_BF16>(p, st);
@@ -395,6 +398,7 @@ int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int va
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
     p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
+    p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     switch (a->epilogue) {
         case DGS_EPI_BF16: return dispatch_deep<DGS_EPI_BF16>(p, bn, st);

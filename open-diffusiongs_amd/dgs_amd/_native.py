@@ -130,14 +130,14 @@ class DgsDitGemmArgs(ctypes.Structure):
                 ("gate", ctypes.c_void_p), ("gate_stride", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32),
                 ("vt", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("k_per_batch", ctypes.c_int32),
                 ("a_batch_stride", ctypes.c_int64), ("w_batch_stride", ctypes.c_int64), ("algo", ctypes.c_int32),
-                ("valid_rows", ctypes.c_int32)]
+                ("valid_rows", ctypes.c_int32), ("q_scale", ctypes.c_float)]
 
 
 class DgsDitAttentionArgs(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("heads", ctypes.c_int32), ("L", ctypes.c_int32), ("lpad", ctypes.c_int32),
                 ("qk", ctypes.c_void_p), ("vt", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_float),
                 ("ld_qk", ctypes.c_int32), ("k_offset", ctypes.c_int32), ("vt_batch_stride", ctypes.c_int64),
-                ("lse2", ctypes.c_void_p)]
+                ("lse2", ctypes.c_void_p), ("q_prescaled", ctypes.c_int32)]
 
 
 class DgsDitAttentionBackwardArgs(ctypes.Structure):

@@ -35,7 +35,8 @@ class DitOps:
             raise RuntimeError(f"dgs dit: {_native.status_string(self.lib, rc)} (status {rc})")
 
     def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None, valid_rows=0,
-             resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None, algo=0):
+             resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None, algo=0,
+             q_scale=0.0):
         """A bf16 [M,K], W bf16 [N,K] -> per epilogue (see dgs_dit.h).  `out` is required for GATE_RESIDUAL (in-place)."""
         if shape is not None:          # batched-reduction form (weight gradients): operands are [batch, rows, tokens]
             M, N, K = shape
@@ -64,11 +65,11 @@ class DitOps:
         a.k_per_batch, a.a_batch_stride, a.w_batch_stride = k_per_batch, a_batch_stride, w_batch_stride
         a.bias, a.epilogue, a.out, a.ldo = _p(bias), epilogue, _p(out), ldo
         a.gate, a.gate_stride, a.rows_per_batch, a.vt = _p(gate), (gate.stride(0) if gate is not None else 0), rows_per_batch, _p(vt)
-        a.valid_rows, a.algo = valid_rows, algo
+        a.valid_rows, a.algo, a.q_scale = valid_rows, algo, q_scale
         self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))
         return (out, vt) if epilogue == _native.EPI_QKV else out
 
-    def attention(self, qk, vt, L, heads, qkv_layout=False, lse2=None):
+    def attention(self, qk, vt, L, heads, qkv_layout=False, lse2=None, q_prescaled=False):
         """qk bf16 [B*lpad, 2*heads*64], vt bf16 [B, heads*64, lpad] -> bf16 [B*lpad, heads*64].
         qkv_layout: `qk` is the training tensor [B*lpad, 3W] and `vt` its transposed copy [B, 3W, lpad]."""
         B, _, lpad = vt.shape
@@ -80,7 +81,7 @@ class DitOps:
         if qkv_layout:
             a.ld_qk, a.k_offset, a.vt_batch_stride = 3 * W, W, 3 * W * lpad
             a.vt = ctypes.c_void_p(vt.data_ptr() + 2 * W * lpad * 2)
-        a.lse2 = _p(lse2)
+        a.lse2, a.q_prescaled = _p(lse2), int(q_prescaled)
         self._check(self.lib.dgs_dit_attention(ctypes.byref(a), _stream(qk.device)))
         return out
 

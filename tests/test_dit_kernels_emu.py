@@ -76,12 +76,15 @@ def test_gemm_qkv_epilogue(ops):
     ref = A.float() @ W.float().t() + bias
     qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=lpad)
     assert torch.allclose(qk.float(), ref[:, :2 * Wd], atol=2e-2, rtol=1e-2)
+    qk2, vt2 = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=lpad, q_scale=0.18)     # pre-scaled queries: q features only
+    assert torch.allclose(qk2.float()[:, :Wd], 0.18 * ref[:, :Wd], atol=4e-3, rtol=1e-2)
+    assert torch.equal(qk2[:, Wd:], qk[:, Wd:]) and torch.equal(vt2, vt)
     v = ref[:, 2 * Wd:].reshape(B, lpad, Wd).transpose(1, 2)
     assert torch.allclose(vt.float(), v, atol=2e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("L", [128, 130, 67, 258, 520])
-def test_attention(ops, L):
+@pytest.mark.parametrize("L,prescaled", [(128, False), (130, False), (130, True), (67, True), (258, False), (520, True), (20, False)])
+def test_attention(ops, L, prescaled):
     g = torch.Generator().manual_seed(3)
     B, heads = 2, 2
     lpad = (L + 127) // 128 * 128
@@ -90,13 +93,17 @@ def test_attention(ops, L):
     v = torch.randn(B, heads, lpad, 64, generator=g)
     q[0, 0, 3] *= 6.0   # a spiky row: exercises the running-max rescale across tiles
     k[0, 0, 70 % L] *= 6.0
-    qb, kb, vb = _bf(q), _bf(k), _bf(v)
+    c = 0.125 * 1.4426950408889634
+    qb, kb, vb = (_bf(q * c) if prescaled else _bf(q)), _bf(k), _bf(v)
     qk = torch.cat([qb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64), kb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64)], 1).contiguous()
     vt = vb.permute(0, 1, 3, 2).reshape(B, heads * 64, lpad).contiguous()
-    out = ops.attention(qk, vt, L, heads).float().reshape(B, lpad, heads, 64).permute(0, 2, 1, 3)
-    s = (qb.float() @ kb.float()[:, :, :L].transpose(-1, -2)) * 0.125
+    lse2 = torch.zeros(B, heads, lpad)
+    out = ops.attention(qk, vt, L, heads, lse2=lse2, q_prescaled=prescaled).float().reshape(B, lpad, heads, 64).permute(0, 2, 1, 3)
+    s = (qb.float()[:, :, :L] @ kb.float()[:, :, :L].transpose(-1, -2)) * (0.6931471805599453 if prescaled else 0.125)
     ref = s.softmax(-1) @ vb.float()[:, :, :L]
-    assert torch.allclose(out[:, :, :L], ref[:, :, :L], atol=2e-2, rtol=2e-2)
+    assert torch.allclose(out[:, :, :L], ref, atol=2e-2, rtol=2e-2)
+    # log2-domain log-sum-exp of every valid query (main path and the L % 32 tail queries)
+    assert torch.allclose(lse2[:, :, :L], torch.logsumexp(s, -1) * 1.4426950408889634, atol=5e-2, rtol=5e-3)
 
 
 def test_layernorm_modulate(ops):
