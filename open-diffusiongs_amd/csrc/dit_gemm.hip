@@ -16,6 +16,7 @@
 
 #include "dit_common.h"
 #include "dgs_dit.h"
+#include "dit_gemm_epilogue.h"
 
 namespace dgs {
 
@@ -159,7 +160,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     else main_loop<BN, NI, 0>(p, lds, m0, n0, wave, lane, wm, wn, acc);
     const int fhalf = lane >> 5;
 
-    // ---- epilogue.  D fragment: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a lane holds, for ONE
+    // ---- epilogue, staged through LDS (dit_gemm_epilogue.h) for everything the inference sequence launches; the stages are
+    //      idle (main_loop ends with a barrier), every wave takes a private patch ----
+    if (epi_staged<EPI>(p)) {
+        char* patch = lds + wave * epi_strip_bytes(NI);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+            if (mi == 0 ? live0 : live1) store_strip<EPI, NI>(p, acc[mi], m0 + wm * 64 + mi * 32, n0 + wn * (BN / 2), lane, patch);
+        return;
+    }
+
+    // ---- epilogue (training variants).  D fragment: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a lane holds, for ONE
     //      output feature, four groups of four consecutive rows -> row-major stores are 2/4-byte per row, the optional
     //      transposed copy ([batch, N, rows_per_batch], wanted by the attention and weight-gradient kernels) is one 8-byte
     //      store per group.
@@ -220,6 +231,8 @@ int deep_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_
 int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
 bool big_gemm_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch);
 int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows, hipStream_t st);
+int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);
+int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
 
 }  // namespace dgs
 
@@ -263,6 +276,10 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     const int algo = a->algo ? a->algo : env_algo;
     if (algo == DGS_GEMM_BIG256 && big_gemm_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
         return launch_big_gemm(a, p.rows_per_batch, p.valid_rows, st0);
+    if (algo == DGS_GEMM_SLICED) {
+        const int sbn = sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
+        if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0);
+    }
     if (algo == DGS_GEMM_DEEP) {
         const int dbn = deep_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
         if (dbn) return launch_deep_gemm(a, dbn, p.rows_per_batch, p.valid_rows, st0);

@@ -14,13 +14,18 @@
 //     columns and read fragments straight from L2 into registers -- no ring, no barriers -- because a tile that streams W
 //     through the ring costs a full tile's latency no matter how few rows are live.
 // Waves: 2 (M) x 4 (N); a wave owns 64 x BN/4 of the tile = 2 x (BN/128) accumulators of v_mfma_f32_32x32x16_bf16.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "dit_common.h"
 #include "dgs_dit.h"
+#include "dit_gemm_epilogue.h"
 
 namespace dgs {
 
 struct DeepParams {
-    int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles;
+    int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles, dbg;
+    int rows_ps, full_rows, tail_rows, nfull_items;             // sliced kernel: 256-row tile rows per sample (all / ring path / one live block), full items
     const bf16_t* A;
     const bf16_t* W;
     const float* bias;
@@ -326,7 +331,7 @@ bool big_gemm_eligible(int M, int N, int K, int epilogue, int k_per_batch, int r
 int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows, hipStream_t st) {
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
-    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows;
+    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
@@ -339,6 +344,232 @@ int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows,
         case DGS_EPI_DGELU_BF16: return launch_big<DGS_EPI_DGELU_BF16>(p, st);
         default: return DGS_ERR_INVALID_ARGUMENT;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// "Sliced" kernel: 256 x BN x 32 tiles (BN = 256 or 128), 8 waves as 4 (M) x 2 (N) -- a wave owns 64 x BN/2 --, 4-stage
+// LDS-DMA ring, counted vmcnt + one raw barrier per K slab, and an explicit issue schedule.
+// tools/ubench/issue_bench (MI355X): one SIMD retires { v_mfma_f32_32x32x16_bf16 + 1 ds_read_b128 } at 32-33 cycles and
+// still ~36 with an LDS-DMA every 4th MFMA, but ONLY if no MFMA has to wait for an operand: hipcc waits with lgkmcnt(0)
+// at the first use of a fragment, so a ds_read issued just before an MFMA exposes the whole LDS latency.  Here every
+// fragment is read one k-substep (>= 4 MFMAs) before it is used, into the other half of a register double buffer:
+//   slab t, substep 0:  MFMAs on fa/fb[0]   while reading fa/fb[1] <- slab t,     k 16..31
+//   slab t, substep 1:  MFMAs on fa/fb[1]   while reading fa/fb[0] <- slab t + 1, k 0..15   (landed one barrier ago)
+// with sched_barrier fences between { 1 MFMA, <= 1 LDS read } slices so the order in the source is the issue order.
+// The slab loop is unrolled by the ring depth: ring slots are literals and every LDS address is register + immediate.
+// ------------------------------------------------------------------------------------------------------------------
+template <int I> struct SIC { static constexpr int value = I; };
+template <int I, int N, class F> __device__ __forceinline__ void sliced_for(F&& f) {
+    if constexpr (I < N) { f(SIC<I>{}); sliced_for<I + 1, N>(f); }
+}
+
+__device__ long long dgs_gemm_dbg[16];   // DGS_GEMM_DBG: cycle stamps of workgroup 0, wave 0 (loop total, wait + barrier share)
+
+template <int EPI, int BN>
+__global__ __launch_bounds__(512) void gemm_sliced_kernel(DeepParams p) {
+    constexpr int BM = 256, BK = 32, NS = 4;
+    constexpr int WN = BN / 2, NI = WN / 32;                      // wave tile 64 x WN: 2 x NI accumulators
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    constexpr int G = A_BYTES / 8192 + W_BYTES / 8192;            // LDS-DMA instructions per wave per slab
+    constexpr int NF = 2 + NI;                                    // fragments per k-substep: 2 of A, NI of W
+    DGS_DYNAMIC_LDS(lds);
+#ifndef HIPEMU
+    const long long dbg_k0 = p.dbg ? clock64() : 0;
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    // Work items: first every full tile -- XCD-aware order --, then the cheap tiles whose sample has a single
+    // live 32-row block left (the two learned-token rows of the DiT): dispatched last, they fill CUs as the full tiles
+    // retire instead of pushing 1/16 of the full tiles into a second round.
+    const int bid = (int)blockIdx.x;
+    if (bid >= p.nfull_items) {
+        const int j = bid - p.nfull_items, tn = j % p.tiles_n, rr = j / p.tiles_n;
+        const int m0 = ((rr / p.tail_rows) * p.rows_ps + p.full_rows + rr % p.tail_rows) * BM, n0 = tn * BN;
+        // no staging: the 8 waves split the BN / 32 column blocks, fragments come straight from L2, 16 k-steps in flight
+        const bf16_t* arow = p.A + (size_t)(m0 + frow) * p.lda + fhalf * 8;
+        for (int cb = wave; cb < BN / 32; cb += 8) {
+            const bf16_t* wrow = p.W + (size_t)(n0 + cb * 32 + frow) * p.ldw + fhalf * 8;
+            f32x16 acc1[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+#pragma unroll 16
+            for (int k = 0; k < p.K; k += 16)
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + k),
+                                                                  *reinterpret_cast<const bf16x8*>(wrow + k), acc1[0], 0, 0, 0);
+            store_block<EPI, 1>(p, acc1, m0 + 4 * fhalf, n0 + cb * 32, lane);
+        }
+        return;
+    }
+    const int tile = xcd_remap(bid, p.nfull_items);
+    const int tn = tile % p.tiles_n, rr = tile / p.tiles_n;
+    const int m0 = ((rr / p.full_rows) * p.rows_ps + rr % p.full_rows) * BM, n0 = tn * BN;
+    f32x16 acc[2][NI];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // fragment f of substep ks: f < 2: A rows wm*64 + 32 f + frow;  f >= 2: W rows wn*WN + 32 (f - 2) + frow; chunk 2 ks + fhalf
+    int foff[2][NF];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            foff[ks][f] = f < 2 ? slab_off<BK>(wm * 64 + 32 * f + frow, 2 * ks + fhalf) : A_BYTES + slab_off<BK>(wn * WN + 32 * (f - 2) + frow, 2 * ks + fhalf);
+    auto frag = [&](int slot, int ks, int f) { return *reinterpret_cast<const bf16x8*>(lds + slot * STAGE + foff[ks][f]); };
+    const int nk = p.K / BK;                                      // a multiple of NS
+    auto stage = [&](int t, int slot) {
+        stage_slab<BM, BK>(p.A, p.lda, m0, t * BK, lds + slot * STAGE, wave, lane);
+        stage_slab<BN, BK>(p.W, p.ldw, n0, t * BK, lds + slot * STAGE + A_BYTES, wave, lane);
+    };
+    // ---- prologue: slabs 0 .. NS-2 in flight, then the fragments of slab 0, substep 0 ----
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) stage(s, s);
+#ifndef HIPEMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#else
+    __syncthreads();
+#endif
+    bf16x8 fr[2][NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) fr[0][f] = frag(0, 0, f);
+
+    long long dbg_wait = 0, dbg_bar = 0;
+    auto iteration = [&](int t, const int slot) {                // slot == t % NS, a literal at the call sites
+        const bool refill = t + NS - 1 < nk;
+        if (refill) stage(t + NS - 1, (slot + NS - 1) % NS);      // into the stage of slab t - 1 (released by the last barrier)
+        sliced_for<0, 4 * NI>([&](auto jc) {
+            constexpr int J = decltype(jc)::value, ks = J / (2 * NI), i = (J % (2 * NI)) / NI, j = J % NI;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks][i], fr[ks][2 + j], acc[i][j], 0, 0, 0);
+            // the other register half: substep 1 of this slab, then substep 0 of the next one (stale data behind the last slab)
+            constexpr int f = J % (2 * NI);
+            if constexpr (f < NF) fr[ks ^ 1][f] = frag(ks == 0 ? slot : (slot + 1) % NS, ks ^ 1, f);
+#ifndef HIPEMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        });
+        // slab t+1 (and older) has landed once at most this iteration's own DMAs are outstanding; then everybody is also
+        // done reading slab t
+#ifndef HIPEMU
+        long long w0 = 0;
+        if (p.dbg) w0 = clock64();
+        if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long w1 = 0;
+        if (p.dbg) w1 = clock64();
+        __builtin_amdgcn_s_barrier();
+        if (p.dbg) { dbg_wait += w1 - w0; dbg_bar += clock64() - w1; }
+#else
+        __syncthreads();
+#endif
+    };
+#ifndef HIPEMU
+    const long long dbg_t0 = p.dbg ? clock64() : 0;
+#endif
+    for (int t = 0; t < nk; t += NS) {
+        iteration(t, 0);
+        iteration(t + 1, 1);
+        iteration(t + 2, 2);
+        iteration(t + 3, 3);
+    }
+#ifndef HIPEMU
+    const long long dbg_t1 = p.dbg ? clock64() : 0;
+#endif
+    if (epi_staged<EPI>(p)) {          // the ring is idle now (everybody passed the last barrier): a private LDS patch per wave
+        char* patch = lds + wave * epi_strip_bytes(2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; j += 2) store_strip<EPI, 2>(p, &acc[i][j], m0 + wm * 64 + 32 * i, n0 + wn * WN + 32 * j, lane, patch);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) store_block<EPI, NI>(p, acc[i], m0 + wm * 64 + 32 * i + 4 * fhalf, n0 + wn * WN, lane);
+    }
+#ifndef HIPEMU
+    if (p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[6]), (unsigned long long)(clock64() - dbg_k0));
+            atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[7]), (unsigned long long)dbg_wait);
+            atomicMin(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[8]), (unsigned long long)dbg_k0);
+            atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[9]), (unsigned long long)clock64());
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            dgs_gemm_dbg[0] = dbg_t1 - dbg_t0; dgs_gemm_dbg[1] = dbg_wait; dgs_gemm_dbg[2] = dbg_bar; dgs_gemm_dbg[3] = nk;
+            dgs_gemm_dbg[4] = dbg_t0 - dbg_k0; dgs_gemm_dbg[5] = clock64() - dbg_t1;
+        }
+    }
+#endif
+}
+
+template <int EPI, int BN>
+static int launch_sliced(DeepParams p, hipStream_t st) {
+    constexpr int LDS = 4 * (256 * 32 * 2 + BN * 32 * 2);          // 128 KiB (BN 256) / 96 KiB (BN 128)
+    p.tiles_n = p.N / BN;
+    p.rows_ps = p.rows_per_batch / 256;
+    p.full_rows = 0; p.tail_rows = 0;
+    for (int i = 0; i < p.rows_ps; ++i) {                          // per sample: tile rows with >= 2 / exactly 1 live 32-row blocks
+        const int live = (p.valid_rows - i * 256 + 31) / 32;
+        if (live > 1) ++p.full_rows; else if (live == 1) ++p.tail_rows;
+    }
+    const int samples = p.M / p.rows_per_batch;
+    p.nfull_items = samples * p.full_rows * p.tiles_n;
+    p.ntiles = p.nfull_items + samples * p.tail_rows * p.tiles_n;
+    auto kern = gemm_sliced_kernel<EPI, BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DGS_ERR_DEVICE;
+        attr_set = true;
+    }
+    static const bool dbg = getenv("DGS_GEMM_DBG") != nullptr;
+    p.dbg = dbg;
+    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(512), LDS, st, p);
+#ifndef HIPEMU
+    if (dbg) {
+        long long h[10];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(dgs_gemm_dbg), sizeof(h));
+        { long long z[4] = {0, 0, 0x7fffffffffffffffLL, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dgs_gemm_dbg), z, sizeof(z), 6 * sizeof(long long)); }
+        fprintf(stderr, "[gemm dbg] M=%d N=%d K=%d BN=%d: prologue %lld, loop %lld cycles (%lld per slab), vmcnt wait %lld, barrier %lld, epilogue %lld | slowest wg %lld cycles, max vmcnt wait %lld per slab, first start -> last end %lld\n", p.M,
+                p.N, p.K, BN, h[4], h[0], h[0] / h[3], h[1] / h[3], h[2] / h[3], h[5], h[6], h[7] / h[3], h[9] - h[8]);
+    }
+#endif
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+// Tile width (256 / 128) of the sliced kernel for this shape; 0 when it is not eligible.
+int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows) {
+    if (k_per_batch != K || K % 128 || M % 256 || rows_per_batch % 256) return 0;
+    if (epilogue == DGS_EPI_QKV && N % 3) return 0;
+    int full_rows = 0;
+    for (int i = 0; i < rows_per_batch / 256; ++i)
+        if ((valid_rows - i * 256 + 31) / 32 > 1) ++full_rows;
+    if (N % 256 == 0 && (M / rows_per_batch) * full_rows * (N / 256) >= 160) return 256;
+    return N % 128 ? 0 : 128;
+}
+
+int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st) {
+    DeepParams p;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
+    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0;
+    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
+    p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
+    p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
+#define DGS_SLICED_CASE(E) case E: return bn == 256 ? launch_sliced<E, 256>(p, st) : launch_sliced<E, 128>(p, st)
+    switch (a->epilogue) {
+        DGS_SLICED_CASE(DGS_EPI_BF16);
+        DGS_SLICED_CASE(DGS_EPI_GELU_BF16);
+        DGS_SLICED_CASE(DGS_EPI_GATE_RESIDUAL);
+        DGS_SLICED_CASE(DGS_EPI_F32);
+        DGS_SLICED_CASE(DGS_EPI_QKV);
+        DGS_SLICED_CASE(DGS_EPI_DGELU_BF16);
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
+#undef DGS_SLICED_CASE
 }
 
 template <int EPI, int BN, int BK, int NS>
@@ -396,7 +627,7 @@ int deep_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_
 int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st) {
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
-    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows;
+    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);

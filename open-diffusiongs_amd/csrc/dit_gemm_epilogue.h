@@ -1,0 +1,118 @@
+// dit_gemm_epilogue.h -- row-major epilogue of the DiT GEMM kernels, staged through LDS.
+//
+// The MFMA D fragment gives a lane ONE output column and 16 rows: writing it straight to a row-major tensor costs 16
+// two- or four-byte stores per 32 x 32 block per lane, each wave-instruction touching two 64/128-byte row segments.  In-kernel
+// cycle stamps on MI355X: that store tail took 11k (QKV) / 21k (fc1 + GELU) / 40k (fc2 gate + residual) cycles per
+// workgroup -- 25-45 % of the K loop it follows (the stores are issue-bound, not bandwidth-bound).
+// Here a wave parks a 32 x (32 NB) strip of fp32 results in its private LDS patch and re-reads it row-major, so that
+// every lane stores 16 contiguous bytes (8 bf16 or 4 fp32) and the residual / gate / aux operands are 16-byte loads too:
+// 2-4 store instructions per block instead of 16.
+#pragma once
+#include "dit_common.h"
+#include "dgs_dit.h"
+
+namespace dgs {
+
+__device__ __forceinline__ float epi_gelu_tanh(float x) {
+    // nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)
+    //   = x / (1 + 2^(-2 log2(e) u)) : two multiplies, one fma, v_exp_f32, one add, v_rcp_f32 (1 ulp), one multiply --
+    // an IEEE division and __expf's range handling cost ~25 VALU per element, which made this epilogue a third of fc1.
+#ifdef HIPEMU
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+#else
+    const float t = x * __builtin_fmaf(x * x, -2.0f * 1.4426950408889634f * 0.7978845608028654f * 0.044715f, -2.0f * 1.4426950408889634f * 0.7978845608028654f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+#endif
+}
+
+constexpr int epi_strip_bytes(int nb) { return 32 * (32 * nb + 4) * 4; }     // LDS per wave
+
+// Which (epilogue, arguments) take the staged path: everything the inference launch sequence uses.  The transposed copies
+// of the training forward (`vt` with BF16 / GELU / DGELU) and DGELU keep the per-register path of their kernel.
+template <int EPI, class P>
+__device__ __forceinline__ bool epi_staged(const P& p) {
+    if (EPI == DGS_EPI_DGELU_BF16) return false;
+    return EPI == DGS_EPI_QKV || p.vt == nullptr;
+}
+
+// acc[0 .. NB): NB side-by-side 32 x 32 accumulator blocks: rows m0 .. m0+31 (m0 = first row of the block), columns
+// n0 .. n0 + 32 NB - 1.  `patch` = this wave's private LDS patch (epi_strip_bytes(NB) bytes); nobody else touches it, so no
+// barrier is needed -- LDS operations of one wave execute in order.
+template <int EPI, int NB, class P>
+__device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch) {
+    constexpr int C = 32 * NB, S = C + 4;
+    const int c = lane & 31, half = lane >> 5;
+    const int b = m0 / p.rows_per_batch;                       // a 32-row block never straddles samples
+    if (EPI == DGS_EPI_QKV && n0 >= (p.N / 3) * 2) {
+        // V features: only the transposed copy V^T[b][feature][token] exists: 4 consecutive tokens per 8-byte store
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            const int n = n0 + 32 * blk + c;
+            const float bias = p.bias ? p.bias[n] : 0.0f;
+            bf16_t* tdst = p.vt + ((size_t)b * (p.N / 3) + (n - (p.N / 3) * 2)) * p.rows_per_batch + (m0 - b * p.rows_per_batch) + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2*>(tdst + 8 * g) = make_uint2(pack_bf2(acc[blk][4 * g] + bias, acc[blk][4 * g + 1] + bias),
+                                                                       pack_bf2(acc[blk][4 * g + 2] + bias, acc[blk][4 * g + 3] + bias));
+        }
+        return;
+    }
+    float* st = reinterpret_cast<float*>(patch);
+    // ---- park: lane (column c, half) owns rows (r & 3) + 8 (r >> 2) + 4 half; a 32-lane group writes 32 consecutive floats ----
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        const int n = n0 + 32 * blk + c;
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+        const float qs = (EPI == DGS_EPI_QKV && n < p.N / 3) ? p.q_scale : 1.0f;      // pre-scaled queries
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            st[row * S + 32 * blk + c] = EPI == DGS_EPI_QKV ? (acc[blk][r] + bias) * qs : acc[blk][r] + bias;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();       // hardware: lanes run in lockstep, LDS operations of a wave execute in order
+    // ---- row-major: 16 bytes per lane ----
+    if (EPI == DGS_EPI_F32 || EPI == DGS_EPI_GATE_RESIDUAL) {
+        constexpr int LPR = C / 4, RPI = 64 / LPR;             // lanes per row, rows per instruction
+        const int rr = lane / LPR, cc = (lane % LPR) * 4;
+        float4 gate = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == DGS_EPI_GATE_RESIDUAL) gate = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + n0 + cc);
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + rr;
+            const float4 v = *reinterpret_cast<const float4*>(st + row * S + cc);
+            const size_t o = (size_t)(m0 + row) * p.ldo + n0 + cc;
+            if (EPI == DGS_EPI_GATE_RESIDUAL) {
+                const float4 x = *reinterpret_cast<const float4*>(p.resid + o);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) =
+                    make_float4(x.x + gate.x * v.x, x.y + gate.y * v.y, x.z + gate.z * v.z, x.w + gate.w * v.w);
+                if (p.aux) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.aux) + o) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = v;
+            }
+        }
+    } else {
+        constexpr int LPR = C / 8, RPI = 64 / LPR;
+        const int rr = lane / LPR, cc = (lane % LPR) * 8;
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + rr;
+            const float4 v0 = *reinterpret_cast<const float4*>(st + row * S + cc), v1 = *reinterpret_cast<const float4*>(st + row * S + cc + 4);
+            const size_t o = (size_t)(m0 + row) * p.ldo + n0 + cc;
+            if (EPI == DGS_EPI_GELU_BF16) {
+                if (p.aux) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.aux) + o) =
+                    make_uint4(pack_bf2(v0.x, v0.y), pack_bf2(v0.z, v0.w), pack_bf2(v1.x, v1.y), pack_bf2(v1.z, v1.w));
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o) =
+                    make_uint4(pack_bf2(epi_gelu_tanh(v0.x), epi_gelu_tanh(v0.y)), pack_bf2(epi_gelu_tanh(v0.z), epi_gelu_tanh(v0.w)),
+                               pack_bf2(epi_gelu_tanh(v1.x), epi_gelu_tanh(v1.y)), pack_bf2(epi_gelu_tanh(v1.z), epi_gelu_tanh(v1.w)));
+            } else {
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o) =
+                    make_uint4(pack_bf2(v0.x, v0.y), pack_bf2(v0.z, v0.w), pack_bf2(v1.x, v1.y), pack_bf2(v1.z, v1.w));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();       // the patch is rewritten by the next strip
+}
+
+}  // namespace dgs

@@ -268,6 +268,7 @@ static inline int __all(int p) { return hipemu::ballot(!p) == 0; }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu::mfma_32x32x16<true>(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipemu::global_load_lds(g, l, size, off)
 #define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_wave_barrier() ((void)hipemu::ballot(1))   /* lanes of a wave run as separate fibers here */
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

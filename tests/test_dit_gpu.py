@@ -34,7 +34,7 @@ def test_gemm_production_shapes(M, N, K):
     ref = A.float() @ W.float().t() + bias
     ops = _ops()
     assert rel_l2(ops.gemm(A, W, bias, _native.EPI_F32), ref) < 1e-5
-    for algo in (_native.GEMM_DEEP, _native.GEMM_BIG256):       # opt-in kernels (the default is the 128-wide two-stage kernel)
+    for algo in (_native.GEMM_DEEP, _native.GEMM_BIG256, _native.GEMM_SLICED):   # every kernel family (ineligible shapes fall back)
         assert rel_l2(ops.gemm(A, W, bias, _native.EPI_F32, algo=algo), ref) < 1e-5, algo
         assert rel_l2(ops.gemm(A, W, bias, _native.EPI_GELU_BF16, algo=algo).float(), F.gelu(ref, approximate="tanh")) < 4e-3, algo
     assert rel_l2(ops.gemm(A, W, bias, _native.EPI_BF16).float(), ref) < 4e-3

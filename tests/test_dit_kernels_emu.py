@@ -321,3 +321,41 @@ def test_gemm_256_tiles(ops):
     qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=M, algo=big)
     assert torch.allclose(qk.float(), ref[:, :2048], atol=3e-2, rtol=1e-2)
     assert torch.allclose(vt.float()[0], ref[:, 2048:].t(), atol=3e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("N", [256, 128])
+def test_gemm_sliced(ops, N):
+    """Sliced-schedule kernel (256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring): several trips round the ring, the padding-row
+    path, and the QKV / gate-residual epilogues."""
+    g = torch.Generator().manual_seed(41 + N)
+    M, K = 512, 384                                 # 12 K slabs = 3 trips round the ring
+    if N == 256:
+        N = 768                                     # 2 x 3 tiles of 256 x 256: needs >= 160 tiles for AUTO, forced via algo here
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.2)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    sl = _native.GEMM_SLICED
+    out = ops.gemm(A, W, bias, _native.EPI_F32, algo=sl)
+    assert torch.allclose(out, ref, atol=3e-3, rtol=1e-4)
+    out = torch.full((M, N), 7.0)
+    ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=256, valid_rows=130, algo=sl)
+    for b in range(2):                              # per sample: rows [0, 130) live; the tile is computed and stored completely
+        assert torch.allclose(out[b * 256:b * 256 + 130], ref[b * 256:b * 256 + 130], atol=3e-3, rtol=1e-4)
+    out = torch.full((M, N), 7.0)
+    ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=256, valid_rows=2, algo=sl)     # one live block: direct path
+    for b in range(2):
+        assert torch.allclose(out[b * 256:b * 256 + 2], ref[b * 256:b * 256 + 2], atol=3e-3, rtol=1e-4)
+        assert bool((out[b * 256 + 32:(b + 1) * 256] == 7.0).all())
+    x0 = torch.randn(M, N, generator=g)
+    gate = torch.randn(2, N, generator=g)
+    x = x0.clone()
+    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=256, algo=sl)
+    assert torch.allclose(x, x0 + gate.repeat_interleave(256, 0) * ref, atol=5e-3, rtol=1e-4)
+    if N % 384 == 0:
+        qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=256, algo=sl, q_scale=0.5)
+        Wd = N // 3
+        assert torch.allclose(qk.float()[:, :Wd], 0.5 * ref[:, :Wd], atol=3e-2, rtol=1e-2)
+        assert torch.allclose(qk.float()[:, Wd:], ref[:, Wd:2 * Wd], atol=3e-2, rtol=1e-2)
+        assert torch.allclose(vt.float(), ref[:, 2 * Wd:].reshape(2, 256, Wd).transpose(1, 2), atol=3e-2, rtol=1e-2)
+
