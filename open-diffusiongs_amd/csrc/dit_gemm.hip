@@ -65,21 +65,35 @@ __device__ __forceinline__ void stage_tile(const bf16_t* g, int ld, int row0, in
     }
 }
 
-// One BK = 64 slab of a wave's accumulators: MI live 32-row blocks x NI 32-column blocks.
+// One BK = 64 slab of a wave's accumulators: MI live 32-row blocks x NI 32-column blocks, 4 k-substeps of 16.
+// Issue order (tools/ubench/issue_bench; hipcc waits with lgkmcnt(0) at the first use of a fragment, so a read issued
+// right before an MFMA exposes the whole LDS latency): the fragments of substep ks + 1 are read into the other half of a
+// register double buffer BEHIND the first MFMA of substep ks, i.e. MI * NI - 1 MFMAs before they are needed; only the
+// first substep of a slab waits for its reads.  sched_barrier fences keep the source order.
 template <int NI, int MI>
 __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int fhalf, int swz, f32x16 (&acc)[2][NI]) {
+    bf16x8 a[2][MI], b[2][NI];
+    auto read = [&](int ks, int h) {
+        const int off = ((2 * ks + fhalf) ^ swz) << 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[h][i] = *reinterpret_cast<const bf16x8*>(la + i * 32 * 128 + off);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[h][j] = *reinterpret_cast<const bf16x8*>(lb + j * 32 * 128 + off);
+    };
+    read(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const int off = ((2 * ks + fhalf) ^ swz) << 4;
-        bf16x8 a[MI], b[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(la + i * 32 * 128 + off);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(lb + j * 32 * 128 + off);
+        const int h = ks & 1;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
+                if (i == 0 && j == 0 && ks < 3) read(ks + 1, h ^ 1);
+#ifndef HIPEMU
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
     }
 }
 
@@ -276,7 +290,11 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     const int algo = a->algo ? a->algo : env_algo;
     if (algo == DGS_GEMM_BIG256 && big_gemm_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
         return launch_big_gemm(a, p.rows_per_batch, p.valid_rows, st0);
-    if (algo == DGS_GEMM_SLICED) {
+    // AUTO: the sliced 256 x 256 kernel where one round of it covers the chip and beats 3+ rounds of 128-wide tiles (measured at
+    // batch 1: the QKV GEMM, 39 vs 44 us); everything else runs the 128-wide two-stage kernel below
+    const bool auto_sliced = algo == DGS_GEMM_AUTO && a->epilogue == DGS_EPI_QKV && a->M <= 8192 &&
+                             sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows) == 256;
+    if (algo == DGS_GEMM_SLICED || auto_sliced) {
         const int sbn = sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
         if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0);
     }

@@ -383,9 +383,17 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
     for (uint32_t w0 = 0; w0 < (uint32_t)p.P; w0 += (uint32_t)wwords * 32u) {
         for (int i = tid; i < wwords; i += 256) bm[i] = 0;
         __syncthreads();
-        for (uint32_t i = rg.x + tid; i < rg.y; i += 256) {
-            const uint32_t r = p.bn.inst_rank[i] - w0;       // unsigned wrap puts other windows out of range
-            if (r < (uint32_t)wwords * 32u) atomicOr(&bm[r >> 5], 1u << (r & 31u));
+        // 8 independent loads in flight per thread: the loop is latency-bound otherwise (one L2 round trip per 256 instances)
+        for (uint32_t i0 = rg.x; i0 < rg.y; i0 += 8u * 256u) {
+            uint32_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)tid;
+                r[u] = i < rg.y ? p.bn.inst_rank[i] - w0 : 0xffffffffu;     // unsigned wrap puts other windows out of range
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r[u] < (uint32_t)wwords * 32u) atomicOr(&bm[r[u] >> 5], 1u << (r[u] & 31u));
         }
         __syncthreads();
         // Emission is wave-cooperative so that stores (and the rank -> index gathers) are coalesced: every wave owns a
@@ -408,12 +416,26 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
             total += c;
         }
         const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        for (int k = 0; k < wpw; k += 2) {
-            const uint32_t word = bm[wave * wpw + k + (lane >> 5)];
-            const bool set = (word >> (lane & 31)) & 1u;
-            const unsigned long long m = __ballot(set);
-            if (set) p.bn.point_list[off + (uint32_t)__popcll(m & lt_mask)] = order[w0 + (uint32_t)(wave * wpw + k) * 32u + (uint32_t)lane];
-            off += (uint32_t)__popcll(m);
+        // sixteen 64-bit chunks per step: the rank -> index gathers of all of them are in flight before the first store needs one
+        // (wwords is a multiple of 256, so wpw is a multiple of 32).  A lane-per-word variant (popcount scan + per-lane bit
+        // peeling) was measured 30 % slower: its stores and gathers scatter.
+        constexpr int EB = 16;
+        for (int k = 0; k < wpw; k += 2 * EB) {
+            uint32_t slot[EB], val[EB];
+            unsigned long long setm = 0;
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const uint32_t word = bm[wave * wpw + k + 2 * u + (lane >> 5)];
+                const bool set = (word >> (lane & 31)) & 1u;
+                const unsigned long long m = __ballot(set);
+                slot[u] = off + (uint32_t)__popcll(m & lt_mask);
+                off += (uint32_t)__popcll(m);
+                val[u] = set ? order[w0 + (uint32_t)(wave * wpw + k + 2 * u) * 32u + (uint32_t)lane] : 0u;
+                setm |= (unsigned long long)set << u;
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u)
+                if ((setm >> u) & 1ull) p.bn.point_list[slot[u]] = val[u];
         }
         emitted += total;
         __syncthreads();
@@ -438,7 +460,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     const size_t vo = (size_t)v * p.P;
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
     for (int i = 0; i < rounds; ++i, todo -= 256) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t pos = rg.x + (uint32_t)i * 256u + (uint32_t)tid;
@@ -450,24 +472,36 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
         }
         __syncthreads();
         const int nb = todo < 256 ? todo : 256;
-        for (int j = 0; !done && j < nb; ++j) {
-            contributor++;
+        // Per (pixel, Gaussian) the common case is a reject (power > 0, or below the Gaussian's alpha cut-off): the loop is kept
+        // free of per-lane branches up to that test and leaves with ONE wave-uniform branch when no lane of the wave passes;
+        // the arithmetic of every lane is the reference's, in the reference's order (forward.cu:332-358).
+        const uint32_t base = (uint32_t)i * 256u;
+        const int nbw = __ballot(!done) == 0ull ? 0 : nb;          // a wave whose 64 pixels are all finished only keeps the barriers
+#pragma unroll 4
+        for (int j = 0; j < nbw; ++j) {
             const float2 xy = s_xy[j];
-            const float dx = xy.x - pfx, dy = xy.y - pfy;
             const float4 co = s_co[j];
+            const float cut = s_rgbc[j].w;
+            const float dx = xy.x - pfx, dy = xy.y - pfy;
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            if (power > 0.0f) continue;
-            const float4 rc = s_rgbc[j];
-            if (power < rc.w) continue;                 // alpha < 1/255 guaranteed (see preprocess_one)
-            const float alpha = fminf(0.99f, co.w * det_expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            C0 += rc.x * alpha * T;
-            C1 += rc.y * alpha * T;
-            C2 += rc.z * alpha * T;
-            T = test_T;
-            last_contributor = contributor;
+            const bool pass = !done && !(power > 0.0f) && !(power < cut);      // alpha < 1/255 guaranteed below `cut` (preprocess_one)
+            if (__ballot(pass) == 0ull) continue;
+            if (pass) {
+                const float alpha = fminf(0.99f, co.w * det_expf(power));
+                if (!(alpha < 1.0f / 255.0f)) {
+                    const float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) {
+                        done = true;
+                    } else {
+                        const float4 rc = s_rgbc[j];
+                        C0 += rc.x * alpha * T;
+                        C1 += rc.y * alpha * T;
+                        C2 += rc.z * alpha * T;
+                        T = test_T;
+                        last_contributor = base + (uint32_t)j + 1u;
+                    }
+                }
+            }
         }
     }
     if (inside) {
