@@ -59,19 +59,8 @@ def measured_traffic(kernel, batch):
 
 
 def synth_batch(B, V, res, device, seed):
-    """Synthetic inputs of the reference's shapes: U[0,1) images, ring cameras radius 3, G-Objaverse
-    intrinsics; rays as TransformInput (systems/utils.py:621-757) computes them -- upstream of the timed step."""
-    from dgs_amd import cameras
-    g = torch.Generator().manual_seed(seed)
-    images = torch.rand(B, V, 3, res, res, generator=g)
-    c2w = np.stack([cameras.ring_cameras(V, phase_deg=13.0 * b + seed) for b in range(B)], 0)
-    k = np.broadcast_to(cameras.default_fxfycxcy(res), (B, V, 4)).copy()
-    rays = [[cameras.pixel_rays(c2w[b, v], k[b, v], res, res) for v in range(V)] for b in range(B)]
-    ray_o = torch.tensor(np.stack([[r[0] for r in row] for row in rays])).permute(0, 1, 4, 2, 3).contiguous()
-    ray_d = torch.tensor(np.stack([[r[1] for r in row] for row in rays])).permute(0, 1, 4, 2, 3).contiguous()
-    t = torch.randint(0, 1000, (B,), generator=g)
-    batch = dict(image=images, ray_o=ray_o, ray_d=ray_d, c2w=torch.tensor(c2w), fxfycxcy=torch.tensor(k))
-    return {a: b.to(device) for a, b in batch.items()}, t.to(device)
+    from dgs_amd import synth
+    return synth.make_batch(B, res, V=V, device=device, seed=seed, with_t=True)
 
 
 def cpu_baseline(model, batch, t, res, V, hip_gaussians, hip_render):
@@ -187,6 +176,22 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # Informational: the reference's 30-step sampling loop end to end -- DGSDenoiser.forward + the device sampler
+    # step (dgs_amd/sampler.py) per iteration; one untimed loop, one timed.  Not part of `value`.
+    from dgs_amd import sampler as sm
+    diffusion = sm.create_diffusion("30", device=dev)
+    loop_batch = dict(batch)
+    loop_ms = None
+    for timed in (False, True):
+        loop_batch["image"] = batch["image"].clone()
+        loop_batch["image_noisy"] = torch.randn_like(batch["image"][:, 1:])
+        torch.cuda.synchronize()
+        l0 = time.perf_counter()
+        diffusion.p_sample_loop(model, loop_batch)
+        torch.cuda.synchronize()
+        if timed:
+            loop_ms = (time.perf_counter() - l0) * 1e3
+
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         value = B * V * world / (elapsed / a.steps)
@@ -207,6 +212,8 @@ def main():
                          "traffic": measured_traffic(a.roofline_kernel, B) if res == 256 and V == 4 else None,
                          "launches_timed": len(kern_ms), "avg_launch_us": round(avg_s * 1e6, 2)},
         }
+        out["sampling_loop_30_steps"] = {"ms_per_loop": round(loop_ms, 2), "renders_per_s": round(B * V * 30 / (loop_ms * 1e-3), 1),
+                                         "note": "per GPU; informational, not part of value"}
         if world == 1 and not a.no_cpu_baseline:
             final = {k: getattr(gaussians[0], "_" + n)[None] for k, n in
                      (("xyz", "xyz"), ("features", "features_dc"), ("scaling", "scaling"), ("rotation", "rotation"), ("opacity", "opacity"))}

@@ -65,7 +65,7 @@ extern "C" size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32
     return bytes;
 }
 
-#define DGS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DGS_OK) return rc_; } while (0)
+#define DGS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DGS_OK) { fprintf(stderr, "[dgs] %s:%d: status %d\n", __FILE__, __LINE__, rc_); return rc_; } } while (0)
 
 namespace {
 // bench.py's roofline hook: HIP events around every launch of one kernel class, on the launch stream.
@@ -75,15 +75,15 @@ struct Prof {
     void after(int k) { if (ev && k == kind && n < cap) { hipEventRecord(static_cast<hipEvent_t>(ev[2 * n + 1]), st); ++n; } }
 };
 }  // namespace
-#define DGS_PROF(k, expr) do { prof.before(k); const int rc_ = (expr); prof.after(k); if (rc_ != DGS_OK) return rc_; } while (0)
+#define DGS_PROF(k, expr) do { prof.before(k); const int rc_ = (expr); prof.after(k); if (rc_ != DGS_OK) { fprintf(stderr, "[dgs] %s:%d: status %d\n", __FILE__, __LINE__, rc_); return rc_; } } while (0)
 
 extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream) {
-    if (!m || !a || a->B <= 0 || a->V <= 0 || a->H <= 0 || a->W <= 0) return DGS_ERR_INVALID_ARGUMENT;
+    if (!m || !a || a->B <= 0 || a->V <= 0 || a->H <= 0 || a->W <= 0) { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
     if (m->width % 256 || m->width != m->heads * 64 || m->layers <= 0 || m->patch <= 0 || a->H % m->patch || a->W % m->patch)
-        return DGS_ERR_INVALID_ARGUMENT;
-    if (m->gs_channels != 14 || m->in_channels != 9 || (m->in_channels * m->patch * m->patch) % 64) return DGS_ERR_INVALID_ARGUMENT;
+        { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
+    if (m->gs_channels != 14 || m->in_channels != 9 || (m->in_channels * m->patch * m->patch) % 64) { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
     if (!a->images || !a->ray_o || !a->ray_d || !a->t || !a->workspace || !a->xyz || !a->features || !a->scaling || !a->rotation || !a->opacity)
-        return DGS_ERR_INVALID_ARGUMENT;
+        { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int B = a->B, V = a->V, H = a->H, Wd = a->W, W = m->width, ng = m->n_gaussians, C = m->gs_channels;
     const int L = token_count(m, V, H, Wd), lpad = dgs_dit_lpad(L), M = B * lpad;

@@ -304,7 +304,10 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     }
     // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each
     if (a->epilogue == DGS_EPI_QKV && a->N % 128) return DGS_ERR_INVALID_ARGUMENT;
-    const int bn = (a->N % 128 || ((a->M / BM) * (a->N / 128) < 512 && a->epilogue != DGS_EPI_QKV)) ? 64 : 128;
+    static const int env_bn = getenv("DGS_GEMM_BN") ? atoi(getenv("DGS_GEMM_BN")) : 0;      // measurement aid
+    int bn = (a->N % 128 || ((a->M / BM) * (a->N / 128) < 512 && a->epilogue != DGS_EPI_QKV)) ? 64 : 128;
+    if (env_bn == 128 && a->N % 128 == 0) bn = 128;
+    if (env_bn == 64) bn = 64;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (a->epilogue) {
         case DGS_EPI_BF16: launch_gemm<DGS_EPI_BF16>(p, bn, st); break;

@@ -113,7 +113,7 @@ __global__ void pos_embed_backward_kernel(const float* dx, float* dpos, int B, i
 
 using namespace dgs;
 
-#define DGS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DGS_OK) return rc_; } while (0)
+#define DGS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DGS_OK) { fprintf(stderr, "[dgs] %s:%d: status %d\n", __FILE__, __LINE__, rc_); return rc_; } } while (0)
 #define HIP_TRY(expr) do { if ((expr) != hipSuccess) return DGS_ERR_DEVICE; } while (0)
 
 extern "C" size_t dgs_dit_saved_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W) {

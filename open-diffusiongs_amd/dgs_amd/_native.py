@@ -268,8 +268,25 @@ def _declare_dit(L):
     return L
 
 
+class DgsSamplerStepArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("per_sample", ctypes.c_int64), ("model_stride", ctypes.c_int64), ("model_offset", ctypes.c_int64),
+                ("model_output", ctypes.c_void_p), ("x_t", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("t", ctypes.c_void_p),
+                ("coef1", ctypes.c_void_p), ("coef2", ctypes.c_void_p), ("sigma", ctypes.c_void_p), ("T", ctypes.c_int32),
+                ("clip_denoised", ctypes.c_int32), ("out", ctypes.c_void_p), ("pred_xstart", ctypes.c_void_p), ("bad_t", ctypes.c_void_p)]
+
+
+# every symbol include/dgs_sampler.h declares (checked by tests/test_abi.py)
+SAMPLER_SYMBOLS = ["dgs_sampler_step"]
+
+
+def _declare_sampler(L):
+    L.dgs_sampler_step.restype = ctypes.c_int
+    L.dgs_sampler_step.argtypes = [ctypes.POINTER(DgsSamplerStepArgs), ctypes.c_void_p]
+    return L
+
+
 _declare_raster = _declare
 
 
-def _declare(L):  # noqa: F811  (raster + DiT prototypes on one library)
-    return _declare_dit(_declare_raster(L))
+def _declare(L):  # noqa: F811  (raster + DiT + sampler prototypes on one library)
+    return _declare_sampler(_declare_dit(_declare_raster(L)))

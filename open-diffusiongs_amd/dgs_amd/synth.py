@@ -6,6 +6,7 @@
 Gaussians; activations follow gs_core.py:330-334 (exp / normalize / sigmoid) and
 denoiser.py:118-119 (scale bias -2.3 clamp -1.2, opacity bias -2.0).
 """
+import torch
 import numpy as np
 
 from . import cameras
@@ -51,3 +52,22 @@ def render_cameras(res, n_views, phase_deg=0.0, res_h=None):
     c2ws = cameras.ring_cameras(n_views, phase_deg=phase_deg)
     fxfycxcy = cameras.default_fxfycxcy(res, res_h)
     return [cameras.camera_from_c2w(c2ws[k], fxfycxcy, res_h, res) for k in range(n_views)], c2ws, fxfycxcy
+
+
+def make_batch(B, res, V=4, device="cuda", seed=0, with_t=False):
+    """Synthetic inputs of the reference's shapes: U[0,1) images, ring cameras radius 3, G-Objaverse
+    intrinsics; rays as TransformInput (systems/utils.py:621-757) computes them -- upstream of the timed step."""
+    from . import cameras
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(B, V, 3, res, res, generator=g)
+    c2w = np.stack([cameras.ring_cameras(V, phase_deg=13.0 * b + seed) for b in range(B)], 0)
+    k = np.broadcast_to(cameras.default_fxfycxcy(res), (B, V, 4)).copy()
+    rays = [[cameras.pixel_rays(c2w[b, v], k[b, v], res, res) for v in range(V)] for b in range(B)]
+    ray_o = torch.tensor(np.stack([[r[0] for r in row] for row in rays])).permute(0, 1, 4, 2, 3).contiguous()
+    ray_d = torch.tensor(np.stack([[r[1] for r in row] for row in rays])).permute(0, 1, 4, 2, 3).contiguous()
+    t = torch.randint(0, 1000, (B,), generator=g)
+    batch = dict(image=images, ray_o=ray_o, ray_d=ray_d, c2w=torch.tensor(c2w), fxfycxcy=torch.tensor(k))
+    batch = {a: b.to(device) for a, b in batch.items()}
+    return (batch, t.to(device)) if with_t else batch
+
+
