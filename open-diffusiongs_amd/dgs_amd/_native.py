@@ -285,8 +285,25 @@ def _declare_sampler(L):
     return L
 
 
+class DgsMseArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("n", ctypes.c_int64), ("rendering", ctypes.c_void_p), ("target", ctypes.c_void_p),
+                ("clamp01", ctypes.c_int32), ("l2", ctypes.c_void_p), ("psnr", ctypes.c_void_p), ("grad", ctypes.c_void_p),
+                ("grad_scale", ctypes.c_float), ("partial", ctypes.c_void_p)]
+
+
+LOSS_CHUNKS = 64
+# every symbol include/dgs_loss.h declares (checked by tests/test_abi.py)
+LOSS_SYMBOLS = ["dgs_mse_psnr"]
+
+
+def _declare_loss(L):
+    L.dgs_mse_psnr.restype = ctypes.c_int
+    L.dgs_mse_psnr.argtypes = [ctypes.POINTER(DgsMseArgs), ctypes.c_void_p]
+    return L
+
+
 _declare_raster = _declare
 
 
-def _declare(L):  # noqa: F811  (raster + DiT + sampler prototypes on one library)
-    return _declare_sampler(_declare_dit(_declare_raster(L)))
+def _declare(L):  # noqa: F811  (raster + DiT + sampler + loss prototypes on one library)
+    return _declare_loss(_declare_sampler(_declare_dit(_declare_raster(L))))

@@ -1,0 +1,59 @@
+"""Image-space loss consumer on the device: per-sample MSE + PSNR and the MSE gradient in one pass.
+
+Mirrors diffusionGS/utils/losses.py: the `l2_loss` / `psnr` terms of LossComputer.forward (:281-285, :303) and `compute_psnr`
+(:399-402).  LPIPS / SSIM (network-based) are out of scope.  csrc/loss.hip through include/dgs_loss.h; no CPU fallback."""
+import ctypes
+
+import torch
+
+from . import _native
+
+
+def _run(rendering, target, clamp01, want_psnr, grad_scale, lib):
+    assert rendering.shape == target.shape and rendering.dtype == torch.float32 and target.dtype == torch.float32
+    r, t = rendering.contiguous(), target.contiguous()
+    B = r.shape[0]
+    n = r[0].numel()
+    dev = r.device
+    l2 = torch.empty(B, dtype=torch.float32, device=dev)
+    psnr = torch.empty(B, dtype=torch.float32, device=dev) if want_psnr else None
+    grad = torch.empty_like(r) if grad_scale is not None else None
+    partial = torch.empty(B, _native.LOSS_CHUNKS, dtype=torch.float32, device=dev)
+    a = _native.DgsMseArgs()
+    ptr = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else None
+    a.B, a.n, a.rendering, a.target, a.clamp01 = B, n, ptr(r), ptr(t), int(clamp01)
+    a.l2, a.psnr, a.grad, a.grad_scale, a.partial = ptr(l2), ptr(psnr), ptr(grad), float(grad_scale or 0.0), ptr(partial)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if r.is_cuda else None
+    rc = (lib or _native.lib()).dgs_mse_psnr(ctypes.byref(a), stream)
+    if rc != 0:
+        raise RuntimeError(f"dgs_mse_psnr failed: {rc}")
+    return l2, psnr, grad
+
+
+def compute_psnr(ground_truth, predicted, lib=None):
+    """losses.py:399-402: clamp to [0, 1], per-image mean squared error over (c, h, w), -10 log10."""
+    return _run(predicted, ground_truth, True, True, None, lib)[1]
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rendering, target, lib):
+        B = rendering.shape[0]
+        l2, psnr, grad = _run(rendering, target, False, True, 1.0 / B, lib)     # d(mean_b l2_b) / d rendering
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(psnr)
+        return l2.mean(), l2, psnr
+
+    @staticmethod
+    def backward(ctx, g_loss, g_l2, _g_psnr):
+        (grad,) = ctx.saved_tensors
+        out = grad * g_loss
+        if g_l2 is not None:     # per-sample weights: d l2_b / d rendering = B * grad_b
+            out = out + grad * (g_l2 * grad.shape[0]).reshape(-1, *([1] * (grad.dim() - 1)))
+        return out, None, None
+
+
+def mse_psnr(rendering, target, lib=None):
+    """rendering / target [b, v, 3, h, w] -> (loss = mean_b l2_b, l2 [b], psnr [b]); loss and l2 are differentiable w.r.t.
+    `rendering` (the gradient was produced by the same pass that formed the sums)."""
+    return _Mse.apply(rendering, target, lib)

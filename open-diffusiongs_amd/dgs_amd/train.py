@@ -3,7 +3,7 @@ systems/diffusion_gs_system.py:71-128, minus the parts that are out of scope: no
 
     gaussians = model.image_to_gaussians(noisy views)          DiT forward, activations saved        (HIP)
     renders   = model.render_gaussians(gaussians, cameras)     all b*v views, one launch sequence    (HIP)
-    loss      = mean((renders - target)^2)                     the reference's lambda_mse term       (torch, a few elementwise ops)
+    loss      = mean((renders - target)^2)                     the reference's lambda_mse term       (HIP: dgs_amd.losses, one pass)
     loss.backward()                                            rasterizer backward + DiT backward    (HIP)
     gradient all-reduce over the ranks                         RCCL over xGMI, a few large buckets   (dgs_amd.parallel)
     optimizer step on the fp32 master parameters               torch.optim (AdamW in the reference configs)
@@ -14,6 +14,7 @@ collectives that start while earlier blocks are still in backward.
 """
 import torch
 
+from . import losses
 from .parallel import BucketedAllReduce
 
 
@@ -45,7 +46,7 @@ class DataParallelTrainer:
         k = batch["fxfycxcy"] if render_fxfycxcy is None else render_fxfycxcy
         H, W = batch["image"].shape[3], batch["image"].shape[4]
         rendered = m.render_gaussians(params, c2w, k, H, W)
-        loss = ((rendered - target) ** 2).mean()
+        loss, _l2, self.last_psnr = losses.mse_psnr(rendered, target.to(rendered.dtype), lib=getattr(m, "_lib", None))
         loss.backward()
         self._reduce_gradients()
         self.opt.step()

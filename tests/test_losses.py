@@ -1,0 +1,47 @@
+"""MSE / PSNR loss consumer against the torch expressions the reference uses (losses.py:281-285, 303, 399-402)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "open-diffusiongs_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _check(lib, device):
+    from dgs_amd import losses
+    g = torch.Generator().manual_seed(5)
+    b, v, h, w = 3, 4, 16, 24
+    render = (torch.rand(b, v, 3, h, w, generator=g) * 1.4 - 0.2).to(device).requires_grad_(True)
+    target = torch.rand(b, v, 3, h, w, generator=g).to(device)
+    loss, l2, psnr = losses.mse_psnr(render, target, lib=lib)
+    ref_el = F.mse_loss(render.detach().cpu().double(), target.cpu().double(), reduction="none").reshape(b, v, -1, h, w)
+    ref_l2 = ref_el.mean(dim=(1, 2, 3, 4))
+    assert torch.allclose(l2.detach().cpu().double(), ref_l2, rtol=2e-6)
+    assert torch.allclose(psnr.cpu().double(), -10.0 * torch.log10(ref_l2), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(loss.detach().cpu().double(), ref_l2.mean(), rtol=2e-6)
+    (0.7 * loss + (l2 * torch.tensor([1.0, 0.0, 2.0], device=device)).sum()).backward()
+    rr = render.detach().cpu().double().requires_grad_(True)
+    rl2 = ((rr - target.cpu().double()) ** 2).mean(dim=(1, 2, 3, 4))
+    (0.7 * rl2.mean() + (rl2 * torch.tensor([1.0, 0.0, 2.0], dtype=torch.float64)).sum()).backward()
+    assert torch.allclose(render.grad.cpu().double(), rr.grad, rtol=1e-5, atol=1e-9)
+    # compute_psnr clamps to [0, 1] and reduces per image
+    img_r, img_t = render.detach().reshape(b * v, 3, h, w), target.reshape(b * v, 3, h, w)
+    want = -10 * torch.log10(((img_t.cpu().clamp(0, 1) - img_r.cpu().clamp(0, 1)) ** 2).mean(dim=(1, 2, 3)))
+    assert torch.allclose(losses.compute_psnr(img_t, img_r, lib=lib).cpu(), want, rtol=1e-5, atol=1e-5)
+    # deterministic: same inputs, same bits
+    assert torch.equal(losses.mse_psnr(render.detach(), target, lib=lib)[1], l2.detach())
+
+
+def test_on_emulator():
+    from emu_util import emu_lib
+    _check(emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_on_gpu():
+    _check(None, "cuda:0")
