@@ -82,6 +82,21 @@ class GaussianModel:
     def get_features(self):
         return self._features_dc if self._features_rest is None else torch.cat((self._features_dc, self._features_rest), dim=1)
 
+    # -- on-disk format, gs_core.py:578-760 (dgs_amd/consumers.py) --
+    def construct_dtypes(self, use_fp16=False, enable_gs_viewer=True):
+        from . import consumers
+        assert not use_fp16, "PLY has no 16-bit float property type"
+        return consumers.construct_dtypes(self, enable_gs_viewer)
+
+    def save_ply(self, path, use_fp16=False, enable_gs_viewer=True, color_code=False, filter_mask=None):
+        from . import consumers
+        assert not use_fp16 and not color_code
+        consumers.save_ply(self, path, enable_gs_viewer, filter_mask)
+
+    def load_ply(self, path, device="cpu"):
+        from . import consumers
+        return consumers.load_ply(self, path, device)
+
 
 class Renderer(nn.Module):
     """renderer.py:20-92.  forward(...) -> [b, v, 3, H, W] float32; all b*v views in one launch sequence."""
