@@ -110,7 +110,7 @@ typedef struct DgsDitAttentionBackwardArgs {
     const uint16_t* dO;        /* bf16 [B*lpad, W] its gradient                                                    */
     const uint16_t* dOT;       /* bf16 [B, W, lpad] token-contiguous copy of dO                                    */
     const float* lse2;         /* [B, heads, lpad] from the forward                                                */
-    float* D;                  /* [B, heads, lpad] scratch: rowsum(dO o O)                                         */
+    float* D;                  /* [B, heads, lpad] scratch: -rowsum(dO o O) (the initial value of the dP accumulators) */
     uint16_t* dqkv;            /* out bf16 [B*lpad, 3W]: dq | dk | dv                                              */
     float scale;
 } DgsDitAttentionBackwardArgs;

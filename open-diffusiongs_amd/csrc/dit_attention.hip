@@ -60,10 +60,6 @@ __device__ __forceinline__ float row_max(const f32x16& s0, const f32x16& s1) {
 
 template <int V> struct Mode { static constexpr int value = V; };
 
-// bf16 query value times scale * log2(e), rounded back to bf16 (the B operand of S' = K (c Q)^T)
-__device__ __forceinline__ uint32_t scale_bf2(uint32_t two, float c) {
-    return pack_bf2(bf2f(two & 0xffffu) * c, bf2f(two >> 16) * c);
-}
 
 // The L % 32 queries behind the last full 32-query unit (the two learned tokens of the DiT: L = 32 k + 2) would cost a
 // whole extra wave per head on the matrix pipe.  Their attention is split over the KEY tiles instead: behind the main loop

@@ -5,6 +5,11 @@
 //     D_q  = sum_d dO[q,d] O[q,d]
 //     dV   = P^T dO            dP = dO V^T            dS = P o (dP - D) * scale
 //     dQ   = dS K              dK = dS^T Q
+// VALU diet (both loops were VALU-bound at 13 VALU per MFMA): the queries enter the S MFMAs as bf16(-scale log2(e) q)
+// (the same rounding as the forward's pre-scaled queries, sign flipped) and the S accumulators START at +lse, so the
+// matrix pipe hands back lse - S' and P = exp2(-(.)) is a bare v_exp_f32 with a source negation; the dP accumulators START
+// at -D (the D scratch holds -D), so dP - D needs no instruction either; `scale` is applied once to the dQ / dK
+// accumulators at the end, and the ragged last tile has its own loop copy: 2.5-3 VALU per score instead of 10.
 // Two kernels, both recomputing S from the saved log-sum-exp (no S x S matrix is ever stored), both free of atomics:
 //   attention_bwd_dq_kernel   one workgroup per 256-query block (like the forward): walks the key tiles, accumulates dQ; also
 //                             produces D.
@@ -54,6 +59,8 @@ __device__ __forceinline__ bf16x8 pack_rows(const f32x16& s, int r0) {
     for (int j = 0; j < 4; ++j) f.u[j] = pack_bf2(s[r0 + 2 * j], s[r0 + 2 * j + 1]);
     return f.v;
 }
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
 __device__ __forceinline__ f32x16 zero_acc() {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     return z;
@@ -87,7 +94,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
         const bf16_t* dp = p.dO + (row0 + q) * p.ld_o + head * 64;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (2 * ks + half) * 8);
+            uint4 raw = *reinterpret_cast<const uint4*>(qp + (2 * ks + half) * 8);      // -> bf16(-scale log2(e) q)
+            raw.x = scale_bf2(raw.x, -p.scale_log2e); raw.y = scale_bf2(raw.y, -p.scale_log2e);
+            raw.z = scale_bf2(raw.z, -p.scale_log2e); raw.w = scale_bf2(raw.w, -p.scale_log2e);
+            qf[ks] = __builtin_bit_cast(bf16x8, raw);
             dof[ks] = *reinterpret_cast<const bf16x8*>(dp + (2 * ks + half) * 8);
             const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + (2 * ks + half) * 8);
 #pragma unroll
@@ -97,7 +107,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
     }
     const size_t stat = ((size_t)b * p.heads + head) * p.lpad + q;
     const float lse = p.lse2[stat];
-    if (half == 0 && q_raw < p.lpad) p.D[stat] = Dq;
+    if (half == 0 && q_raw < p.lpad) p.D[stat] = -Dq;          // the scratch holds -D: it is the dP accumulators' initial value
+    f32x16 lse16, negd16;                                       // per-lane (= per-query) constants as MFMA C operands
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { lse16[r] = lse; negd16[r] = -Dq; }
 
     f32x16 dq0 = zero_acc(), dq1 = zero_acc();
     const int ntiles = (p.L + BT - 1) / BT;
@@ -118,28 +131,30 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
     publish(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): retire the fragment loads before the loop (see forward kernel)
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](int t, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const bool more = t + 1 < ntiles;
         if (more) issue(t + 1);
         if (wave_live) {
             const char* base = lds + (t & 1) * 3 * TILE_B;
-            f32x16 s0, s1, e0, e1;
+            f32x16 s0, s1, e0, e1;                       // s = lse - S', e = dP - D
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, l31, ks, half), qf[ks], ks == 0 ? zero_acc() : s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, 32 + l31, ks, half), qf[ks], ks == 0 ? zero_acc() : s1, 0, 0, 0);
-                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, l31, ks, half), dof[ks], ks == 0 ? zero_acc() : e0, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, 32 + l31, ks, half), dof[ks], ks == 0 ? zero_acc() : e1, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, l31, ks, half), qf[ks], ks == 0 ? lse16 : s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, 32 + l31, ks, half), qf[ks], ks == 0 ? lse16 : s1, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, l31, ks, half), dof[ks], ks == 0 ? negd16 : e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, 32 + l31, ks, half), dof[ks], ks == 0 ? negd16 : e1, 0, 0, 0);
             }
-            const bool ragged = (t + 1) * BT > p.L;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = t * BT + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float p0 = fast_exp2(__builtin_fmaf(s0[r], p.scale_log2e, -lse));
-                float p1 = fast_exp2(__builtin_fmaf(s1[r], p.scale_log2e, -lse));
-                if (ragged) { if (key >= p.L) p0 = 0.f; if (key + 32 >= p.L) p1 = 0.f; }
-                s0[r] = p0 * (e0[r] - Dq) * p.scale;
-                s1[r] = p1 * (e1[r] - Dq) * p.scale;
+                float p0 = fast_exp2(-s0[r]), p1 = fast_exp2(-s1[r]);
+                if (RAGGED) {
+                    const int key = t * BT + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (key >= p.L) { p0 = 0.f; e0[r] = 0.f; }
+                    if (key + 32 >= p.L) { p1 = 0.f; e1[r] = 0.f; }
+                }
+                s0[r] = p0 * e0[r];                      // dS / scale
+                s1[r] = p1 * e1[r];
             }
             const char* kt = base + 2 * TILE_B;
 #pragma unroll
@@ -151,13 +166,17 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
         }
         if (more) publish((t + 1) & 1);
         __syncthreads();
-    }
+    };
+    const int nplain = p.L / BT;                          // tiles without keys >= L
+    for (int t = 0; t < nplain; ++t) tile(t, BoolTag<false>{});
+    if (nplain < ntiles) tile(nplain, BoolTag<true>{});
     if (!wave_live) return;
     bf16_t* orow = p.dq + (row0 + q) * p.ld_d + head * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = make_uint2(pack_bf2(dq0[4 * g], dq0[4 * g + 1]), pack_bf2(dq0[4 * g + 2], dq0[4 * g + 3]));
-        *reinterpret_cast<uint2*>(orow + 32 + 8 * g + 4 * half) = make_uint2(pack_bf2(dq1[4 * g], dq1[4 * g + 1]), pack_bf2(dq1[4 * g + 2], dq1[4 * g + 3]));
+        const float c = p.scale;
+        *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = make_uint2(pack_bf2(c * dq0[4 * g], c * dq0[4 * g + 1]), pack_bf2(c * dq0[4 * g + 2], c * dq0[4 * g + 3]));
+        *reinterpret_cast<uint2*>(orow + 32 + 8 * g + 4 * half) = make_uint2(pack_bf2(c * dq1[4 * g], c * dq1[4 * g + 1]), pack_bf2(c * dq1[4 * g + 2], c * dq1[4 * g + 3]));
     }
 }
 
@@ -209,7 +228,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
     };
     auto publish = [&](int stage) {
         char* base = lds + stage * STAGE;
-        put_rows(base, sr, sc, qreg);
+        uint4 qs = qreg;                                  // the S operand: bf16(-scale log2(e) q); Q^T below stays raw (it feeds dK)
+        qs.x = scale_bf2(qs.x, -p.scale_log2e); qs.y = scale_bf2(qs.y, -p.scale_log2e);
+        qs.z = scale_bf2(qs.z, -p.scale_log2e); qs.w = scale_bf2(qs.w, -p.scale_log2e);
+        put_rows(base, sr, sc, qs);
         put_rows(base + TILE_B, sr, sc, doreg);
         put_perm(base + 2 * TILE_B, sr, sc, qtreg);
         put_perm(base + 3 * TILE_B, sr, sc, dotreg);
@@ -218,40 +240,43 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
     publish(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](int t, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const bool more = t + 1 < ntiles;
         if (more) issue(t + 1);
         if (wave_live) {
             const char* base = lds + (t & 1) * STAGE;
-            const float* lt = lseg + t * BT;      // per-query statistics straight from L2 (same address across a half-wave)
-            const float* dt = Dg + t * BT;
-            f32x16 s0, s1, e0, e1;     // rows: queries of 32-query block 0 / 1 of the tile
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, l31, ks, half), kf[ks], ks == 0 ? zero_acc() : s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, 32 + l31, ks, half), kf[ks], ks == 0 ? zero_acc() : s1, 0, 0, 0);
-                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, l31, ks, half), vf[ks], ks == 0 ? zero_acc() : e0, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, 32 + l31, ks, half), vf[ks], ks == 0 ? zero_acc() : e1, 0, 0, 0);
-            }
-            const bool ragged = (t + 1) * BT > p.L;
+            // per-query statistics straight from L2 (same address across a half-wave), loaded INTO the accumulators' initial
+            // values: register r of block 0 / 1 is query 8 (r >> 2) + 4 half + (r & 3) (+ 32) of the tile
+            const float* lt = lseg + t * BT + 4 * half;
+            const float* dt = Dg + t * BT + 4 * half;
+            f32x16 s0, s1, e0, e1;                       // s = lse - S', e = dP - D
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int qq = 8 * g + 4 * half;                          // first of 4 consecutive query rows
-                const float4 l0 = *reinterpret_cast<const float4*>(lt + qq), l1 = *reinterpret_cast<const float4*>(lt + 32 + qq);
-                const float4 d0 = *reinterpret_cast<const float4*>(dt + qq), d1 = *reinterpret_cast<const float4*>(dt + 32 + qq);
-                const float la[4] = {l0.x, l0.y, l0.z, l0.w}, lb[4] = {l1.x, l1.y, l1.z, l1.w};
-                const float da[4] = {d0.x, d0.y, d0.z, d0.w}, db[4] = {d1.x, d1.y, d1.z, d1.w};
+                const float4 l0 = *reinterpret_cast<const float4*>(lt + 8 * g), l1 = *reinterpret_cast<const float4*>(lt + 32 + 8 * g);
+                const float4 d0 = *reinterpret_cast<const float4*>(dt + 8 * g), d1 = *reinterpret_cast<const float4*>(dt + 32 + 8 * g);
+                s0[4 * g] = l0.x; s0[4 * g + 1] = l0.y; s0[4 * g + 2] = l0.z; s0[4 * g + 3] = l0.w;
+                s1[4 * g] = l1.x; s1[4 * g + 1] = l1.y; s1[4 * g + 2] = l1.z; s1[4 * g + 3] = l1.w;
+                e0[4 * g] = d0.x; e0[4 * g + 1] = d0.y; e0[4 * g + 2] = d0.z; e0[4 * g + 3] = d0.w;
+                e1[4 * g] = d1.x; e1[4 * g + 1] = d1.y; e1[4 * g + 2] = d1.z; e1[4 * g + 3] = d1.w;
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    float p0 = fast_exp2(__builtin_fmaf(s0[r], p.scale_log2e, -la[j]));
-                    float p1 = fast_exp2(__builtin_fmaf(s1[r], p.scale_log2e, -lb[j]));
-                    if (!key_ok) { p0 = 0.f; p1 = 0.f; }
-                    if (ragged) { if (t * BT + qq + j >= p.L) p0 = 0.f; if (t * BT + 32 + qq + j >= p.L) p1 = 0.f; }
-                    const float ds0 = p0 * (e0[r] - da[j]) * p.scale, ds1 = p1 * (e1[r] - db[j]) * p.scale;
-                    e0[r] = ds0; e1[r] = ds1;      // dS
-                    s0[r] = p0; s1[r] = p1;        // P
+            for (int ks = 0; ks < 4; ++ks) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, l31, ks, half), kf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, 32 + l31, ks, half), kf[ks], s1, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, l31, ks, half), vf[ks], e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, 32 + l31, ks, half), vf[ks], e1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p0 = fast_exp2(-s0[r]), p1 = fast_exp2(-s1[r]);
+                if (RAGGED) {                            // queries >= L: lse / D of padding rows are not meaningful
+                    const int qq = t * BT + 8 * (r >> 2) + 4 * half + (r & 3);
+                    if (qq >= p.L) { p0 = 0.f; e0[r] = 0.f; }
+                    if (qq + 32 >= p.L) { p1 = 0.f; e1[r] = 0.f; }
                 }
+                e0[r] = p0 * e0[r]; e1[r] = p1 * e1[r];   // dS / scale
+                s0[r] = p0; s1[r] = p1;                    // P
             }
             const char* qt = base + 2 * TILE_B;
             const char* dot = base + 3 * TILE_B;
@@ -267,16 +292,27 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
         }
         if (more) publish((t + 1) & 1);
         __syncthreads();
-    }
+    };
+    const int nplain = p.L / BT;                          // tiles without queries >= L
+    for (int t = 0; t < nplain; ++t) tile(t, BoolTag<false>{});
+    if (nplain < ntiles) tile(nplain, BoolTag<true>{});
     if (!wave_live) return;
+    // lane = key: a key >= L only ever polluted its own dK / dV rows -- they are padding rows and receive exact zeros;
+    // dK carries the `scale` the loop left out
+    const float ck = p.scale;
     bf16_t* krow = p.dk + (row0 + key) * p.ld_d + head * 64;
     bf16_t* vrow = p.dv + (row0 + key) * p.ld_d + head * 64;
+    const uint2 zero2 = make_uint2(0u, 0u);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<uint2*>(krow + 8 * g + 4 * half) = make_uint2(pack_bf2(dk0[4 * g], dk0[4 * g + 1]), pack_bf2(dk0[4 * g + 2], dk0[4 * g + 3]));
-        *reinterpret_cast<uint2*>(krow + 32 + 8 * g + 4 * half) = make_uint2(pack_bf2(dk1[4 * g], dk1[4 * g + 1]), pack_bf2(dk1[4 * g + 2], dk1[4 * g + 3]));
-        *reinterpret_cast<uint2*>(vrow + 8 * g + 4 * half) = make_uint2(pack_bf2(dv0[4 * g], dv0[4 * g + 1]), pack_bf2(dv0[4 * g + 2], dv0[4 * g + 3]));
-        *reinterpret_cast<uint2*>(vrow + 32 + 8 * g + 4 * half) = make_uint2(pack_bf2(dv1[4 * g], dv1[4 * g + 1]), pack_bf2(dv1[4 * g + 2], dv1[4 * g + 3]));
+        const uint2 k0 = make_uint2(pack_bf2(ck * dk0[4 * g], ck * dk0[4 * g + 1]), pack_bf2(ck * dk0[4 * g + 2], ck * dk0[4 * g + 3]));
+        const uint2 k1 = make_uint2(pack_bf2(ck * dk1[4 * g], ck * dk1[4 * g + 1]), pack_bf2(ck * dk1[4 * g + 2], ck * dk1[4 * g + 3]));
+        const uint2 v0 = make_uint2(pack_bf2(dv0[4 * g], dv0[4 * g + 1]), pack_bf2(dv0[4 * g + 2], dv0[4 * g + 3]));
+        const uint2 v1 = make_uint2(pack_bf2(dv1[4 * g], dv1[4 * g + 1]), pack_bf2(dv1[4 * g + 2], dv1[4 * g + 3]));
+        *reinterpret_cast<uint2*>(krow + 8 * g + 4 * half) = key_ok ? k0 : zero2;
+        *reinterpret_cast<uint2*>(krow + 32 + 8 * g + 4 * half) = key_ok ? k1 : zero2;
+        *reinterpret_cast<uint2*>(vrow + 8 * g + 4 * half) = key_ok ? v0 : zero2;
+        *reinterpret_cast<uint2*>(vrow + 32 + 8 * g + 4 * half) = key_ok ? v1 : zero2;
     }
 }
 

@@ -39,6 +39,11 @@ __device__ __forceinline__ uint32_t f2bf_fast(float v) { return (uint32_t)__buil
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif
 
+// two packed bf16 values times c, rounded back to bf16 (pre-scaled attention queries: c = +-scale * log2(e))
+__device__ __forceinline__ uint32_t scale_bf2(uint32_t two, float c) {
+    return pack_bf2(bf2f(two & 0xffffu) * c, bf2f(two >> 16) * c);
+}
+
 // 16-byte global -> LDS DMA.  `lds_wave_base` must be wave-uniform: lane i's 16 bytes land at base + 16*i.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 #ifdef HIPEMU
