@@ -60,6 +60,11 @@ __device__ __forceinline__ bf16x8 pack_rows(const f32x16& s, int r0) {
     return f.v;
 }
 template <bool V> struct BoolTag { static constexpr bool value = V; };
+#ifdef HIPEMU
+#define DGS_SCHED_FENCE() ((void)0)
+#else
+#define DGS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 __device__ __forceinline__ f32x16 zero_acc() {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -138,12 +143,29 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
         if (wave_live) {
             const char* base = lds + (t & 1) * 3 * TILE_B;
             f32x16 s0, s1, e0, e1;                       // s = lse - S', e = dP - D
+            // Every LDS fragment is read into the other half of a register double buffer behind the first MFMA of the step
+            // before the one that consumes it (hipcc waits lgkmcnt(0) at first use: a read issued right before its MFMA
+            // exposes the whole LDS latency, 24 times per tile); sched_barrier fences keep this order.
+            const char* kt = base + 2 * TILE_B;
+            bf16x8 fa[2][4], fk[2][2];
+            auto read4 = [&](int ks, int h) {
+                fa[h][0] = get_rows(base, l31, ks, half); fa[h][1] = get_rows(base, 32 + l31, ks, half);
+                fa[h][2] = get_rows(base + TILE_B, l31, ks, half); fa[h][3] = get_rows(base + TILE_B, 32 + l31, ks, half);
+            };
+            auto read2 = [&](int ks, int h) { fk[h][0] = get_rows(kt, l31, ks, half); fk[h][1] = get_rows(kt, 32 + l31, ks, half); };
+            read4(0, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, l31, ks, half), qf[ks], ks == 0 ? lse16 : s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, 32 + l31, ks, half), qf[ks], ks == 0 ? lse16 : s1, 0, 0, 0);
-                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, l31, ks, half), dof[ks], ks == 0 ? negd16 : e0, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, 32 + l31, ks, half), dof[ks], ks == 0 ? negd16 : e1, 0, 0, 0);
+                const int h = ks & 1;
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0], qf[ks], ks == 0 ? lse16 : s0, 0, 0, 0);
+                if (ks < 3) read4(ks + 1, h ^ 1); else read2(0, 0);
+                DGS_SCHED_FENCE();
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1], qf[ks], ks == 0 ? lse16 : s1, 0, 0, 0);
+                DGS_SCHED_FENCE();
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][2], dof[ks], ks == 0 ? negd16 : e0, 0, 0, 0);
+                DGS_SCHED_FENCE();
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][3], dof[ks], ks == 0 ? negd16 : e1, 0, 0, 0);
+                DGS_SCHED_FENCE();
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -156,12 +178,15 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
                 s0[r] = p0 * e0[r];                      // dS / scale
                 s1[r] = p1 * e1[r];
             }
-            const char* kt = base + 2 * TILE_B;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                const int h = ks & 1;
                 const bf16x8 dsf = pack_rows(ks < 2 ? s0 : s1, 8 * (ks & 1));
-                dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(kt, l31, ks, half), dsf, dq0, 0, 0, 0);
-                dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(kt, 32 + l31, ks, half), dsf, dq1, 0, 0, 0);
+                dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[h][0], dsf, dq0, 0, 0, 0);
+                if (ks < 3) read2(ks + 1, h ^ 1);
+                DGS_SCHED_FENCE();
+                dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[h][1], dsf, dq1, 0, 0, 0);
+                DGS_SCHED_FENCE();
             }
         }
         if (more) publish((t + 1) & 1);
@@ -260,12 +285,31 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
                 e0[4 * g] = d0.x; e0[4 * g + 1] = d0.y; e0[4 * g + 2] = d0.z; e0[4 * g + 3] = d0.w;
                 e1[4 * g] = d1.x; e1[4 * g + 1] = d1.y; e1[4 * g + 2] = d1.z; e1[4 * g + 3] = d1.w;
             }
+            // fragments one step ahead in a register double buffer (see the dQ kernel)
+            const char* qt = base + 2 * TILE_B;
+            const char* dot = base + 3 * TILE_B;
+            bf16x8 fa[2][4];
+            auto read_s = [&](int ks, int h) {
+                fa[h][0] = get_rows(base, l31, ks, half); fa[h][1] = get_rows(base, 32 + l31, ks, half);
+                fa[h][2] = get_rows(base + TILE_B, l31, ks, half); fa[h][3] = get_rows(base + TILE_B, 32 + l31, ks, half);
+            };
+            auto read_g = [&](int ks, int h) {
+                fa[h][0] = get_rows(dot, l31, ks, half); fa[h][1] = get_rows(dot, 32 + l31, ks, half);
+                fa[h][2] = get_rows(qt, l31, ks, half); fa[h][3] = get_rows(qt, 32 + l31, ks, half);
+            };
+            read_s(0, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, l31, ks, half), kf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base, 32 + l31, ks, half), kf[ks], s1, 0, 0, 0);
-                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, l31, ks, half), vf[ks], e0, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(base + TILE_B, 32 + l31, ks, half), vf[ks], e1, 0, 0, 0);
+                const int h = ks & 1;
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0], kf[ks], s0, 0, 0, 0);
+                if (ks < 3) read_s(ks + 1, h ^ 1); else read_g(0, 0);
+                DGS_SCHED_FENCE();
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1], kf[ks], s1, 0, 0, 0);
+                DGS_SCHED_FENCE();
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][2], vf[ks], e0, 0, 0, 0);
+                DGS_SCHED_FENCE();
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][3], vf[ks], e1, 0, 0, 0);
+                DGS_SCHED_FENCE();
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -278,16 +322,20 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
                 e0[r] = p0 * e0[r]; e1[r] = p1 * e1[r];   // dS / scale
                 s0[r] = p0; s1[r] = p1;                    // P
             }
-            const char* qt = base + 2 * TILE_B;
-            const char* dot = base + 3 * TILE_B;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                const int h = ks & 1;
                 const bf16x8 pf = pack_rows(ks < 2 ? s0 : s1, 8 * (ks & 1));
                 const bf16x8 dsf = pack_rows(ks < 2 ? e0 : e1, 8 * (ks & 1));
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(dot, l31, ks, half), pf, dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(dot, 32 + l31, ks, half), pf, dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(qt, l31, ks, half), dsf, dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(get_rows(qt, 32 + l31, ks, half), dsf, dk1, 0, 0, 0);
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0], pf, dv0, 0, 0, 0);
+                if (ks < 3) read_g(ks + 1, h ^ 1);
+                DGS_SCHED_FENCE();
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1], pf, dv1, 0, 0, 0);
+                DGS_SCHED_FENCE();
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][2], dsf, dk0, 0, 0, 0);
+                DGS_SCHED_FENCE();
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][3], dsf, dk1, 0, 0, 0);
+                DGS_SCHED_FENCE();
             }
         }
         if (more) publish((t + 1) & 1);
