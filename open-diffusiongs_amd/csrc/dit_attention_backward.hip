@@ -213,8 +213,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
 //   dK^T += Q^T . dS       (A: Q^T permuted tile,  B: packed dS accumulator registers)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 4 * TILE_B];   // [stage][Q | dO | Q^T | dO^T] : 64 KiB
-    constexpr int STAGE = 4 * TILE_B;
+    DGS_DYNAMIC_LDS(lds);                                                // [stage][Q | dO | Q^T | dO^T | lse[64] | -D[64]] : 65 KiB
+    constexpr int STAGE = 4 * TILE_B + 512;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -245,7 +245,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
     const int ntiles = (p.L + BT - 1) / BT;            // queries >= L have dO = 0 and no valid lse: never visited / masked
     const int sr = tid >> 3, sc = tid & 7;
     uint4 qreg, doreg, qtreg, dotreg;
+    float statreg = 0.f;                              // threads 0..63: lse of query t*64 + tid; 64..127: -D of query t*64 + tid - 64
     auto issue = [&](int t) {
+        if (tid < 128) statreg = (tid < 64 ? lseg : Dg)[t * BT + (tid & 63)];
         qreg = *reinterpret_cast<const uint4*>(Qg + (size_t)(t * BT + sr) * p.ld + sc * 8);
         doreg = *reinterpret_cast<const uint4*>(dOg + (size_t)(t * BT + sr) * p.ld_o + sc * 8);
         qtreg = *reinterpret_cast<const uint4*>(QTg + (size_t)sr * p.lpad + t * BT + sc * 8);
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
         put_rows(base + TILE_B, sr, sc, doreg);
         put_perm(base + 2 * TILE_B, sr, sc, qtreg);
         put_perm(base + 3 * TILE_B, sr, sc, dotreg);
+        if (tid < 128) reinterpret_cast<float*>(base + 4 * TILE_B)[tid] = statreg;
     };
     issue(0);
     publish(0);
@@ -271,10 +274,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
         if (more) issue(t + 1);
         if (wave_live) {
             const char* base = lds + (t & 1) * STAGE;
-            // per-query statistics straight from L2 (same address across a half-wave), loaded INTO the accumulators' initial
-            // values: register r of block 0 / 1 is query 8 (r >> 2) + 4 half + (r & 3) (+ 32) of the tile
-            const float* lt = lseg + t * BT + 4 * half;
-            const float* dt = Dg + t * BT + 4 * half;
+            // per-query statistics, loaded INTO the accumulators' initial values: register r of block 0 / 1 is query 8 (r >> 2) + 4 half + (r & 3) (+ 32) of the tile
+            const float* lt = reinterpret_cast<const float*>(base + 4 * TILE_B) + 4 * half;     // staged with the tiles: an L2
+            const float* dt = lt + 64;                                                          // round trip per tile otherwise
             f32x16 s0, s1, e0, e1;                       // s = lse - S', e = dP - D
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -383,6 +385,13 @@ extern "C" int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((a->L + BQ - 1) / BQ, a->heads, a->B);
     hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(512), 0, st, p);
-    hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(512), 0, st, p);
+    constexpr int DKV_LDS = 2 * (4 * TILE_B + 512);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS) != hipSuccess)
+            return DGS_ERR_DEVICE;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(512), DKV_LDS, st, p);
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }
