@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
     __shared__ float4 s_rgb[256];
+    __shared__ float s_cut[256];
     __shared__ uint32_t s_max[4];
     const int v = blockIdx.z, s = v / p.vps;
     const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,31 +83,32 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             s_id[tid] = id;
             s_xy[tid] = p.g.means2D[vo + id];
             s_co[tid] = p.g.conic_opacity[vo + id];
+            const float4 rc = p.g.rgb_cut[vo + id];
+            s_cut[tid] = rc.w;
             if (colors_per_set) {
                 const float* c = p.colors_pre + 3 * ((size_t)s * p.P + id);
                 s_rgb[tid] = make_float4(c[0], c[1], c[2], 0.f);
             } else {
-                s_rgb[tid] = p.g.rgb_cut[vo + id];
+                s_rgb[tid] = rc;
             }
         }
         __syncthreads();
         const int nb = min(256, (int)todo - i * 256);
         for (int j = 0; j < nb; ++j, --contributor) {
             // contributor = 1-based index of this entry; pixel took part iff index <= last_contributor (backward.cu:463-468)
-            bool take = inside && contributor <= last_contributor;
-            float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
-            float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+            // branch-free up to the cheap rejects (outside the ellipse, or below the Gaussian's alpha cut-off: alpha < 1/255
+            // guaranteed, see preprocess_one -- the same test the forward used to drop the pair), ONE wave-uniform branch out
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float dx = xy.x - pfx, dy = xy.y - pfy;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            bool take = inside && contributor <= last_contributor && !(power > 0.0f) && !(power < s_cut[j]);
+            if (!__any(take)) continue;
+            float G = 0.f, alpha = 0.f;
             if (take) {
-                const float2 xy = s_xy[j];
-                dx = xy.x - pfx; dy = xy.y - pfy;
-                co = s_co[j];
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                take = !(power > 0.0f);
-                if (take) {
-                    G = det_expf(power);
-                    alpha = fminf(0.99f, co.w * G);
-                    take = !(alpha < 1.0f / 255.0f);
-                }
+                G = det_expf(power);
+                alpha = fminf(0.99f, co.w * G);
+                take = !(alpha < 1.0f / 255.0f);
             }
             if (!__any(take)) continue;      // wave-uniform: nobody in this 16x4 strip touches the Gaussian
             float c9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
