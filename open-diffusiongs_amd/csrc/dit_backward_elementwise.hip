@@ -60,12 +60,15 @@ __global__ __launch_bounds__(256) void gate_mul_kernel(const float* dx, const bf
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm(+weight)+modulate backward.  h = LN(x) * w * (1 + scale) + shift.  One wave per row; a workgroup of 4 waves
-// walks `rows_per_block` consecutive rows of ONE sample so the per-column sums stay in registers until the end.
+// LayerNorm(+weight)+modulate backward.  h = LN(x) * w * (1 + scale) + shift.  One wave per row; a workgroup of 8 waves
+// walks `rows_per_block` (32) consecutive rows of ONE sample so the per-column sums stay in registers until the end.
+// (A row is a chain of dependent loads and wave reductions: with 4 waves x 32 rows and 136 workgroups the kernel was
+// latency-bound at 1.1 TB/s; 8 waves x 4 rows on 544 workgroups keep every CU busy;
+// 16-wave workgroups would cap the kernel at 128 VGPRs and spill at width 1024.)
 // ------------------------------------------------------------------------------------------------
 
 template <int VPL>
-__global__ __launch_bounds__(256) void layernorm_backward_kernel(LnBwdParams p) {
+__global__ __launch_bounds__(512) void layernorm_backward_kernel(LnBwdParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * p.rows_per_block;
     const int b = row0 / p.rows_per_batch;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(LnBwdParams p) 
 #pragma unroll
     for (int i = 0; i < VPL; ++i) a_shift[i] = a_scale[i] = a_w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_w = 1.0f / (float)p.width;
-    for (int r = wave; r < p.rows_per_block; r += 4) {
+    for (int r = wave; r < p.rows_per_block; r += 8) {
         const int row = row0 + r;
         if (row >= p.rows) break;       // (no barrier inside the loop)
         const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)row * p.width);
@@ -127,20 +130,23 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(LnBwdParams p) 
             out[c4] = d;
         }
     }
-    // column sums: waves -> LDS -> one fp32 atomic per column per workgroup (128 rows)
-    __shared__ float red[3][4][VPL * 256];
+    // column sums: 8 waves -> LDS -> one fp32 atomic per column per workgroup, one quantity at a time (32 KiB of LDS)
+    __shared__ float red[8][VPL * 256];
+    float* const dst[3] = {p.dshift ? p.dshift + (size_t)b * p.mod_stride : nullptr, p.dscale ? p.dscale + (size_t)b * p.mod_stride : nullptr, p.dweight};
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        *reinterpret_cast<float4*>(&red[0][wave][c]) = a_shift[i];
-        *reinterpret_cast<float4*>(&red[1][wave][c]) = a_scale[i];
-        *reinterpret_cast<float4*>(&red[2][wave][c]) = a_w[i];
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < p.width; c += 256) {
-        if (p.dshift) atomicAdd(p.dshift + (size_t)b * p.mod_stride + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-        if (p.dscale) atomicAdd(p.dscale + (size_t)b * p.mod_stride + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
-        if (p.dweight) atomicAdd(p.dweight + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
+    for (int qn = 0; qn < 3; ++qn) {
+        if (!dst[qn]) continue;                        // uniform
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            *reinterpret_cast<float4*>(&red[wave][(i * 64 + lane) * 4]) = qn == 0 ? a_shift[i] : qn == 1 ? a_scale[i] : a_w[i];
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.width; c += 512) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) acc += red[w][c];
+            atomicAdd(dst[qn] + c, acc);
+        }
     }
 }
 
@@ -311,8 +317,9 @@ int launch_layernorm_backward(const LnBwdParams& p0, hipStream_t st) {
     LnBwdParams p = p0;
     if (p.rows <= 0 || p.width % 256 || p.width > 2048) return DGS_ERR_INVALID_ARGUMENT;
     if (p.rows_per_batch <= 0) p.rows_per_batch = p.rows;
-    p.rows_per_block = p.rows_per_batch % 128 == 0 ? 128 : p.rows_per_batch;   // never straddles samples
-    const dim3 grid((p.rows + p.rows_per_block - 1) / p.rows_per_block), block(256);
+    static const int rpb = [] { const char* e = getenv("DGS_LN_BWD_ROWS"); return e ? atoi(e) : 32; }();
+    p.rows_per_block = p.rows_per_batch % rpb == 0 ? rpb : p.rows_per_batch;   // never straddles samples
+    const dim3 grid((p.rows + p.rows_per_block - 1) / p.rows_per_block), block(512);
     switch (p.width / 256) {
         case 1: hipLaunchKernelGGL((layernorm_backward_kernel<1>), grid, block, 0, st, p); break;
         case 2: hipLaunchKernelGGL((layernorm_backward_kernel<2>), grid, block, 0, st, p); break;
