@@ -85,7 +85,14 @@ typedef struct DgsDitGemmArgs {
     float q_scale;             /* DGS_EPI_QKV: the q features (n < N/3) are multiplied by q_scale before the bf16 rounding
                                   (0 -> 1).  The denoiser passes scale * log2(e) so that the attention kernel gets its
                                   pre-scaled queries with a single rounding (DgsDitAttentionArgs.q_prescaled).        */
+    float* splitk_ws;          /* optional f32 scratch of dgs_dit_gemm_splitk_bytes(M, N, K, k_per_batch) bytes.  When set,
+                                  DGS_EPI_F32 without bias and that size is non-zero, the reduction is split over
+                                  workgroups (256 x 256 tiles, one partial product per split, summed by a second kernel
+                                  into `out`): weight gradients have few output tiles and a very long K.              */
 } DgsDitGemmArgs;
+
+/* Bytes of DgsDitGemmArgs.splitk_ws for this shape; 0 when the split-K path does not apply to it. */
+size_t dgs_dit_gemm_splitk_bytes(int32_t M, int32_t N, int32_t K, int32_t k_per_batch);
 
 typedef struct DgsDitAttentionArgs {
     int32_t B, heads, L, lpad; /* head dim is 64; L valid tokens per sample, lpad padded rows         */

@@ -247,6 +247,8 @@ bool big_gemm_eligible(int M, int N, int K, int epilogue, int k_per_batch, int r
 int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows, hipStream_t st);
 int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);
 int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
+int splitk_plan(int M, int N, int K, int k_per_batch, int* splits_per_batch);
+int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st);
 
 }  // namespace dgs
 
@@ -290,6 +292,12 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     const int algo = a->algo ? a->algo : env_algo;
     if (algo == DGS_GEMM_BIG256 && big_gemm_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
         return launch_big_gemm(a, p.rows_per_batch, p.valid_rows, st0);
+    // weight-gradient shapes with a scratch buffer: split-K on the sliced kernel (any algo but an explicit SIMPLE128 / DEEP / BIG256)
+    if ((algo == DGS_GEMM_AUTO || algo == DGS_GEMM_SLICED) && a->splitk_ws && a->epilogue == DGS_EPI_F32 && !a->bias && a->ldo % 4 == 0 &&
+        p.rows_per_batch == a->M && p.valid_rows == a->M) {
+        int spb = 0;
+        if (splitk_plan(a->M, a->N, a->K, kpb, &spb)) return launch_splitk_gemm(a, kpb, st0);
+    }
     // AUTO: the sliced 256 x 256 kernel where one round of it covers the chip and beats 3+ rounds of 128-wide tiles (measured at
     // batch 1: the QKV GEMM, 39 vs 44 us); everything else runs the 128-wide two-stage kernel below
     const bool auto_sliced = algo == DGS_GEMM_AUTO && a->epilogue == DGS_EPI_QKV && a->M <= 8192 &&
@@ -319,4 +327,10 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
         default: return DGS_ERR_INVALID_ARGUMENT;
     }
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+extern "C" size_t dgs_dit_gemm_splitk_bytes(int32_t M, int32_t N, int32_t K, int32_t k_per_batch) {
+    int spb = 0;
+    const int nsplit = dgs::splitk_plan(M, N, K, k_per_batch > 0 ? k_per_batch : K, &spb);
+    return (size_t)nsplit * M * N * sizeof(float);
 }

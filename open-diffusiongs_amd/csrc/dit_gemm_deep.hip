@@ -26,6 +26,8 @@ namespace dgs {
 struct DeepParams {
     int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles, dbg;
     int rows_ps, full_rows, tail_rows, nfull_items;             // sliced kernel: 256-row tile rows per sample (all / ring path / one live block), full items
+    int nsplit, splits_per_batch;                               // sliced kernel, split-K: items = nsplit x tiles, K = k_per_batch
+    long long a_batch_stride, w_batch_stride, out_split_stride;
     const bf16_t* A;
     const bf16_t* W;
     const float* bias;
@@ -384,7 +386,19 @@ __global__ __launch_bounds__(512) void gemm_sliced_kernel(DeepParams p) {
     // live 32-row block left (the two learned-token rows of the DiT): dispatched last, they fill CUs as the full tiles
     // retire instead of pushing 1/16 of the full tiles into a second round.
     const int bid = (int)blockIdx.x;
-    if (bid >= p.nfull_items) {
+    int tile;
+    if (p.nsplit > 1) {
+        // split-K (weight gradients): item = (split, tile), split-major so that an XCD's tiles share operand panels; a split is
+        // a range of 128-wide K units of one sample; its partial product goes to its own [M, N] f32 plane
+        const int all = xcd_remap(bid, p.nfull_items * p.nsplit);
+        const int sp = all / p.nfull_items, b = sp / p.splits_per_batch, part = sp % p.splits_per_batch;
+        tile = all - sp * p.nfull_items;
+        const int units = p.K / 128, u0 = part * units / p.splits_per_batch, u1 = (part + 1) * units / p.splits_per_batch;
+        p.A += (size_t)b * p.a_batch_stride + u0 * 128;
+        p.W += (size_t)b * p.w_batch_stride + u0 * 128;
+        p.out = static_cast<float*>(p.out) + (size_t)sp * p.out_split_stride;
+        p.K = (u1 - u0) * 128;
+    } else if (bid >= p.nfull_items) {
         const int j = bid - p.nfull_items, tn = j % p.tiles_n, rr = j / p.tiles_n;
         const int m0 = ((rr / p.tail_rows) * p.rows_ps + p.full_rows + rr % p.tail_rows) * BM, n0 = tn * BN;
         // no staging: the 8 waves split the BN / 32 column blocks, fragments come straight from L2, 16 k-steps in flight
@@ -401,8 +415,9 @@ __global__ __launch_bounds__(512) void gemm_sliced_kernel(DeepParams p) {
             store_block<EPI, 1>(p, acc1, m0 + 4 * fhalf, n0 + cb * 32, lane);
         }
         return;
+    } else {
+        tile = xcd_remap(bid, p.nfull_items);
     }
-    const int tile = xcd_remap(bid, p.nfull_items);
     const int tn = tile % p.tiles_n, rr = tile / p.tiles_n;
     const int m0 = ((rr / p.full_rows) * p.rows_ps + rr % p.full_rows) * BM, n0 = tn * BN;
     f32x16 acc[2][NI];
@@ -519,6 +534,10 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
     const int samples = p.M / p.rows_per_batch;
     p.nfull_items = samples * p.full_rows * p.tiles_n;
     p.ntiles = p.nfull_items + samples * p.tail_rows * p.tiles_n;
+    if (p.nsplit > 1) {
+        if (p.tail_rows || samples != 1) return DGS_ERR_INVALID_ARGUMENT;
+        p.ntiles = p.nfull_items * p.nsplit;
+    }
     auto kern = gemm_sliced_kernel<EPI, BN>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -555,7 +574,8 @@ int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int row
 int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st) {
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
-    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0;
+    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0; p.nsplit = 1; p.splits_per_batch = 1;
+    p.a_batch_stride = p.w_batch_stride = p.out_split_stride = 0;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
@@ -570,6 +590,58 @@ int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int 
         default: return DGS_ERR_INVALID_ARGUMENT;
     }
 #undef DGS_SLICED_CASE
+}
+
+// ---- split-K on the sliced kernel (weight gradients: [N_out, N_in] outputs = 16 .. 64 tiles of 256 x 256, K = all tokens) ----
+// Splits never straddle samples (the operands of a sample are contiguous in K, samples are a batch stride apart); a sample
+// is cut further while that keeps the item count within one round of the 256 CUs and the partial planes at 8 or fewer.
+// Measured on MI355X (tools/wgrad_bench.py, lpad 4224): at 4 samples every DiT shape gains (183 -> 130, 201 -> 147, 182 -> 144,
+// 154 -> 64 us); at 1 sample only the 1024 x 1024 gradient does (41 -> 31 us) -- splits of fewer than 16 K units pay more
+// for prologue, epilogue and the reduction than they win, unless the single-pass grid is tiny (<= 16 tiles).
+int splitk_plan(int M, int N, int K, int k_per_batch, int* splits_per_batch) {
+    if (M <= 0 || N <= 0 || k_per_batch <= 0 || M % 256 || N % 256 || k_per_batch % 128 || K % k_per_batch) return 0;
+    const int nb = K / k_per_batch, tiles = (M / 256) * (N / 256), units = k_per_batch / 128;
+    if (nb > 8) return 0;
+    const bool tiny = tiles <= 16;
+    int s = 256 / (nb * tiles);
+    if (s > 8 / nb) s = 8 / nb;
+    if (s > units / (tiny ? 4 : 16)) s = units / (tiny ? 4 : 16);
+    if (s < 1) s = 1;
+    const char* e = getenv("DGS_SPLITK_MIN_ITEMS");            // tests lower it to reach the path at emulator-sized shapes
+    if (nb * s < 2 || nb * s * tiles < (e ? atoi(e) : tiny ? 96 : 160)) return 0;
+    *splits_per_batch = s;
+    return nb * s;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nsplit, int N, int ldo,
+                                                            size_t plane) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;     // element of the [M, N] plane
+    if (i >= plane) return;
+    float4 acc = *reinterpret_cast<const float4*>(part + i);
+    for (int s = 1; s < nsplit; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(part + s * plane + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const size_t m = i / N, n = i - m * N;
+    *reinterpret_cast<float4*>(out + m * ldo + n) = acc;
+}
+
+int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st) {
+    int spb = 1;
+    const int nsplit = splitk_plan(a->M, a->N, a->K, k_per_batch, &spb);
+    if (!nsplit || a->epilogue != DGS_EPI_F32 || a->bias || !a->splitk_ws || a->ldo % 4) return DGS_ERR_INVALID_ARGUMENT;
+    DeepParams p;
+    p.M = a->M; p.N = a->N; p.K = k_per_batch; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->N; p.gate_stride = 0;
+    p.rows_per_batch = a->M; p.valid_rows = a->M; p.dbg = 0; p.nsplit = nsplit; p.splits_per_batch = spb;
+    p.a_batch_stride = a->a_batch_stride; p.w_batch_stride = a->w_batch_stride; p.out_split_stride = (long long)a->M * a->N;
+    p.A = a->A; p.W = a->W; p.bias = nullptr; p.out = a->splitk_ws; p.gate = nullptr; p.vt = nullptr; p.aux = nullptr; p.q_scale = 1.0f;
+    p.resid = nullptr;
+    const int rc = launch_sliced<DGS_EPI_F32, 256>(p, st);
+    if (rc != DGS_OK) return rc;
+    const size_t plane = (size_t)a->M * a->N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((plane / 4 + 255) / 256)), dim3(256), 0, st, a->splitk_ws, static_cast<float*>(a->out), nsplit,
+                       a->N, a->ldo, plane);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }
 
 template <int EPI, int BN, int BK, int NS>

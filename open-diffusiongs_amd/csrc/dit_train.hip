@@ -70,6 +70,8 @@ struct BwdScratch {
     bf16_t* embT;            // [B, kin, lpad]
     float* D;                // [B, heads, lpad]
     float *dmod, *dup, *dupn, *dcvec, *dc1, *ones;
+    size_t wpart_bytes;
+    float* wpart;            // split-K partial planes of the weight-gradient GEMMs (largest: fc1 / fc2)
     static BwdScratch carve(void* buf, const DgsDitModel* m, size_t B, size_t lpad, size_t* bytes) {
         Carver c(buf);
         BwdScratch s;
@@ -88,6 +90,8 @@ struct BwdScratch {
         s.dmod = c.take<float>(B * (6 * (size_t)m->layers + 4) * W);
         s.dup = c.take<float>(B * m->n_gaussians * m->gs_channels); s.dupn = c.take<float>(B * m->n_gaussians * W);
         s.dcvec = c.take<float>(B * W); s.dc1 = c.take<float>(B * W); s.ones = c.take<float>(B * W);
+        s.wpart_bytes = dgs_dit_gemm_splitk_bytes((int)(4 * W), (int)W, (int)M, (int)lpad);
+        s.wpart = c.take<float>(s.wpart_bytes / sizeof(float));
         if (bytes) *bytes = c.bytes();
         return s;
     }
@@ -236,10 +240,12 @@ extern "C" int dgs_dit_forward_train(const DgsDitModel* m, const DgsDitForwardAr
 namespace {
 
 // C[N, K] (f32) = sum over samples and tokens of  dYT[b, n, t] * XT[b, k, t]
-int wgrad(const bf16_t* dyT, int N, const bf16_t* xT, int K, float* dW, int B, int lpad, dgs_stream_t stream) {
+int wgrad(const bf16_t* dyT, int N, const bf16_t* xT, int K, float* dW, int B, int lpad, const BwdScratch& ws, dgs_stream_t stream) {
     DgsDitGemmArgs g{};
     g.M = N; g.N = K; g.K = B * lpad; g.A = dyT; g.lda = lpad; g.W = xT; g.ldw = lpad; g.epilogue = DGS_EPI_F32; g.out = dW; g.ldo = K;
     g.k_per_batch = lpad; g.a_batch_stride = (int64_t)N * lpad; g.w_batch_stride = (int64_t)K * lpad;
+    const size_t need = dgs_dit_gemm_splitk_bytes(N, K, B * lpad, lpad);     // scratch is sized for the 4W x W gradients
+    g.splitk_ws = need && need <= ws.wpart_bytes ? ws.wpart : nullptr;
     return dgs_dit_gemm(&g, stream);
 }
 
@@ -295,7 +301,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
     float* dmod_dec = dmod_up + 2 * W;
     DGS_TRY(launch_transpose(ws.ddec, ND, ws.ddecT, B, lpad, ND, st));
     DGS_TRY(launch_transpose(sv.xn_dec, W, ws.actT, B, lpad, W, st));
-    DGS_TRY(wgrad(ws.ddecT, ND, ws.actT, W, gr->dec_w, B, lpad, stream));
+    DGS_TRY(wgrad(ws.ddecT, ND, ws.actT, W, gr->dec_w, B, lpad, ws, stream));
     DGS_TRY(dgrad(ws.ddec, ND, mt->dec_wT, W, ws.dh, M, lpad, L, DGS_EPI_BF16, nullptr, nullptr, stream));
     LnBwdParams lb{};
     lb.rows = M; lb.width = W; lb.mod_stride = nmod; lb.rows_per_batch = lpad; lb.eps = 1e-5f; lb.x = sv.x_out; lb.dh = ws.dh;
@@ -332,12 +338,12 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         DGS_TRY(launch_gate_mul(dx, k.y2, mod + 5 * W, nmod, ws.dy, ws.dyT, dmod + 5 * W, B, lpad, W, st));
         HIP_TRY(hipMemsetAsync(lg.fc2_b, 0, W * sizeof(float), st));
         DGS_TRY(launch_colsum(ws.dy, W, M, W, lg.fc2_b, st));
-        DGS_TRY(wgrad(ws.dyT, W, k.gT, 4 * W, lg.fc2_w, B, lpad, stream));
+        DGS_TRY(wgrad(ws.dyT, W, k.gT, 4 * W, lg.fc2_w, B, lpad, ws, stream));
         DGS_TRY(dgrad(ws.dy, W, lt.fc2_wT, 4 * W, ws.du, M, lpad, L, DGS_EPI_DGELU_BF16, k.u, ws.duT, stream));
         HIP_TRY(hipMemsetAsync(lg.fc1_b, 0, 4 * W * sizeof(float), st));
         DGS_TRY(launch_colsum(ws.du, 4 * W, M, 4 * W, lg.fc1_b, st));
         DGS_TRY(launch_transpose(k.h2, W, ws.actT, B, lpad, W, st));
-        DGS_TRY(wgrad(ws.duT, 4 * W, ws.actT, W, lg.fc1_w, B, lpad, stream));
+        DGS_TRY(wgrad(ws.duT, 4 * W, ws.actT, W, lg.fc1_w, B, lpad, ws, stream));
         DGS_TRY(dgrad(ws.du, 4 * W, lt.fc1_wT, W, ws.dh, M, lpad, L, DGS_EPI_BF16, nullptr, nullptr, stream));
         LnBwdParams l2{};
         l2.rows = M; l2.width = W; l2.mod_stride = nmod; l2.rows_per_batch = lpad; l2.eps = 1e-6f; l2.x = k.x_mid; l2.dh = ws.dh;
@@ -348,7 +354,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         HIP_TRY(hipMemsetAsync(lg.proj_b, 0, W * sizeof(float), st));
         DGS_TRY(launch_colsum(ws.dy, W, M, W, lg.proj_b, st));
         DGS_TRY(launch_transpose(k.a, W, ws.actT, B, lpad, W, st));
-        DGS_TRY(wgrad(ws.dyT, W, ws.actT, W, lg.proj_w, B, lpad, stream));
+        DGS_TRY(wgrad(ws.dyT, W, ws.actT, W, lg.proj_w, B, lpad, ws, stream));
         DGS_TRY(dgrad(ws.dy, W, lt.proj_wT, W, ws.da, M, lpad, L, DGS_EPI_BF16, nullptr, ws.daT, stream));
         DgsDitAttentionBackwardArgs ab{};
         ab.B = B; ab.heads = m->heads; ab.L = L; ab.lpad = lpad; ab.qkv = k.qkv; ab.qkvT = k.qkvT; ab.o = k.a; ab.dO = ws.da; ab.dOT = ws.daT;
@@ -358,7 +364,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         DGS_TRY(launch_colsum(ws.dqkv, 3 * W, M, 3 * W, lg.qkv_b, st));
         DGS_TRY(launch_transpose(ws.dqkv, 3 * W, ws.dqkvT, B, lpad, 3 * W, st));
         DGS_TRY(launch_transpose(k.h1, W, ws.actT, B, lpad, W, st));
-        DGS_TRY(wgrad(ws.dqkvT, 3 * W, ws.actT, W, lg.qkv_w, B, lpad, stream));
+        DGS_TRY(wgrad(ws.dqkvT, 3 * W, ws.actT, W, lg.qkv_w, B, lpad, ws, stream));
         DGS_TRY(dgrad(ws.dqkv, 3 * W, lt.qkv_wT, W, ws.dh, M, lpad, L, DGS_EPI_BF16, nullptr, nullptr, stream));
         LnBwdParams l1{};
         l1.rows = M; l1.width = W; l1.mod_stride = nmod; l1.rows_per_batch = lpad; l1.eps = 1e-6f; l1.x = k.x_in; l1.dh = ws.dh;
@@ -376,7 +382,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
     DGS_TRY(launch_gate_mul(dx_mid, sv.xn_dec, ws.ones, W, ws.dy, ws.dyT, ws.dcvec, B, lpad, W, st));
     HIP_TRY(hipMemsetAsync(ws.dcvec, 0, (size_t)B * W * sizeof(float), st));
     DGS_TRY(launch_transpose(sv.emb, kin, ws.embT, B, lpad, kin, st));
-    DGS_TRY(wgrad(ws.dyT, W, ws.embT, kin, gr->tok_w, B, lpad, stream));   // kin = 576: 64-column tiles
+    DGS_TRY(wgrad(ws.dyT, W, ws.embT, kin, gr->tok_w, B, lpad, ws, stream));   // kin = 576: 64-column tiles
 
     // ---- adaLN modulation Linear (all blocks + heads), TimestepEmbedder ----
     RowLinBwdParams ra{};

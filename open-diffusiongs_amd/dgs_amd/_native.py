@@ -130,7 +130,7 @@ class DgsDitGemmArgs(ctypes.Structure):
                 ("gate", ctypes.c_void_p), ("gate_stride", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32),
                 ("vt", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("k_per_batch", ctypes.c_int32),
                 ("a_batch_stride", ctypes.c_int64), ("w_batch_stride", ctypes.c_int64), ("algo", ctypes.c_int32),
-                ("valid_rows", ctypes.c_int32), ("q_scale", ctypes.c_float)]
+                ("valid_rows", ctypes.c_int32), ("q_scale", ctypes.c_float), ("splitk_ws", ctypes.c_void_p)]
 
 
 class DgsDitAttentionArgs(ctypes.Structure):
@@ -238,7 +238,7 @@ class DgsDitBackwardArgs(ctypes.Structure):
 DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward", "dgs_dit_layernorm_backward",
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
-               "dgs_dit_workspace_bytes", "dgs_dit_forward"]
+               "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes"]
 
 
 def _declare_dit(L):
@@ -250,6 +250,8 @@ def _declare_dit(L):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(argt), ctypes.c_void_p]
+    L.dgs_dit_gemm_splitk_bytes.restype = ctypes.c_size_t
+    L.dgs_dit_gemm_splitk_bytes.argtypes = [ctypes.c_int32] * 4
     L.dgs_dit_lpad.restype = ctypes.c_int32
     L.dgs_dit_lpad.argtypes = [ctypes.c_int32]
     L.dgs_dit_workspace_bytes.restype = ctypes.c_size_t

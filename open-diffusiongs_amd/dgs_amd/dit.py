@@ -36,8 +36,9 @@ class DitOps:
 
     def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None, valid_rows=0,
              resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None, algo=0,
-             q_scale=0.0):
-        """A bf16 [M,K], W bf16 [N,K] -> per epilogue (see dgs_dit.h).  `out` is required for GATE_RESIDUAL (in-place)."""
+             q_scale=0.0, splitk=False):
+        """A bf16 [M,K], W bf16 [N,K] -> per epilogue (see dgs_dit.h).  `out` is required for GATE_RESIDUAL (in-place).
+        splitk: hand the library its split-K scratch (weight-gradient shapes; a no-op where the split does not apply)."""
         if shape is not None:          # batched-reduction form (weight gradients): operands are [batch, rows, tokens]
             M, N, K = shape
         else:
@@ -66,6 +67,10 @@ class DitOps:
         a.bias, a.epilogue, a.out, a.ldo = _p(bias), epilogue, _p(out), ldo
         a.gate, a.gate_stride, a.rows_per_batch, a.vt = _p(gate), (gate.stride(0) if gate is not None else 0), rows_per_batch, _p(vt)
         a.valid_rows, a.algo, a.q_scale = valid_rows, algo, q_scale
+        if splitk:
+            nbytes = self.lib.dgs_dit_gemm_splitk_bytes(M, N, K, k_per_batch)
+            ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dev)
+            a.splitk_ws = _p(ws) if nbytes else None
         self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))
         return (out, vt) if epilogue == _native.EPI_QKV else out
 

@@ -38,6 +38,28 @@ def test_attention_backward_L4098():
     assert float(got[:, L:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,N,K,planes", [(4, 3072, 1024, 4), (4, 1024, 4096, 4), (4, 4096, 1024, 4), (4, 1024, 1024, 8), (2, 4096, 1024, 4),
+                                          (1, 1024, 1024, 8), (1, 4096, 1024, 0), (2, 1024, 576, 0)])
+def test_weight_gradient_split_k(B, N, K, planes):
+    """Weight-gradient GEMMs at the training shapes (tokens of 4 views at 256^2: lpad 4224 = 33 K units, uneven splits): the
+    split-K path vs fp32 torch and vs the single-pass kernel; shapes with 0 planes are not eligible and must take the plain path."""
+    from dgs_amd import _native
+    from dgs_amd.dit import DitOps
+    ops = DitOps()
+    T = 4224
+    g = torch.Generator(device=DEV).manual_seed(B * N + K)
+    dyT = (torch.randn(B, N, T, generator=g, device=DEV) * 0.1).to(torch.bfloat16)
+    xT = torch.randn(B, K, T, generator=g, device=DEV).to(torch.bfloat16)
+    ref = torch.einsum("bnt,bkt->nk", dyT.float(), xT.float())
+    nbytes = ops.lib.dgs_dit_gemm_splitk_bytes(N, K, B * T, T)
+    assert nbytes == planes * N * K * 4
+    kw = dict(shape=(N, K, B * T), k_per_batch=T, a_batch_stride=N * T, w_batch_stride=K * T, lda=T, ldw=T)
+    out = torch.full((N, K), 7.0, device=DEV)
+    ops.gemm(dyT, xT, None, _native.EPI_F32, out=out, splitk=True, **kw)
+    assert rel_l2(out, ref) < 1e-5
+    assert rel_l2(ops.gemm(dyT, xT, None, _native.EPI_F32, **kw), ref) < 1e-5
+
+
 def test_full_model_gradients_64():
     from dgs_amd.dit import DitEngine
     cfg = D.Cfg()

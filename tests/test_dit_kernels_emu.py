@@ -323,6 +323,27 @@ def test_gemm_256_tiles(ops):
     assert torch.allclose(vt.float()[0], ref[:, 2048:].t(), atol=3e-2, rtol=1e-2)
 
 
+def test_gemm_split_k_weight_gradient(ops, monkeypatch):
+    """Split-K form of the weight-gradient GEMM: per-sample operands, uneven K ranges (9 units of 128 over 2 splits), partial planes
+    summed into a strided output; the scratch size query says when the path applies."""
+    monkeypatch.setenv("DGS_SPLITK_MIN_ITEMS", "1")
+    g = torch.Generator().manual_seed(97)
+    B, N, K, T = 2, 256, 512, 1152
+    dyT = _bf(torch.randn(B, N, T, generator=g) * 0.3)
+    xT = _bf(torch.randn(B, K, T, generator=g) * 0.3)
+    ref = torch.einsum("bnt,bkt->nk", dyT.float(), xT.float())
+    assert ops.lib.dgs_dit_gemm_splitk_bytes(N, K, B * T, T) == 4 * N * K * 4          # 2 samples x 2 K ranges
+    assert ops.lib.dgs_dit_gemm_splitk_bytes(N, K + 64, B * T, T) == 0
+    assert ops.lib.dgs_dit_gemm_splitk_bytes(N, K, B * T, B * T) == 4 * N * K * 4      # one sample of 18 units: 4 ranges
+    out = torch.full((N, K), 7.0)
+    ops.gemm(dyT, xT, None, _native.EPI_F32, out=out, shape=(N, K, B * T), k_per_batch=T, a_batch_stride=N * T, w_batch_stride=K * T,
+             lda=T, ldw=T, splitk=True)
+    assert torch.allclose(out, ref, atol=2e-3, rtol=1e-4)
+    plain = ops.gemm(dyT, xT, None, _native.EPI_F32, shape=(N, K, B * T), k_per_batch=T, a_batch_stride=N * T, w_batch_stride=K * T,
+                     lda=T, ldw=T)
+    assert torch.allclose(out, plain, atol=2e-3, rtol=1e-4)
+
+
 @pytest.mark.parametrize("N", [256, 128])
 def test_gemm_sliced(ops, N):
     """Sliced-schedule kernel (256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring): several trips round the ring, the padding-row
