@@ -26,15 +26,25 @@ __device__ __forceinline__ float epi_gelu_tanh(float x) {
 #endif
 }
 
+// d/dx of the above: s + x s (1 - s) 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2),  s = sigmoid(2u)
+__device__ __forceinline__ float epi_dgelu_tanh(float x) {
+#ifdef HIPEMU
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float sg = 1.0f / (1.0f + __expf(-2.0f * u));
+#else
+    const float t = x * __builtin_fmaf(x * x, -2.0f * 1.4426950408889634f * 0.7978845608028654f * 0.044715f, -2.0f * 1.4426950408889634f * 0.7978845608028654f);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+#endif
+    return sg + x * sg * (1.0f - sg) * (2.0f * 0.7978845608028654f) * __builtin_fmaf(x * x, 3.0f * 0.044715f, 1.0f);
+}
+
 constexpr int epi_strip_bytes(int nb) { return 32 * (32 * nb + 4) * 4; }     // LDS per wave
 
-// Which (epilogue, arguments) take the staged path: everything the inference launch sequence uses.  The transposed copies
-// of the training forward (`vt` with BF16 / GELU / DGELU) and DGELU keep the per-register path of their kernel.
+// Which (epilogue, arguments) take the staged path: all of them.  (The training epilogues -- DGELU and the transposed `vt`
+// copies of BF16 / GELU / DGELU -- used to keep the per-register path of their kernel: 16 two-byte loads and stores per block
+// per lane made the fc2 input-gradient GEMM 489 us at 4 samples, 175 us more than the forward fc1 of the same shape.)
 template <int EPI, class P>
-__device__ __forceinline__ bool epi_staged(const P& p) {
-    if (EPI == DGS_EPI_DGELU_BF16) return false;
-    return EPI == DGS_EPI_QKV || p.vt == nullptr;
-}
+__device__ __forceinline__ bool epi_staged(const P&) { return true; }
 
 // acc[0 .. NB): NB side-by-side 32 x 32 accumulator blocks: rows m0 .. m0+31 (m0 = first row of the block), columns
 // n0 .. n0 + 32 NB - 1.  `patch` = this wave's private LDS patch (epi_strip_bytes(NB) bytes); nobody else touches it, so no
@@ -95,20 +105,43 @@ __device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m
     } else {
         constexpr int LPR = C / 8, RPI = 64 / LPR;
         const int rr = lane / LPR, cc = (lane % LPR) * 8;
+        // BF16 / GELU / DGELU with `vt`: the final values go back into the patch (each lane over what it has just read) and
+        // leave a second time in the D-fragment layout: 4 consecutive tokens of one feature per 8-byte store
+        const bool transposed = EPI != DGS_EPI_QKV && p.vt != nullptr;
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
             const int row = it * RPI + rr;
-            const float4 v0 = *reinterpret_cast<const float4*>(st + row * S + cc), v1 = *reinterpret_cast<const float4*>(st + row * S + cc + 4);
+            float4 v0 = *reinterpret_cast<const float4*>(st + row * S + cc), v1 = *reinterpret_cast<const float4*>(st + row * S + cc + 4);
             const size_t o = (size_t)(m0 + row) * p.ldo + n0 + cc;
             if (EPI == DGS_EPI_GELU_BF16) {
                 if (p.aux) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.aux) + o) =
                     make_uint4(pack_bf2(v0.x, v0.y), pack_bf2(v0.z, v0.w), pack_bf2(v1.x, v1.y), pack_bf2(v1.z, v1.w));
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o) =
-                    make_uint4(pack_bf2(epi_gelu_tanh(v0.x), epi_gelu_tanh(v0.y)), pack_bf2(epi_gelu_tanh(v0.z), epi_gelu_tanh(v0.w)),
-                               pack_bf2(epi_gelu_tanh(v1.x), epi_gelu_tanh(v1.y)), pack_bf2(epi_gelu_tanh(v1.z), epi_gelu_tanh(v1.w)));
-            } else {
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o) =
-                    make_uint4(pack_bf2(v0.x, v0.y), pack_bf2(v0.z, v0.w), pack_bf2(v1.x, v1.y), pack_bf2(v1.z, v1.w));
+                v0 = make_float4(epi_gelu_tanh(v0.x), epi_gelu_tanh(v0.y), epi_gelu_tanh(v0.z), epi_gelu_tanh(v0.w));
+                v1 = make_float4(epi_gelu_tanh(v1.x), epi_gelu_tanh(v1.y), epi_gelu_tanh(v1.z), epi_gelu_tanh(v1.w));
+            } else if (EPI == DGS_EPI_DGELU_BF16) {
+                const uint4 ax = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux) + o);   // 8 pre-activations
+                v0 = make_float4(v0.x * epi_dgelu_tanh(__uint_as_float(ax.x << 16)), v0.y * epi_dgelu_tanh(__uint_as_float(ax.x & 0xffff0000u)),
+                                 v0.z * epi_dgelu_tanh(__uint_as_float(ax.y << 16)), v0.w * epi_dgelu_tanh(__uint_as_float(ax.y & 0xffff0000u)));
+                v1 = make_float4(v1.x * epi_dgelu_tanh(__uint_as_float(ax.z << 16)), v1.y * epi_dgelu_tanh(__uint_as_float(ax.z & 0xffff0000u)),
+                                 v1.z * epi_dgelu_tanh(__uint_as_float(ax.w << 16)), v1.w * epi_dgelu_tanh(__uint_as_float(ax.w & 0xffff0000u)));
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o) =
+                make_uint4(pack_bf2(v0.x, v0.y), pack_bf2(v0.z, v0.w), pack_bf2(v1.x, v1.y), pack_bf2(v1.z, v1.w));
+            if (transposed && EPI != DGS_EPI_BF16) {
+                *reinterpret_cast<float4*>(st + row * S + cc) = v0;
+                *reinterpret_cast<float4*>(st + row * S + cc + 4) = v1;
+            }
+        }
+        if (transposed) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                bf16_t* tdst = p.vt + ((size_t)b * p.N + n0 + 32 * blk + c) * p.rows_per_batch + (m0 - b * p.rows_per_batch) + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float* src = st + (4 * half + 8 * g) * S + 32 * blk + c;
+                    *reinterpret_cast<uint2*>(tdst + 8 * g) = make_uint2(pack_bf2(src[0], src[S]), pack_bf2(src[2 * S], src[3 * S]));
+                }
             }
         }
     }

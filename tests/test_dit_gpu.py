@@ -52,6 +52,34 @@ def test_gemm_production_shapes(M, N, K):
         assert rel_l2(vt.float()[0], ref[:, 2 * Wd:].t()) < 4e-3
 
 
+@pytest.mark.parametrize("algo", [0, _native.GEMM_SLICED])
+def test_gemm_training_epilogues_production_shapes(algo):
+    """fc1 forward (GELU + saved pre-activation + transposed copy) and the fc2 input gradient (dGELU + transposed copy) at the
+    4-view token count, 2 samples with padding rows: values vs fp32 torch, transposed copies bit-equal to the row-major ones."""
+    B, rows, L, W = 2, 4224, 4098, 1024
+    g = torch.Generator(device=DEV).manual_seed(5)
+    ops = _ops()
+    x = _bf(torch.randn(B * rows, W, generator=g, device=DEV))
+    w1 = _bf(torch.randn(4 * W, W, generator=g, device=DEV) * 0.03)
+    b1 = torch.randn(4 * W, generator=g, device=DEV) * 0.1
+    u_ref = x.float() @ w1.float().t() + b1
+    live = (torch.arange(B * rows, device=DEV) % rows) < L
+    tr = lambda t, n: t.reshape(B, rows, n).transpose(1, 2)
+    vt = torch.zeros(B, 4 * W, rows, dtype=torch.bfloat16, device=DEV)
+    aux = torch.zeros(B * rows, 4 * W, dtype=torch.bfloat16, device=DEV)
+    out = ops.gemm(x, w1, b1, _native.EPI_GELU_BF16, rows_per_batch=rows, valid_rows=L, vt=vt, aux=aux, algo=algo)
+    assert rel_l2(aux.float()[live], u_ref[live]) < 4e-3
+    assert rel_l2(out.float()[live], F.gelu(u_ref, approximate="tanh")[live]) < 4e-3
+    assert torch.equal(vt[:, :, :L], tr(out, 4 * W)[:, :, :L])
+    dy = _bf(torch.randn(B * rows, W, generator=g, device=DEV))
+    w2t = _bf(torch.randn(4 * W, W, generator=g, device=DEV) * 0.03)          # K-contiguous copy of fc2.weight
+    uu = aux.float().requires_grad_(True)
+    F.gelu(uu, approximate="tanh").sum().backward()
+    du = ops.gemm(dy, w2t, None, _native.EPI_DGELU_BF16, rows_per_batch=rows, valid_rows=L, vt=vt, aux=aux, algo=algo)
+    assert rel_l2(du.float()[live], ((dy.float() @ w2t.float().t()) * uu.grad)[live]) < 5e-3
+    assert torch.equal(vt[:, :, :L], tr(du, 4 * W)[:, :, :L])
+
+
 @pytest.mark.parametrize("prescaled", [True, False])
 @pytest.mark.parametrize("L,B", [(4098, 1), (258, 2), (1026, 1)])
 def test_attention_production_shapes(L, B, prescaled):
