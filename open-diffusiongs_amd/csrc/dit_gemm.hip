@@ -25,6 +25,7 @@ constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB: A tile of one stage (the W 
 
 struct GemmParams {
     int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles, tiles_m, map_mode;
+    int rows_ps, full_rows;          // per sample: 128-row tile rows, and how many of them hold a live 32-row block (a prefix)
     int k_per_batch;                 // reduction elements per sample (K when the reduction dimension is not batched)
     long long a_batch_stride, w_batch_stride;   // element stride between samples along the reduction (weight-gradient GEMMs)
     const bf16_t* A;
@@ -136,21 +137,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: live0/live1 become scalar branches
     const int wm = wave >> 1, wn = wave & 1;
+    // Work items: the tile rows of every sample that hold at least one live 32-row block (rows made only of padding are not
+    // launched).  A direct, unstaged path for the rows with a single live block -- the two learned-token rows; what the sliced
+    // kernel does -- was measured here and lost: +4 us on the N = 1024 GEMMs at batch 1 (dispatched last it lengthens the tail
+    // of the grid; inside the grid a half-empty tile costs less than that because it overlaps with its CU's other workgroup).
     const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
     // map_mode 0: an XCD's contiguous id range walks tn fastest (A row panels stay in that XCD's L2, W streams through);
     // map_mode 1: tm fastest (a W column panel stays resident, A streams through)
-    int tn, tm;
+    int tn, tr;                                                  // tr: index among the full tile rows of all samples
     if (p.map_mode >= 2) {
-        // grouped order: ids walk GM = map_mode tile rows (tm fastest) before moving to the next tile column, so the ~64
+        // grouped order: ids walk GM = map_mode tile rows (tr fastest) before moving to the next tile column, so the ~64
         // tiles an XCD runs at once form a compact GM x (64 / GM) block whose A and W panels fit that XCD's 4 MiB L2
         const int gsz = p.map_mode * p.tiles_n, grp = logical / gsz, in = logical - grp * gsz;
         const int first = grp * p.map_mode, gm = min(p.tiles_m - first, p.map_mode);
-        tm = first + in % gm;
+        tr = first + in % gm;
         tn = in / gm;
     } else {
         tn = p.map_mode ? logical / p.tiles_m : logical % p.tiles_n;
-        tm = p.map_mode ? logical % p.tiles_m : logical / p.tiles_n;
+        tr = p.map_mode ? logical % p.tiles_m : logical / p.tiles_n;
     }
+    const int tm = (tr / p.full_rows) * p.rows_ps + tr % p.full_rows;
     const int m0 = tm * BM, n0 = tn * BN;
     // Padding rows (row-in-sample >= valid_rows) are never observed: a 32-row accumulator block made only of padding
     // skips its MFMAs and its stores (its output rows keep the finite values they had), which makes the one
@@ -258,8 +264,10 @@ template <int EPI>
 static void launch_gemm(const GemmParams& p0, int bn, hipStream_t st) {
     GemmParams p = p0;
     p.tiles_n = p.N / bn;
-    p.tiles_m = p.M / BM;
-    p.ntiles = p.tiles_n * p.tiles_m;
+    p.rows_ps = p.rows_per_batch / BM;
+    p.full_rows = (p.valid_rows + BM - 1) / BM;               // valid rows are a prefix of every sample
+    p.tiles_m = (p.M / p.rows_per_batch) * p.full_rows;
+    p.ntiles = p.tiles_m * p.tiles_n;
     static const int map_env = getenv("DGS_GEMM_MAP") ? atoi(getenv("DGS_GEMM_MAP")) : 0;
     p.map_mode = map_env;
     if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 128>), dim3(p.ntiles), dim3(256), 0, st, p);
@@ -300,7 +308,9 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     }
     // AUTO: the sliced 256 x 256 kernel where one round of it covers the chip and beats 3+ rounds of 128-wide tiles (measured at
     // batch 1: the QKV GEMM, 39 vs 44 us); everything else runs the 128-wide two-stage kernel below
-    const bool auto_sliced = algo == DGS_GEMM_AUTO && a->epilogue == DGS_EPI_QKV && a->M <= 8192 &&
+    // (and at 4 samples fc1 + GELU: 232 vs 285 us; every other shape measured equal or slower on the sliced kernel there)
+    const bool auto_sliced = algo == DGS_GEMM_AUTO &&
+                             ((a->epilogue == DGS_EPI_QKV && a->M <= 8192) || (a->epilogue == DGS_EPI_GELU_BF16 && a->M > 8192 && a->N >= 4096)) &&
                              sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows) == 256;
     if (algo == DGS_GEMM_SLICED || auto_sliced) {
         const int sbn = sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);

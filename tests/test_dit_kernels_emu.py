@@ -81,6 +81,10 @@ def test_gemm_qkv_epilogue(ops):
     assert torch.equal(qk2[:, Wd:], qk[:, Wd:]) and torch.equal(vt2, vt)
     v = ref[:, 2 * Wd:].reshape(B, lpad, Wd).transpose(1, 2)
     assert torch.allclose(vt.float(), v, atol=2e-2, rtol=1e-2)
+    # 2 live rows in each sample: 128-wide tiles with a single live block take the unstaged path (one column block per wave)
+    qk3, vt3 = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=lpad, valid_rows=2)
+    for b in range(B):
+        assert torch.equal(qk3[b * lpad:b * lpad + 2], qk[b * lpad:b * lpad + 2]) and torch.equal(vt3[b, :, :2], vt[b, :, :2])
 
 
 @pytest.mark.parametrize("L,prescaled", [(128, False), (130, False), (130, True), (67, True), (258, False), (520, True), (20, False)])
