@@ -55,7 +55,8 @@ typedef enum DgsGemmAlgo {
     DGS_GEMM_SIMPLE128 = 1,    /* 128 x 128|64 tiles, two LDS stages, 2 workgroups / CU (what AUTO picks)              */
     DGS_GEMM_DEEP = 2,         /* 128 x N/8 tiles, NS-stage LDS-DMA ring, counted vmcnt + raw barrier                  */
     DGS_GEMM_BIG256 = 3,       /* 256 x 256 tiles, two stages (N >= 3072)                                              */
-    DGS_GEMM_SLICED = 4        /* 256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring, explicit MFMA / LDS issue slices       */
+    DGS_GEMM_SLICED = 4,       /* 256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring, explicit MFMA / LDS issue slices       */
+    DGS_GEMM_QUAD = 5          /* the same with 4 waves of 128 x 128 (256 x 256 tiles only; else as SLICED)              */
 } DgsGemmAlgo;
 
 typedef struct DgsDitGemmArgs {

@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     // Work items: the tile rows of every sample that hold at least one live 32-row block (rows made only of padding are not
     // launched).  A direct, unstaged path for the rows with a single live block -- the two learned-token rows; what the sliced
-    // kernel does -- was measured here and lost: +4 us on the N = 1024 GEMMs at batch 1 (dispatched last it lengthens the tail
-    // of the grid; inside the grid a half-empty tile costs less than that because it overlaps with its CU's other workgroup).
+    // kernel does -- was measured here and lost: +4..7 us on the N = 1024 GEMMs at batch 1.  Such a block is a chain of L2 round trips
+    // (4 waves cannot hold K = 4096 worth of fragments in flight); inside the grid a half-empty tile costs less than that because
+    // it overlaps with its CU's other workgroup.
     const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
     // map_mode 0: an XCD's contiguous id range walks tn fastest (A row panels stay in that XCD's L2, W streams through);
     // map_mode 1: tm fastest (a W column panel stays resident, A streams through)
@@ -252,7 +253,7 @@ int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int va
 bool big_gemm_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch);
 int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows, hipStream_t st);
 int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);
-int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
+int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad);
 int splitk_plan(int M, int N, int K, int k_per_batch, int* splits_per_batch);
 int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st);
 
@@ -293,9 +294,9 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     hipStream_t st0 = static_cast<hipStream_t>(stream);
-    // Kernel choice.  Measured on MI355X at the DiT shapes (profiles/r01_*gemm*): all three kernels stream ~12-40 GB/s per CU
-    // from L2 into LDS and none beats the 128-wide two-stage kernel by more than ~10 % on any shape, so AUTO = that kernel;
-    // the deep-ring (dit_gemm_deep.hip) and 256 x 256 kernels are selectable for experiments and are covered by the tests.
+    // Kernel choice.  The default is the 128-wide two-stage kernel below; the sliced 256-row kernel (dit_gemm_deep.hip) takes over
+    // where its tile count fits the chip (see AUTO); the deep-ring and two-stage 256 x 256 kernels are selectable for experiments
+    // and covered by the tests.
     static const int env_algo = getenv("DGS_GEMM_ALGO") ? atoi(getenv("DGS_GEMM_ALGO")) : 0;
     const int algo = a->algo ? a->algo : env_algo;
     if (algo == DGS_GEMM_BIG256 && big_gemm_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
@@ -306,15 +307,16 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
         int spb = 0;
         if (splitk_plan(a->M, a->N, a->K, kpb, &spb)) return launch_splitk_gemm(a, kpb, st0);
     }
-    // AUTO: the sliced 256 x 256 kernel where one round of it covers the chip and beats 3+ rounds of 128-wide tiles (measured at
-    // batch 1: the QKV GEMM, 39 vs 44 us); everything else runs the 128-wide two-stage kernel below
-    // (and at 4 samples fc1 + GELU: 232 vs 285 us; every other shape measured equal or slower on the sliced kernel there)
-    const bool auto_sliced = algo == DGS_GEMM_AUTO &&
-                             ((a->epilogue == DGS_EPI_QKV && a->M <= 8192) || (a->epilogue == DGS_EPI_GELU_BF16 && a->M > 8192 && a->N >= 4096)) &&
-                             sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows) == 256;
-    if (algo == DGS_GEMM_SLICED || auto_sliced) {
+    // AUTO (measured on MI355X, tools/gemm_check.py; 128-wide kernel -> sliced kernel):
+    //   1 sample  (M = 4352):  QKV 41 -> 39 us, fc1 + GELU 58 -> 44 us on 256 x 256 tiles (one round of the chip); the N = 1024
+    //                          GEMMs (64 tiles of 256 x 256) stay on the 128-wide kernel (fc2 67, proj 23 us)
+    //   4 samples (M = 17408): QKV 137 -> 119, fc2 219 -> 144, proj 68 -> 54, fc1 172 -> 178, f32 230 -> 171 us: everything eligible
+    const int sbn_auto = algo == DGS_GEMM_AUTO ? sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows) : 0;
+    const bool auto_sliced = sbn_auto != 0 && (a->M > 8192 || (sbn_auto == 256 && (a->epilogue == DGS_EPI_QKV ||
+                                                                                  (a->epilogue == DGS_EPI_GELU_BF16 && a->N >= 4096))));
+    if (algo == DGS_GEMM_SLICED || algo == DGS_GEMM_QUAD || auto_sliced) {
         const int sbn = sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
-        if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0);
+        if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0, algo == DGS_GEMM_QUAD);
     }
     if (algo == DGS_GEMM_DEEP) {
         const int dbn = deep_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);

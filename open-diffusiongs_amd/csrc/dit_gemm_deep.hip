@@ -16,6 +16,7 @@
 // Waves: 2 (M) x 4 (N); a wave owns 64 x BN/4 of the tile = 2 x (BN/128) accumulators of v_mfma_f32_32x32x16_bf16.
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "dit_common.h"
 #include "dgs_dit.h"
@@ -26,6 +27,7 @@ namespace dgs {
 struct DeepParams {
     int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles, dbg;
     int rows_ps, full_rows, tail_rows, nfull_items;             // sliced kernel: 256-row tile rows per sample (all / ring path / one live block), full items
+    int ntail;                                                  // sliced kernel: 32 x 64 items of the single-live-block tile rows
     int nsplit, splits_per_batch;                               // sliced kernel, split-K: items = nsplit x tiles, K = k_per_batch
     long long a_batch_stride, w_batch_stride, out_split_stride;
     const bf16_t* A;
@@ -57,21 +59,32 @@ __device__ __forceinline__ int slab_off(int r, int c) {
     return BK == 64 ? r * 128 + ((c ^ ((r >> 1) & 7)) << 4) : r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
 }
 
-// DMA one [ROWS][BK] slab: wave-instructions of 1 KiB (1024 / (2 BK) rows each), spread over the 8 waves.
-template <int ROWS, int BK>
+// DMA one [ROWS][BK] slab: wave-instructions of 1 KiB (1024 / (2 BK) rows each), spread over the NW waves.
+template <int ROWS, int BK, int NW = 8>
 __device__ __forceinline__ void stage_slab(const bf16_t* g, int ld, int row0, int k0, char* dst, int wave, int lane) {
     constexpr int RPI = 1024 / (2 * BK);          // rows per instruction: 8 (BK 64) or 16 (BK 32)
     constexpr int CPR = BK / 8;                   // 16-byte chunks per row
     constexpr int NINST = ROWS / RPI;
 #pragma unroll
-    for (int q = 0; q < (NINST + 7) / 8; ++q) {
-        const int piece = wave + 8 * q;
-        if (NINST % 8 != 0 && piece >= NINST) break;
+    for (int q = 0; q < (NINST + NW - 1) / NW; ++q) {
+        const int piece = wave + NW * q;
+        if (NINST % NW != 0 && piece >= NINST) break;
         const int row = piece * RPI + lane / CPR;
         const int slot = lane % CPR;
         const int chunk = BK == 64 ? (slot ^ ((row >> 1) & 7)) : (slot ^ ((row >> 2) & 3));
         glds16(g + (size_t)(row0 + row) * ld + k0 + chunk * 8, dst + piece * 1024);
     }
+}
+
+// One wave-instruction of stage_slab (piece = wave + NW * q), for kernels that spread the DMA issue over their MFMA slices.
+template <int BK, int NW>
+__device__ __forceinline__ void stage_piece(const bf16_t* g, int ld, int row0, int k0, char* dst, int wave, int lane, int q) {
+    constexpr int RPI = 1024 / (2 * BK), CPR = BK / 8;
+    const int piece = wave + NW * q;
+    const int row = piece * RPI + lane / CPR;
+    const int slot = lane % CPR;
+    const int chunk = BK == 64 ? (slot ^ ((row >> 1) & 7)) : (slot ^ ((row >> 2) & 3));
+    glds16(g + (size_t)(row0 + row) * ld + k0 + chunk * 8, dst + piece * 1024);
 }
 
 template <int EPI, int NI>
@@ -153,12 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_deep_kernel(DeepParams p) {
             f32x16 acc1[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < p.K; k += 16) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + k);
-                const bf16x8 w = *reinterpret_cast<const bf16x8*>(wrow + k);
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc1[0], 0, 0, 0);
-            }
+            for (int k = 0; k < p.K; k += BK) direct_block_mfma<BK / 16>(arow + k, wrow + k, acc1[0]);
             store_block<EPI, 1>(p, acc1, m0 + 4 * fhalf, n0 + cb * 32, lane);
         }
         return;
@@ -367,25 +375,65 @@ template <int I, int N, class F> __device__ __forceinline__ void sliced_for(F&& 
 
 __device__ long long dgs_gemm_dbg[16];   // DGS_GEMM_DBG: cycle stamps of workgroup 0, wave 0 (loop total, wait + barrier share)
 
-template <int EPI, int BN>
-__global__ __launch_bounds__(512) void gemm_sliced_kernel(DeepParams p) {
+// NW = 4 ("quad"): the same ring and schedule with 4 waves as 2 x 2, a wave owning 128 x 128 (4 x 4 accumulators = 256
+// registers, which hipcc keeps in AGPRs: MFMA reads and writes them there, nothing else touches them before the epilogue).
+// Why: LDS bandwidth, not L2, bounds these kernels (tools/ubench/l2_tile_bench: the L2 -> LDS DMA alone streams GEMM tiles at
+// 30 TB/s = 60 B/clk/CU).  Per 32 x 32 x 16 MFMA (32 cycles) a wave with an I x J block tile reads (I + J) / (I J) KiB of
+// fragments; four SIMDs at full MFMA rate therefore pull 128 (I + J) / (I J) B/clk from a 128 B/clk LDS that also absorbs the
+// DMA writes:   2 x 1 (the 128 x 64 tile): 192 + 48,   2 x 2: 128 + 32,   2 x 4 (NW = 8): 96 + 32,   4 x 4 (NW = 4): 64 + 32.
+// EXP (measurement only, wrong results): 1 = no DMA refills in the loop, 2 = no fragment reads in the loop
+template <int EPI, int BN, int NW, int EXP = 0>
+__global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepParams p) {
     constexpr int BM = 256, BK = 32, NS = 4;
-    constexpr int WN = BN / 2, NI = WN / 32;                      // wave tile 64 x WN: 2 x NI accumulators
+    constexpr int WMB = NW == 8 ? 2 : 4, WROWS = 32 * WMB;        // A blocks per wave
+    constexpr int WN = BN / 2, NI = WN / 32;                      // wave tile WROWS x WN: WMB x NI accumulators
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
-    constexpr int G = A_BYTES / 8192 + W_BYTES / 8192;            // LDS-DMA instructions per wave per slab
-    constexpr int NF = 2 + NI;                                    // fragments per k-substep: 2 of A, NI of W
+    constexpr int G = (A_BYTES / 1024 + W_BYTES / 1024) / NW;     // LDS-DMA instructions per wave per slab
+    constexpr int NF = WMB + NI, MF = WMB * NI;                   // per k-substep: fragments (WMB of A, NI of W), MFMAs
+    static_assert(NW == 8 || BN == 256, "quad layout: 256 x 256 tiles");
     DGS_DYNAMIC_LDS(lds);
 #ifndef HIPEMU
-    const long long dbg_k0 = p.dbg ? clock64() : 0;
+    const long long dbg_k0 = p.dbg == 1 ? clock64() : 0;
+    const long long dbg_w0 = p.dbg == 1 ? wall_clock64() : 0;         // constant 100 MHz: gives the shader clock the cycle stamps ran at
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 31, fhalf = lane >> 5;
-    // Work items: first every full tile -- XCD-aware order --, then the cheap tiles whose sample has a single
-    // live 32-row block left (the two learned-token rows of the DiT): dispatched last, they fill CUs as the full tiles
-    // retire instead of pushing 1/16 of the full tiles into a second round.
+    // Work items: every full tile, XCD-aware order.  (The tile rows with a single live 32-row block -- the two learned-token
+    // rows of the DiT -- are 32 x 64 side jobs of the first workgroups, see the prologue.)
     const int bid = (int)blockIdx.x;
+    auto side_jobs = [&]() {
+    for (int j = p.nsplit > 1 ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
+        constexpr int CBW = BN == 256 ? 1 : 2, KQ = NW / CBW, TPC = BN / (32 * CBW);   // column blocks, K ranges per item; items per tile column
+        const int sub = j % TPC, ttn = (j / TPC) % p.tiles_n, trr = j / (TPC * p.tiles_n);
+        const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = ttn * BN + sub * 32 * CBW;
+        const int cbl = wave % CBW, kq = wave / CBW, kper = p.K / KQ;  // kper % 128 == 0 (launch_sliced)
+        const bf16_t* arow = p.A + (size_t)(tm0 + frow) * p.lda + kq * kper + fhalf * 8;
+        const bf16_t* wrow = p.W + (size_t)(tn0 + cbl * 32 + frow) * p.ldw + kq * kper + fhalf * 8;
+        f32x16 acc1[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+        if (kper % 256 == 0)
+            for (int k = 0; k < kper; k += 256) direct_block_mfma<16>(arow + k, wrow + k, acc1[0]);
+        else
+            for (int k = 0; k < kper; k += 128) direct_block_mfma<8>(arow + k, wrow + k, acc1[0]);
+        float* red = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);          // (KQ - 1) * CBW * 4 KiB <= STAGE
+        if (kq > 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((kq - 1) * CBW + cbl) * 1024 + r * 64 + lane] = acc1[0][r];
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+            for (int q = 1; q < KQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[0][r] += red[((q - 1) * CBW + cbl) * 1024 + r * 64 + lane];
+            store_block<EPI, 1>(p, acc1, tm0 + 4 * fhalf, tn0 + cbl * 32, lane);
+        }
+        __syncthreads();                                            // `red` is rewritten by the next item / the ring
+    }
+    };
+    if (p.nfull_items == 0) { side_jobs(); return; }           // no full tile at all (<= 32 valid rows per sample)
     int tile;
     if (p.nsplit > 1) {
         // split-K (weight gradients): item = (split, tile), split-major so that an XCD's tiles share operand panels; a split is
@@ -398,53 +446,45 @@ __global__ __launch_bounds__(512) void gemm_sliced_kernel(DeepParams p) {
         p.W += (size_t)b * p.w_batch_stride + u0 * 128;
         p.out = static_cast<float*>(p.out) + (size_t)sp * p.out_split_stride;
         p.K = (u1 - u0) * 128;
-    } else if (bid >= p.nfull_items) {
-        const int j = bid - p.nfull_items, tn = j % p.tiles_n, rr = j / p.tiles_n;
-        const int m0 = ((rr / p.tail_rows) * p.rows_ps + p.full_rows + rr % p.tail_rows) * BM, n0 = tn * BN;
-        // no staging: the 8 waves split the BN / 32 column blocks, fragments come straight from L2, 16 k-steps in flight
-        const bf16_t* arow = p.A + (size_t)(m0 + frow) * p.lda + fhalf * 8;
-        for (int cb = wave; cb < BN / 32; cb += 8) {
-            const bf16_t* wrow = p.W + (size_t)(n0 + cb * 32 + frow) * p.ldw + fhalf * 8;
-            f32x16 acc1[1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-#pragma unroll 16
-            for (int k = 0; k < p.K; k += 16)
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + k),
-                                                                  *reinterpret_cast<const bf16x8*>(wrow + k), acc1[0], 0, 0, 0);
-            store_block<EPI, 1>(p, acc1, m0 + 4 * fhalf, n0 + cb * 32, lane);
-        }
-        return;
     } else {
         tile = xcd_remap(bid, p.nfull_items);
     }
     const int tn = tile % p.tiles_n, rr = tile / p.tiles_n;
     const int m0 = ((rr / p.full_rows) * p.rows_ps + rr % p.full_rows) * BM, n0 = tn * BN;
-    f32x16 acc[2][NI];
+    f32x16 acc[WMB][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMB; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    // fragment f of substep ks: f < 2: A rows wm*64 + 32 f + frow;  f >= 2: W rows wn*WN + 32 (f - 2) + frow; chunk 2 ks + fhalf
+    // fragment f of substep ks: f < WMB: A rows wm*WROWS + 32 f + frow;  f >= WMB: W rows wn*WN + 32 (f - WMB) + frow; chunk 2 ks + fhalf
     int foff[2][NF];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NF; ++f)
-            foff[ks][f] = f < 2 ? slab_off<BK>(wm * 64 + 32 * f + frow, 2 * ks + fhalf) : A_BYTES + slab_off<BK>(wn * WN + 32 * (f - 2) + frow, 2 * ks + fhalf);
+            foff[ks][f] = f < WMB ? slab_off<BK>(wm * WROWS + 32 * f + frow, 2 * ks + fhalf) : A_BYTES + slab_off<BK>(wn * WN + 32 * (f - WMB) + frow, 2 * ks + fhalf);
     auto frag = [&](int slot, int ks, int f) { return *reinterpret_cast<const bf16x8*>(lds + slot * STAGE + foff[ks][f]); };
     const int nk = p.K / BK;                                      // a multiple of NS
     auto stage = [&](int t, int slot) {
-        stage_slab<BM, BK>(p.A, p.lda, m0, t * BK, lds + slot * STAGE, wave, lane);
-        stage_slab<BN, BK>(p.W, p.ldw, n0, t * BK, lds + slot * STAGE + A_BYTES, wave, lane);
+        stage_slab<BM, BK, NW>(p.A, p.lda, m0, t * BK, lds + slot * STAGE, wave, lane);
+        stage_slab<BN, BK, NW>(p.W, p.ldw, n0, t * BK, lds + slot * STAGE + A_BYTES, wave, lane);
     };
     // ---- prologue: slabs 0 .. NS-2 in flight, then the fragments of slab 0, substep 0 ----
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) stage(s, s);
+    // ---- tiles with a single live 32-row block (the learned-token rows of every sample), folded into the first workgroups ----
+    // An item is 32 rows x 32 columns (64 for BN = 128): the NW waves are ranges of K, every wave pulls its fragments straight from
+    // L2 in one round trip per 128 / 256 columns of K (one trip for K = 1024), the ranges meet in the ring stage that iteration 0
+    // refills.  The loads are gathers -- 32 rows, 32 cache lines per wave-instruction -- and the CU's address path, not latency,
+    // sets their price (~2.5 cycles per line): the smaller the item, the more workgroups share that cost.  It runs here, while this workgroup's first slabs are in flight, because a memory round trip costs
+    // 2-4 us when the chip is streaming GEMM tiles and nothing else can hide it: as workgroups of their own (256 full tiles on
+    // 256 CUs, so they start when the first full tiles retire) these items added 36 us when a wave walked all of K for one
+    // column block, and still 14 us in this one-trip form.
+    side_jobs();
 #ifndef HIPEMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the slabs, and the stores above (the counted waits of the loop see DMAs only)
     __builtin_amdgcn_s_barrier();
 #else
     __syncthreads();
@@ -454,15 +494,25 @@ __global__ __launch_bounds__(512) void gemm_sliced_kernel(DeepParams p) {
     for (int f = 0; f < NF; ++f) fr[0][f] = frag(0, 0, f);
 
     long long dbg_wait = 0, dbg_bar = 0;
-    auto iteration = [&](int t, const int slot) {                // slot == t % NS, a literal at the call sites
-        const bool refill = t + NS - 1 < nk;
-        if (refill) stage(t + NS - 1, (slot + NS - 1) % NS);      // into the stage of slab t - 1 (released by the last barrier)
-        sliced_for<0, 4 * NI>([&](auto jc) {
-            constexpr int J = decltype(jc)::value, ks = J / (2 * NI), i = (J % (2 * NI)) / NI, j = J % NI;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks][i], fr[ks][2 + j], acc[i][j], 0, 0, 0);
+    // NW = 4: the wave is alone on its SIMD, so a burst of G DMA issues at the top of the iteration is a bubble in the MFMA
+    // stream; one DMA goes out behind each MFMA of the second half of substep 0 instead (those slices have no LDS read)
+    constexpr int GA = A_BYTES / 1024 / NW;
+    constexpr bool SPREAD = NW == 4;
+    auto iteration = [&](int t, const int slot, auto refill_tag) {   // slot == t % NS, a literal at the call sites
+        constexpr bool refill = decltype(refill_tag)::value;           // slab t + NS - 1 exists
+        char* const dst = lds + ((slot + NS - 1) % NS) * STAGE;        // the stage of slab t - 1 (released by the last barrier)
+        if (refill && !SPREAD && EXP != 1) stage(t + NS - 1, (slot + NS - 1) % NS);
+        sliced_for<0, 2 * MF>([&](auto jc) {
+            constexpr int J = decltype(jc)::value, ks = J / MF, i = (J % MF) / NI, j = J % NI;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks][i], fr[ks][WMB + j], acc[i][j], 0, 0, 0);
             // the other register half: substep 1 of this slab, then substep 0 of the next one (stale data behind the last slab)
-            constexpr int f = J % (2 * NI);
-            if constexpr (f < NF) fr[ks ^ 1][f] = frag(ks == 0 ? slot : (slot + 1) % NS, ks ^ 1, f);
+            constexpr int f = J % MF;
+            if constexpr (f < NF && EXP != 2) fr[ks ^ 1][f] = frag(ks == 0 ? slot : (slot + 1) % NS, ks ^ 1, f);
+            if constexpr (SPREAD && refill && ks == 0 && f >= MF - G && EXP != 1) {
+                constexpr int q = f - (MF - G);
+                if constexpr (q < GA) stage_piece<BK, NW>(p.A, p.lda, m0, (t + NS - 1) * BK, dst, wave, lane, q);
+                else stage_piece<BK, NW>(p.W, p.ldw, n0, (t + NS - 1) * BK, dst + A_BYTES, wave, lane, q - GA);
+            }
 #ifndef HIPEMU
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -471,41 +521,45 @@ __global__ __launch_bounds__(512) void gemm_sliced_kernel(DeepParams p) {
         // done reading slab t
 #ifndef HIPEMU
         long long w0 = 0;
-        if (p.dbg) w0 = clock64();
+        if (p.dbg == 1) w0 = clock64();
         if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long w1 = 0;
-        if (p.dbg) w1 = clock64();
+        if (p.dbg == 1) w1 = clock64();
         __builtin_amdgcn_s_barrier();
-        if (p.dbg) { dbg_wait += w1 - w0; dbg_bar += clock64() - w1; }
+        if (p.dbg == 1) { dbg_wait += w1 - w0; dbg_bar += clock64() - w1; }
 #else
         __syncthreads();
 #endif
     };
 #ifndef HIPEMU
-    const long long dbg_t0 = p.dbg ? clock64() : 0;
+    const long long dbg_t0 = p.dbg == 1 ? clock64() : 0;
 #endif
-    for (int t = 0; t < nk; t += NS) {
-        iteration(t, 0);
-        iteration(t + 1, 1);
-        iteration(t + 2, 2);
-        iteration(t + 3, 3);
+    for (int t = 0; t < nk - NS; t += NS) {
+        iteration(t, 0, std::true_type{});
+        iteration(t + 1, 1, std::true_type{});
+        iteration(t + 2, 2, std::true_type{});
+        iteration(t + 3, 3, std::true_type{});
     }
+    iteration(nk - 4, 0, std::true_type{});                       // the last slab goes out here
+    iteration(nk - 3, 1, std::false_type{});
+    iteration(nk - 2, 2, std::false_type{});
+    iteration(nk - 1, 3, std::false_type{});
 #ifndef HIPEMU
-    const long long dbg_t1 = p.dbg ? clock64() : 0;
+    const long long dbg_t1 = p.dbg == 1 ? clock64() : 0;
 #endif
     if (epi_staged<EPI>(p)) {          // the ring is idle now (everybody passed the last barrier): a private LDS patch per wave
         char* patch = lds + wave * epi_strip_bytes(2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WMB; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; j += 2) store_strip<EPI, 2>(p, &acc[i][j], m0 + wm * 64 + 32 * i, n0 + wn * WN + 32 * j, lane, patch);
+            for (int j = 0; j < NI; j += 2) store_strip<EPI, 2>(p, &acc[i][j], m0 + wm * WROWS + 32 * i, n0 + wn * WN + 32 * j, lane, patch);
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) store_block<EPI, NI>(p, acc[i], m0 + wm * 64 + 32 * i + 4 * fhalf, n0 + wn * WN, lane);
+        for (int i = 0; i < WMB; ++i) store_block<EPI, NI>(p, acc[i], m0 + wm * WROWS + 32 * i + 4 * fhalf, n0 + wn * WN, lane);
     }
 #ifndef HIPEMU
-    if (p.dbg) {
+    if (p.dbg == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
             atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[6]), (unsigned long long)(clock64() - dbg_k0));
@@ -516,45 +570,60 @@ __global__ __launch_bounds__(512) void gemm_sliced_kernel(DeepParams p) {
         if (blockIdx.x == 0 && tid == 0) {
             dgs_gemm_dbg[0] = dbg_t1 - dbg_t0; dgs_gemm_dbg[1] = dbg_wait; dgs_gemm_dbg[2] = dbg_bar; dgs_gemm_dbg[3] = nk;
             dgs_gemm_dbg[4] = dbg_t0 - dbg_k0; dgs_gemm_dbg[5] = clock64() - dbg_t1;
+            dgs_gemm_dbg[10] = clock64() - dbg_k0; dgs_gemm_dbg[11] = wall_clock64() - dbg_w0;
         }
     }
 #endif
 }
 
-template <int EPI, int BN>
+template <int EPI, int BN, int NW = 8>
 static int launch_sliced(DeepParams p, hipStream_t st) {
     constexpr int LDS = 4 * (256 * 32 * 2 + BN * 32 * 2);          // 128 KiB (BN 256) / 96 KiB (BN 128)
     p.tiles_n = p.N / BN;
     p.rows_ps = p.rows_per_batch / 256;
     p.full_rows = 0; p.tail_rows = 0;
+    const bool direct_ok = p.K % (NW / (BN == 256 ? 1 : 2) * 128) == 0;   // else single-block tiles run the ring like the others
     for (int i = 0; i < p.rows_ps; ++i) {                          // per sample: tile rows with >= 2 / exactly 1 live 32-row blocks
         const int live = (p.valid_rows - i * 256 + 31) / 32;
-        if (live > 1) ++p.full_rows; else if (live == 1) ++p.tail_rows;
+        if (live > 1 || (live == 1 && !direct_ok)) ++p.full_rows; else if (live == 1) ++p.tail_rows;
     }
     const int samples = p.M / p.rows_per_batch;
     p.nfull_items = samples * p.full_rows * p.tiles_n;
-    p.ntiles = p.nfull_items + samples * p.tail_rows * p.tiles_n;
+    p.ntail = samples * p.tail_rows * p.tiles_n * (BN == 256 ? 8 : 2);
+    p.ntiles = p.nfull_items ? p.nfull_items : p.ntail;
     if (p.nsplit > 1) {
         if (p.tail_rows || samples != 1) return DGS_ERR_INVALID_ARGUMENT;
         p.ntiles = p.nfull_items * p.nsplit;
     }
-    auto kern = gemm_sliced_kernel<EPI, BN>;
+    auto kern = gemm_sliced_kernel<EPI, BN, NW>;
+    if constexpr (EPI == DGS_EPI_F32 && BN == 256) {              // DGS_GEMM_EXP=1|2: the measurement variants
+        static const int exp = getenv("DGS_GEMM_EXP") ? atoi(getenv("DGS_GEMM_EXP")) : 0;
+        if (exp == 1) kern = gemm_sliced_kernel<EPI, BN, NW, 1>;
+        if (exp == 2) kern = gemm_sliced_kernel<EPI, BN, NW, 2>;
+        if (exp && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DGS_ERR_DEVICE;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DGS_ERR_DEVICE;
         attr_set = true;
     }
-    static const bool dbg = getenv("DGS_GEMM_DBG") != nullptr;
+    static const int dbg = getenv("DGS_GEMM_DBG") ? atoi(getenv("DGS_GEMM_DBG")) : 0;   // 1: cycle stamps
     p.dbg = dbg;
-    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(512), LDS, st, p);
 #ifndef HIPEMU
-    if (dbg) {
-        long long h[10];
+    if (dbg == 1) {
+        const long long z[4] = {0, 0, 0x7fffffffffffffffLL, 0};
+        (void)hipStreamSynchronize(st);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dgs_gemm_dbg), z, sizeof(z), 6 * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess) fprintf(stderr, "[gemm dbg] reset failed\n");
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(64 * NW), LDS, st, p);
+#ifndef HIPEMU
+    if (dbg == 1) {
+        long long h[12];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(dgs_gemm_dbg), sizeof(h));
-        { long long z[4] = {0, 0, 0x7fffffffffffffffLL, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dgs_gemm_dbg), z, sizeof(z), 6 * sizeof(long long)); }
-        fprintf(stderr, "[gemm dbg] M=%d N=%d K=%d BN=%d: prologue %lld, loop %lld cycles (%lld per slab), vmcnt wait %lld, barrier %lld, epilogue %lld | slowest wg %lld cycles, max vmcnt wait %lld per slab, first start -> last end %lld\n", p.M,
-                p.N, p.K, BN, h[4], h[0], h[0] / h[3], h[1] / h[3], h[2] / h[3], h[5], h[6], h[7] / h[3], h[9] - h[8]);
+        fprintf(stderr, "[gemm dbg] M=%d N=%d K=%d BN=%d: prologue %lld, loop %lld cycles (%lld per slab), vmcnt wait %lld, barrier %lld, epilogue %lld | slowest wg %lld cycles, max vmcnt wait %lld per slab, workgroup 0: %lld cycles in %.2f us = %.0f MHz\n", p.M,
+                p.N, p.K, BN, h[4], h[0], h[0] / h[3], h[1] / h[3], h[2] / h[3], h[5], h[6], h[7] / h[3], h[10], h[11] / 100.0, h[10] / (h[11] / 100.0));
     }
 #endif
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
@@ -571,7 +640,7 @@ int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int row
     return N % 128 ? 0 : 128;
 }
 
-int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st) {
+int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad) {
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
     p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0; p.nsplit = 1; p.splits_per_batch = 1;
@@ -579,7 +648,7 @@ int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int 
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
-#define DGS_SLICED_CASE(E) case E: return bn == 256 ? launch_sliced<E, 256>(p, st) : launch_sliced<E, 128>(p, st)
+#define DGS_SLICED_CASE(E) case E: return bn == 256 ? (quad ? launch_sliced<E, 256, 4>(p, st) : launch_sliced<E, 256>(p, st)) : launch_sliced<E, 128>(p, st)
     switch (a->epilogue) {
         DGS_SLICED_CASE(DGS_EPI_BF16);
         DGS_SLICED_CASE(DGS_EPI_GELU_BF16);

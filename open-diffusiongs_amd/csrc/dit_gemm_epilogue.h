@@ -38,6 +38,24 @@ __device__ __forceinline__ float epi_dgelu_tanh(float x) {
     return sg + x * sg * (1.0f - sg) * (2.0f * 0.7978845608028654f) * __builtin_fmaf(x * x, 3.0f * 0.044715f, 1.0f);
 }
 
+// One 32 x 32 output block straight from global memory (no LDS): acc += A[32 rows, 16 U] . W[32 rows, 16 U]^T with both operands
+// read in MFMA fragment layout (arow / wrow already point at this lane's row and 8-element half).  Used for the tiles that hold a
+// single live 32-row block.  All 2 U loads are issued before the first MFMA: such a block is a chain of L2 round trips, and
+// each one costs 3-4 us when the rest of the chip is streaming GEMM tiles (measured: 8 of them made 16 of these tiles cost
+// 36 us behind 256 full tiles that take 40 us).  Left to `#pragma unroll`, hipcc even emitted load, load, s_waitcnt vmcnt(0),
+// MFMA per k-step -- one round trip per 16 columns of K.
+template <int U>
+__device__ __forceinline__ void direct_block_mfma(const bf16_t* arow, const bf16_t* wrow, f32x16& acc) {
+    bf16x8 a[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        a[u] = *reinterpret_cast<const bf16x8*>(arow + 16 * u);
+        w[u] = *reinterpret_cast<const bf16x8*>(wrow + 16 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], w[u], acc, 0, 0, 0);
+}
+
 constexpr int epi_strip_bytes(int nb) { return 32 * (32 * nb + 4) * 4; }     // LDS per wave
 
 // Which (epilogue, arguments) take the staged path: all of them.  (The training epilogues -- DGELU and the transposed `vt`

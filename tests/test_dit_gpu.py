@@ -34,7 +34,7 @@ def test_gemm_production_shapes(M, N, K):
     ref = A.float() @ W.float().t() + bias
     ops = _ops()
     assert rel_l2(ops.gemm(A, W, bias, _native.EPI_F32), ref) < 1e-5
-    for algo in (_native.GEMM_DEEP, _native.GEMM_BIG256, _native.GEMM_SLICED):   # every kernel family (ineligible shapes fall back)
+    for algo in (_native.GEMM_DEEP, _native.GEMM_BIG256, _native.GEMM_SLICED, _native.GEMM_QUAD):   # every kernel family (ineligible shapes fall back)
         assert rel_l2(ops.gemm(A, W, bias, _native.EPI_F32, algo=algo), ref) < 1e-5, algo
         assert rel_l2(ops.gemm(A, W, bias, _native.EPI_GELU_BF16, algo=algo).float(), F.gelu(ref, approximate="tanh")) < 4e-3, algo
     assert rel_l2(ops.gemm(A, W, bias, _native.EPI_BF16).float(), ref) < 4e-3
@@ -52,7 +52,7 @@ def test_gemm_production_shapes(M, N, K):
         assert rel_l2(vt.float()[0], ref[:, 2 * Wd:].t()) < 4e-3
 
 
-@pytest.mark.parametrize("algo", [0, _native.GEMM_SLICED])
+@pytest.mark.parametrize("algo", [0, _native.GEMM_SLICED, _native.GEMM_QUAD])
 def test_gemm_training_epilogues_production_shapes(algo):
     """fc1 forward (GELU + saved pre-activation + transposed copy) and the fc2 input gradient (dGELU + transposed copy) at the
     4-view token count, 2 samples with padding rows: values vs fp32 torch, transposed copies bit-equal to the row-major ones."""

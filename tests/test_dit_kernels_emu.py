@@ -46,7 +46,7 @@ def test_gemm_epilogues(ops):
 
 def test_gemm_padding_blocks_are_skipped(ops):
     g = torch.Generator().manual_seed(7)
-    rows, B, N, K = 256, 2, 128, 64
+    rows, B, N, K = 256, 2, 128, 128
     A = _bf(torch.randn(B * rows, K, generator=g))
     W = _bf(torch.randn(N, K, generator=g) * 0.1)
     ref = A.float() @ W.float().t()
@@ -69,7 +69,7 @@ def test_gemm_padding_blocks_are_skipped(ops):
 
 def test_gemm_qkv_epilogue(ops):
     g = torch.Generator().manual_seed(2)
-    lpad, B, Wd, K = 128, 2, 128, 64
+    lpad, B, Wd, K = 128, 2, 128, 128
     A = _bf(torch.randn(B * lpad, K, generator=g))
     W = _bf(torch.randn(3 * Wd, K, generator=g) * 0.1)
     bias = torch.randn(3 * Wd, generator=g)
@@ -348,19 +348,21 @@ def test_gemm_split_k_weight_gradient(ops, monkeypatch):
     assert torch.allclose(out, plain, atol=2e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("N", [256, 128])
+@pytest.mark.parametrize("N", [256, 128, -256])
 def test_gemm_sliced(ops, N):
     """Sliced-schedule kernel (256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring): several trips round the ring, the padding-row
     path, and the QKV / gate-residual epilogues."""
+    sl = _native.GEMM_SLICED
+    if N < 0:                                       # the 4-wave variant (128 x 128 per wave) of the 256 x 256 tile
+        sl, N = _native.GEMM_QUAD, -N
     g = torch.Generator().manual_seed(41 + N)
-    M, K = 512, 384                                 # 12 K slabs = 3 trips round the ring
+    M, K = 512, 1024                                # 32 K slabs = 8 trips round the ring; K % 1024 == 0: single-block tiles go direct
     if N == 256:
         N = 768                                     # 2 x 3 tiles of 256 x 256: needs >= 160 tiles for AUTO, forced via algo here
     A = _bf(torch.randn(M, K, generator=g))
     W = _bf(torch.randn(N, K, generator=g) * 0.2)
     bias = torch.randn(N, generator=g)
     ref = A.float() @ W.float().t() + bias
-    sl = _native.GEMM_SLICED
     out = ops.gemm(A, W, bias, _native.EPI_F32, algo=sl)
     assert torch.allclose(out, ref, atol=3e-3, rtol=1e-4)
     out = torch.full((M, N), 7.0)

@@ -14,21 +14,26 @@ from dgs_amd.dit import DitOps
 DEV = "cuda:0"
 ops = DitOps()
 L, lpad, W = 4098, 4352, 1024
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 g = torch.Generator(device=DEV).manual_seed(0)
 bf = lambda *s: torch.randn(*s, generator=g, device=DEV).to(torch.bfloat16)
-xn, h = bf(lpad, W), bf(lpad, 4 * W)
+xn, h = bf(B * lpad, W), bf(B * lpad, 4 * W)
 w1, w2, wq, wp = bf(4 * W, W) * 0.02, bf(W, 4 * W) * 0.02, bf(3 * W, W) * 0.02, bf(W, W) * 0.02
-x = torch.randn(lpad, W, device=DEV)
-gate = torch.randn(1, W, device=DEV)
+x = torch.randn(B * lpad, W, device=DEV)
+gate = torch.randn(B, W, device=DEV)
 algos = [int(a) for a in (sys.argv[1] if len(sys.argv) > 1 else "0,4").split(",")]
 cases = {
     "qkv": lambda al: ops.gemm(xn, wq, None, _native.EPI_QKV, rows_per_batch=lpad, valid_rows=L, algo=al),
     "fc1": lambda al: ops.gemm(xn, w1, None, _native.EPI_GELU_BF16, rows_per_batch=lpad, valid_rows=L, algo=al),
     "fc2": lambda al: ops.gemm(h, w2, None, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=lpad, valid_rows=L, algo=al),
+    "f32": lambda al: ops.gemm(xn, w1, None, _native.EPI_F32, rows_per_batch=lpad, valid_rows=L, algo=al),
     "proj": lambda al: ops.gemm(xn, wp, None, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=lpad, valid_rows=L, algo=al),
 }
-flops = {"qkv": 2 * L * 3 * W * W, "fc1": 2 * L * 4 * W * W, "fc2": 2 * L * 4 * W * W, "proj": 2 * L * W * W}
+flops = {"f32": 2 * B * L * 4 * W * W, "qkv": 2 * B * L * 3 * W * W, "fc1": 2 * B * L * 4 * W * W, "fc2": 2 * B * L * 4 * W * W, "proj": 2 * B * L * W * W}
+only = os.environ.get("GEMM_CASES")
 for name, fn in cases.items():
+    if only and name not in only.split(","):
+        continue
     for al in algos:
         for _ in range(2):
             fn(al)
