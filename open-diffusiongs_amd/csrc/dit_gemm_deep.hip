@@ -30,6 +30,9 @@ struct DeepParams {
     int ntail;                                                  // sliced kernel: 32 x 64 items of the single-live-block tile rows
     int nsplit, splits_per_batch;                               // sliced kernel, split-K: items = nsplit x tiles, K = k_per_batch
     long long a_batch_stride, w_batch_stride, out_split_stride;
+    int fused;                                                  // split-K with the reduction in the kernel (last arriver), any epilogue
+    float* ws;                                                  // fused: [tile][split][256 x 256] f32 partial tiles, fragment order
+    int* cnt;                                                   // fused: arrival counter per tile (library-owned, zero between launches)
     const bf16_t* A;
     const bf16_t* W;
     const float* bias;
@@ -403,14 +406,17 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     // Work items: every full tile, XCD-aware order.  (The tile rows with a single live 32-row block -- the two learned-token
     // rows of the DiT -- are 32 x 64 side jobs of the first workgroups, see the prologue.)
     const int bid = (int)blockIdx.x;
+    const bf16_t* const A_all = p.A;                            // the split-K modes narrow p.A / p.W / p.K to this workgroup's range
+    const bf16_t* const W_all = p.W;
+    const int K_all = p.K;
     auto side_jobs = [&]() {
-    for (int j = p.nsplit > 1 ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
+    for (int j = (p.nsplit > 1 && !p.fused) ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
         constexpr int CBW = BN == 256 ? 1 : 2, KQ = NW / CBW, TPC = BN / (32 * CBW);   // column blocks, K ranges per item; items per tile column
         const int sub = j % TPC, ttn = (j / TPC) % p.tiles_n, trr = j / (TPC * p.tiles_n);
         const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = ttn * BN + sub * 32 * CBW;
-        const int cbl = wave % CBW, kq = wave / CBW, kper = p.K / KQ;  // kper % 128 == 0 (launch_sliced)
-        const bf16_t* arow = p.A + (size_t)(tm0 + frow) * p.lda + kq * kper + fhalf * 8;
-        const bf16_t* wrow = p.W + (size_t)(tn0 + cbl * 32 + frow) * p.ldw + kq * kper + fhalf * 8;
+        const int cbl = wave % CBW, kq = wave / CBW, kper = K_all / KQ;  // kper % 128 == 0 (launch_sliced)
+        const bf16_t* arow = A_all + (size_t)(tm0 + frow) * p.lda + kq * kper + fhalf * 8;
+        const bf16_t* wrow = W_all + (size_t)(tn0 + cbl * 32 + frow) * p.ldw + kq * kper + fhalf * 8;
         f32x16 acc1[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
@@ -434,8 +440,18 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     }
     };
     if (p.nfull_items == 0) { side_jobs(); return; }           // no full tile at all (<= 32 valid rows per sample)
-    int tile;
-    if (p.nsplit > 1) {
+    int tile, fsp = 0;
+    if (p.fused) {
+        // fused split-K (few output tiles, long K: fc2 at one sample): nsplit workgroups share an output tile, each a range of
+        // 128-wide K units; they sit on the same XCD (block id mod 8), so their partial tiles meet in that XCD's L2
+        const int x = bid & 7, q = bid >> 3;
+        fsp = q % p.nsplit;
+        tile = (q / p.nsplit) * 8 + x;
+        const int units = p.K / 128, u0 = fsp * units / p.nsplit, u1 = (fsp + 1) * units / p.nsplit;
+        p.A += u0 * 128;
+        p.W += u0 * 128;
+        p.K = (u1 - u0) * 128;
+    } else if (p.nsplit > 1) {
         // split-K (weight gradients): item = (split, tile), split-major so that an XCD's tiles share operand panels; a split is
         // a range of 128-wide K units of one sample; its partial product goes to its own [M, N] f32 plane
         const int all = xcd_remap(bid, p.nfull_items * p.nsplit);
@@ -548,6 +564,49 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #ifndef HIPEMU
     const long long dbg_t1 = p.dbg == 1 ? clock64() : 0;
 #endif
+    if (p.fused) {
+        // every workgroup leaves its partial tile in fragment order (coalesced 16-byte stores); the LAST one to arrive sums all
+        // nsplit partials in split order -- its own included, read back: the result does not depend on who is last -- and runs
+        // the epilogue.  No release fence (an agent-scope release writes the whole L2 back: 15 us): the stores are complete in
+        // the XCD's L2 once vmcnt reaches 0, the counter is an L2 atomic, the reader invalidates its L1 (acquire) first.
+        float* const mine = p.ws + ((size_t)tile * p.nsplit + fsp) * (BM * BN) + ((size_t)wave * WMB * NI * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < WMB; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(mine + ((i * NI + j) * 4 + g) * 256) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+#ifndef HIPEMU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();
+        int* const flag = reinterpret_cast<int*>(lds);
+        if (tid == 0) {
+            const int old = atomicAdd(p.cnt + tile, 1);          // relaxed, agent scope: executes in L2
+            *flag = old == p.nsplit - 1;
+            if (old == p.nsplit - 1) atomicExch(p.cnt + tile, 0);
+        }
+        __syncthreads();
+        if (!*flag) return;
+        __syncthreads();                                            // `flag` lives in the first epilogue patch
+#ifndef HIPEMU
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        for (int sq = 0; sq < p.nsplit; ++sq) {
+            const float* src = p.ws + ((size_t)tile * p.nsplit + sq) * (BM * BN) + ((size_t)wave * WMB * NI * 4) * 256 + lane * 4;
+#pragma unroll
+            for (int i = 0; i < WMB; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + ((i * NI + j) * 4 + g) * 256);
+                        if (sq == 0) { acc[i][j][4 * g] = v.x; acc[i][j][4 * g + 1] = v.y; acc[i][j][4 * g + 2] = v.z; acc[i][j][4 * g + 3] = v.w; }
+                        else { acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y; acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w; }
+                    }
+        }
+    }
     if (epi_staged<EPI>(p)) {          // the ring is idle now (everybody passed the last barrier): a private LDS patch per wave
         char* patch = lds + wave * epi_strip_bytes(2);
 #pragma unroll
@@ -591,7 +650,10 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
     p.nfull_items = samples * p.full_rows * p.tiles_n;
     p.ntail = samples * p.tail_rows * p.tiles_n * (BN == 256 ? 8 : 2);
     p.ntiles = p.nfull_items ? p.nfull_items : p.ntail;
-    if (p.nsplit > 1) {
+    if (p.fused) {
+        if (p.nfull_items % 8 || p.nfull_items * p.nsplit > 65536) return DGS_ERR_INVALID_ARGUMENT;
+        p.ntiles = p.nfull_items * p.nsplit;
+    } else if (p.nsplit > 1) {
         if (p.tail_rows || samples != 1) return DGS_ERR_INVALID_ARGUMENT;
         p.ntiles = p.nfull_items * p.nsplit;
     }
@@ -644,7 +706,7 @@ int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int 
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
     p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0; p.nsplit = 1; p.splits_per_batch = 1;
-    p.a_batch_stride = p.w_batch_stride = p.out_split_stride = 0;
+    p.a_batch_stride = p.w_batch_stride = p.out_split_stride = 0; p.fused = 0; p.ws = nullptr; p.cnt = nullptr;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
@@ -701,7 +763,7 @@ int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st)
     if (!nsplit || a->epilogue != DGS_EPI_F32 || a->bias || !a->splitk_ws || a->ldo % 4) return DGS_ERR_INVALID_ARGUMENT;
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = k_per_batch; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->N; p.gate_stride = 0;
-    p.rows_per_batch = a->M; p.valid_rows = a->M; p.dbg = 0; p.nsplit = nsplit; p.splits_per_batch = spb;
+    p.rows_per_batch = a->M; p.valid_rows = a->M; p.dbg = 0; p.nsplit = nsplit; p.splits_per_batch = spb; p.fused = 0; p.ws = nullptr; p.cnt = nullptr;
     p.a_batch_stride = a->a_batch_stride; p.w_batch_stride = a->w_batch_stride; p.out_split_stride = (long long)a->M * a->N;
     p.A = a->A; p.W = a->W; p.bias = nullptr; p.out = a->splitk_ws; p.gate = nullptr; p.vt = nullptr; p.aux = nullptr; p.q_scale = 1.0f;
     p.resid = nullptr;
@@ -711,6 +773,41 @@ int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((plane / 4 + 255) / 256)), dim3(256), 0, st, a->splitk_ws, static_cast<float*>(a->out), nsplit,
                        a->N, a->ldo, plane);
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+// ---- fused split-K: few 256 x 256 output tiles, long K, any epilogue (the fc2 GEMM at one sample: 64 tiles, K = 4096) ----
+// nsplit workgroups per tile so that one round covers the chip; 0 when the shape does not qualify.
+int fused_splitk_plan(int M, int N, int K, int k_per_batch, int rows_per_batch, int valid_rows) {
+    if (k_per_batch != K || M % 256 || N % 256 || rows_per_batch % 256 || K % 1024) return 0;
+    int full_rows = 0;
+    for (int i = 0; i < rows_per_batch / 256; ++i)
+        if ((valid_rows - i * 256 + 31) / 32 > 1) ++full_rows;
+    const int tiles = (M / rows_per_batch) * full_rows * (N / 256);
+    if (tiles <= 0 || tiles % 8 || tiles > 128) return 0;
+    int s = 256 / tiles;
+    if (s > 8) s = 8;
+    if (s > K / 1024) s = K / 1024;                               // a split is at least 32 slabs: shorter ones are all prologue and fix-up
+    return s >= 2 ? s : 0;
+}
+
+int launch_fused_splitk_gemm(const DgsDitGemmArgs* a, int nsplit, int rows_per_batch, int valid_rows, hipStream_t st) {
+    static int* counters = nullptr;                               // one per tile; every launch leaves them zero
+    if (!counters) {
+        if (hipMalloc(&counters, 256 * sizeof(int)) != hipSuccess || hipMemset(counters, 0, 256 * sizeof(int)) != hipSuccess) return DGS_ERR_ALLOC;
+    }
+    DeepParams p;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
+    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0; p.nsplit = nsplit; p.splits_per_batch = nsplit;
+    p.a_batch_stride = p.w_batch_stride = p.out_split_stride = 0; p.fused = 1; p.ws = a->splitk_ws; p.cnt = counters;
+    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
+    p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
+    p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
+    switch (a->epilogue) {
+        case DGS_EPI_BF16: return launch_sliced<DGS_EPI_BF16, 256>(p, st);
+        case DGS_EPI_GATE_RESIDUAL: return launch_sliced<DGS_EPI_GATE_RESIDUAL, 256>(p, st);
+        case DGS_EPI_F32: return launch_sliced<DGS_EPI_F32, 256>(p, st);
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
 }
 
 template <int EPI, int BN, int BK, int NS>

@@ -238,7 +238,7 @@ class DgsDitBackwardArgs(ctypes.Structure):
 DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward", "dgs_dit_layernorm_backward",
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
-               "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes"]
+               "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes", "dgs_dit_gemm_fused_splitk_bytes"]
 
 
 def _declare_dit(L):
@@ -252,6 +252,8 @@ def _declare_dit(L):
         fn.argtypes = [ctypes.POINTER(argt), ctypes.c_void_p]
     L.dgs_dit_gemm_splitk_bytes.restype = ctypes.c_size_t
     L.dgs_dit_gemm_splitk_bytes.argtypes = [ctypes.c_int32] * 4
+    L.dgs_dit_gemm_fused_splitk_bytes.restype = ctypes.c_size_t
+    L.dgs_dit_gemm_fused_splitk_bytes.argtypes = [ctypes.c_int32] * 5
     L.dgs_dit_lpad.restype = ctypes.c_int32
     L.dgs_dit_lpad.argtypes = [ctypes.c_int32]
     L.dgs_dit_workspace_bytes.restype = ctypes.c_size_t

@@ -348,6 +348,33 @@ def test_gemm_split_k_weight_gradient(ops, monkeypatch):
     assert torch.allclose(out, plain, atol=2e-3, rtol=1e-4)
 
 
+def test_gemm_fused_split_k(ops):
+    """Few output tiles, long K: several workgroups share a 256 x 256 tile, the last arriver sums the partial tiles in split
+    order and applies the epilogue (gated residual in place; bf16).  8 tiles x 2 splits; the 2 learned-token rows ride as side jobs."""
+    g = torch.Generator().manual_seed(77)
+    rows, B, N, K, valid = 512, 1, 1024, 2048, 258
+    A = _bf(torch.randn(B * rows, K, generator=g) * 0.5)
+    W = _bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, K, rows, 0) == 8 * 2 * 256 * 256 * 4
+    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, K, rows, valid) == 4 * 2 * 256 * 256 * 4 * 0   # 4 tiles: not a multiple of 8
+    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, 1024, rows, 0) == 0                       # K too short to split
+    x0 = torch.randn(B * rows, N, generator=g)
+    gate = torch.randn(B, N, generator=g)
+    x = x0.clone()
+    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=rows, splitk=True)
+    assert torch.allclose(x, x0 + gate.repeat_interleave(rows, 0) * ref, atol=5e-3, rtol=1e-4)
+    plain = x0.clone()
+    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=plain, gate=gate, rows_per_batch=rows)
+    assert torch.allclose(x, plain, atol=5e-3, rtol=1e-4)
+    out = ops.gemm(A, W, bias, _native.EPI_BF16, rows_per_batch=rows, splitk=True)
+    assert torch.allclose(out.float(), ref, atol=3e-2, rtol=1e-2)
+    x2 = x0.clone()                                 # a second launch finds the arrival counters at zero again
+    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x2, gate=gate, rows_per_batch=rows, splitk=True)
+    assert torch.equal(x2, x)
+
+
 @pytest.mark.parametrize("N", [256, 128, -256])
 def test_gemm_sliced(ops, N):
     """Sliced-schedule kernel (256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring): several trips round the ring, the padding-row
