@@ -256,8 +256,8 @@ int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int row
 int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad);
 int splitk_plan(int M, int N, int K, int k_per_batch, int* splits_per_batch);
 int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st);
-int fused_splitk_plan(int M, int N, int K, int k_per_batch, int rows_per_batch, int valid_rows);
-int launch_fused_splitk_gemm(const DgsDitGemmArgs* a, int nsplit, int rows_per_batch, int valid_rows, hipStream_t st);
+int fused_splitk_plan(int M, int N, int K, int k_per_batch, int rows_per_batch, int valid_rows, int* bn);
+int launch_fused_splitk_gemm(const DgsDitGemmArgs* a, int nsplit, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
 
 }  // namespace dgs
 
@@ -312,8 +312,9 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     // few output tiles, long K, a scratch buffer: split-K with the reduction inside the sliced kernel (fc2 at one sample)
     if ((algo == DGS_GEMM_AUTO || algo == DGS_GEMM_SLICED) && a->splitk_ws &&
         (a->epilogue == DGS_EPI_GATE_RESIDUAL || a->epilogue == DGS_EPI_BF16 || a->epilogue == DGS_EPI_F32) && (a->epilogue == DGS_EPI_F32 || !a->vt)) {
-        const int fs = fused_splitk_plan(a->M, a->N, a->K, kpb, p.rows_per_batch, p.valid_rows);
-        if (fs) return launch_fused_splitk_gemm(a, fs, p.rows_per_batch, p.valid_rows, st0);
+        int fbn = 0;
+        const int fs = fused_splitk_plan(a->M, a->N, a->K, kpb, p.rows_per_batch, p.valid_rows, &fbn);
+        if (fs) return launch_fused_splitk_gemm(a, fs, fbn, p.rows_per_batch, p.valid_rows, st0);
     }
     // AUTO (measured on MI355X, tools/gemm_check.py; 128-wide kernel -> sliced kernel):
     //   1 sample  (M = 4352):  QKV 41 -> 39 us, fc1 + GELU 58 -> 44 us on 256 x 256 tiles (one round of the chip); the N = 1024
@@ -357,10 +358,11 @@ extern "C" size_t dgs_dit_gemm_splitk_bytes(int32_t M, int32_t N, int32_t K, int
 
 extern "C" size_t dgs_dit_gemm_fused_splitk_bytes(int32_t M, int32_t N, int32_t K, int32_t rows_per_batch, int32_t valid_rows) {
     const int rpb = rows_per_batch > 0 ? rows_per_batch : M, vr = (valid_rows > 0 && valid_rows < rpb) ? valid_rows : rpb;
-    const int s = dgs::fused_splitk_plan(M, N, K, K, rpb, vr);
+    int bn = 0;
+    const int s = dgs::fused_splitk_plan(M, N, K, K, rpb, vr, &bn);
     if (!s) return 0;
     int full_rows = 0;
     for (int i = 0; i < rpb / 256; ++i)
         if ((vr - i * 256 + 31) / 32 > 1) ++full_rows;
-    return (size_t)(M / rpb) * full_rows * (N / 256) * s * 256 * 256 * sizeof(float);
+    return (size_t)(M / rpb) * full_rows * (N / bn) * s * 256 * bn * sizeof(float);
 }

@@ -27,7 +27,7 @@ namespace dgs {
 struct DeepParams {
     int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles, dbg;
     int rows_ps, full_rows, tail_rows, nfull_items;             // sliced kernel: 256-row tile rows per sample (all / ring path / one live block), full items
-    int ntail;                                                  // sliced kernel: 32 x 64 items of the single-live-block tile rows
+    int ntail, tail_mode;                                       // sliced kernel: side jobs of the single-live-block tile rows (1: MFMA items, 2: two-row GEMV items)
     int nsplit, splits_per_batch;                               // sliced kernel, split-K: items = nsplit x tiles, K = k_per_batch
     long long a_batch_stride, w_batch_stride, out_split_stride;
     int fused;                                                  // split-K with the reduction in the kernel (last arriver), any epilogue
@@ -410,6 +410,62 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const bf16_t* const W_all = p.W;
     const int K_all = p.K;
     auto side_jobs = [&]() {
+    if (p.tail_mode == 2) {
+        // At most two live rows behind the last full tile row (the DiT's learned tokens): a 2-row GEMV per 32-column block, on
+        // the vector pipe.  A wave takes 32 / NW columns; its lanes span K with 16-byte loads (a wave-instruction = 1 KiB of one
+        // row = 8 cache lines, against the 32 lines of a fragment-layout gather), v_dot2c_f32_bf16 into fp32, a wave reduction
+        // per (row, column).  The 2 x 32 results go through LDS into the accumulator layout and out through the epilogue.
+        constexpr int CPW = 32 / NW;
+        const int nblk = p.N / 32, nch = K_all / 512;               // K_all % 512 == 0, nch <= 8 (launch_sliced)
+        float* const tile2 = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);
+        for (int j = bid; j < p.ntail; j += (int)gridDim.x) {
+            const int blk = j % nblk, trr = j / nblk;
+            const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = blk * 32;
+            uint4 a0[8], a1[8];
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch)
+                if (ch < nch) {
+                    a0[ch] = *reinterpret_cast<const uint4*>(A_all + (size_t)tm0 * p.lda + ch * 512 + lane * 8);
+                    a1[ch] = *reinterpret_cast<const uint4*>(A_all + (size_t)(tm0 + 1) * p.lda + ch * 512 + lane * 8);
+                }
+            // all loads of a group of columns go out before the first dot product (one L2 round trip per group): every column of
+            // the wave at once for K <= 1024, two at a time beyond (register budget)
+            auto columns = [&](auto gtag, auto ctag) {
+                constexpr int GC = decltype(gtag)::value, NCH = decltype(ctag)::value;
+#pragma unroll
+                for (int c0 = 0; c0 < CPW; c0 += GC) {
+                    uint4 w[GC][NCH];
+#pragma unroll
+                    for (int c = 0; c < GC; ++c)
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ++ch)
+                            if (ch < nch) w[c][ch] = *reinterpret_cast<const uint4*>(W_all + (size_t)(tn0 + wave * CPW + c0 + c) * p.ldw + ch * 512 + lane * 8);
+#pragma unroll
+                    for (int c = 0; c < GC; ++c) {
+                        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ++ch)
+                            if (ch < nch) { s0 = dot8_bf16(a0[ch], w[c][ch], s0); s1 = dot8_bf16(a1[ch], w[c][ch], s1); }
+                        s0 = wave_sum(s0);
+                        s1 = wave_sum(s1);
+                        if (lane == 0) { tile2[wave * CPW + c0 + c] = s0; tile2[32 + wave * CPW + c0 + c] = s1; }
+                    }
+                }
+            };
+            if (nch <= 2) columns(SIC<CPW>{}, SIC<2>{});
+            else columns(SIC<(CPW < 2 ? CPW : 2)>{}, SIC<8>{});
+            __syncthreads();
+            if (wave == 0) {
+                f32x16 acc1[1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+                if (fhalf == 0) { acc1[0][0] = tile2[frow]; acc1[0][1] = tile2[32 + frow]; }      // rows 0, 1 of the block: registers 0, 1 of lanes 0..31
+                store_block<EPI, 1>(p, acc1, tm0 + 4 * fhalf, tn0, lane);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int j = (p.nsplit > 1 && !p.fused) ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
         constexpr int CBW = BN == 256 ? 1 : 2, KQ = NW / CBW, TPC = BN / (32 * CBW);   // column blocks, K ranges per item; items per tile column
         const int sub = j % TPC, ttn = (j / TPC) % p.tiles_n, trr = j / (TPC * p.tiles_n);
@@ -593,7 +649,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #ifndef HIPEMU
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
+        // two splits: own + other is the same sum whoever is last, the own partial stays in registers; more: all of them, in order
         for (int sq = 0; sq < p.nsplit; ++sq) {
+            if (p.nsplit == 2 && sq == fsp) continue;
+            const bool first = p.nsplit > 2 && sq == 0;
             const float* src = p.ws + ((size_t)tile * p.nsplit + sq) * (BM * BN) + ((size_t)wave * WMB * NI * 4) * 256 + lane * 4;
 #pragma unroll
             for (int i = 0; i < WMB; ++i)
@@ -602,7 +661,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 v = *reinterpret_cast<const float4*>(src + ((i * NI + j) * 4 + g) * 256);
-                        if (sq == 0) { acc[i][j][4 * g] = v.x; acc[i][j][4 * g + 1] = v.y; acc[i][j][4 * g + 2] = v.z; acc[i][j][4 * g + 3] = v.w; }
+                        if (first) { acc[i][j][4 * g] = v.x; acc[i][j][4 * g + 1] = v.y; acc[i][j][4 * g + 2] = v.z; acc[i][j][4 * g + 3] = v.w; }
                         else { acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y; acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w; }
                     }
         }
@@ -641,14 +700,20 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
     p.tiles_n = p.N / BN;
     p.rows_ps = p.rows_per_batch / 256;
     p.full_rows = 0; p.tail_rows = 0;
-    const bool direct_ok = p.K % (NW / (BN == 256 ? 1 : 2) * 128) == 0;   // else single-block tiles run the ring like the others
+    // A tile row with a single live 32-row block is not a tile: its blocks are side jobs of the first workgroups -- a two-row
+    // GEMV on the vector pipe when at most 2 rows are live (the DiT's learned tokens), MFMA items otherwise; if the shape fits
+    // neither, it runs the ring like a full row.
+    const int last_live = p.valid_rows - (p.valid_rows - 1) / 256 * 256;                     // live rows of the last tile row that has any
+    const bool gemv_ok = last_live <= 2 && p.K % 512 == 0 && p.K <= 4096;
+    const bool mfma_ok = p.K % (NW / (BN == 256 ? 1 : 2) * 128) == 0;
     for (int i = 0; i < p.rows_ps; ++i) {                          // per sample: tile rows with >= 2 / exactly 1 live 32-row blocks
         const int live = (p.valid_rows - i * 256 + 31) / 32;
-        if (live > 1 || (live == 1 && !direct_ok)) ++p.full_rows; else if (live == 1) ++p.tail_rows;
+        if (live > 1 || (live == 1 && !gemv_ok && !mfma_ok)) ++p.full_rows; else if (live == 1) ++p.tail_rows;
     }
     const int samples = p.M / p.rows_per_batch;
     p.nfull_items = samples * p.full_rows * p.tiles_n;
-    p.ntail = samples * p.tail_rows * p.tiles_n * (BN == 256 ? 8 : 2);
+    p.tail_mode = gemv_ok ? 2 : 1;
+    p.ntail = samples * p.tail_rows * (gemv_ok ? p.N / 32 : p.tiles_n * (BN == 256 ? 8 : 2));
     p.ntiles = p.nfull_items ? p.nfull_items : p.ntail;
     if (p.fused) {
         if (p.nfull_items % 8 || p.nfull_items * p.nsplit > 65536) return DGS_ERR_INVALID_ARGUMENT;
@@ -777,20 +842,28 @@ int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st)
 
 // ---- fused split-K: few 256 x 256 output tiles, long K, any epilogue (the fc2 GEMM at one sample: 64 tiles, K = 4096) ----
 // nsplit workgroups per tile so that one round covers the chip; 0 when the shape does not qualify.
-int fused_splitk_plan(int M, int N, int K, int k_per_batch, int rows_per_batch, int valid_rows) {
+int fused_splitk_plan(int M, int N, int K, int k_per_batch, int rows_per_batch, int valid_rows, int* bn) {
     if (k_per_batch != K || M % 256 || N % 256 || rows_per_batch % 256 || K % 1024) return 0;
     int full_rows = 0;
     for (int i = 0; i < rows_per_batch / 256; ++i)
         if ((valid_rows - i * 256 + 31) / 32 > 1) ++full_rows;
-    const int tiles = (M / rows_per_batch) * full_rows * (N / 256);
-    if (tiles <= 0 || tiles % 8 || tiles > 128) return 0;
-    int s = 256 / tiles;
-    if (s > 8) s = 8;
-    if (s > K / 1024) s = K / 1024;                               // a split is at least 32 slabs: shorter ones are all prologue and fix-up
-    return s >= 2 ? s : 0;
+    // 256 x 128 tiles with two splits when that fills the chip: one 128 KiB partial per tile travels, and it stays in L2;
+    // otherwise 256 x 256 tiles with up to 8 splits (their partials spill to HBM: only worth it for very few tiles)
+    static const int force_bn = getenv("DGS_GEMM_FUSED_BN") ? atoi(getenv("DGS_GEMM_FUSED_BN")) : 0;   // measurement aid
+    for (int w = 128; w <= 256; w += 128) {
+        if (force_bn && force_bn != w) continue;
+        const int tiles = (M / rows_per_batch) * full_rows * (N / w);
+        if (tiles <= 0 || tiles % 8 || tiles > 128) continue;
+        int s = 256 / tiles;
+        if (s > 8) s = 8;
+        if (s > K / 1024) s = K / 1024;                           // a split is at least 32 slabs: shorter ones are all prologue and fix-up
+        if (w == 128 && s != 2) continue;
+        if (s >= 2) { *bn = w; return s; }
+    }
+    return 0;
 }
 
-int launch_fused_splitk_gemm(const DgsDitGemmArgs* a, int nsplit, int rows_per_batch, int valid_rows, hipStream_t st) {
+int launch_fused_splitk_gemm(const DgsDitGemmArgs* a, int nsplit, int bn, int rows_per_batch, int valid_rows, hipStream_t st) {
     static int* counters = nullptr;                               // one per tile; every launch leaves them zero
     if (!counters) {
         if (hipMalloc(&counters, 256 * sizeof(int)) != hipSuccess || hipMemset(counters, 0, 256 * sizeof(int)) != hipSuccess) return DGS_ERR_ALLOC;
@@ -803,9 +876,9 @@ int launch_fused_splitk_gemm(const DgsDitGemmArgs* a, int nsplit, int rows_per_b
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     switch (a->epilogue) {
-        case DGS_EPI_BF16: return launch_sliced<DGS_EPI_BF16, 256>(p, st);
-        case DGS_EPI_GATE_RESIDUAL: return launch_sliced<DGS_EPI_GATE_RESIDUAL, 256>(p, st);
-        case DGS_EPI_F32: return launch_sliced<DGS_EPI_F32, 256>(p, st);
+        case DGS_EPI_BF16: return bn == 256 ? launch_sliced<DGS_EPI_BF16, 256>(p, st) : launch_sliced<DGS_EPI_BF16, 128>(p, st);
+        case DGS_EPI_GATE_RESIDUAL: return bn == 256 ? launch_sliced<DGS_EPI_GATE_RESIDUAL, 256>(p, st) : launch_sliced<DGS_EPI_GATE_RESIDUAL, 128>(p, st);
+        case DGS_EPI_F32: return bn == 256 ? launch_sliced<DGS_EPI_F32, 256>(p, st) : launch_sliced<DGS_EPI_F32, 128>(p, st);
         default: return DGS_ERR_INVALID_ARGUMENT;
     }
 }

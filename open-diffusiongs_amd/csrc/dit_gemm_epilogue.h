@@ -56,6 +56,22 @@ __device__ __forceinline__ void direct_block_mfma(const bf16_t* arow, const bf16
     for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], w[u], acc, 0, 0, 0);
 }
 
+// dot product of 8 bf16 pairs held in two 16-byte registers, fp32 accumulate (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b, float acc) {
+#ifdef HIPEMU
+    const unsigned x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+    for (int i = 0; i < 4; ++i)
+        acc += __uint_as_float(x[i] << 16) * __uint_as_float(y[i] << 16) + __uint_as_float(x[i] & 0xffff0000u) * __uint_as_float(y[i] & 0xffff0000u);
+    return acc;
+#else
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a.x), __builtin_bit_cast(bf2_t, b.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a.y), __builtin_bit_cast(bf2_t, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a.z), __builtin_bit_cast(bf2_t, b.z), acc, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a.w), __builtin_bit_cast(bf2_t, b.w), acc, false);
+#endif
+}
+
 constexpr int epi_strip_bytes(int nb) { return 32 * (32 * nb + 4) * 4; }     // LDS per wave
 
 // Which (epilogue, arguments) take the staged path: all of them.  (The training epilogues -- DGELU and the transposed `vt`

@@ -64,7 +64,7 @@ def test_gemm_fused_split_k_fc2(B):
     bias = torch.randn(W, generator=g, device=DEV)
     x0 = torch.randn(B * lpad, W, generator=g, device=DEV)
     gate = torch.randn(B, W, generator=g, device=DEV)
-    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * lpad, W, 4 * W, lpad, L) == 256 * 256 * 256 * 4
+    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * lpad, W, 4 * W, lpad, L) == (128 * 2 * 256 * 128 * 4 if B == 1 else 128 * 2 * 256 * 256 * 4)
     live = (torch.arange(B * lpad, device=DEV) % lpad) < L
     ref = x0 + gate.repeat_interleave(lpad, 0) * (h.float() @ w2.float().t() + bias)
     outs = []

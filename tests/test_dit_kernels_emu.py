@@ -350,15 +350,16 @@ def test_gemm_split_k_weight_gradient(ops, monkeypatch):
 
 def test_gemm_fused_split_k(ops):
     """Few output tiles, long K: several workgroups share a 256 x 256 tile, the last arriver sums the partial tiles in split
-    order and applies the epilogue (gated residual in place; bf16).  8 tiles x 2 splits; the 2 learned-token rows ride as side jobs."""
+    order and applies the epilogue (gated residual in place; bf16).  16 tiles of 256 x 128, 2 splits each; then with 258 valid rows:
+    8 tiles, the 2 rows past the last full tile ride as side jobs."""
     g = torch.Generator().manual_seed(77)
     rows, B, N, K, valid = 512, 1, 1024, 2048, 258
     A = _bf(torch.randn(B * rows, K, generator=g) * 0.5)
     W = _bf(torch.randn(N, K, generator=g) * 0.05)
     bias = torch.randn(N, generator=g)
     ref = A.float() @ W.float().t() + bias
-    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, K, rows, 0) == 8 * 2 * 256 * 256 * 4
-    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, K, rows, valid) == 4 * 2 * 256 * 256 * 4 * 0   # 4 tiles: not a multiple of 8
+    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, K, rows, 0) == 16 * 2 * 256 * 128 * 4          # 16 tiles of 256 x 128, 2 splits
+    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, K, rows, valid) == 8 * 2 * 256 * 128 * 4      # one full tile row of 256 x 128 tiles
     assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, 1024, rows, 0) == 0                       # K too short to split
     x0 = torch.randn(B * rows, N, generator=g)
     gate = torch.randn(B, N, generator=g)
@@ -373,6 +374,10 @@ def test_gemm_fused_split_k(ops):
     x2 = x0.clone()                                 # a second launch finds the arrival counters at zero again
     ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x2, gate=gate, rows_per_batch=rows, splitk=True)
     assert torch.equal(x2, x)
+    x3 = x0.clone()
+    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x3, gate=gate, rows_per_batch=rows, valid_rows=valid, splitk=True)
+    assert torch.equal(x3[:256], x[:256]) and torch.equal(x3[288:], x0[288:])        # full tile: same arithmetic; padding untouched
+    assert torch.allclose(x3[256:valid], x[256:valid], atol=5e-3, rtol=1e-4)           # side jobs: K summed in 4 ranges
 
 
 @pytest.mark.parametrize("N", [256, 128, -256])
