@@ -29,6 +29,7 @@ struct FwdParams {
     const float *bg, *means3D, *shs, *colors_pre, *opac, *scales, *rots, *cov_pre, *viewm, *projm, *campos, *tanfov;
     float tanfovx, tanfovy, scale_mod;
     int prefiltered, raw_act;
+    int bin_mode;            // binning form: 0 by instance density (on the device), 1 instance list + per-tile sort, 2 per-tile scan
     int* radii;
     float* out_color;
     GeomState g;
@@ -318,6 +319,15 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* count,
     }
 }
 
+// Which binning form runs (both are launched when the host cannot know the instance count, i.e. in the async mode; the one
+// whose turn it is not returns at once).  bin_mode 1: instance list + per-tile sort, 2: per-tile scan, 0: scan when at least a
+// tenth of all (tile, Gaussian) pairs are instances -- measured crossover at 256^2, 4 views: the scan is 0.17 ms faster at a
+// density of 0.2 (random-init weights) and 0.15 ms slower at 0.012 (trained-like scenes).
+__device__ __forceinline__ bool binning_is_scan(const FwdParams& p) {
+    if (p.bin_mode) return p.bin_mode == 2;
+    return (long long)(uint32_t)p.im.totals[0] * 10 >= (long long)p.T * p.P * p.V;
+}
+
 // grid (ceil(P/256), V).  Writes, for every (Gaussian, touched tile), the Gaussian's depth rank into that tile's segment.
 // Slot order inside a segment is arbitrary (tile_sort_kernel is order-independent).
 template <bool LDS_AGG>
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256) void emit_instances_kernel(FwdParams p) {
     DGS_DYNAMIC_LDS(smem);
     uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem);
     uint32_t* lbase = lcnt + p.T;
-    if (p.im.totals[1] != 0) return;
+    if (p.im.totals[1] != 0 || binning_is_scan(p)) return;
     const int v = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const size_t gi = (size_t)v * p.P + idx;
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
     DGS_DYNAMIC_LDS(smem);
     uint32_t* bm = reinterpret_cast<uint32_t*>(smem);
     __shared__ uint32_t scratch[8];
-    if (p.im.totals[1] != 0) return;
+    if (p.im.totals[1] != 0 || binning_is_scan(p)) return;
     const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
     const uint2 rg = p.im.ranges[(size_t)v * p.T + t];
     if (rg.x == rg.y) return;
@@ -436,6 +446,95 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
 #pragma unroll
             for (int u = 0; u < EB; ++u)
                 if ((setm >> u) & 1ull) p.bn.point_list[slot[u]] = val[u];
+        }
+        emitted += total;
+        __syncthreads();
+    }
+}
+
+// ---- binning, dense form ("scan") -------------------------------------------------------------------------------------
+// When Gaussians are large (random-init weights: ~50 tiles each, a tile is touched by a fifth of all Gaussians) listing the
+// instances first (emit) and sorting every tile's list (bitmap) moves each instance three times and expands 8 k bitmap words
+// per tile.  Here every tile filters the depth-ORDERED Gaussians directly: rank_rects_kernel leaves each Gaussian's tile
+// rectangle, packed in 32 bits, at its depth rank; tile_scan_kernel walks the ranks 64 at a time -- test, ballot, popcount --
+// and writes the hits in order: the same list the sort produces, with no atomics and no instance list.  Work is T x P tests
+// per view, so the host picks this form only where that product is small (256^2: 67 M).
+__global__ __launch_bounds__(256) void rank_rects_kernel(FwdParams p) {
+    if (p.im.totals[1] != 0 || !binning_is_scan(p)) return;
+    const int v = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.P) return;
+    const size_t gi = (size_t)v * p.P + idx;
+    uint32_t packed = 0;                                   // empty rectangle: never hit
+    if (p.radii[gi] > 0) {
+        int x0, y0, x1, y1;
+        const float2 m = p.g.means2D[gi];
+        tile_rect(m.x, m.y, p.radii[gi], p.gx, p.gy, &x0, &y0, &x1, &y1);
+        packed = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);     // gx, gy <= 255 (host)
+    }
+    p.g.vals[1][(size_t)v * p.P + p.g.rank_of[gi]] = packed;   // the sort's spare value buffer
+}
+
+// grid (T, V), 256 threads, dynamic LDS = wgroups * 8 bytes (one 64-bit hit mask per group of 64 ranks of the window).
+__global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups) {
+    DGS_DYNAMIC_LDS(smem);
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ uint32_t scratch[4];
+    if (p.im.totals[1] != 0 || !binning_is_scan(p)) return;
+    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint2 rg = p.im.ranges[(size_t)v * p.T + t];
+    if (rg.x == rg.y) return;
+    const uint32_t tx = (uint32_t)(t % p.gx), ty = (uint32_t)(t / p.gx);
+    const uint32_t* rects = p.g.vals[1] + (size_t)v * p.P;
+    const uint32_t* order = p.g.vals[0] + (size_t)v * p.P;   // rank -> Gaussian index
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t emitted = rg.x;
+    for (uint32_t w0 = 0; w0 < (uint32_t)p.P; w0 += (uint32_t)wgroups * 64u) {
+        const int ng = min(wgroups, (int)(((uint32_t)p.P - w0 + 63u) / 64u));
+        const int gpw = (ng + 3) / 4, g0 = wave * gpw, g1 = min(ng, g0 + gpw);        // a wave owns a contiguous quarter
+        uint32_t cnt = 0;
+        for (int g = g0; g < g1; g += 8) {                   // 8 loads in flight
+            uint32_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t rank = w0 + (uint32_t)(g + u) * 64u + (uint32_t)lane;
+                r[u] = (g + u < g1 && rank < (uint32_t)p.P) ? rects[rank] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t x0 = r[u] & 255u, y0 = (r[u] >> 8) & 255u, x1 = (r[u] >> 16) & 255u, y1 = r[u] >> 24;
+                const bool hit = (tx - x0 < x1 - x0) & (ty - y0 < y1 - y0);        // unsigned: x0 <= tx < x1, y0 <= ty < y1
+                const unsigned long long m = __ballot(hit);
+                if (g + u < g1) {
+                    if (lane == 0) masks[g + u] = m;
+                    cnt += (uint32_t)__popcll(m);
+                }
+            }
+        }
+        if (lane == 0) scratch[wave] = cnt;
+        __syncthreads();
+        uint32_t off = emitted, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = scratch[w];
+            if (w < wave) off += c;
+            total += c;
+        }
+        // the wave re-reads its own masks: 8 groups per step, the rank -> index loads of all of them in flight before the stores
+        for (int g = g0; g < g1; g += 8) {
+            uint32_t slot[8], val[8];
+            uint32_t setm = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned long long m = g + u < g1 ? masks[g + u] : 0ull;
+                const bool set = (m >> lane) & 1ull;
+                slot[u] = off + (uint32_t)__popcll(m & lt_mask);
+                off += (uint32_t)__popcll(m);
+                val[u] = set ? order[w0 + (uint32_t)(g + u) * 64u + (uint32_t)lane] : 0u;
+                setm |= (uint32_t)set << u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if ((setm >> u) & 1u) p.bn.point_list[slot[u]] = val[u];
         }
         emitted += total;
         __syncthreads();
@@ -641,10 +740,24 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
             hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
     }
 
-    if (lds_tiles) hipLaunchKernelGGL((emit_instances_kernel<true>), gridP, dim3(256), (size_t)p.T * 8, st, p);
-    else hipLaunchKernelGGL((emit_instances_kernel<false>), gridP, dim3(256), 0, st, p);
-    const int wwords = pick_window_words(P);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(p.T, V), dim3(256), (size_t)wwords * 4, st, p, wwords);
+    // binning: per tile, either filter the depth-ordered Gaussians (dense scenes, T x P small) or list the instances and sort
+    // them; the kernels pick by instance density on the device (binning_is_scan), the host only rules forms out
+    const char* bin_s = getenv("DGS_RASTER_BIN");                   // 1: sort, 2: scan (tests and measurement)
+    const bool can_scan = p.gx <= 255 && p.gy <= 255 && (long long)p.T * P <= (1ll << 27);
+    p.bin_mode = bin_s ? atoi(bin_s) : 0;
+    if (!can_scan || p.bin_mode < 0 || p.bin_mode > 2) p.bin_mode = 1;
+    if (p.bin_mode != 1) {
+        int wgroups = ((P + 63) / 64 + 7) / 8 * 8;
+        if (wgroups > 7680) wgroups = 7680;                      // 60 KiB of masks per workgroup
+        hipLaunchKernelGGL(rank_rects_kernel, gridP, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(p.T, V), dim3(256), (size_t)wgroups * 8, st, p, wgroups);
+    }
+    if (p.bin_mode != 2) {
+        if (lds_tiles) hipLaunchKernelGGL((emit_instances_kernel<true>), gridP, dim3(256), (size_t)p.T * 8, st, p);
+        else hipLaunchKernelGGL((emit_instances_kernel<false>), gridP, dim3(256), 0, st, p);
+        const int wwords = pick_window_words(P);
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(p.T, V), dim3(256), (size_t)wwords * 4, st, p, wwords);
+    }
     hipLaunchKernelGGL(blend_forward_kernel, dim3(p.gx, p.gy, V), dim3(kTile, kTile), 0, st, p);
     return check(st, a->debug);
 }

@@ -12,6 +12,13 @@ from util_scene import small_scene
 CPU = torch.device("cpu")
 
 
+@pytest.fixture(params=["scan", "sort"], autouse=True)
+def binning_form(request, monkeypatch):
+    """Both binning forms of raster_forward.hip (per-tile scan of the depth-ordered Gaussians / instance list + per-tile bitmap
+    sort) must give the reference's per-tile lists: every test runs with each forced (DGS_RASTER_BIN)."""
+    monkeypatch.setenv("DGS_RASTER_BIN", {"sort": "1", "scan": "2"}[request.param])
+
+
 @pytest.mark.parametrize("deg,seed,H,W", [(0, 1, 40, 56), (3, 3, 33, 17), (1, 5, 64, 64)])
 def test_small_scenes_bit_exact(deg, seed, H, W):
     sc, cams = small_scene(200, W, H, seed=seed, sh_degree=deg, n_views=2)
