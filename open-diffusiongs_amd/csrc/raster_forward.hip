@@ -474,6 +474,8 @@ __global__ __launch_bounds__(256) void rank_rects_kernel(FwdParams p) {
     p.g.vals[1][(size_t)v * p.P + p.g.rank_of[gi]] = packed;   // the sort's spare value buffer
 }
 
+template <bool B> struct BoolC { static constexpr bool value = B; };
+
 // grid (T, V), 256 threads, dynamic LDS = wgroups * 8 bytes (one 64-bit hit mask per group of 64 ranks of the window).
 __global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups) {
     DGS_DYNAMIC_LDS(smem);
@@ -491,25 +493,33 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups
     for (uint32_t w0 = 0; w0 < (uint32_t)p.P; w0 += (uint32_t)wgroups * 64u) {
         const int ng = min(wgroups, (int)(((uint32_t)p.P - w0 + 63u) / 64u));
         const int gpw = (ng + 3) / 4, g0 = wave * gpw, g1 = min(ng, g0 + gpw);        // a wave owns a contiguous quarter
+        // The loops are issue-bound (a wave tests 1 k groups per window): full batches of 8 groups take a path without bounds
+        // checks -- one base address + immediate offsets, the two compares AND-ed as wave masks, every lane writes the
+        // (uniform) mask, no exec juggling; the ragged end of a wave's range takes the checked path.
         uint32_t cnt = 0;
-        for (int g = g0; g < g1; g += 8) {                   // 8 loads in flight
+        auto test_batch = [&](int g, auto checked) {
+            constexpr bool CHECK = decltype(checked)::value;
+            const uint32_t rank0 = w0 + (uint32_t)g * 64u + (uint32_t)lane;
             uint32_t r[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t rank = w0 + (uint32_t)(g + u) * 64u + (uint32_t)lane;
-                r[u] = (g + u < g1 && rank < (uint32_t)p.P) ? rects[rank] : 0u;
-            }
+            for (int u = 0; u < 8; ++u)
+                r[u] = (!CHECK || (g + u < g1 && rank0 + 64u * u < (uint32_t)p.P)) ? rects[rank0 + 64u * u] : 0u;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t x0 = r[u] & 255u, y0 = (r[u] >> 8) & 255u, x1 = (r[u] >> 16) & 255u, y1 = r[u] >> 24;
-                const bool hit = (tx - x0 < x1 - x0) & (ty - y0 < y1 - y0);        // unsigned: x0 <= tx < x1, y0 <= ty < y1
-                const unsigned long long m = __ballot(hit);
-                if (g + u < g1) {
-                    if (lane == 0) masks[g + u] = m;
+                const unsigned long long m = __ballot(tx - x0 < x1 - x0) & __ballot(ty - y0 < y1 - y0);   // unsigned: x0 <= tx < x1, y0 <= ty < y1
+                if (!CHECK || g + u < g1) {
+                    masks[g + u] = m;
                     cnt += (uint32_t)__popcll(m);
                 }
             }
+        };
+        const int gfull = g0 + (g1 > g0 ? (g1 - g0) / 8 * 8 : 0);
+        const bool window_inside = w0 + (uint32_t)ng * 64u <= (uint32_t)p.P;      // no partial group in this window
+        for (int g = g0; g < gfull; g += 8) {
+            if (window_inside) test_batch(g, BoolC<false>{}); else test_batch(g, BoolC<true>{});
         }
+        if (gfull < g1) test_batch(gfull, BoolC<true>{});
         if (lane == 0) scratch[wave] = cnt;
         __syncthreads();
         uint32_t off = emitted, total = 0;
@@ -520,22 +530,32 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups
             total += c;
         }
         // the wave re-reads its own masks: 8 groups per step, the rank -> index loads of all of them in flight before the stores
-        for (int g = g0; g < g1; g += 8) {
+        auto emit_batch = [&](int g, auto checked) {
+            constexpr bool CHECK = decltype(checked)::value;
+            const uint32_t rank0 = w0 + (uint32_t)g * 64u + (uint32_t)lane;
             uint32_t slot[8], val[8];
             uint32_t setm = 0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const unsigned long long m = g + u < g1 ? masks[g + u] : 0ull;
+                const unsigned long long mv = (!CHECK || g + u < g1) ? masks[g + u] : 0ull;
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)mv), hi = __builtin_amdgcn_readfirstlane((uint32_t)(mv >> 32));
+                const unsigned long long m = ((unsigned long long)hi << 32) | lo;           // wave-uniform: scalar registers
                 const bool set = (m >> lane) & 1ull;
+#ifdef HIPEMU
                 slot[u] = off + (uint32_t)__popcll(m & lt_mask);
+#else
+                slot[u] = off + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));      // set bits below this lane
+#endif
                 off += (uint32_t)__popcll(m);
-                val[u] = set ? order[w0 + (uint32_t)(g + u) * 64u + (uint32_t)lane] : 0u;
+                val[u] = set ? order[rank0 + 64u * u] : 0u;
                 setm |= (uint32_t)set << u;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if ((setm >> u) & 1u) p.bn.point_list[slot[u]] = val[u];
-        }
+        };
+        for (int g = g0; g < gfull; g += 8) emit_batch(g, BoolC<false>{});
+        if (gfull < g1) emit_batch(gfull, BoolC<true>{});
         emitted += total;
         __syncthreads();
     }
