@@ -404,96 +404,96 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 31, fhalf = lane >> 5;
     // Work items: every full tile, XCD-aware order.  (The tile rows with a single live 32-row block -- the two learned-token
-    // rows of the DiT -- are 32 x 64 side jobs of the first workgroups, see the prologue.)
+    // rows of the DiT -- are side jobs of the first workgroups: `side_jobs`, called from the prologue.)
     const int bid = (int)blockIdx.x;
     const bf16_t* const A_all = p.A;                            // the split-K modes narrow p.A / p.W / p.K to this workgroup's range
     const bf16_t* const W_all = p.W;
     const int K_all = p.K;
     auto side_jobs = [&]() {
-    if (p.tail_mode == 2) {
-        // At most two live rows behind the last full tile row (the DiT's learned tokens): a 2-row GEMV per 32-column block, on
-        // the vector pipe.  A wave takes 32 / NW columns; its lanes span K with 16-byte loads (a wave-instruction = 1 KiB of one
-        // row = 8 cache lines, against the 32 lines of a fragment-layout gather), v_dot2c_f32_bf16 into fp32, a wave reduction
-        // per (row, column).  The 2 x 32 results go through LDS into the accumulator layout and out through the epilogue.
-        constexpr int CPW = 32 / NW;
-        const int nblk = p.N / 32, nch = K_all / 512;               // K_all % 512 == 0, nch <= 8 (launch_sliced)
-        float* const tile2 = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);
-        for (int j = bid; j < p.ntail; j += (int)gridDim.x) {
-            const int blk = j % nblk, trr = j / nblk;
-            const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = blk * 32;
-            uint4 a0[8], a1[8];
+        if (p.tail_mode == 2) {
+            // At most two live rows behind the last full tile row (the DiT's learned tokens): a 2-row GEMV per 32-column block, on
+            // the vector pipe.  A wave takes 32 / NW columns; its lanes span K with 16-byte loads (a wave-instruction = 1 KiB of one
+            // row = 8 cache lines, against the 32 lines of a fragment-layout gather), v_dot2c_f32_bf16 into fp32, a wave reduction
+            // per (row, column).  The 2 x 32 results go through LDS into the accumulator layout and out through the epilogue.
+            constexpr int CPW = 32 / NW;
+            const int nblk = p.N / 32, nch = K_all / 512;               // K_all % 512 == 0, nch <= 8 (launch_sliced)
+            float* const tile2 = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);
+            for (int j = bid; j < p.ntail; j += (int)gridDim.x) {
+                const int blk = j % nblk, trr = j / nblk;
+                const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = blk * 32;
+                uint4 a0[8], a1[8];
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch)
-                if (ch < nch) {
-                    a0[ch] = *reinterpret_cast<const uint4*>(A_all + (size_t)tm0 * p.lda + ch * 512 + lane * 8);
-                    a1[ch] = *reinterpret_cast<const uint4*>(A_all + (size_t)(tm0 + 1) * p.lda + ch * 512 + lane * 8);
-                }
-            // all loads of a group of columns go out before the first dot product (one L2 round trip per group): every column of
-            // the wave at once for K <= 1024, two at a time beyond (register budget)
-            auto columns = [&](auto gtag, auto ctag) {
-                constexpr int GC = decltype(gtag)::value, NCH = decltype(ctag)::value;
-#pragma unroll
-                for (int c0 = 0; c0 < CPW; c0 += GC) {
-                    uint4 w[GC][NCH];
-#pragma unroll
-                    for (int c = 0; c < GC; ++c)
-#pragma unroll
-                        for (int ch = 0; ch < NCH; ++ch)
-                            if (ch < nch) w[c][ch] = *reinterpret_cast<const uint4*>(W_all + (size_t)(tn0 + wave * CPW + c0 + c) * p.ldw + ch * 512 + lane * 8);
-#pragma unroll
-                    for (int c = 0; c < GC; ++c) {
-                        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                        for (int ch = 0; ch < NCH; ++ch)
-                            if (ch < nch) { s0 = dot8_bf16(a0[ch], w[c][ch], s0); s1 = dot8_bf16(a1[ch], w[c][ch], s1); }
-                        s0 = wave_sum(s0);
-                        s1 = wave_sum(s1);
-                        if (lane == 0) { tile2[wave * CPW + c0 + c] = s0; tile2[32 + wave * CPW + c0 + c] = s1; }
+                for (int ch = 0; ch < 8; ++ch)
+                    if (ch < nch) {
+                        a0[ch] = *reinterpret_cast<const uint4*>(A_all + (size_t)tm0 * p.lda + ch * 512 + lane * 8);
+                        a1[ch] = *reinterpret_cast<const uint4*>(A_all + (size_t)(tm0 + 1) * p.lda + ch * 512 + lane * 8);
                     }
+                // all loads of a group of columns go out before the first dot product (one L2 round trip per group): every column of
+                // the wave at once for K <= 1024, two at a time beyond (register budget)
+                auto columns = [&](auto gtag, auto ctag) {
+                    constexpr int GC = decltype(gtag)::value, NCH = decltype(ctag)::value;
+#pragma unroll
+                    for (int c0 = 0; c0 < CPW; c0 += GC) {
+                        uint4 w[GC][NCH];
+#pragma unroll
+                        for (int c = 0; c < GC; ++c)
+#pragma unroll
+                            for (int ch = 0; ch < NCH; ++ch)
+                                if (ch < nch) w[c][ch] = *reinterpret_cast<const uint4*>(W_all + (size_t)(tn0 + wave * CPW + c0 + c) * p.ldw + ch * 512 + lane * 8);
+#pragma unroll
+                        for (int c = 0; c < GC; ++c) {
+                            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                            for (int ch = 0; ch < NCH; ++ch)
+                                if (ch < nch) { s0 = dot8_bf16(a0[ch], w[c][ch], s0); s1 = dot8_bf16(a1[ch], w[c][ch], s1); }
+                            s0 = wave_sum(s0);
+                            s1 = wave_sum(s1);
+                            if (lane == 0) { tile2[wave * CPW + c0 + c] = s0; tile2[32 + wave * CPW + c0 + c] = s1; }
+                        }
+                    }
+                };
+                if (nch <= 2) columns(SIC<CPW>{}, SIC<2>{});
+                else columns(SIC<(CPW < 2 ? CPW : 2)>{}, SIC<8>{});
+                __syncthreads();
+                if (wave == 0) {
+                    f32x16 acc1[1];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+                    if (fhalf == 0) { acc1[0][0] = tile2[frow]; acc1[0][1] = tile2[32 + frow]; }      // rows 0, 1 of the block: registers 0, 1 of lanes 0..31
+                    store_block<EPI, 1>(p, acc1, tm0 + 4 * fhalf, tn0, lane);
                 }
-            };
-            if (nch <= 2) columns(SIC<CPW>{}, SIC<2>{});
-            else columns(SIC<(CPW < 2 ? CPW : 2)>{}, SIC<8>{});
-            __syncthreads();
-            if (wave == 0) {
-                f32x16 acc1[1];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-                if (fhalf == 0) { acc1[0][0] = tile2[frow]; acc1[0][1] = tile2[32 + frow]; }      // rows 0, 1 of the block: registers 0, 1 of lanes 0..31
-                store_block<EPI, 1>(p, acc1, tm0 + 4 * fhalf, tn0, lane);
+                __syncthreads();
             }
+            return;
+        }
+        for (int j = (p.nsplit > 1 && !p.fused) ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
+            constexpr int CBW = BN == 256 ? 1 : 2, KQ = NW / CBW, TPC = BN / (32 * CBW);   // column blocks, K ranges per item; items per tile column
+            const int sub = j % TPC, ttn = (j / TPC) % p.tiles_n, trr = j / (TPC * p.tiles_n);
+            const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = ttn * BN + sub * 32 * CBW;
+            const int cbl = wave % CBW, kq = wave / CBW, kper = K_all / KQ;  // kper % 128 == 0 (launch_sliced)
+            const bf16_t* arow = A_all + (size_t)(tm0 + frow) * p.lda + kq * kper + fhalf * 8;
+            const bf16_t* wrow = W_all + (size_t)(tn0 + cbl * 32 + frow) * p.ldw + kq * kper + fhalf * 8;
+            f32x16 acc1[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+            if (kper % 256 == 0)
+                for (int k = 0; k < kper; k += 256) direct_block_mfma<16>(arow + k, wrow + k, acc1[0]);
+            else
+                for (int k = 0; k < kper; k += 128) direct_block_mfma<8>(arow + k, wrow + k, acc1[0]);
+            float* red = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);          // (KQ - 1) * CBW * 4 KiB <= STAGE
+            if (kq > 0)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((kq - 1) * CBW + cbl) * 1024 + r * 64 + lane] = acc1[0][r];
             __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int q = 1; q < KQ; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[0][r] += red[((q - 1) * CBW + cbl) * 1024 + r * 64 + lane];
+                store_block<EPI, 1>(p, acc1, tm0 + 4 * fhalf, tn0 + cbl * 32, lane);
+            }
+            __syncthreads();                                            // `red` is rewritten by the next item / the ring
         }
-        return;
-    }
-    for (int j = (p.nsplit > 1 && !p.fused) ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
-        constexpr int CBW = BN == 256 ? 1 : 2, KQ = NW / CBW, TPC = BN / (32 * CBW);   // column blocks, K ranges per item; items per tile column
-        const int sub = j % TPC, ttn = (j / TPC) % p.tiles_n, trr = j / (TPC * p.tiles_n);
-        const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = ttn * BN + sub * 32 * CBW;
-        const int cbl = wave % CBW, kq = wave / CBW, kper = K_all / KQ;  // kper % 128 == 0 (launch_sliced)
-        const bf16_t* arow = A_all + (size_t)(tm0 + frow) * p.lda + kq * kper + fhalf * 8;
-        const bf16_t* wrow = W_all + (size_t)(tn0 + cbl * 32 + frow) * p.ldw + kq * kper + fhalf * 8;
-        f32x16 acc1[1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-        if (kper % 256 == 0)
-            for (int k = 0; k < kper; k += 256) direct_block_mfma<16>(arow + k, wrow + k, acc1[0]);
-        else
-            for (int k = 0; k < kper; k += 128) direct_block_mfma<8>(arow + k, wrow + k, acc1[0]);
-        float* red = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);          // (KQ - 1) * CBW * 4 KiB <= STAGE
-        if (kq > 0)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((kq - 1) * CBW + cbl) * 1024 + r * 64 + lane] = acc1[0][r];
-        __syncthreads();
-        if (kq == 0) {
-#pragma unroll
-            for (int q = 1; q < KQ; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[0][r] += red[((q - 1) * CBW + cbl) * 1024 + r * 64 + lane];
-            store_block<EPI, 1>(p, acc1, tm0 + 4 * fhalf, tn0 + cbl * 32, lane);
-        }
-        __syncthreads();                                            // `red` is rewritten by the next item / the ring
-    }
     };
     if (p.nfull_items == 0) { side_jobs(); return; }           // no full tile at all (<= 32 valid rows per sample)
     int tile, fsp = 0;
