@@ -52,10 +52,11 @@ typedef enum DgsGemmEpilogue {
 
 typedef enum DgsGemmAlgo {
     DGS_GEMM_AUTO = 0,
-    DGS_GEMM_SIMPLE128 = 1,    /* 128 x 128|64 tiles, two LDS stages, 2 workgroups / CU (what AUTO picks)              */
+    DGS_GEMM_SIMPLE128 = 1,    /* 128 x 128|64 tiles, two LDS stages, 2 workgroups / CU (AUTO: the N = 1024 GEMMs at 1 sample) */
     DGS_GEMM_DEEP = 2,         /* 128 x N/8 tiles, NS-stage LDS-DMA ring, counted vmcnt + raw barrier                  */
     DGS_GEMM_BIG256 = 3,       /* 256 x 256 tiles, two stages (N >= 3072)                                              */
-    DGS_GEMM_SLICED = 4,       /* 256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring, explicit MFMA / LDS issue slices       */
+    DGS_GEMM_SLICED = 4,       /* 256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring, explicit MFMA / LDS issue slices (AUTO: QKV and
+                                  fc1 at 1 sample, every eligible shape above 8192 rows)                               */
     DGS_GEMM_QUAD = 5          /* the same with 4 waves of 128 x 128 (256 x 256 tiles only; else as SLICED)              */
 } DgsGemmAlgo;
 
