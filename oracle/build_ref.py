@@ -1,0 +1,86 @@
+"""Recipe: build the REFERENCE rasterizer itself for MI355X as a checker (oracle/_ref/).
+
+TEST INFRASTRUCTURE ONLY.  The product (open-diffusiongs_amd/) is written from scratch and never includes,
+links or loads anything produced here; this exists so that the restatement in raster_oracle.cpp and the HIP
+product path can be compared with the reference's OWN code running on the same GPU (tests/test_raster_ref_gpu.py,
+oracle/make_raster_ref_golden.py).
+
+What it does (only where /root/reference exists, i.e. in the build container -- the GPU box uses the prebuilt
+.so files, which travel with the snapshot because oracle/_ref/ is git-ignored but not gpurun-ignored):
+
+  1. hipify-perl each of cuda_rasterizer/{*.h,*.cu} of the reference's diff-gaussian-rasterization submodule into
+     oracle/_ref/src/ (git-ignored: no reference source is ever committed), plus four mechanical text fix-ups that
+     hipify-perl leaves: `<< <`/`>> >` launch brackets, two CUDA-only includes, `__trap()`, GLM_FORCE_CUDA.
+  2. hipcc --offload-arch=gfx950 those three translation units + oracle/ref_shim.hip (our host-pointer C ABI around
+     CudaRasterizer::Rasterizer::forward / backward / markVisible) against the reference's vendored glm, twice:
+       libdgs_ref_strict.so  -ffp-contract=off  (every a*b+c rounded twice: the arithmetic the oracle restates)
+       libdgs_ref_fast.so    compiler defaults  (fused multiply-adds wherever hipcc likes, as nvcc's --fmad=true
+                                                 default does in its own places: what a user's build looks like)
+
+rasterize_points.cu / ext.cpp (the torch binding) are not built: ref_shim.hip plays that role without torch.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/submodules/diff-gaussian-rasterization"
+OUT = os.path.join(HERE, "_ref")
+SRC = os.path.join(OUT, "src")
+FILES = ["auxiliary.h", "config.h", "forward.h", "forward.cu", "backward.h", "backward.cu", "rasterizer.h",
+         "rasterizer_impl.h", "rasterizer_impl.cu"]
+VARIANTS = {"strict": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"], "fast": []}
+
+
+def lib_path(variant):
+    return os.path.join(OUT, f"libdgs_ref_{variant}.so")
+
+
+def available():
+    return all(os.path.exists(lib_path(v)) for v in VARIANTS)
+
+
+def _translate():
+    os.makedirs(SRC, exist_ok=True)
+    hipify = shutil.which("hipify-perl") or "/opt/rocm/bin/hipify-perl"
+    for f in FILES:
+        text = subprocess.run([hipify, os.path.join(REF, "cuda_rasterizer", f)], check=True, capture_output=True, text=True).stdout
+        text = text.replace("<< <", "<<<").replace(">> >", ">>>")
+        text = re.sub(r'#include ""\n', "", text)
+        text = re.sub(r"#include <cub/device/device_radix_sort.cuh>\n", "", text)
+        text = re.sub(r"#include <cooperative_groups/reduce.h>\n", "", text)
+        text = text.replace("__trap()", "__builtin_trap()").replace("#define GLM_FORCE_CUDA", "")
+        with open(os.path.join(SRC, f.replace(".cu", ".hip")), "w") as fh:
+            fh.write(text)
+
+
+def build(force=False, verbose=False):
+    """Returns True when both libraries exist afterwards."""
+    if not os.path.isdir(REF):
+        return available()           # GPU box: prebuilt or nothing
+    shim = os.path.join(HERE, "ref_shim.hip")
+    deps = [shim, os.path.abspath(__file__)] + [os.path.join(REF, "cuda_rasterizer", f) for f in FILES]
+    newest = max(os.path.getmtime(d) for d in deps)
+    if not force and available() and all(os.path.getmtime(lib_path(v)) >= newest for v in VARIANTS):
+        return True
+    _translate()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    glm = os.path.join(REF, "third_party", "glm")
+    for variant, flags in VARIANTS.items():
+        objs = []
+        for s in [os.path.join(SRC, "forward.hip"), os.path.join(SRC, "backward.hip"), os.path.join(SRC, "rasterizer_impl.hip"), shim]:
+            o = os.path.join(OUT, f"{variant}_{os.path.basename(s).replace('.hip', '.o')}")
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-I" + glm, "-I" + SRC] + flags + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            objs.append(o)
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path(variant)] + objs)
+    return True
+
+
+if __name__ == "__main__":
+    ok = build(force="--force" in sys.argv, verbose=True)
+    print("oracle/_ref:", "built" if ok else "unavailable (no /root/reference and no prebuilt libraries)")
