@@ -7,14 +7,27 @@ MFMA) followed by the rasterization of every sample's P = 262,146 per-pixel Gaus
 the reference's sampler calls once per denoising step (gaussian_diffusion.py:350 -> denoiser.py:284-287).
 value = renders / s = B * 4 * n_gpus / t_step, inputs resident in HBM, synthetic data, random-init weights.
 
-    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, HIP events on the launch stream inside the
-timed region) and `cpu_baseline` (the CPU oracle timed on the host cores on ONE sample of the same workload).
+With N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks (torch.distributed.run, 127.0.0.1, one
+per GPU, RCCL); launched BY torch.distributed.run (the driver's way) it reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+Prints ONE JSON line (rank 0).  Extra objects next to the contract keys:
+  roofline      dominant DiT kernel, HIP events on the launch stream inside the timed region; `traffic` from the PMC passes of
+                tools/pmc_traffic.py IF they were taken on exactly these kernel sources (else null)
+  raster        the rasterizer on its HBM roofline, forward and forward+backward, in the regime the step renders (random-init
+                Gaussians) and the trained-like regime, algorithmic bytes 104 P + 84 N + 20 HW per view
+  train_step    BASELINE configs[3]: B = 4 samples / GPU, 10 rendered views, forward + backward + gradient all-reduce
+                (overlapped, RCCL) + AdamW step + weight refresh, `DataParallelTrainer.step` end to end
+  cpu_baseline  the CPU oracle on the host cores on ONE sample of the same workload (N = 1 only)
+`--mode train` makes the training step the timed region of the line instead (metric: training samples/s).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,10 +36,8 @@ for _p in (ROOT, os.path.join(ROOT, "open-diffusiongs_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np
-import torch
-
 PEAK_BF16_MFMA = 2.5e15      # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_HBM = 8.0e12            # spec, same guide "HBM3E peak BW"
 PROF_KINDS = {"attention": 1, "gemm_qkv": 2, "gemm_gate_residual": 3, "gemm_fc1_gelu": 4, "layernorm": 5}
 
 
@@ -47,49 +58,65 @@ def kernel_flops(kind, L, B, width=1024):
     return 2.0 * L * n * B
 
 
-def measured_traffic(kernel, batch):
-    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_pmc_traffic.json; collected
-    with tools/pmc_run.py exactly as MI355X_MICROARCH.md prescribes).  Only valid for the shape it was measured on (batch 1)."""
+def kernel_source_sha():
+    """Identity of the kernels a PMC measurement belongs to: SHA-256 over every csrc/ source and header."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "open-diffusiongs_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic():
+    """profiles/pmc_traffic.json (tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this
+    very script, FETCH doubled per MI355X_MICROARCH.md).  Only returned when it was measured on the current kernel sources."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        v = d.get(kernel, {}).get("traffic_bytes_per_launch")
-        return int(v) if (v is not None and batch == 1) else None
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return d if d.get("kernel_source_sha") == kernel_source_sha() else None
     except Exception:
         return None
 
 
-def synth_batch(B, V, res, device, seed):
-    from dgs_amd import synth
-    return synth.make_batch(B, res, V=V, device=device, seed=seed, with_t=True)
+def respawn(a):
+    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL over xGMI)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(model, batch, t, res, V, hip_gaussians, hip_render):
-    """CPU leg (rank 0, N = 1 only): the oracle -- fp32 PyTorch-CPU restatement of the denoiser on all host cores + the
-    C++ restatement of the reference rasterizer (1 thread) -- timed on ONE sample of the same workload (1 DiT step +
-    V rasterizations).  Also returns the PSNR of the HIP render against the oracle render of the same Gaussians."""
+    """CPU leg (rank 0, N = 1 only): the oracle on ONE sample of the same workload -- the fp32 PyTorch-CPU restatement of the
+    denoiser, all 24 blocks, all host cores, and the C++ restatement of the reference rasterizer with OpenMP over Gaussians /
+    tiles on all host cores.  Also returns the PSNR of the HIP render against the oracle render of the same
+    Gaussians."""
+    import numpy as np
+    import torch
     from oracle import dit_oracle as D
     from oracle import raster_oracle as RO
     RO.build()
-    cores = min(os.cpu_count() or 1, 64)           # more threads than this only adds oversubscription at L=4098
-    torch.set_num_threads(cores)
+    cores = os.cpu_count() or 1
+    dit_threads = min(cores, 64)                   # more torch threads than this only add oversubscription at L = 4098
+    torch.set_num_threads(dit_threads)
+    RO.set_threads(dit_threads)                    # torch and the oracle share one OpenMP runtime: keep its pool at the torch size for the DiT leg
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     cpu = {k: v[:1].cpu() for k, v in batch.items()}
-    # bounded sample: 4 of the 24 (identical-cost) DiT blocks are timed and scaled by 6; tokenizer + heads are timed in
-    # full (they are inside both runs, so subtract the 0-block run)
-    def run(n_layers):
-        cfg = D.Cfg(num_layers=n_layers)
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            g_, _ = D.image_to_gaussians(sd, cfg, cpu["image"], cpu["ray_o"], cpu["ray_d"], t[:1].cpu())
-        return time.perf_counter() - t0, g_
-    t_0, _ = run(0)
-    t_4, g = run(4)
-    t_dit = t_0 + (t_4 - t_0) * 6.0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        g, _ = D.image_to_gaussians(sd, D.Cfg(), cpu["image"], cpu["ray_o"], cpu["ray_d"], t[:1].cpu())
+    t_dit = time.perf_counter() - t0
     view, proj, campos, tanfov = D.camera_matrices(cpu["c2w"][0], cpu["fxfycxcy"][0], res, res)
     act = lambda gm: dict(xyz=gm["xyz"][0].numpy(), shs=gm["features"][0].numpy(),
                           op=torch.sigmoid(gm["opacity"][0]).numpy(), sc=torch.exp(gm["scaling"][0]).numpy(),
                           rot=torch.nn.functional.normalize(gm["rotation"][0]).numpy())
     a = act(g)
+    raster_threads = RO.set_threads(0)             # all host cores for the rasterizer leg
     t0 = time.perf_counter()
     for v in range(V):
         o = RO.RasterOracle()
@@ -105,10 +132,114 @@ def cpu_baseline(model, batch, t, res, V, hip_gaussians, hip_render):
     mine = np.clip(hip_render[0, 0].cpu().numpy(), 0, 1)
     mse = float(np.mean((ref.astype(np.float64) - mine) ** 2))
     psnr = 200.0 if mse == 0 else -10.0 * np.log10(mse)
-    return dict(value=V / (t_dit + t_raster), unit="renders/s", cores=cores, kind="port",
-                sample=f"1 sample: DiT step at L=4098 extrapolated from 4 of 24 blocks ({t_4:.1f} s measured -> {t_dit:.1f} s, "
-                       f"torch-CPU fp32 oracle, {cores} threads) + {V} oracle rasterizations at {res}^2 ({t_raster:.1f} s "
-                       f"measured, C++ oracle, 1 thread)"), float(psnr)
+    return dict(value=V / (t_dit + t_raster), unit="renders/s", cores=max(dit_threads, raster_threads), kind="port",
+                sample=f"1 sample of the same step: DiT forward at L=4098, all 24 blocks ({t_dit:.1f} s, torch-CPU fp32 oracle, "
+                       f"{dit_threads} threads) + {V} oracle rasterizations at {res}^2 ({t_raster:.2f} s, C++ oracle, OpenMP over "
+                       f"Gaussians / tiles, {raster_threads} threads); host has {cores} cores"), float(psnr)
+
+
+def raster_roofline(dev, res, V, iters=10):
+    """Rasterizer on its roofline (HBM, 8 TB/s): forward and forward+backward of V views of the DiffusionGS-shaped synthetic
+    scenes of SURVEY.md 8d, timed with HIP events on the launch stream (the rasterizer launches on torch's current stream).
+    Algorithmic bytes per view: forward 104 P + 84 N + 20 HW, backward 251 P + 40 N + 20 HW; blend work 256 N pair
+    evaluations (upper bound, before early-out)."""
+    import numpy as np
+    import torch
+    from dgs_amd import cameras, synth
+    from dgs_amd.raster import default_backend, render_views_autograd
+    be = default_backend()
+    out = {"bound": "hbm", "peak": PEAK_HBM / 1e9, "unit": "GB/s", "views": V, "resolution": res}
+    tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
+    traffic = pmc_traffic()
+    for regime in ("init", "trained"):
+        sc = synth.gaussian_scene(res, regime=regime, seed=0, activated=False)
+        leaves = [tt(sc[k])[None].requires_grad_(True) for k in ("xyz", "shs", "scales", "rotations", "opacities")]
+        c2w = tt(cameras.ring_cameras(V, phase_deg=10))[None]
+        k = tt(cameras.default_fxfycxcy(res)).expand(1, V, 4).contiguous()
+        w = torch.randn(1, V, 3, res, res, device=dev) / (3 * res * res)
+        P = int(leaves[0].shape[1])
+        view, proj, campos, tanfov = be.cameras_from_c2w(c2w, k, res, res)
+        fwd = lambda: be.forward_views(torch.ones(3, device=dev), leaves[0].detach(), None, leaves[4].detach().reshape(1, -1),
+                                       leaves[2].detach(), leaves[3].detach(), 1.0, None, view, proj, campos, tanfov, 0.0, 0.0,
+                                       res, res, leaves[1].detach(), 0, False, False, views_per_set=V, raw_activations=True)
+        N = int(fwd()[0])
+
+        def fb():
+            for x in leaves:
+                x.grad = None
+            render_views_autograd(be, *leaves, res, res, c2w, k).backward(w)
+
+        rec = {"P": P, "N_per_view": N // V}
+        for name, fn, nbytes in (("forward", fwd, V * (104 * P + 20 * res * res) + 84 * N),
+                                 ("forward_backward", fb, V * (355 * P + 40 * res * res) + 124 * N)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            rec[name] = {"ms": round(ms, 4), "views_per_s": round(V / ms * 1e3, 1), "algorithmic_bytes": int(nbytes),
+                         "achieved": round(nbytes / ms / 1e6, 1), "frac": round(nbytes / (ms * 1e-3) / PEAK_HBM, 4),
+                         "pair_evals_per_s": round(256.0 * N * (1 if name == "forward" else 2) / (ms * 1e-3), 0)}
+            if traffic and traffic.get("raster", {}).get(regime, {}).get(name) is not None:
+                rec[name]["traffic"] = traffic["raster"][regime][name]
+        out[regime] = rec
+    return out
+
+
+def train_bench(a, dev, rank, world, steps, warmup):
+    """BASELINE configs[3] (train_obj_stage1.sh, diffusionGS_rel.yaml): per GPU B samples x 4 input views at 256^2, `--train-views`
+    rendered views; one `DataParallelTrainer.step` = DiT forward (activations saved) + rasterization + MSE + rasterizer backward +
+    DiT backward with the gradient all-reduce of the 460 M parameters overlapped bucket by bucket (RCCL when world > 1) + fused
+    AdamW + in-place refresh of the engine's bf16 / transposed weights."""
+    import numpy as np
+    import torch
+    from dgs_amd import cameras, denoiser as dn, synth
+    from dgs_amd.train import DataParallelTrainer
+    B, V, res, RV = a.train_batch, a.views, a.res, a.train_views
+    model = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="relative_plk"), device=dev)
+    model.reset_parameters(seed=0)          # identical replicas on every rank
+    model = model.to(dev)                   # fp32 master parameters + optimizer state on the GPU
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True)
+    tr = DataParallelTrainer(model, opt, bucket_bytes=a.bucket_mb << 20)
+    batch, t = synth.make_batch(B, res, V=V, device=dev, seed=100 + rank, with_t=True)
+    rc2w = torch.tensor(np.stack([cameras.ring_cameras(RV, phase_deg=5.0 + 7 * b) for b in range(B)])).to(dev)
+    rk = torch.tensor(cameras.default_fxfycxcy(res)).expand(B, RV, 4).contiguous().to(dev)
+    target = torch.rand(B, RV, 3, res, res, device=dev)
+    for _ in range(warmup):
+        loss = tr.step(batch, t, target, rc2w, rk)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(batch, t, target, rc2w, rk)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    eng = model.engine()
+    L = eng.num_tokens(V, res, res)
+    ms = elapsed / steps * 1e3
+    recompute = bool(eng._train.get("recompute"))
+    flops = (4 if recompute else 3) * dit_flops(L) * B
+    log = tr.reducer.launch_log
+    return {"ms_per_step": round(ms, 2), "samples_per_s": round(B * world / (ms * 1e-3), 2), "batch_per_gpu": B, "rendered_views": RV,
+            "steps": steps, "warmup": warmup, "loss": round(float(loss), 6), "recompute": recompute,
+            "dit_tflops_per_gpu": round(flops / (ms * 1e-3) / 1e12, 1), "frac_of_bf16_peak": round(flops / (ms * 1e-3) / PEAK_BF16_MFMA, 4),
+            "saved_activation_gib": round(eng._train["saved"].numel() / 2 ** 30, 2),
+            "allreduce": {"world": world, "buckets": len(tr.reducer.bounds), "bucket_mib": a.bucket_mb,
+                          "launched_during_backward": sum(1 for _, tag in log if isinstance(tag, int)),
+                          "gradient_bytes": int(tr.fg.flat.numel() * 4)},
+            "note": "DataParallelTrainer.step end to end: fwd + raster + MSE + bwd (+ overlapped all-reduce) + fused AdamW + weight refresh"}
 
 
 def main():
@@ -116,13 +247,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU per step (pipline_obj.py samples one object)")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--roofline-kernel", default="attention", choices=sorted(PROF_KINDS))
+    ap.add_argument("--train-batch", type=int, default=4)
+    ap.add_argument("--train-views", type=int, default=10)
+    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--bucket-mb", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(a)
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -136,21 +277,36 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # RCCL
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    from dgs_amd import denoiser as dn
+    if a.mode == "train":
+        tb = train_bench(a, dev, rank, world, a.steps, a.warmup)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "training samples/sec (DiT fwd+bwd + GS raster fwd+bwd + grad all-reduce + AdamW) at 256^2",
+                "value": tb["samples_per_s"], "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": tb["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                "data": "synthetic", "config": {"workload": f"obj-{a.res} training step (BASELINE.json configs[3]): B={a.train_batch} samples/GPU, "
+                                                            f"4 input views, {a.train_views} rendered views, 460 M parameters, random init",
+                                                "parallelism": f"dp{world}"}, "train_step": tb}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    from dgs_amd import denoiser as dn, synth
     model = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="relative_plk"), device=dev)
     model.reset_parameters(seed=0)          # every rank the same random-init weights (pure data parallel inference)
     B, V, res = a.batch, a.views, a.res
-    batch, t = synth_batch(B, V, res, dev, seed=rank)
+    batch, t = synth.make_batch(B, res, V=V, device=dev, seed=rank, with_t=True)
     eng = model.engine()
     L = eng.num_tokens(V, res, res)
 
     def step(prof=None):
         # == DGSDenoiser.forward (denoiser.py:284-287); the profiling hook only adds event records on the stream
-        params, _ = eng.image_to_gaussians(batch["image"], batch["ray_o"], batch["ray_d"], t, prof=prof)
-        pc = params.pop("prof_count", 0)
-        p = dn.AttrDict(params)
-        rendered = model.render_gaussians(p, batch["c2w"], batch["fxfycxcy"], res, res)
-        return rendered, model.prepare_to_save(p), pc
+        with torch.no_grad():
+            params, _ = eng.image_to_gaussians(batch["image"], batch["ray_o"], batch["ray_d"], t, prof=prof)
+            pc = params.pop("prof_count", 0)
+            p = dn.AttrDict(params)
+            rendered = model.render_gaussians(p, batch["c2w"], batch["fxfycxcy"], res, res)
+            return rendered, model.prepare_to_save(p), pc
 
     def barrier():
         if world > 1:
@@ -165,10 +321,8 @@ def main():
             e.record()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n_prof = 0
     for i in range(a.steps):
-        rendered, gaussians, pc = step(prof=(PROF_KINDS[a.roofline_kernel], events[i]))
-        n_prof += pc
+        rendered, gaussians, _pc = step(prof=(PROF_KINDS[a.roofline_kernel], events[i]))
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -176,28 +330,35 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # Informational: the reference's 30-step sampling loop end to end -- DGSDenoiser.forward + the device sampler
-    # step (dgs_amd/sampler.py) per iteration; one untimed loop, one timed.  Not part of `value`.
-    from dgs_amd import sampler as sm
-    diffusion = sm.create_diffusion("30", device=dev)
-    loop_batch = dict(batch)
     loop_ms = None
-    for timed in (False, True):
-        loop_batch["image"] = batch["image"].clone()
-        loop_batch["image_noisy"] = torch.randn_like(batch["image"][:, 1:])
-        torch.cuda.synchronize()
-        l0 = time.perf_counter()
-        diffusion.p_sample_loop(model, loop_batch)
-        torch.cuda.synchronize()
-        if timed:
-            loop_ms = (time.perf_counter() - l0) * 1e3
+    if not a.no_extras:
+        # Informational: the reference's 30-step sampling loop end to end -- DGSDenoiser.forward + the device
+        # sampler step (dgs_amd/sampler.py) per iteration; one untimed loop, one timed.  Not part of `value`.
+        from dgs_amd import sampler as sm
+        diffusion = sm.create_diffusion("30", device=dev)
+        loop_batch = dict(batch)
+        for timed in (False, True):
+            loop_batch["image"] = batch["image"].clone()
+            loop_batch["image_noisy"] = torch.randn_like(batch["image"][:, 1:])
+            torch.cuda.synchronize()
+            l0 = time.perf_counter()
+            with torch.no_grad():
+                diffusion.p_sample_loop(model, loop_batch)
+            torch.cuda.synchronize()
+            if timed:
+                loop_ms = (time.perf_counter() - l0) * 1e3
 
+    out = None
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         value = B * V * world / (elapsed / a.steps)
         kern_ms = [events[i][2 * j].elapsed_time(events[i][2 * j + 1]) for i in range(a.steps) for j in range(per_step)]
         avg_s = float(np.mean(kern_ms)) * 1e-3
         achieved = kernel_flops(a.roofline_kernel, L, B) / avg_s / 1e12
+        traffic = pmc_traffic()
+        tr_bytes = None
+        if traffic and B == 1 and res == 256 and V == 4:
+            tr_bytes = traffic.get("dit", {}).get(a.roofline_kernel, {}).get("traffic_bytes_per_launch")
         out = {
             "metric": "novel-view renders/sec (DiT step + GS raster) at 256^2", "value": round(value, 2), "unit": "renders/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
@@ -208,13 +369,25 @@ def main():
                        "batch_per_gpu": B, "views": V, "resolution": res, "tokens": L, "gaussians": 2 + V * res * res,
                        "dit_tflop_per_sample": round(dit_flops(L) / 1e12, 3), "parallelism": f"dp{world}"},
             "roofline": {"kernel": a.roofline_kernel, "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_MFMA, 4),
-                         "traffic": measured_traffic(a.roofline_kernel, B) if res == 256 and V == 4 else None,
-                         "launches_timed": len(kern_ms), "avg_launch_us": round(avg_s * 1e6, 2)},
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_MFMA, 4), "traffic": tr_bytes,
+                         "launches_timed": len(kern_ms), "avg_launch_us": round(avg_s * 1e6, 2),
+                         "step_frac_of_peak": round(dit_flops(L) * B / (ms * 1e-3) / PEAK_BF16_MFMA, 4)},
         }
-        out["sampling_loop_30_steps"] = {"ms_per_loop": round(loop_ms, 2), "renders_per_s": round(B * V * 30 / (loop_ms * 1e-3), 1),
-                                         "note": "per GPU; informational, not part of value"}
-        if world == 1 and not a.no_cpu_baseline:
+        if loop_ms is not None:
+            out["sampling_loop_30_steps"] = {"ms_per_loop": round(loop_ms, 2), "renders_per_s": round(B * V * 30 / (loop_ms * 1e-3), 1),
+                                             "note": "per GPU; informational, not part of value"}
+    if not a.no_extras:
+        rr = raster_roofline(dev, res, V) if rank == 0 else None
+        del model, eng
+        torch.cuda.empty_cache()
+        tb = train_bench(a, dev, rank, world, a.train_steps, 2)      # every rank: the step has a collective
+        if rank == 0:
+            out["raster"] = rr
+            out["train_step"] = tb
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline and not a.no_extras:
+            model = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="relative_plk"), device=dev)
+            model.reset_parameters(seed=0)
             final = {k: getattr(gaussians[0], "_" + n)[None] for k, n in
                      (("xyz", "xyz"), ("features", "features_dc"), ("scaling", "scaling"), ("rotation", "rotation"), ("opacity", "opacity"))}
             base, psnr = cpu_baseline(model, batch, t, res, V, final, rendered)

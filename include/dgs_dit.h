@@ -118,7 +118,15 @@ typedef struct DgsDitAttentionArgs {
     float* lse2;               /* optional out [B, heads, lpad]: log2-domain log-sum-exp per query (for backward)  */
     int32_t q_prescaled;       /* nonzero: the q features already carry the factor scale * log2(e) (DgsDitGemmArgs.q_scale);
                                   0: the kernel applies it to the bf16 queries itself (one extra bf16 rounding)       */
+    void* tail_ws;             /* scratch of dgs_dit_attention_tail_bytes(B, heads, L) bytes, required when L % 32 != 0 (the
+                                  DiT's two learned tokens): partial records of the L % 32 tail queries + arrival counters.
+                                  Zero-filled ONCE by the caller (the kernel leaves the counters at zero); one per stream
+                                  that launches concurrently.                                                          */
+    size_t tail_ws_bytes;
 } DgsDitAttentionArgs;
+
+/* Bytes of DgsDitAttentionArgs.tail_ws for this shape (0 when L % 32 == 0). */
+size_t dgs_dit_attention_tail_bytes(int32_t B, int32_t heads, int32_t L);
 
 typedef struct DgsDitAttentionBackwardArgs {
     int32_t B, heads, L, lpad;
@@ -242,6 +250,9 @@ typedef struct DgsDitForwardArgs {
     int32_t prof_kind;
     int32_t prof_capacity;
     int32_t* prof_count;
+    int32_t train_recompute;   /* dgs_dit_forward_train only. 0: save every activation the backward needs (nothing is recomputed);
+                                  1: the reference's per-block checkpointing (torch.utils.checkpoint(run_layers(i, i+1)),
+                                  denoiser.py:348-354): keep only each block's input, dgs_dit_backward re-runs the block       */
 } DgsDitForwardArgs;
 
 /* ---- training: forward that saves activations, and the backward ------------------------------------------------ */
@@ -271,9 +282,19 @@ typedef struct DgsDitBackwardArgs {
     void* saved;        size_t saved_bytes;    /* arena filled by dgs_dit_forward_train                  */
     void* workspace;    size_t workspace_bytes;/* dgs_dit_backward_workspace_bytes, zero-filled once     */
     const float *dxyz, *dfeatures, *dscaling, *drotation, *dopacity;   /* gradients of the five outputs  */
+    int32_t recompute;                         /* must equal the forward's train_recompute              */
+    /* Optional host callback, called from inside dgs_dit_backward as soon as the kernels that complete a GROUP of
+     * gradients have been enqueued on `stream` (they have not run yet: order follow-up work behind the stream):
+     * stage = layers: the two heads (dec_w, dec_ln_w, up_w, up_ln_w); stage = layers-1 .. 0: that block's eight tensors;
+     * stage = -1: the rest (embeddings, adaLN stack, timestep MLP).  This is where a data-parallel caller enqueues the
+     * all-reduce of a finished gradient bucket so that it overlaps the remaining backward (Lightning DDP's overlap,
+     * configs/diffusionGS_rel.yaml:80).                                                                            */
+    void (*block_done)(void* user, int32_t stage);
+    void* block_user;
 } DgsDitBackwardArgs;
 
-size_t dgs_dit_saved_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W);
+/* recompute: 0 / 1 as DgsDitForwardArgs.train_recompute */
+size_t dgs_dit_saved_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W, int32_t recompute);
 size_t dgs_dit_backward_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W);
 /* same outputs as dgs_dit_forward (a->workspace is not used); B <= 4 */
 int dgs_dit_forward_train(const DgsDitModel* m, const DgsDitForwardArgs* a, void* saved, size_t saved_bytes, dgs_stream_t stream);

@@ -520,8 +520,11 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     if (!tail_r) return;
     // the last workgroup of this (sample, head) to get here merges the per-tile records
 #ifndef HIPEMU
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stores retire in order: all but the 8 output stores, i.e. every record
-                                                       // store of this wave, have been performed (sc1: at the memory side)
+    // stores retire in order: with at most the 8 output stores outstanding, every record store of this wave has been
+    // performed (sc1: at the memory side).  A wave without live queries issued no output stores behind its records,
+    // so it has to drain completely.
+    if (wave_live) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     int* flag = reinterpret_cast<int*>(lds);
 #ifndef HIPEMU
@@ -547,6 +550,15 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
 
 using namespace dgs;
 
+static size_t tail_counter_bytes(int B, int heads) { return ((size_t)B * heads * sizeof(unsigned) + 255) / 256 * 256; }
+
+extern "C" size_t dgs_dit_attention_tail_bytes(int32_t B, int32_t heads, int32_t L) {
+    const int r = L % 32;
+    if (B <= 0 || heads <= 0 || L <= 0 || !r) return 0;
+    const size_t ntiles = (size_t)(L + KB - 1) / KB;
+    return tail_counter_bytes(B, heads) + (size_t)B * heads * ntiles * r * TAIL_REC * sizeof(float);
+}
+
 extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream) {
     if (!a || a->B <= 0 || a->heads <= 0 || a->L <= 0 || a->lpad < a->L || a->lpad % 128 || !a->qk || !a->vt || !a->out)
         return DGS_ERR_INVALID_ARGUMENT;
@@ -561,25 +573,14 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     p.nmain = a->B * a->heads * p.nqb;
     static const int dbg = getenv("DGS_ATTN_DBG") ? atoi(getenv("DGS_ATTN_DBG")) : 0;
     p.dbg = dbg;
-    const int r = a->L % 32, ntiles_h = (a->L + KB - 1) / KB;
+    const int r = a->L % 32;
     p.tail_ws = nullptr; p.tail_cnt = nullptr;
     if (r) {
-        // library-owned scratch of the tail records (a few hundred KiB), grown on demand, never shrunk
-        static float* ws = nullptr; static unsigned* cnt = nullptr; static size_t ws_floats = 0, cnt_n = 0;
-        const size_t need = (size_t)a->B * a->heads * ntiles_h * r * TAIL_REC, need_cnt = (size_t)a->B * a->heads;
-        if (need > ws_floats) {
-            if (ws) (void)hipFree(ws);
-            if (hipMalloc(&ws, need * sizeof(float)) != hipSuccess) { ws = nullptr; ws_floats = 0; return DGS_ERR_DEVICE; }
-            ws_floats = need;
-        }
-        if (need_cnt > cnt_n) {
-            if (cnt) (void)hipFree(cnt);
-            if (hipMalloc(&cnt, need_cnt * sizeof(unsigned)) != hipSuccess || hipMemset(cnt, 0, need_cnt * sizeof(unsigned)) != hipSuccess) {
-                cnt = nullptr; cnt_n = 0; return DGS_ERR_DEVICE;
-            }
-            cnt_n = need_cnt;
-        }
-        p.tail_ws = ws; p.tail_cnt = cnt;
+        // caller-owned scratch (per call site / per stream): [counters | records]; the counters are zero between launches
+        const size_t need = dgs_dit_attention_tail_bytes(a->B, a->heads, a->L);
+        if (!a->tail_ws || a->tail_ws_bytes < need) return DGS_ERR_INVALID_ARGUMENT;
+        p.tail_cnt = static_cast<unsigned*>(a->tail_ws);
+        p.tail_ws = reinterpret_cast<float*>(static_cast<char*>(a->tail_ws) + tail_counter_bytes(a->B, a->heads));
     }
     p.qk = a->qk; p.vt = a->vt; p.out = a->out; p.q_prescaled = a->q_prescaled;
     p.scale_log2e = a->scale * 1.44269504088896341f;

@@ -25,7 +25,9 @@ struct DitWorkspace {
     float* mod;      // [B, (6*layers + 4) * W]
     float* upn;      // [B*ng, W]
     float* up;       // [B*ng, C]
-    static DitWorkspace carve(void* buf, const DgsDitModel* m, size_t B, size_t lpad, size_t* bytes) {
+    void* attn_tail; // dgs_dit_attention_tail_bytes: records + counters of the learned-token queries
+    size_t attn_tail_bytes;
+    static DitWorkspace carve(void* buf, const DgsDitModel* m, size_t B, size_t lpad, int L, size_t* bytes) {
         Carver c(buf);
         DitWorkspace w;
         const size_t M = B * lpad, W = (size_t)m->width;
@@ -44,6 +46,8 @@ struct DitWorkspace {
         w.mod = c.take<float>(B * (6 * (size_t)m->layers + 4) * W);
         w.upn = c.take<float>(B * m->n_gaussians * W);
         w.up = c.take<float>(B * m->n_gaussians * m->gs_channels);
+        w.attn_tail_bytes = dgs_dit_attention_tail_bytes((int)B, m->heads, L);
+        w.attn_tail = c.take<char>(w.attn_tail_bytes);
         if (bytes) *bytes = c.bytes();
         return w;
     }
@@ -61,7 +65,7 @@ extern "C" int32_t dgs_dit_lpad(int32_t L) { return (L + 255) / 256 * 256; }
 extern "C" size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W) {
     if (!m || B <= 0 || V <= 0 || H <= 0 || W <= 0 || m->patch <= 0) return 0;
     size_t bytes = 0;
-    DitWorkspace::carve(nullptr, m, (size_t)B, (size_t)dgs_dit_lpad(token_count(m, V, H, W)), &bytes);
+    DitWorkspace::carve(nullptr, m, (size_t)B, (size_t)dgs_dit_lpad(token_count(m, V, H, W)), token_count(m, V, H, W), &bytes);
     return bytes;
 }
 
@@ -89,7 +93,7 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     const int L = token_count(m, V, H, Wd), lpad = dgs_dit_lpad(L), M = B * lpad;
     const int pp = m->patch * m->patch, kin = m->in_channels * pp;
     size_t need = 0;
-    DitWorkspace ws = DitWorkspace::carve(a->workspace, m, (size_t)B, (size_t)lpad, &need);
+    DitWorkspace ws = DitWorkspace::carve(a->workspace, m, (size_t)B, (size_t)lpad, L, &need);
     if (a->workspace_bytes < need) return DGS_ERR_ALLOC;
     const int nmod = (6 * m->layers + 4) * W;
     Prof prof{a->prof_events, a->prof_kind, a->prof_capacity, 0, st};
@@ -125,6 +129,7 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     // ---- 24 x DiTBlock (utils_transformer.py:271-290) ----
     DgsDitAttentionArgs at{};
     at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = ws.qk; at.vt = ws.vt; at.out = ws.ao; at.scale = 0.125f; at.q_prescaled = 1;
+    at.tail_ws = ws.attn_tail; at.tail_ws_bytes = ws.attn_tail_bytes;
     for (int i = 0; i < m->layers; ++i) {
         const DgsDitLayerWeights& lw = m->layer[i];
         const float* mod = ws.mod + (size_t)i * 6 * W;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp

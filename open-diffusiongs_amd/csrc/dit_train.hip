@@ -2,8 +2,12 @@
 // C calls, each one launch sequence on one stream with no host synchronisation.
 //
 // The reference trains with per-block activation checkpointing (torch.utils.checkpoint, denoiser.py:348-354): every block
-// is recomputed in backward, 4x the forward FLOPs per step.  MI355X has 288 GB of HBM, so the training forward SAVES what
-// the backward needs (54 W bytes per token and block, ~22 GB at batch 4 x 256^2) and nothing is recomputed: 3x.
+// is recomputed in backward, 4x the forward FLOPs per step.  MI355X has 288 GB of HBM, so by default the training forward
+// SAVES what the backward needs (54 W bytes per token and block, ~22 GB at batch 4 x 256^2) and nothing is recomputed: 3x.
+// `recompute` (DgsDitForwardArgs.train_recompute / DgsDitBackwardArgs.recompute) is the reference's mode: only each
+// block's INPUT is kept (4 W bytes per token and block) plus ONE block's worth of activations; the backward re-runs a
+// block's forward (same kernels, same inputs: same bits) right before differentiating it.  That is what makes the 512^2
+// configuration (L = 16,386; BASELINE configs[4]) trainable at the reference's batch sizes.
 // Gradients come out as fp32 tensors in caller-provided buffers (one flat buffer in practice: dgs_amd/parallel.py), weight
 // gradients are GEMMs whose reduction runs over the tokens of token-contiguous ("transposed") activation copies.
 #include "dit_kernels.h"
@@ -35,12 +39,18 @@ struct DitSaved {
     bf16_t* xn_dec;  // [M, W]
     float* dec;      // [M, pp*C]
     float *upn, *up, *temb, *c1, *cvec, *mod;
-    static DitSaved carve(void* buf, const DgsDitModel* m, size_t B, size_t lpad, size_t* bytes) {
+    void* attn_tail; size_t attn_tail_bytes;
+    static DitSaved carve(void* buf, const DgsDitModel* m, size_t B, size_t lpad, int L, int recompute, size_t* bytes) {
         Carver c(buf);
         DitSaved s;
         const size_t M = B * lpad, W = (size_t)m->width, pp = (size_t)m->patch * m->patch;
         for (int i = 0; i < m->layers; ++i) {
             BlockSaved& k = s.blk[i];
+            if (recompute && i > 0) {            // every block shares block 0's activation slots; only x_in is its own
+                k = s.blk[0];
+                k.x_in = c.take<float>(M * W);
+                continue;
+            }
             k.x_in = c.take<float>(M * W); k.h1 = c.take<bf16_t>(M * W); k.qkv = c.take<bf16_t>(M * 3 * W);
             k.qkvT = c.take<bf16_t>(M * 3 * W); k.lse2 = c.take<float>(B * m->heads * lpad); k.a = c.take<bf16_t>(M * W);
             k.y1 = c.take<bf16_t>(M * W); k.x_mid = c.take<float>(M * W); k.h2 = c.take<bf16_t>(M * W);
@@ -53,6 +63,8 @@ struct DitSaved {
         s.upn = c.take<float>(B * m->n_gaussians * W); s.up = c.take<float>(B * m->n_gaussians * m->gs_channels);
         s.temb = c.take<float>(B * 256); s.c1 = c.take<float>(B * W); s.cvec = c.take<float>(B * W);
         s.mod = c.take<float>(B * (6 * (size_t)m->layers + 4) * W);
+        s.attn_tail_bytes = dgs_dit_attention_tail_bytes((int)B, m->heads, L);
+        s.attn_tail = c.take<char>(s.attn_tail_bytes);
         if (bytes) *bytes = c.bytes();
         return s;
     }
@@ -72,6 +84,7 @@ struct BwdScratch {
     float *dmod, *dup, *dupn, *dcvec, *dc1, *ones;
     size_t wpart_bytes;
     float* wpart;            // split-K partial planes of the weight-gradient GEMMs (largest: fc1 / fc2)
+    float* xre;              // [M, W] recompute mode: where a re-run block writes its (already known) output
     static BwdScratch carve(void* buf, const DgsDitModel* m, size_t B, size_t lpad, size_t* bytes) {
         Carver c(buf);
         BwdScratch s;
@@ -92,6 +105,7 @@ struct BwdScratch {
         s.dcvec = c.take<float>(B * W); s.dc1 = c.take<float>(B * W); s.ones = c.take<float>(B * W);
         s.wpart_bytes = dgs_dit_gemm_splitk_bytes((int)(4 * W), (int)W, (int)M, (int)lpad);
         s.wpart = c.take<float>(s.wpart_bytes / sizeof(float));
+        s.xre = c.take<float>(M * W);
         if (bytes) *bytes = c.bytes();
         return s;
     }
@@ -120,12 +134,54 @@ using namespace dgs;
 #define DGS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DGS_OK) { fprintf(stderr, "[dgs] %s:%d: status %d\n", __FILE__, __LINE__, rc_); return rc_; } } while (0)
 #define HIP_TRY(expr) do { if ((expr) != hipSuccess) return DGS_ERR_DEVICE; } while (0)
 
-extern "C" size_t dgs_dit_saved_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W) {
+extern "C" size_t dgs_dit_saved_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W, int32_t recompute) {
     if (!m || B <= 0 || m->layers > 64) return 0;
     size_t b = 0;
-    DitSaved::carve(nullptr, m, (size_t)B, (size_t)dgs_dit_lpad(tokens_of(m, V, H, W)), &b);
+    DitSaved::carve(nullptr, m, (size_t)B, (size_t)dgs_dit_lpad(tokens_of(m, V, H, W)), tokens_of(m, V, H, W), recompute, &b);
     return b;
 }
+
+namespace {
+// One DiTBlock of the training forward (utils_transformer.py:271-290): reads k.x_in, fills k's activation slots, writes the
+// block output to x_next.  Also what the recompute mode re-runs inside the backward.
+int block_forward_train(const DgsDitModel* m, int i, const BlockSaved& k, float* x_next, const float* mod_all, void* attn_tail,
+                        size_t attn_tail_bytes, int B, int lpad, int L, dgs_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int W = m->width, M = B * lpad, nmod = (6 * m->layers + 4) * W;
+    const DgsDitLayerWeights& lw = m->layer[i];
+    const float* mod = mod_all + (size_t)i * 6 * W;
+    DgsDitLayerNormArgs l1{};
+    l1.rows = M; l1.width = W; l1.x = k.x_in; l1.shift = mod; l1.scale = mod + W; l1.mod_stride = nmod; l1.rows_per_batch = lpad;
+    l1.eps = 1e-6f; l1.out = k.h1;
+    DGS_TRY(launch_layernorm(&l1, st));
+    DgsDitGemmArgs q{};
+    q.M = M; q.N = 3 * W; q.K = W; q.A = k.h1; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_BF16;
+    q.out = k.qkv; q.ldo = 3 * W; q.vt = k.qkvT; q.rows_per_batch = lpad; q.valid_rows = L;
+    DGS_TRY(dgs_dit_gemm(&q, stream));
+    DgsDitAttentionArgs at{};
+    at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = k.qkv; at.ld_qk = 3 * W; at.k_offset = W;
+    at.vt = k.qkvT + (size_t)2 * W * lpad; at.vt_batch_stride = (int64_t)3 * W * lpad; at.out = k.a; at.scale = 0.125f; at.lse2 = k.lse2;
+    at.tail_ws = attn_tail; at.tail_ws_bytes = attn_tail_bytes;
+    DGS_TRY(dgs_dit_attention(&at, stream));
+    DgsDitGemmArgs pr{};
+    pr.M = M; pr.N = W; pr.K = W; pr.A = k.a; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
+    pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.resid = k.x_in; pr.out = k.x_mid; pr.aux = k.y1; pr.ldo = W; pr.gate = mod + 2 * W;
+    pr.gate_stride = nmod; pr.rows_per_batch = lpad; pr.valid_rows = L;
+    DGS_TRY(dgs_dit_gemm(&pr, stream));
+    l1.x = k.x_mid; l1.shift = mod + 3 * W; l1.scale = mod + 4 * W; l1.out = k.h2;
+    DGS_TRY(launch_layernorm(&l1, st));
+    DgsDitGemmArgs f1{};
+    f1.M = M; f1.N = 4 * W; f1.K = W; f1.A = k.h2; f1.lda = W; f1.W = lw.fc1_w; f1.ldw = W; f1.bias = lw.fc1_b;
+    f1.epilogue = DGS_EPI_GELU_BF16; f1.out = k.g; f1.aux = k.u; f1.vt = k.gT; f1.ldo = 4 * W; f1.rows_per_batch = lpad; f1.valid_rows = L;
+    DGS_TRY(dgs_dit_gemm(&f1, stream));
+    DgsDitGemmArgs f2{};
+    f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = k.g; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
+    f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.resid = k.x_mid; f2.out = x_next; f2.aux = k.y2; f2.ldo = W; f2.gate = mod + 5 * W;
+    f2.gate_stride = nmod; f2.rows_per_batch = lpad; f2.valid_rows = L;
+    DGS_TRY(dgs_dit_gemm(&f2, stream));
+    return DGS_OK;
+}
+}  // namespace
 
 extern "C" size_t dgs_dit_backward_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W) {
     if (!m || B <= 0) return 0;
@@ -145,7 +201,7 @@ extern "C" int dgs_dit_forward_train(const DgsDitModel* m, const DgsDitForwardAr
     const int L = tokens_of(m, V, H, Wd), lpad = dgs_dit_lpad(L), M = B * lpad;
     const int pp = m->patch * m->patch, kin = m->in_channels * pp, nmod = (6 * m->layers + 4) * W;
     size_t need = 0;
-    DitSaved sv = DitSaved::carve(saved, m, (size_t)B, (size_t)lpad, &need);
+    DitSaved sv = DitSaved::carve(saved, m, (size_t)B, (size_t)lpad, L, a->train_recompute, &need);
     if (saved_bytes < need) return DGS_ERR_ALLOC;
 
     DGS_TRY(launch_timestep(a->t, sv.temb, B, st));
@@ -171,40 +227,9 @@ extern "C" int dgs_dit_forward_train(const DgsDitModel* m, const DgsDitForwardAr
     ln.rows = M; ln.width = W; ln.x = sv.x0_pre; ln.weight = m->in_ln_w; ln.eps = 1e-5f; ln.out = sv.blk[0].x_in; ln.out_f32 = 1; ln.rows_per_batch = lpad;
     DGS_TRY(launch_layernorm(&ln, st));
 
-    for (int i = 0; i < m->layers; ++i) {
-        const DgsDitLayerWeights& lw = m->layer[i];
-        BlockSaved& k = sv.blk[i];
-        float* x_next = (i + 1 < m->layers) ? sv.blk[i + 1].x_in : sv.x_out;
-        const float* mod = sv.mod + (size_t)i * 6 * W;
-        DgsDitLayerNormArgs l1{};
-        l1.rows = M; l1.width = W; l1.x = k.x_in; l1.shift = mod; l1.scale = mod + W; l1.mod_stride = nmod; l1.rows_per_batch = lpad;
-        l1.eps = 1e-6f; l1.out = k.h1;
-        DGS_TRY(launch_layernorm(&l1, st));
-        DgsDitGemmArgs q{};
-        q.M = M; q.N = 3 * W; q.K = W; q.A = k.h1; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_BF16;
-        q.out = k.qkv; q.ldo = 3 * W; q.vt = k.qkvT; q.rows_per_batch = lpad; q.valid_rows = L;
-        DGS_TRY(dgs_dit_gemm(&q, stream));
-        DgsDitAttentionArgs at{};
-        at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = k.qkv; at.ld_qk = 3 * W; at.k_offset = W;
-        at.vt = k.qkvT + (size_t)2 * W * lpad; at.vt_batch_stride = (int64_t)3 * W * lpad; at.out = k.a; at.scale = 0.125f; at.lse2 = k.lse2;
-        DGS_TRY(dgs_dit_attention(&at, stream));
-        DgsDitGemmArgs pr{};
-        pr.M = M; pr.N = W; pr.K = W; pr.A = k.a; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
-        pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.resid = k.x_in; pr.out = k.x_mid; pr.aux = k.y1; pr.ldo = W; pr.gate = mod + 2 * W;
-        pr.gate_stride = nmod; pr.rows_per_batch = lpad; pr.valid_rows = L;
-        DGS_TRY(dgs_dit_gemm(&pr, stream));
-        l1.x = k.x_mid; l1.shift = mod + 3 * W; l1.scale = mod + 4 * W; l1.out = k.h2;
-        DGS_TRY(launch_layernorm(&l1, st));
-        DgsDitGemmArgs f1{};
-        f1.M = M; f1.N = 4 * W; f1.K = W; f1.A = k.h2; f1.lda = W; f1.W = lw.fc1_w; f1.ldw = W; f1.bias = lw.fc1_b;
-        f1.epilogue = DGS_EPI_GELU_BF16; f1.out = k.g; f1.aux = k.u; f1.vt = k.gT; f1.ldo = 4 * W; f1.rows_per_batch = lpad; f1.valid_rows = L;
-        DGS_TRY(dgs_dit_gemm(&f1, stream));
-        DgsDitGemmArgs f2{};
-        f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = k.g; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
-        f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.resid = k.x_mid; f2.out = x_next; f2.aux = k.y2; f2.ldo = W; f2.gate = mod + 5 * W;
-        f2.gate_stride = nmod; f2.rows_per_batch = lpad; f2.valid_rows = L;
-        DGS_TRY(dgs_dit_gemm(&f2, stream));
-    }
+    for (int i = 0; i < m->layers; ++i)
+        DGS_TRY(block_forward_train(m, i, sv.blk[i], (i + 1 < m->layers) ? sv.blk[i + 1].x_in : sv.x_out, sv.mod, sv.attn_tail,
+                                    sv.attn_tail_bytes, B, lpad, L, stream));
     if (a->tokens) DGS_TRY(launch_gather_tokens(sv.x_out, a->tokens, B, lpad, L, ng, W, st));
 
     const float* mod_up = sv.mod + (size_t)m->layers * 6 * W;
@@ -270,7 +295,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
     const int pp = m->patch * m->patch, kin = m->in_channels * pp, nmod = (6 * m->layers + 4) * W, ND = pp * C;
     if (ND % 128 || kin % 64) return DGS_ERR_INVALID_ARGUMENT;
     size_t need = 0;
-    DitSaved sv = DitSaved::carve(a->saved, m, (size_t)B, (size_t)lpad, &need);
+    DitSaved sv = DitSaved::carve(a->saved, m, (size_t)B, (size_t)lpad, L, a->recompute, &need);
     if (a->saved_bytes < need) return DGS_ERR_ALLOC;
     BwdScratch ws = BwdScratch::carve(a->workspace, m, (size_t)B, (size_t)lpad, &need);
     if (a->workspace_bytes < need) return DGS_ERR_ALLOC;
@@ -322,6 +347,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         lu.dshift = dmod_up + (size_t)b * nmod; lu.dscale = dmod_up + W + (size_t)b * nmod; lu.dweight = gr->up_ln_w;
         DGS_TRY(launch_layernorm_backward(lu, st));
     }
+    if (a->block_done) a->block_done(a->block_user, m->layers);     // dec_w, dec_ln_w, up_w, up_ln_w are final (enqueued)
 
     // ---- 24 x DiTBlock, last to first ----
     float* dx = ws.dxa;      // gradient w.r.t. the block output
@@ -334,6 +360,9 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         const float* mod = sv.mod + (size_t)i * 6 * W;
         float* dmod = ws.dmod + (size_t)i * 6 * W;
         (void)lw;
+        // recompute mode: block i's activations are rebuilt from its saved input (the last block's are still in place)
+        if (a->recompute && i + 1 < m->layers)
+            DGS_TRY(block_forward_train(m, i, k, ws.xre, sv.mod, sv.attn_tail, sv.attn_tail_bytes, B, lpad, L, stream));
         // MLP branch
         DGS_TRY(launch_gate_mul(dx, k.y2, mod + 5 * W, nmod, ws.dy, ws.dyT, dmod + 5 * W, B, lpad, W, st));
         HIP_TRY(hipMemsetAsync(lg.fc2_b, 0, W * sizeof(float), st));
@@ -370,6 +399,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         l1.rows = M; l1.width = W; l1.mod_stride = nmod; l1.rows_per_batch = lpad; l1.eps = 1e-6f; l1.x = k.x_in; l1.dh = ws.dh;
         l1.scale = mod + W; l1.dx_in = dx_mid; l1.dx_out = dx; l1.dshift = dmod; l1.dscale = dmod + W;
         DGS_TRY(launch_layernorm_backward(l1, st));
+        if (a->block_done) a->block_done(a->block_user, i);            // block i's eight gradients are final (enqueued)
     }
 
     // ---- input LayerNorm, learned tokens, tokenizer weight ----
@@ -395,5 +425,6 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
     RowLinBwdParams r0{};
     r0.M = B; r0.N = W; r0.K = 256; r0.silu_in = 0; r0.x = sv.temb; r0.W = m->t_w0; r0.dy = ws.dc1; r0.dW = gr->t_w0; r0.db = gr->t_b0;
     DGS_TRY(launch_rowlinear_backward(r0, st));
+    if (a->block_done) a->block_done(a->block_user, -1);               // everything else
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }

@@ -137,7 +137,8 @@ class DgsDitAttentionArgs(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("heads", ctypes.c_int32), ("L", ctypes.c_int32), ("lpad", ctypes.c_int32),
                 ("qk", ctypes.c_void_p), ("vt", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_float),
                 ("ld_qk", ctypes.c_int32), ("k_offset", ctypes.c_int32), ("vt_batch_stride", ctypes.c_int64),
-                ("lse2", ctypes.c_void_p), ("q_prescaled", ctypes.c_int32)]
+                ("lse2", ctypes.c_void_p), ("q_prescaled", ctypes.c_int32), ("tail_ws", ctypes.c_void_p),
+                ("tail_ws_bytes", ctypes.c_size_t)]
 
 
 class DgsDitAttentionBackwardArgs(ctypes.Structure):
@@ -205,7 +206,8 @@ class DgsDitForwardArgs(ctypes.Structure):
                 ("rotation", ctypes.c_void_p), ("opacity", ctypes.c_void_p), ("aligned_xyz", ctypes.c_void_p),
                 ("tokens", ctypes.c_void_p),
                 ("prof_events", ctypes.POINTER(ctypes.c_void_p)), ("prof_kind", ctypes.c_int32),
-                ("prof_capacity", ctypes.c_int32), ("prof_count", ctypes.POINTER(ctypes.c_int32))]
+                ("prof_capacity", ctypes.c_int32), ("prof_count", ctypes.POINTER(ctypes.c_int32)),
+                ("train_recompute", ctypes.c_int32)]
 
 
 class DgsDitLayerWeightsT(ctypes.Structure):
@@ -231,14 +233,19 @@ class DgsDitBackwardArgs(ctypes.Structure):
                 ("ray_d", ctypes.c_void_p), ("saved", ctypes.c_void_p), ("saved_bytes", ctypes.c_size_t),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
                 ("dxyz", ctypes.c_void_p), ("dfeatures", ctypes.c_void_p), ("dscaling", ctypes.c_void_p),
-                ("drotation", ctypes.c_void_p), ("dopacity", ctypes.c_void_p)]
+                ("drotation", ctypes.c_void_p), ("dopacity", ctypes.c_void_p), ("recompute", ctypes.c_int32),
+                ("block_done", ctypes.c_void_p), ("block_user", ctypes.c_void_p)]
+
+
+BLOCK_DONE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32)
 
 
 # every symbol include/dgs_dit.h declares (checked by tests/test_abi.py)
 DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward", "dgs_dit_layernorm_backward",
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
-               "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes", "dgs_dit_gemm_fused_splitk_bytes"]
+               "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes", "dgs_dit_gemm_fused_splitk_bytes",
+               "dgs_dit_attention_tail_bytes"]
 
 
 def _declare_dit(L):
@@ -254,6 +261,8 @@ def _declare_dit(L):
     L.dgs_dit_gemm_splitk_bytes.argtypes = [ctypes.c_int32] * 4
     L.dgs_dit_gemm_fused_splitk_bytes.restype = ctypes.c_size_t
     L.dgs_dit_gemm_fused_splitk_bytes.argtypes = [ctypes.c_int32] * 5
+    L.dgs_dit_attention_tail_bytes.restype = ctypes.c_size_t
+    L.dgs_dit_attention_tail_bytes.argtypes = [ctypes.c_int32] * 3
     L.dgs_dit_lpad.restype = ctypes.c_int32
     L.dgs_dit_lpad.argtypes = [ctypes.c_int32]
     L.dgs_dit_workspace_bytes.restype = ctypes.c_size_t
@@ -261,6 +270,7 @@ def _declare_dit(L):
     for fn in (L.dgs_dit_saved_bytes, L.dgs_dit_backward_workspace_bytes):
         fn.restype = ctypes.c_size_t
         fn.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.dgs_dit_saved_bytes.argtypes = L.dgs_dit_saved_bytes.argtypes + [ctypes.c_int32]
     L.dgs_dit_forward_train.restype = ctypes.c_int
     L.dgs_dit_forward_train.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitForwardArgs), ctypes.c_void_p,
                                         ctypes.c_size_t, ctypes.c_void_p]

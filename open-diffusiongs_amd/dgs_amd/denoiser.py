@@ -158,29 +158,65 @@ class _Head(nn.Module):
         self.adaLN_modulation = _seq(nn.Identity(), _Linear(w, 2 * w))
 
 
+def _aligned_to_points(d_aligned, ps):
+    """Inverse of the reference's "b (v h w ph pw) c -> b v c (h ph) (w pw)" rearrange (denoiser.py:371-379,401-406)."""
+    B, V, C, H, W = d_aligned.shape
+    x = d_aligned.reshape(B, V, C, H // ps, ps, W // ps, ps).permute(0, 1, 3, 5, 4, 6, 2)
+    return x.reshape(B, V * H * W, C)
+
+
+class _PendingGuard:
+    """Marks the engine's single activation arena as in use between a training forward and its backward."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        eng.pending_backward = id(self)      # a token, not a reference: the guard must die with the autograd graph
+
+    def release(self):
+        if self.eng.pending_backward == id(self):
+            self.eng.pending_backward = False
+
+    __del__ = release
+
+
 class _DitFunction(torch.autograd.Function):
-    """image_to_gaussians under torch autograd: forward = dgs_dit_forward_train (activations saved in the engine's arena,
-    nothing recomputed -- the reference checkpoints every block, denoiser.py:348-354), backward = dgs_dit_backward.  The
-    parameter gradients are views into the engine's flat fp32 buffer (dgs_amd.parallel.FlatGrads), returned to autograd
-    in named_parameters() order."""
+    """image_to_gaussians under torch autograd: forward = dgs_dit_forward_train (activations saved in the engine's arena;
+    per-block recompute when the module's checkpoint policy says so, denoiser.py:348-354), backward = dgs_dit_backward.
+    The parameter gradients land in the engine's flat fp32 buffer (dgs_amd.parallel.FlatGrads); autograd receives COPIES
+    of its slices in named_parameters() order (so .grad accumulation over several backward passes is correct), unless a
+    trainer owns the buffer (module._grads_in_place: the .grad tensors ARE views of it and nothing is copied)."""
 
     @staticmethod
     def forward(ctx, module, names, images, ray_o, ray_d, t, *params):
         eng = module.engine()
-        out, aligned = eng.forward_train(images, ray_o, ray_d, t)
-        ctx.engine, ctx.names, ctx.param_shapes = eng, names, [tuple(p.shape) for p in params]
-        ctx.mark_non_differentiable(aligned)
+        if eng.pending_backward:
+            raise RuntimeError("DGSDenoiser: a second training forward before the backward of the first one would overwrite "
+                               "its saved activations (one activation arena per engine); call backward() first")
+        B, V, _, H, W = images.shape
+        out, aligned = eng.forward_train(images, ray_o, ray_d, t, recompute=module.recompute_policy(B, V, H, W))
+        ctx.guard = _PendingGuard(eng)     # released by backward, or when the graph (and with it ctx) is dropped unused
+        ctx.engine, ctx.module, ctx.names, ctx.param_shapes = eng, module, names, [tuple(p.shape) for p in params]
         return out["xyz"], out["features"], out["scaling"], out["rotation"], out["opacity"], aligned
 
     @staticmethod
-    def backward(ctx, dxyz, dfeat, dscal, drot, dopa, _daligned):
-        z = lambda g, like: g if g is not None else torch.zeros(like, device=ctx.engine.device)
-        eng = ctx.engine
+    def backward(ctx, dxyz, dfeat, dscal, drot, dopa, daligned):
+        eng, module = ctx.engine, ctx.module
+        z = lambda g, like: g if g is not None else torch.zeros(like, device=eng.device)
         B, V, H, W = eng._train["shape"]
         P = eng.ng + V * H * W
-        eng.backward(z(dxyz, (B, P, 3)), z(dfeat, (B, P, 1, 3)), z(dscal, (B, P, 3)), z(drot, (B, P, 4)), z(dopa, (B, P, 1)))
+        dxyz = z(dxyz, (B, P, 3))
+        if daligned is not None:      # img_aligned_xyz is a rearranged view of xyz[:, n_gaussians:] (denoiser.py:401-409)
+            dxyz = dxyz.clone()
+            dxyz[:, eng.ng:] += _aligned_to_points(daligned.to(dxyz.dtype), eng.patch)
+        try:
+            eng.backward(dxyz, z(dfeat, (B, P, 1, 3)), z(dscal, (B, P, 3)), z(drot, (B, P, 4)), z(dopa, (B, P, 1)),
+                         block_hook=module._block_hook)
+        finally:
+            ctx.guard.release()
+        if module._grads_in_place:
+            return (None,) * (6 + len(ctx.names))
         views = eng.grad_views()
-        grads = tuple(views[n].reshape(shape) for n, shape in zip(ctx.names, ctx.param_shapes))
+        grads = tuple(views[n].reshape(shape).clone() for n, shape in zip(ctx.names, ctx.param_shapes))
         return (None, None, None, None, None, None) + grads
 
 
@@ -234,6 +270,9 @@ class DGSDenoiser(nn.Module):
         self.gs_renderer = Renderer(c, backend=RasterBackend(lib) if lib is not None else None)
         self.reset_parameters()
         self._engine, self._engine_version = None, None
+        self._block_hook = None          # set by a data-parallel trainer: called per finished gradient group during backward
+        self._grads_in_place = False     # set by a trainer that made the .grad tensors views of the flat gradient buffer
+        self.activation_budget_bytes = None   # None: 60 % of the device's free memory when the first training forward runs
         if c.pretrained_model_name_or_path:
             self._load_pretrained(c.pretrained_model_name_or_path)
 
@@ -263,16 +302,48 @@ class DGSDenoiser(nn.Module):
 
     # -- engine -------------------------------------------------------------------------------------------
     def engine(self):
+        """The device-resident bf16 copy of the parameters + workspaces.  Built once; when parameter versions change
+        (optimizer.step(), load_state_dict) the new values are copied INTO the existing buffers (no reallocation of the
+        weights, the activation arenas or the flat gradient buffer).  Updates that bypass version counters (`p.data = ...`,
+        an EMA swap) need an explicit `refresh_engine_weights()`."""
         version = tuple(p._version for p in self.parameters())
-        if self._engine is None or version != self._engine_version:
+        if self._engine is None:
             c = self.cfg
             self._engine = DitEngine(self.state_dict(), width=c.width, patch_size=c.patch_size, n_gaussians=c.n_gaussians,
                                      dim_heads=c.dim_heads, num_layers=c.num_layers, in_channels=c.in_channels,
                                      ray_pe_type=c.ray_pe_type, gaussians_sh_degree=c.gaussians_sh_degree, scene=self.SCENE,
                                      range_near=c.range_setting_near, range_far=c.range_setting_far, device=self.device,
                                      lib=self._lib)
-            self._engine_version = version
+        elif version != self._engine_version:
+            self._engine.refresh_weights(self.state_dict())
+        self._engine_version = version
         return self._engine
+
+    def refresh_engine_weights(self):
+        if self._engine is not None:
+            self._engine.refresh_weights(self.state_dict())
+            self._engine_version = tuple(p._version for p in self.parameters())
+
+    def recompute_policy(self, B, V, H, W):
+        """Per-block activation recompute (the reference's torch.utils.checkpoint(run_layers(i, i+1)), denoiser.py:348-354,
+        `use_checkpoint` / `grad_checkpoint_every: 1`) costs a fourth forward per step; MI355X has 288 GB, so it is only
+        used when saving every activation would not fit: use_checkpoint=False never recomputes; otherwise recompute iff the
+        save-all arena exceeds `activation_budget_bytes`."""
+        if not self.cfg.use_checkpoint:
+            return False
+        if self.cfg.grad_checkpoint_every != 1:
+            raise NotImplementedError("grad_checkpoint_every other than 1 (every shipped config uses 1)")
+        eng = self.engine()
+        need = eng.saved_bytes(B, V, H, W, recompute=False)
+        budget = self.activation_budget_bytes
+        if budget is None:
+            if self.device.type == "cuda":
+                tr = eng._train or {}
+                have = tr["saved"].numel() if tr.get("saved") is not None and not tr.get("recompute") else 0
+                budget = int(0.6 * (torch.cuda.mem_get_info(self.device)[0] + have))
+            else:
+                budget = 1 << 62
+        return need > budget
 
     # -- reference surface ------------------------------------------------------------------------------------
     def forward(self, input_batch, timesteps):   # denoiser.py:284-287
@@ -291,12 +362,20 @@ class DGSDenoiser(nn.Module):
         return out
 
     def image_to_gaussians(self, images, ray_o, ray_d, t, training=False):   # denoiser.py:306-416
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        ng = self.cfg.n_gaussians
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):   # differentiable in train AND eval mode
             names = [n for n, _ in self.named_parameters()]
             outs = _DitFunction.apply(self, names, images, ray_o, ray_d, t, *[p for _, p in self.named_parameters()])
-            out = dict(zip(("xyz", "features", "scaling", "rotation", "opacity"), outs[:5]))
-            return AttrDict(out), outs[5]
+            xyz, aligned = outs[0], outs[5]
+            if self.cfg.clip_xyz and training:        # denoiser.py:397-398 (no shipped caller passes training=True)
+                xyz = torch.cat((xyz[:, :ng], xyz[:, ng:].clamp(-1.0, 1.0)), dim=1)
+                aligned = aligned.clamp(-1.0, 1.0)
+            out = dict(zip(("xyz", "features", "scaling", "rotation", "opacity"), (xyz,) + tuple(outs[1:5])))
+            return AttrDict(out), aligned
         out, aligned = self.engine().image_to_gaussians(images, ray_o, ray_d, t)
+        if self.cfg.clip_xyz and training:
+            out["xyz"][:, ng:].clamp_(-1.0, 1.0)
+            aligned.clamp_(-1.0, 1.0)
         return AttrDict(out), aligned
 
     def render_gaussians(self, gaussian_params, c2w, fxfycxcy, height, width):   # denoiser.py:420-434

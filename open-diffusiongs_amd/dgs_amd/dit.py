@@ -89,6 +89,10 @@ class DitOps:
             a.ld_qk, a.k_offset, a.vt_batch_stride = 3 * W, W, 3 * W * lpad
             a.vt = ctypes.c_void_p(vt.data_ptr() + 2 * W * lpad * 2)
         a.lse2, a.q_prescaled = _p(lse2), int(q_prescaled)
+        nb = int(self.lib.dgs_dit_attention_tail_bytes(B, heads, L))
+        if nb:      # caller-owned scratch of the L % 32 tail queries (zero-filled: holds the arrival counters)
+            tail = torch.zeros(nb, dtype=torch.uint8, device=qk.device)
+            a.tail_ws, a.tail_ws_bytes = _p(tail), nb
         self._check(self.lib.dgs_dit_attention(ctypes.byref(a), _stream(qk.device)))
         return out
 
@@ -140,15 +144,14 @@ class DitEngine:
         self.heads = width // dim_heads
         self.gs_channels = 3 + 3 + 3 + 4 + 1
         sd = state_dict
-        bf = lambda k: sd[k].detach().to(self.device, torch.bfloat16).contiguous()
-        f32 = lambda k: sd[k].detach().to(self.device, torch.float32).contiguous()
+        bf = lambda k: torch.empty(tuple(sd[k].shape), dtype=torch.bfloat16, device=self.device)
+        f32 = lambda k: torch.empty(tuple(sd[k].shape), dtype=torch.float32, device=self.device)
         keep = {}
         keep["t_w0"], keep["t_b0"] = bf("t_embedder.mlp.0.weight"), f32("t_embedder.mlp.0.bias")
         keep["t_w1"], keep["t_b1"] = bf("t_embedder.mlp.2.weight"), f32("t_embedder.mlp.2.bias")
         keep["tok_w"] = bf("image_tokenizer.1.weight")
-        keep["pos_emb"] = f32("gaussians_pos_embedding").reshape(n_gaussians, width).contiguous()
+        keep["pos_emb"] = torch.empty((n_gaussians, width), dtype=torch.float32, device=self.device)
         keep["in_ln_w"] = f32("transformer_input_layernorm.weight")
-        ada_w, ada_b = [], []
         self._layers = (DgsDitLayerWeights * num_layers)()
         for i in range(num_layers):
             p = f"transformer.{i}."
@@ -157,13 +160,9 @@ class DitEngine:
                 keep[f"{i}.{short}_b"] = f32(p + key + ".bias")
                 setattr(self._layers[i], short + "_w", keep[f"{i}.{short}_w"].data_ptr())
                 setattr(self._layers[i], short + "_b", keep[f"{i}.{short}_b"].data_ptr())
-            ada_w.append(sd[p + "adaLN_modulation.1.weight"])
-            ada_b.append(sd[p + "adaLN_modulation.1.bias"])
-        for head in ("upsampler", "image_token_decoder"):
-            ada_w.append(sd[head + ".adaLN_modulation.1.weight"])
-            ada_b.append(sd[head + ".adaLN_modulation.1.bias"])
-        keep["ada_w"] = torch.cat([w.detach().float() for w in ada_w], 0).to(self.device, torch.bfloat16).contiguous()
-        keep["ada_b"] = torch.cat([b.detach().float() for b in ada_b], 0).to(self.device, torch.float32).contiguous()
+        nmod = (6 * num_layers + 4) * width
+        keep["ada_w"] = torch.empty((nmod, width), dtype=torch.bfloat16, device=self.device)
+        keep["ada_b"] = torch.empty((nmod,), dtype=torch.float32, device=self.device)
         keep["up_ln_w"], keep["up_w"] = f32("upsampler.layernorm.weight"), bf("upsampler.linear.weight")
         keep["dec_ln_w"], keep["dec_w"] = f32("image_token_decoder.layernorm.weight"), bf("image_token_decoder.linear.weight")
         self._keep = keep
@@ -178,6 +177,40 @@ class DitEngine:
         self.model = m
         self._ws, self._ws_shape = None, None
         self._train = None           # lazily built: transposed weights, gradient buffer, arenas
+        self.pending_backward = False
+        self.refresh_weights(sd)
+
+    # state-dict key of every engine tensor (adaLN tensors are stacked: see refresh_weights)
+    _DIRECT = (("t_w0", "t_embedder.mlp.0.weight"), ("t_b0", "t_embedder.mlp.0.bias"), ("t_w1", "t_embedder.mlp.2.weight"),
+               ("t_b1", "t_embedder.mlp.2.bias"), ("tok_w", "image_tokenizer.1.weight"), ("in_ln_w", "transformer_input_layernorm.weight"),
+               ("up_ln_w", "upsampler.layernorm.weight"), ("up_w", "upsampler.linear.weight"),
+               ("dec_ln_w", "image_token_decoder.layernorm.weight"), ("dec_w", "image_token_decoder.linear.weight"))
+
+    @torch.no_grad()
+    def refresh_weights(self, state_dict):
+        """Copy (and convert to bf16 / transpose) the current parameter values INTO the engine's existing device buffers:
+        what has to happen after every optimizer step.  Pointers, workspaces, the activation arenas and the flat gradient
+        buffer all stay as they are."""
+        sd, k, W, L = state_dict, self._keep, self.width, self.layers
+        for name, key in self._DIRECT:
+            k[name].copy_(sd[key])
+        k["pos_emb"].copy_(sd["gaussians_pos_embedding"].reshape(self.ng, W))
+        tk = self._train["tkeep"] if self._train is not None else None
+        for i in range(L):
+            p = f"transformer.{i}."
+            for short, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+                k[f"{i}.{short}_w"].copy_(sd[p + key + ".weight"])
+                k[f"{i}.{short}_b"].copy_(sd[p + key + ".bias"])
+                if tk is not None:
+                    tk[f"{i}.{short}"].copy_(k[f"{i}.{short}_w"].t())
+            k["ada_w"][6 * W * i:6 * W * (i + 1)].copy_(sd[p + "adaLN_modulation.1.weight"])
+            k["ada_b"][6 * W * i:6 * W * (i + 1)].copy_(sd[p + "adaLN_modulation.1.bias"])
+        o = 6 * W * L
+        for j, head in enumerate(("upsampler", "image_token_decoder")):
+            k["ada_w"][o + 2 * W * j:o + 2 * W * (j + 1)].copy_(sd[head + ".adaLN_modulation.1.weight"])
+            k["ada_b"][o + 2 * W * j:o + 2 * W * (j + 1)].copy_(sd[head + ".adaLN_modulation.1.bias"])
+        if tk is not None:
+            tk["dec"].copy_(k["dec_w"].t())
 
     def _workspace(self, B, V, H, W):
         need = int(self.lib.dgs_dit_workspace_bytes(ctypes.byref(self.model), B, V, H, W))
@@ -293,16 +326,24 @@ class DitEngine:
         out["image_token_decoder.layernorm.weight"], out["image_token_decoder.linear.weight"] = fg.view("dec_ln_w"), fg.view("dec_w")
         return out
 
-    def forward_train(self, images, ray_o, ray_d, t):
-        """image_to_gaussians that keeps what `backward` needs (no recomputation).  Returns (dict, aligned_xyz)."""
+    def saved_bytes(self, B, V, H, W, recompute=False):
+        """Bytes of the activation arena of one training forward (save-all, or the reference's per-block recompute mode)."""
+        return int(self.lib.dgs_dit_saved_bytes(ctypes.byref(self.model), B, V, H, W, int(bool(recompute))))
+
+    def forward_train(self, images, ray_o, ray_d, t, recompute=False):
+        """image_to_gaussians that keeps what `backward` needs.  recompute=False: every activation is saved, nothing is
+        recomputed; True: only block inputs are kept and `backward` re-runs each block (torch.utils.checkpoint's role,
+        denoiser.py:348-354).  Returns (dict, aligned_xyz)."""
         dev = self.device
         tr = self._train_state()
         B, V, _, H, W = images.shape
-        if tr["shape"] != (B, V, H, W):
+        recompute = bool(recompute)
+        if tr["shape"] != (B, V, H, W) or tr.get("recompute") != recompute:
             m = ctypes.byref(self.model)
-            tr["saved"] = torch.zeros(int(self.lib.dgs_dit_saved_bytes(m, B, V, H, W)), dtype=torch.uint8, device=dev)
+            tr["saved"] = tr["bws"] = None       # release before allocating the new arenas
+            tr["saved"] = torch.zeros(self.saved_bytes(B, V, H, W, recompute), dtype=torch.uint8, device=dev)
             tr["bws"] = torch.zeros(int(self.lib.dgs_dit_backward_workspace_bytes(m, B, V, H, W)), dtype=torch.uint8, device=dev)
-            tr["shape"] = (B, V, H, W)
+            tr["shape"], tr["recompute"] = (B, V, H, W), recompute
         img = images[:, :, :3].to(dev, torch.float32).contiguous()
         ro, rd = ray_o.to(dev, torch.float32).contiguous(), ray_d.to(dev, torch.float32).contiguous()
         tt = t.to(dev, torch.int64).contiguous()
@@ -315,14 +356,17 @@ class DitEngine:
         a.images, a.ray_o, a.ray_d, a.t = _p(img), _p(ro), _p(rd), _p(tt)
         a.xyz, a.features, a.scaling, a.rotation, a.opacity = (_p(out[k]) for k in ("xyz", "features", "scaling", "rotation", "opacity"))
         a.aligned_xyz = _p(aligned)
+        a.train_recompute = int(recompute)
         rc = self.lib.dgs_dit_forward_train(ctypes.byref(self.model), ctypes.byref(a), _p(tr["saved"]), tr["saved"].numel(), _stream(dev))
         if rc != 0:
             raise RuntimeError(f"dgs dit forward_train: {_native.status_string(self.lib, rc)} (status {rc})")
         tr["ray_d"] = rd
         return out, aligned
 
-    def backward(self, dxyz, dfeatures, dscaling, drotation, dopacity):
-        """Gradients of every parameter into the flat buffer (overwritten).  Must follow `forward_train`."""
+    def backward(self, dxyz, dfeatures, dscaling, drotation, dopacity, block_hook=None):
+        """Gradients of every parameter into the flat buffer (overwritten).  Must follow `forward_train`.
+        block_hook(stage) is called on the host as soon as a group of gradients has been ENQUEUED on the current stream
+        (stage = layers: heads, layers-1..0: that block, -1: the rest) -- the place to start a bucket's all-reduce."""
         tr = self._train_state()
         B, V, H, W = tr["shape"]
         dev = self.device
@@ -332,8 +376,20 @@ class DitEngine:
         a.ray_d = _p(tr["ray_d"])
         a.saved, a.saved_bytes, a.workspace, a.workspace_bytes = _p(tr["saved"]), tr["saved"].numel(), _p(tr["bws"]), tr["bws"].numel()
         a.dxyz, a.dfeatures, a.dscaling, a.drotation, a.dopacity = (_p(x) for x in g)
+        a.recompute = int(tr.get("recompute", False))
+        errors = []
+        if block_hook is not None:
+            def _cb(_user, stage):
+                try:
+                    block_hook(int(stage))
+                except BaseException as e:       # never unwind through the C frame
+                    errors.append(e)
+            cb = _native.BLOCK_DONE_FN(_cb)
+            a.block_done = ctypes.cast(cb, ctypes.c_void_p)
         rc = self.lib.dgs_dit_backward(ctypes.byref(self.model), ctypes.byref(tr["mt"]), ctypes.byref(tr["gr"]), ctypes.byref(a),
                                        _stream(dev))
         if rc != 0:
             raise RuntimeError(f"dgs dit backward: {_native.status_string(self.lib, rc)} (status {rc})")
+        if errors:
+            raise errors[0]
         return tr["fg"]

@@ -8,8 +8,10 @@ MI355X-first choices (xGMI is a point-to-point mesh, ring collectives are per-li
     its slice, so there is no per-tensor copy-in / copy-out around the collective;
   * the buffer is reduced in a few LARGE buckets (default 256 MiB, i.e. ~8 collectives for 1.84 GB instead of DDP's ~74
     of 25 MB) -- large messages are what saturates all seven links;
-  * a bucket is enqueued the moment the blocks that fill it have finished their backward (reverse layer order), on
-    RCCL's own stream behind an event, so the collectives overlap the rest of the backward.
+  * a bucket is enqueued the moment the blocks that fill it have finished their backward (reverse layer order): the C
+    backward calls back after every block (DgsDitBackwardArgs.block_done -> DataParallelTrainer._on_gradients_final ->
+    `ready_up_to`), the collective runs on RCCL's own stream behind the compute stream's work so far, and so overlaps the
+    backward of the earlier blocks.
 """
 import os
 
@@ -71,21 +73,26 @@ class BucketedAllReduce:
         n = flat.numel()
         self.bounds = [(a, min(n, a + per)) for a in range(0, n, per)]
         self.next_bucket, self.works = 0, []
+        self.launch_log = []          # (bucket index, tag) of the last step, in launch order (tests, diagnostics)
 
-    def ready_up_to(self, end_element):
-        """Everything in flat[:end_element] is final: launch every not-yet-launched bucket that lies inside it."""
-        if self.world == 1:
-            return
+    def ready_up_to(self, end_element, tag=None):
+        """Everything in flat[:end_element] is final (once the work enqueued on the current stream so far has run): launch
+        every not-yet-launched bucket that lies inside it.  `tag` only labels the launch in `launch_log`."""
+        if self.next_bucket == 0:
+            self.launch_log = []
         while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][1] <= end_element:
             a, b = self.bounds[self.next_bucket]
-            self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.world > 1:
+                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.launch_log.append((self.next_bucket, tag))
             self.next_bucket += 1
 
-    def finish(self):
-        """Launch what is left, wait for everything, turn sums into means.  Resets for the next step."""
-        if self.world > 1:
-            self.ready_up_to(self.flat.numel())
-            for w in self.works:
-                w.wait()
+    def finish(self, average=True):
+        """Launch what is left, wait for everything; average=True turns sums into means (a caller that already folded
+        1 / world into its loss scale passes False and saves the pass over the buffer).  Resets for the next step."""
+        self.ready_up_to(self.flat.numel(), tag="finish")
+        for w in self.works:
+            w.wait()
+        if self.world > 1 and average:
             self.flat.mul_(1.0 / self.world)
         self.works, self.next_bucket = [], 0

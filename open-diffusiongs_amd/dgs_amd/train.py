@@ -1,16 +1,20 @@
 """One data-parallel training step of the hot path (what PointDiffusionSystem.training_step does around the model,
 systems/diffusion_gs_system.py:71-128, minus the parts that are out of scope: noise schedule, LPIPS, logging):
 
-    gaussians = model.image_to_gaussians(noisy views)          DiT forward, activations saved        (HIP)
-    renders   = model.render_gaussians(gaussians, cameras)     all b*v views, one launch sequence    (HIP)
-    loss      = mean((renders - target)^2)                     the reference's lambda_mse term       (HIP: dgs_amd.losses, one pass)
-    loss.backward()                                            rasterizer backward + DiT backward    (HIP)
-    gradient all-reduce over the ranks                         RCCL over xGMI, a few large buckets   (dgs_amd.parallel)
+    gaussians = model.image_to_gaussians(noisy views)          DiT forward, activations saved / per-block recompute   (HIP)
+    renders   = model.render_gaussians(gaussians, cameras)     all b*v views, one launch sequence                     (HIP)
+    loss      = mean((renders - target)^2)                     the reference's lambda_mse term                        (HIP: dgs_amd.losses)
+    loss.backward()                                            rasterizer backward + DiT backward                     (HIP)
+      `- per finished gradient group: all-reduce of the buckets it completes, on RCCL's stream, WHILE the backward of the
+         earlier blocks is still being enqueued / executed                                                           (dgs_amd.parallel)
     optimizer step on the fp32 master parameters               torch.optim (AdamW in the reference configs)
+    refresh of the engine's bf16 / transposed weight copies    in place
 
-Lightning DDP in the reference (`strategy: ddp_find_unused_parameters_true`) reduces ~74 buckets of 25 MB; here the
-gradients already live in one flat buffer in backward-completion order, so the exchange is a handful of large
-collectives that start while earlier blocks are still in backward.
+Lightning DDP in the reference (`strategy: ddp_find_unused_parameters_true`, configs/diffusionGS_rel.yaml:80;
+scripts/train_obj_stage1.sh:5-7) reduces ~74 buckets of 25 MB behind autograd hooks.  Here dgs_dit_backward writes every
+gradient into ONE flat fp32 buffer in backward-completion order and calls back after each block (DgsDitBackwardArgs.block_done);
+the callback launches every bucket that just became final.  The parameters' .grad tensors ARE views of that buffer: the
+collective reduces them in place and nothing is copied in or out.  Averaging is folded into the loss scale.
 """
 import torch
 
@@ -19,35 +23,77 @@ from .parallel import BucketedAllReduce
 
 
 class DataParallelTrainer:
-    def __init__(self, model, optimizer, bucket_bytes=256 << 20):
+    def __init__(self, model, optimizer, bucket_bytes=256 << 20, accumulate_grad_batches=1, group=None):
         self.model, self.opt = model, optimizer
-        self.bucket_bytes = bucket_bytes
-        self._reducer = None
+        self.accumulate = int(accumulate_grad_batches)
+        eng = model.engine()
+        self.fg = eng._train_state()["fg"]
+        if next(model.parameters()).device != self.fg.flat.device:
+            raise RuntimeError("DataParallelTrainer: the module's parameters must live on the engine's device (model.to(device))")
+        self.reducer = BucketedAllReduce(self.fg.flat, bucket_bytes, group=group)
+        self.world = self.reducer.world
+        self._accum = torch.zeros_like(self.fg.flat) if self.accumulate > 1 else None
+        self._summed_to = 0
+        self._last_micro = True
+        self._layers = eng.layers
+        model._grads_in_place = True
+        model._block_hook = self._on_gradients_final
+        self._attach_grads()
+        self.last_psnr = None
 
-    def _reduce_gradients(self):
-        """All-reduce (mean) of the engine's flat gradient buffer; parameter .grad tensors are then refreshed from it."""
-        eng = self.model.engine()
-        fg = eng._train["fg"]
-        if self._reducer is None or self._reducer.flat.data_ptr() != fg.flat.data_ptr():
-            self._reducer = BucketedAllReduce(fg.flat, self.bucket_bytes)
-        if self._reducer.world > 1:
-            self._reducer.finish()
-            views = eng.grad_views()
-            with torch.no_grad():
-                for n, p in self.model.named_parameters():
-                    p.grad.copy_(views[n].reshape(p.shape))
+    def _attach_grads(self):
+        """.grad of every parameter = its slice of the flat buffer (adaLN slices included): written by the backward, reduced
+        in place by the collectives, read by the optimizer."""
+        views = self.model.engine().grad_views()
+        for n, p in self.model.named_parameters():
+            v = views[n].reshape(p.shape)
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+
+    def _end_of_stage(self, stage):
+        if stage < 0:
+            return self.fg.flat.numel()
+        if stage >= self._layers:
+            return self.fg.end_of("up_ln_w")
+        return self.fg.end_of(f"{stage}.qkv_b")
+
+    def _on_gradients_final(self, stage):
+        """Host callback from inside dgs_dit_backward: flat[:end] is final once the kernels enqueued so far have run."""
+        if not self._last_micro:
+            return
+        end = self._end_of_stage(stage)
+        if self._accum is not None and end > self._summed_to:      # fold in the earlier micro-batches, slice by slice
+            self.fg.flat[self._summed_to:end] += self._accum[self._summed_to:end]
+            self._summed_to = end
+        self.reducer.ready_up_to(end, tag=stage)
 
     def step(self, batch, t, target, render_c2w=None, render_fxfycxcy=None):
-        """batch: dict(image, ray_o, ray_d, c2w, fxfycxcy) like the reference's input_batch; target [b, v, 3, H, W]."""
-        m = self.model
-        self.opt.zero_grad(set_to_none=True)
-        params, _ = m.image_to_gaussians(batch["image"], batch["ray_o"], batch["ray_d"], t)
+        """batch: dict(image, ray_o, ray_d, c2w, fxfycxcy) like the reference's input_batch (leading dim = accumulate *
+        per-micro-batch size when accumulate_grad_batches > 1); target [b, v, 3, H, W].  Returns the (local) mean loss."""
+        m, K = self.model, self.accumulate
+        self._attach_grads()
         c2w = batch["c2w"] if render_c2w is None else render_c2w
         k = batch["fxfycxcy"] if render_fxfycxcy is None else render_fxfycxcy
         H, W = batch["image"].shape[3], batch["image"].shape[4]
-        rendered = m.render_gaussians(params, c2w, k, H, W)
-        loss, _l2, self.last_psnr = losses.mse_psnr(rendered, target.to(rendered.dtype), lib=getattr(m, "_lib", None))
-        loss.backward()
-        self._reduce_gradients()
+        nb = batch["image"].shape[0]
+        assert nb % K == 0, "batch size must be a multiple of accumulate_grad_batches"
+        mb = nb // K
+        total = 0.0
+        self._summed_to = 0
+        for j in range(K):
+            sl = slice(j * mb, (j + 1) * mb)
+            self._last_micro = j == K - 1
+            params, _ = m.image_to_gaussians(batch["image"][sl], batch["ray_o"][sl], batch["ray_d"][sl], t[sl])
+            rendered = m.render_gaussians(params, c2w[sl], k[sl], H, W)
+            loss, _l2, self.last_psnr = losses.mse_psnr(rendered, target[sl].to(rendered.dtype), lib=getattr(m, "_lib", None))
+            (loss * (1.0 / (K * self.world))).backward()       # mean over micro-batches and ranks folded into the scale
+            total = total + loss.detach()
+            if not self._last_micro:
+                if j == 0:
+                    self._accum.copy_(self.fg.flat)
+                else:
+                    self._accum += self.fg.flat
+        self.reducer.finish(average=False)
         self.opt.step()
-        return loss.detach()
+        m.engine()                                             # weights changed: refresh the bf16 / transposed copies in place
+        return total / K

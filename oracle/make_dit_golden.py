@@ -179,7 +179,7 @@ def main():
         print("wrote", path, {k: tuple(params[k].shape) for k in params})
 
 
-def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5):
+def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5, kinds=("obj", "scene")):
     """Fixture the gfx950 kernels can run (head_dim 64, width % 256 == 0): weights are NOT stored -- they are
     dit_oracle.parity_state_dict(cfg, seed), loaded into the reference modules with load_state_dict."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -189,6 +189,8 @@ def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5):
     out = {}
     for kind, modcls, extra in (("obj", obj.DGSDenoiser, dict(ray_pe_type="relative_plk")),
                                 ("scene", scene.DGSDenoiser, dict(ray_pe_type="plk", range_setting_near=0.0, range_setting_far=50.0))):
+        if kind not in kinds:
+            continue
         cfg = dict(width=width, in_channels=9, patch_size=8, n_gaussians=2, dim_heads=64, num_layers=layers,
                    gaussians_sh_degree=0, hard_pixelalign=True, **extra)
         model = modcls(cfg).float().eval()
@@ -218,5 +220,7 @@ def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5):
 if __name__ == "__main__":
     if "--hip" in sys.argv:
         main_hip()
+        # 258 tokens (res 64, 4 views): the attention kernel's multi-tile / ring / tail-merge paths, from the reference's code
+        main_hip(tag="hip256_l258", res=64, b=1, v=4, seed=9, kinds=("obj",))
     else:
         main()

@@ -30,6 +30,8 @@
 //     type_mat3x3.inl:486-519) is reproduced by struct M3 below.
 // =============================================================================
 #include <algorithm>
+#include <omp.h>
+#include <parallel/algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -267,7 +269,8 @@ int forward(Oracle& o) {
 
     const float* vm = o.vm.data();
     const float* pm = o.pm.data();
-    // ---- preprocessCUDA, forward.cu:155-256 ----
+    // ---- preprocessCUDA, forward.cu:155-256 ----  (one Gaussian per iteration, no shared state: OpenMP over Gaussians)
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < P; ++i) {
         const V3 p = {o.means[3 * i], o.means[3 * i + 1], o.means[3 * i + 2]};
         // in_frustum, auxiliary.h:139-164 (only the near-plane test is live)
@@ -344,8 +347,8 @@ int forward(Oracle& o) {
     // full 64-bit key: order = (tile, depth bits, emission order == Gaussian index).
     std::vector<uint32_t> perm(N);
     for (int k = 0; k < N; ++k) perm[k] = (uint32_t)k;
-    std::stable_sort(perm.begin(), perm.end(),
-                     [&](uint32_t a, uint32_t b) { return keys_uns[a] < keys_uns[b]; });
+    __gnu_parallel::stable_sort(perm.begin(), perm.end(),
+                                [&](uint32_t a, uint32_t b) { return keys_uns[a] < keys_uns[b]; });
     o.keys.resize(N); o.point_list.resize(N);
     for (int k = 0; k < N; ++k) { o.keys[k] = keys_uns[perm[k]]; o.point_list[k] = vals_uns[perm[k]]; }
     // ---- identifyTileRanges, rasterizer_impl.cu:116-138 (+ memset :310) ----
@@ -360,6 +363,8 @@ int forward(Oracle& o) {
     }
     // ---- renderCUDA, forward.cu:261-374 ----
     const float* feat = o.has_col_pre ? o.colors_pre.data() : o.rgb.data();
+    // tiles are independent ("OpenMP-over-tiles" CPU baseline); results do not depend on the thread count
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int ty = 0; ty < o.gy; ++ty)
         for (int tx = 0; tx < o.gx; ++tx) {
             const uint32_t r0 = o.ranges[2 * (ty * o.gx + tx)], r1 = o.ranges[2 * (ty * o.gx + tx) + 1];
@@ -669,6 +674,8 @@ extern "C" {
 void* dgs_oracle_create() { return new Oracle(); }
 void dgs_oracle_destroy(void* h) { delete static_cast<Oracle*>(h); }
 float dgs_oracle_det_expf(float x) { return det_expf(x); }
+// threads used by the forward's preprocess / sort / per-tile blend loops (0: OpenMP default = all cores); returns the count in effect
+int dgs_oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : omp_get_num_procs()); return omp_get_max_threads(); }
 
 // Mirrors CudaRasterizer::Rasterizer::forward's argument list (rasterizer.h / rasterizer_impl.cu:198-221);
 // null pointer == absent optional input.  Returns num_rendered, or <0 on error.

@@ -38,6 +38,8 @@ def lib():
         L.dgs_oracle_destroy.argtypes = [ctypes.c_void_p]
         L.dgs_oracle_det_expf.restype = ctypes.c_float
         L.dgs_oracle_det_expf.argtypes = [ctypes.c_float]
+        L.dgs_oracle_set_threads.restype = ctypes.c_int
+        L.dgs_oracle_set_threads.argtypes = [ctypes.c_int]
         L.dgs_oracle_forward.restype = ctypes.c_int
         L.dgs_oracle_forward.argtypes = [
             ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int,
@@ -73,6 +75,11 @@ _DT = {"out_color": np.float32, "radii": np.int32, "depths": np.float32, "means2
        "dL_dmeans2D": np.float32, "dL_dconic": np.float32, "dL_dopacity": np.float32,
        "dL_dcolors": np.float32, "dL_dmeans3D": np.float32, "dL_dcov3D": np.float32,
        "dL_dsh": np.float32, "dL_dscales": np.float32, "dL_drotations": np.float32}
+
+
+def set_threads(n=0):
+    """Threads of the forward's OpenMP loops (0 keeps the default: all host cores).  Returns the count in effect."""
+    return int(lib().dgs_oracle_set_threads(int(n)))
 
 
 def det_expf(x):

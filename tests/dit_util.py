@@ -30,10 +30,10 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-def golden_case(kind):
+def golden_case(kind, tag="hip256"):
     """(cfg, state_dict, inputs, reference outputs) of tests/golden/dit_golden_hip256.npz for kind in {'obj','scene'}."""
     import os
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_golden_hip256.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"dit_golden_{tag}.npz"))
     cfg = D.Cfg(width=int(z["width"]), num_layers=int(z["layers"]), scene=(kind == "scene"), range_far=50.0,
                 ray_pe_type="plk" if kind == "scene" else "relative_plk")
     sd = D.parity_state_dict(cfg, int(z["seed"]))

@@ -99,3 +99,98 @@ def test_training_step_end_to_end_emulated():
         if e > 0.1:
             bad.append((n_, e))
     assert not bad, bad[:5]
+
+
+def _tiny_model(seed=6, layers=1):
+    m = dn.DGSDenoiser(dict(OBJ_CFG, num_layers=layers), device="cpu", lib=emu_lib())
+    m.reset_parameters(seed=seed)
+    with torch.no_grad():
+        m.image_token_decoder.linear.weight.mul_(20.0)
+    return m
+
+
+def test_img_aligned_xyz_is_differentiable():
+    """The reference's loss_xyz / loss_pointsdist are built from the SECOND output of image_to_gaussians
+    (systems/diffusion_gs_system.py:90-104; lambda_pointsdist is the only active term of the first 150 steps): its gradient
+    must reach the parameters, and equal the gradient of the same function of xyz[:, n_gaussians:] (of which it is a view)."""
+    m = _tiny_model()
+    cfg = D.Cfg(width=256, num_layers=1)
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 1, 2, 16, seed=3)
+    w = torch.randn(1, 2, 3, 16, 16, generator=torch.Generator().manual_seed(0))
+    params, aligned = m.image_to_gaussians(images, ray_o, ray_d, t)
+    assert aligned.requires_grad
+    (aligned * w).sum().backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    assert float(g1["image_token_decoder.linear.weight"].abs().max()) > 0
+    m.zero_grad()
+    params, _ = m.image_to_gaussians(images, ray_o, ray_d, t)
+    ps = m.cfg.patch_size
+    pts = params.xyz[:, m.cfg.n_gaussians:].reshape(1, 2, 16 // ps, 16 // ps, ps, ps, 3).permute(0, 1, 6, 2, 4, 3, 5).reshape(1, 2, 3, 16, 16)
+    assert torch.equal(pts.detach(), aligned.detach())          # the rearrange of denoiser.py:371-379
+    (pts * w).sum().backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, g1[n], rtol=1e-5, atol=1e-7), n
+
+
+def test_gradient_accumulation_and_pending_forward():
+    """Two backward passes before zero_grad accumulate g1 + g2 in .grad (autograd receives copies of the flat buffer's
+    slices); a second training forward before the first one's backward is refused (one activation arena); a forward whose
+    graph is dropped unused releases the arena; eval mode with grad enabled is differentiable too."""
+    import pytest
+    m = _tiny_model(seed=7)
+    cfg = D.Cfg(width=256, num_layers=1)
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 2, 2, 16, seed=5)
+    f = lambda sl: m.image_to_gaussians(images[sl], ray_o[sl], ray_d[sl], t[sl])[0]
+    loss = lambda p: (p.xyz ** 2).mean() + (p.opacity ** 2).mean() + (p.features ** 2).mean()
+    loss(f(slice(0, 1))).backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    loss(f(slice(1, 2))).backward()
+    g2 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    loss(f(slice(0, 1))).backward()
+    loss(f(slice(1, 2))).backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, g1[n] + g2[n], rtol=1e-5, atol=1e-8), n
+    a = f(slice(0, 1))
+    with pytest.raises(RuntimeError, match="second training forward"):
+        f(slice(1, 2))
+    del a                                                       # graph dropped without backward: arena released
+    import gc; gc.collect()
+    m.eval()
+    b = f(slice(1, 2))
+    assert b.xyz.grad_fn is not None
+    loss(b).backward()
+    with torch.no_grad():
+        assert f(slice(0, 1)).xyz.grad_fn is None
+
+
+def test_engine_survives_optimizer_steps_in_place():
+    """optimizer.step() changes parameter versions: the engine must pick the new weights up IN PLACE (same engine, same
+    device buffers, same flat gradient buffer) -- and an update that bypasses version counters needs the explicit refresh."""
+    m = _tiny_model(seed=9)
+    cfg = D.Cfg(width=256, num_layers=1)
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 1, 2, 16, seed=5)
+    eng = m.engine()
+    ptr = eng._keep["0.qkv_w"].data_ptr()
+    opt = torch.optim.SGD(m.parameters(), lr=0.5)
+    p0, _ = m.image_to_gaussians(images, ray_o, ray_d, t)
+    (p0.xyz ** 2).mean().backward()
+    flat_ptr = eng._train["fg"].flat.data_ptr()
+    opt.step()
+    with torch.no_grad():
+        p1, _ = m.image_to_gaussians(images, ray_o, ray_d, t)
+    assert m.engine() is eng and eng._keep["0.qkv_w"].data_ptr() == ptr and eng._train["fg"].flat.data_ptr() == flat_ptr
+    assert not torch.equal(p0.xyz.detach(), p1.xyz)
+    fresh = dn.DGSDenoiser(dict(OBJ_CFG, num_layers=1), device="cpu", lib=emu_lib())
+    fresh.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        p2, _ = fresh.image_to_gaussians(images, ray_o, ray_d, t)
+    assert torch.equal(p1.xyz, p2.xyz)                           # refreshed engine == engine built from the new weights
+    # and the transposed copies used by the backward were refreshed too
+    assert torch.equal(eng._train["tkeep"]["0.fc1"], eng._keep["0.fc1_w"].t())
+    m.transformer[0].mlp.fc2.weight.data = m.transformer[0].mlp.fc2.weight.data * 2.0     # bypasses the version counter
+    m.refresh_engine_weights()
+    with torch.no_grad():
+        p3, _ = m.image_to_gaussians(images, ray_o, ray_d, t)
+    assert not torch.equal(p3.xyz, p1.xyz)

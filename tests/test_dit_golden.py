@@ -29,3 +29,11 @@ def test_emulated_hip_matches_reference_golden(kind):
     for k in FIELDS:
         assert rel_l2(out[k], ref[k]) < 2e-2, (k, rel_l2(out[k], ref[k]))
     assert rel_l2(aligned, ref["aligned"]) < 2e-2
+
+
+def test_oracle_matches_reference_golden_258_tokens():
+    cfg, sd, inp, ref = golden_case("obj", tag="hip256_l258")
+    out, aligned = D.image_to_gaussians(sd, cfg, inp["images"], inp["ray_o"], inp["ray_d"], inp["t"])
+    for k in FIELDS:
+        assert rel_l2(out[k], ref[k]) < 1e-5, k
+    assert rel_l2(aligned, ref["aligned"]) < 1e-5

@@ -108,10 +108,12 @@ def test_gemm_training_epilogues_production_shapes(algo):
 
 
 @pytest.mark.parametrize("prescaled", [True, False])
-@pytest.mark.parametrize("L,B", [(4098, 1), (258, 2), (1026, 1)])
+@pytest.mark.parametrize("L,B", [(4098, 1), (258, 2), (1026, 1), (16386, 1), (290, 1), (18, 2), (4130, 1)])
 def test_attention_production_shapes(L, B, prescaled):
     """prescaled: q arrives as bf16(scale * log2(e) * q) like from the QKV GEMM epilogue (one rounding, the path the
-    denoiser uses); otherwise the kernel scales the bf16 queries itself (a second bf16 rounding: looser max-abs bound)."""
+    denoiser uses); otherwise the kernel scales the bf16 queries itself (a second bf16 rounding: looser max-abs bound).
+    L = 16386 is the 512^2 configuration (BASELINE configs[4]); 290 / 4130 have a tail tile behind a number of full tiles
+    that is not a multiple of the 8 waves, 18 has no full tile at all (the tail-record hand-off of every wave shape)."""
     heads = 16
     lpad = (L + 127) // 128 * 128
     g = torch.Generator(device=DEV).manual_seed(L)
@@ -123,10 +125,16 @@ def test_attention_production_shapes(L, B, prescaled):
     qk = torch.cat([qb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64), kb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64)], 1).contiguous()
     vt = vb.permute(0, 1, 3, 2).reshape(B, heads * 64, lpad).contiguous()
     out = _ops().attention(qk, vt, L, heads, q_prescaled=prescaled).float().reshape(B, lpad, heads, 64).permute(0, 2, 1, 3)[:, :, :L]
-    s = (qb.double()[:, :, :L] @ kb.double()[:, :, :L].transpose(-1, -2)) * (0.6931471805599453 if prescaled else 0.125)
-    ref = s.softmax(-1) @ vb.double()[:, :, :L]
-    assert rel_l2(out, ref) < 6e-3
-    assert float((out.double() - ref).abs().max()) < (3e-2 if prescaled else 4e-2)
+    num = den = 0.0
+    worst = 0.0
+    for b in range(B):
+        for h in range(heads):     # one head at a time: the fp64 score matrix of L = 16386 is 2 GB
+            s = (qb[b, h, :L].double() @ kb[b, h, :L].double().t()) * (0.6931471805599453 if prescaled else 0.125)
+            ref = s.softmax(-1) @ vb[b, h, :L].double()
+            d = out[b, h].double() - ref
+            num += float((d * d).sum()); den += float((ref * ref).sum()); worst = max(worst, float(d.abs().max()))
+    assert (num / den) ** 0.5 < 6e-3
+    assert worst < (3e-2 if prescaled else 4e-2)
 
 
 @pytest.mark.parametrize("kind", ["obj", "scene"])
@@ -141,12 +149,26 @@ def test_forward_matches_reference_golden(kind):
     assert rel_l2(aligned.cpu(), ref["aligned"]) < 2e-2
 
 
-def _full_model_case(res, B, oracle_device):
+@pytest.mark.parametrize("kind", ["obj"])
+def test_forward_matches_reference_golden_258_tokens(kind):
+    """A fixture from the reference's own denoiser code at 258 tokens (res 64, 4 views): multi-tile attention, the key
+    ring and the learned-token tail merge are pinned to the reference directly, not through the oracle."""
     from dgs_amd.dit import DitEngine
-    cfg = D.Cfg()   # width 1024, 24 blocks, patch 8: the shipped object model
+    cfg, sd, inp, ref = golden_case(kind, tag="hip256_l258")
+    eng = DitEngine(sd, width=cfg.width, num_layers=cfg.num_layers, ray_pe_type=cfg.ray_pe_type, scene=cfg.scene,
+                    range_near=cfg.range_near, range_far=cfg.range_far, device=DEV)
+    out, aligned = eng.image_to_gaussians(inp["images"], inp["ray_o"], inp["ray_d"], inp["t"])
+    for k in FIELDS:
+        assert rel_l2(out[k].cpu(), ref[k]) < 2e-2, (k, rel_l2(out[k].cpu(), ref[k]))
+    assert rel_l2(aligned.cpu(), ref["aligned"]) < 2e-2
+
+
+def _full_model_case(res, B, oracle_device, scene=False):
+    from dgs_amd.dit import DitEngine
+    cfg = D.Cfg(scene=scene, ray_pe_type="plk" if scene else "relative_plk")   # width 1024, 24 blocks, patch 8: the shipped models
     sd = D.parity_state_dict(cfg, seed=11)
     images, ray_o, ray_d, t, _, _ = synth_inputs(cfg, B, 4, res, seed=3)
-    eng = DitEngine(sd, device=DEV)
+    eng = DitEngine(sd, device=DEV, scene=cfg.scene, ray_pe_type=cfg.ray_pe_type, range_near=cfg.range_near, range_far=cfg.range_far)
     out, aligned = eng.image_to_gaussians(images, ray_o, ray_d, t, return_tokens=True)
     torch.cuda.synchronize()
     sd_o = {k: v.to(oracle_device) for k, v in sd.items()}
@@ -166,6 +188,11 @@ def test_full_model_64_vs_cpu_oracle():
 
 def test_full_model_256_vs_fp32_oracle_on_gpu():
     _full_model_case(256, 1, DEV)
+
+
+def test_full_model_512_vs_fp32_oracle_on_gpu():
+    """BASELINE configs[4] (scene model, 512^2): L = 16,386 tokens, P = 1,048,578 Gaussians, all 24 blocks."""
+    _full_model_case(512, 1, DEV, scene=True)
 
 
 def test_denoiser_forward_end_to_end_256():

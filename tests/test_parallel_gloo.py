@@ -79,7 +79,11 @@ def _train_worker(rank, world, port, out):
     tr = DataParallelTrainer(m, torch.optim.SGD(m.parameters(), lr=0.0), bucket_bytes=1 << 20)
     loss = tr.step(batch, t[sl], target)
     g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
-    out.put((rank, float(loss), g.numpy()))
+    # the .grad tensors ARE the flat buffer (reduced in place, nothing copied out)
+    flat = tr.fg.flat
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    assert all(lo <= p.grad.data_ptr() < hi for p in m.parameters())
+    out.put((rank, float(loss), g.numpy(), list(tr.reducer.launch_log)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -107,6 +111,54 @@ def test_data_parallel_step_equals_single_process_step():
     p1.join(60)
     res.sort(key=lambda r: r[0])
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=0)            # ranks hold identical averaged gradients
+    # overlap: buckets were enqueued from inside dgs_dit_backward (tag = the block / head group that completed them), i.e.
+    # BEFORE the backward call returned; at most the last partial bucket is left for finish()
+    log = res[0][3]
+    early = [b for b, tag in log if isinstance(tag, int)]
+    assert len(early) >= 2 and len(early) >= len(log) - 1, log
+    assert [b for b, _ in log] == list(range(len(log)))
+    assert any(tag == 0 for _, tag in log) and any(tag == -1 for _, tag in log), log    # completed by block 0, then by the rest
     np.testing.assert_allclose(0.5 * (res[0][1] + res[1][1]), single[1], rtol=1e-5)
     denom = np.abs(single[2]).max()
     assert np.abs(res[0][2] - single[2]).max() <= 2e-3 * denom
+
+
+def _accum_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "..", "open-diffusiongs_amd"), os.path.join(here, "..")):
+        sys.path.insert(0, os.path.abspath(p))
+    from dgs_amd import denoiser as dn
+    from dgs_amd.train import DataParallelTrainer
+    from dit_util import synth_inputs
+    from emu_util import emu_lib
+    from oracle import dit_oracle as D
+    cfg = D.Cfg(width=256, num_layers=1)
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 2, 2, 16, seed=9)
+    batch = dict(image=images, ray_o=ray_o, ray_d=ray_d, c2w=c2w, fxfycxcy=k)
+    target = torch.rand(2, 2, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    res = []
+    for accumulate in (1, 2):
+        m = dn.DGSDenoiser(dict(width=256, in_channels=9, patch_size=8, num_layers=1), device="cpu", lib=emu_lib())
+        m.reset_parameters(seed=1)
+        tr = DataParallelTrainer(m, torch.optim.SGD(m.parameters(), lr=0.0), bucket_bytes=1 << 20, accumulate_grad_batches=accumulate)
+        loss = tr.step(batch, t, target)
+        res.append((float(loss), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()))
+    out.put(res)
+
+
+def test_accumulate_grad_batches_equals_one_large_batch():
+    """accumulate_grad_batches = 2 over micro-batches of 1 == one batch of 2 (the way the 512^2 configuration reaches the
+    reference's per-rank batch of 12 with micro-batches of 4): gradients of the earlier micro-batches are folded into the
+    flat buffer slice by slice inside the last backward, right before each bucket's all-reduce."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_accum_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    (l1, g1), (l2, g2) = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert abs(l1 - l2) < 1e-6 * max(1.0, abs(l1))
+    assert np.abs(g1 - g2).max() <= 2e-3 * np.abs(g1).max()

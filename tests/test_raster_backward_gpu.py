@@ -31,6 +31,15 @@ def test_diffusiongs_shaped(res, regime, views):
     assert_backward_parity(_backend(), sc, cams, res, res, DEV)
 
 
+@pytest.mark.parametrize("regime,views", [("trained", 2), ("init", 1)])
+def test_full_size_256_vs_oracle(regime, views):
+    """256^2, P = 262,146 (BASELINE configs[2]/[3]): all gradients against the oracle's fp64-accumulated sums, in the
+    trained-like regime and in the regime the bench / a random-init training step renders."""
+    sc = synth.gaussian_scene(256, regime=regime, seed=0)
+    cams, _, _ = synth.render_cameras(256, 4, phase_deg=10)
+    assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV)
+
+
 def test_precomputed_colors_and_long_lists():
     H, W = 32, 48
     sc, cams = small_scene(120, W, H, seed=8, n_views=2)

@@ -42,6 +42,43 @@ def test_diffusiongs_shaped_bit_exact(res, regime, views):
     assert_forward_parity(_backend(), sc, cams, res, res, _dev())
 
 
+def test_bench_regime_256_four_views_and_512_bit_exact(request, binning_form):
+    """The regime bench.py renders (random-init Gaussians, N/P ~ 50) at 256^2, 4 views in one call, and one view of the 512^2
+    configuration (P = 1,048,578): every artefact bit-exact against the oracle.  Device-chosen binning form only (the forced
+    forms are covered at the smaller sizes above)."""
+    if request.node.callspec.params["binning_form"] != "auto":
+        pytest.skip("full-size oracle runs once")
+    sc = synth.gaussian_scene(256, regime="init", seed=0)
+    cams, _, _ = synth.render_cameras(256, 4, phase_deg=10)
+    assert_forward_parity(_backend(), sc, cams, 256, 256, _dev())
+    sc = synth.gaussian_scene(512, regime="trained", seed=1)
+    cams, _, _ = synth.render_cameras(512, 2, phase_deg=5)
+    assert_forward_parity(_backend(), sc, cams[1:], 512, 512, _dev())
+
+
+def test_camera_and_ray_kernels_match_oracle_on_gpu(request):
+    """`Camera` (gs_core.py:277-316) and `TransformInput` (systems/utils.py:621-757) kernels on the MI355X vs the oracle's
+    torch restatements (pinned against the reference's own functions in tests/test_dit_oracle.py), incl. the 512^2 shape."""
+    if request.node.callspec.params["binning_form"] != "auto":
+        pytest.skip("independent of the binning form")
+    from dgs_amd import cameras
+    from oracle import dit_oracle as D
+    be = _backend()
+    for (B, V, H, W) in ((2, 3, 24, 40), (1, 4, 256, 256), (2, 2, 512, 512)):
+        c2w = torch.tensor(np.stack([cameras.ring_cameras(V, phase_deg=21.0 * b, radius=2.5 + b) for b in range(B)]))
+        k = torch.tensor(cameras.default_fxfycxcy(W, H)).expand(B, V, 4).contiguous() * torch.tensor([1.0, 1.1, 0.97, 1.02])
+        ro, rd = be.rays_from_c2w(c2w.to(_dev()), k.to(_dev()), H, W)
+        ro_ref, rd_ref = D.transform_input_rays(c2w, k, H, W)
+        np.testing.assert_allclose(ro.cpu().numpy(), ro_ref.numpy(), atol=1e-6)
+        np.testing.assert_allclose(rd.cpu().numpy(), rd_ref.numpy(), atol=2e-6)
+        view, proj, campos, tanfov = be.cameras_from_c2w(c2w.to(_dev()), k.to(_dev()), H, W)
+        v_ref, p_ref, c_ref, t_ref = D.camera_matrices(c2w.reshape(-1, 4, 4), k.reshape(-1, 4), H, W)
+        np.testing.assert_allclose(view.cpu().numpy(), v_ref.numpy(), atol=2e-6)
+        np.testing.assert_allclose(proj.cpu().numpy(), p_ref.numpy(), atol=2e-5)
+        np.testing.assert_allclose(campos.cpu().numpy(), c_ref.numpy(), atol=0)
+        np.testing.assert_allclose(tanfov.cpu().numpy(), t_ref.numpy(), rtol=1e-6)
+
+
 def test_many_instances_ties_and_windows():
     H, W = 48, 48
     sc, cams = small_scene(5000, W, H, seed=9, log_scale=-1.2)

@@ -1,0 +1,103 @@
+"""HBM traffic per launch from the PMC counters, as MI355X_MICROARCH.md's HBM / rocprofv3 sections prescribe: FETCH_SIZE and
+WRITE_SIZE in SEPARATE `rocprofv3 --kernel-trace --pmc` passes (never combined with other tracing), FETCH_SIZE doubled (gfx950
+tallies a 128-B request as 64 B), units KiB.  Passes run over bench.py itself (DiT kernels) and over this file's
+`--target` mode (the rasterizer, per regime, forward and forward+backward).
+
+    python tools/pmc_traffic.py            -> profiles/pmc_traffic.json (+ gpurun_out/pmc/ raw csv)
+
+The JSON carries the SHA-256 of the kernel sources it was measured on; bench.py reports `traffic` only when that matches
+the sources it runs.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "open-diffusiongs_amd"))
+
+
+def target(regime, what, iters):
+    import numpy as np
+    import torch
+    from dgs_amd import cameras, synth
+    from dgs_amd.raster import default_backend, render_views_autograd
+    dev, res, V = torch.device("cuda:0"), 256, 4
+    be = default_backend()
+    tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
+    sc = synth.gaussian_scene(res, regime=regime, seed=0, activated=False)
+    leaves = [tt(sc[k])[None].requires_grad_(what != "forward") for k in ("xyz", "shs", "scales", "rotations", "opacities")]
+    c2w = tt(cameras.ring_cameras(V, phase_deg=10))[None]
+    k = tt(cameras.default_fxfycxcy(res)).expand(1, V, 4).contiguous()
+    w = torch.randn(1, V, 3, res, res, device=dev) / (3 * res * res)
+    for _ in range(iters):
+        if what == "forward":
+            be.render_views(*leaves, res, res, c2w, k)
+        else:
+            for x in leaves:
+                x.grad = None
+            render_views_autograd(be, *leaves, res, res, c2w, k).backward(w)
+    torch.cuda.synchronize()
+
+
+def collect(counter, out_dir, cmd):
+    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--"] + cmd,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    rows = {}
+    for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            d = rows.setdefault(r.get("Kernel_Name", "?"), [0.0, 0])
+            d[0] += float(r.get("Counter_Value", 0) or 0)
+            d[1] += 1
+    return rows
+
+
+def main():
+    from bench import kernel_source_sha
+    raw = os.path.join(ROOT, "gpurun_out", "pmc")
+    os.makedirs(raw, exist_ok=True)
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+    out = {"_source": "tools/pmc_traffic.py: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes; FETCH_SIZE x 2 "
+                      "(MI355X_MICROARCH.md, HBM); KiB -> bytes; averages per dispatch (dit) / per call of 4 views at 256^2 (raster)",
+           "kernel_source_sha": kernel_source_sha(), "git_head": head or None, "dit": {}, "raster": {}, "kernels": {}}
+    py = sys.executable
+    bench = [py, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras"]
+    f = collect("FETCH_SIZE", os.path.join(raw, "dit_fetch"), bench)
+    w = collect("WRITE_SIZE", os.path.join(raw, "dit_write"), bench)
+    for name in sorted(set(f) | set(w)):
+        if "dgs::" not in name:
+            continue
+        fb = 2.0 * 1024 * f[name][0] / max(f[name][1], 1) if name in f else None
+        wb = 1024.0 * w[name][0] / max(w[name][1], 1) if name in w else None
+        out["kernels"][name[:90]] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "launches": f.get(name, w.get(name))[1]}
+        if "attention_fwd_kernel" in name and fb is not None and wb is not None:
+            out["dit"]["attention"] = {"fetch_bytes_per_launch": int(fb), "write_bytes_per_launch": int(wb),
+                                       "traffic_bytes_per_launch": int(fb + wb), "algorithmic_bytes_per_launch": 4098 * 1024 * 2 * 4}
+    iters = 3
+    for regime in ("init", "trained"):
+        out["raster"][regime] = {}
+        for what in ("forward", "forward_backward"):
+            cmd = [py, os.path.abspath(__file__), "--target", regime, what, str(iters)]
+            f = collect("FETCH_SIZE", os.path.join(raw, f"raster_{regime}_{what}_fetch"), cmd)
+            w = collect("WRITE_SIZE", os.path.join(raw, f"raster_{regime}_{what}_write"), cmd)
+            fb = sum(2.0 * 1024 * v[0] for k, v in f.items() if "dgs::" in k) / iters
+            wb = sum(1024.0 * v[0] for k, v in w.items() if "dgs::" in k) / iters
+            out["raster"][regime][what] = int(fb + wb)
+            out["raster"][regime][what + "_detail"] = {"fetch_bytes": int(fb), "write_bytes": int(wb), "calls": iters,
+                                                       "per_kernel_fetch_bytes": {k[:60]: int(2048 * v[0] / iters) for k, v in f.items() if "dgs::" in k}}
+    path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("dit", "raster")}, indent=1))
+    print("wrote", path, "-> copy to profiles/pmc_traffic.json")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--target":
+        target(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    else:
+        main()
