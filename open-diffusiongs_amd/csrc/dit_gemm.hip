@@ -26,6 +26,8 @@ constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB: A tile of one stage (the W 
 struct GemmParams {
     int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles, tiles_m, map_mode;
     int rows_ps, full_rows;          // per sample: 128-row tile rows, and how many of them hold a live 32-row block (a prefix)
+    int ntail, tail_row0;            // GEMV items (one 32-column block of one sample each) for a last tile row with <= 2 live rows,
+                                     // taken by the first `ntail` workgroups; tail_row0 = that row's first token (row in sample)
     int k_per_batch;                 // reduction elements per sample (K when the reduction dimension is not batched)
     long long a_batch_stride, w_batch_stride;   // element stride between samples along the reduction (weight-gradient GEMMs)
     const bf16_t* A;
@@ -127,6 +129,73 @@ __device__ __forceinline__ void main_loop(const GemmParams& p, char* lds, int m0
     }
 }
 
+// The <= 2 live rows behind a sample's last full 128-row tile (the DiT's two learned tokens: L = 4098 = 32 x 128 + 2) as
+// a GEMV on the vector pipe.  As a 33rd tile row these two rows cost a whole extra tile per tile column -- 528 tiles for
+// 512 two-per-CU slots: the N = 1024 GEMMs took 71 us instead of 52 (fc2) and 24 instead of 20 (proj).  An item = 8 output
+// columns of one sample, a small workgroup BEHIND the tiles in the grid: the 512 tiles are placed first, two per CU, and the
+// items take the third (LDS-limited) slot of some CUs right away.  (Items placed first shifted the tile placement: some CUs got
+// three tiles, +10 us.)  While the chip
+// streams GEMM tiles an L2 round trip costs microseconds, so an item is ONE trip: the four waves split K, every wave
+// issues all of its loads (8 columns x its K quarter, 16 bytes per lane) before the first v_dot2c_f32_bf16; the partial
+// sums meet in LDS and 16 lanes apply the epilogue element-wise (same arithmetic as store_strip).
+template <int EPI>
+__device__ __forceinline__ void tail_store(const GemmParams& p, int m, int n, float v) {
+    v += p.bias ? p.bias[n] : 0.0f;
+    const int b = m / p.rows_per_batch;
+    const size_t o = (size_t)m * p.ldo + n;
+    auto bf1 = [](float x) { return (bf16_t)(pack_bf2(x, 0.0f) & 0xffffu); };
+    if (EPI == DGS_EPI_F32) { reinterpret_cast<float*>(p.out)[o] = v; return; }
+    if (EPI == DGS_EPI_GATE_RESIDUAL) {
+        reinterpret_cast<float*>(p.out)[o] = p.resid[o] + p.gate[(size_t)b * p.gate_stride + n] * v;
+        if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = bf1(v);
+        return;
+    }
+    if (EPI == DGS_EPI_GELU_BF16) {
+        if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = bf1(v);
+        v = epi_gelu_tanh(v);
+    } else if (EPI == DGS_EPI_DGELU_BF16) {
+        v *= epi_dgelu_tanh(__uint_as_float((unsigned)reinterpret_cast<const bf16_t*>(p.aux)[o] << 16));
+    }
+    reinterpret_cast<bf16_t*>(p.out)[o] = bf1(v);
+    if (p.vt) p.vt[((size_t)b * p.N + n) * p.rows_per_batch + (m - b * p.rows_per_batch)] = bf1(v);
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemv_tail_rows(const GemmParams& p, char* lds, int item, int wave, int lane) {
+    constexpr int CPI = 8;                                   // columns per item
+    const int nblk = p.N / CPI, b = item / nblk, tn0 = (item - b * nblk) * CPI;
+    const int tm0 = b * p.rows_per_batch + p.tail_row0;
+    const int kw = p.K / 4, k_lo = wave * kw;                // this wave's K quarter (K % 512 == 0: a multiple of 128)
+    const int nch = (kw + 511) / 512;                        // 512-element chunks (64 lanes x 8), at most 2 (K <= 4096)
+    const bool on0 = lane * 8 < kw, on1 = 512 + lane * 8 < kw;
+    const bf16_t* a_row0 = p.A + (size_t)tm0 * p.lda + k_lo + lane * 8;
+    const bf16_t* w_col0 = p.W + (size_t)tn0 * p.ldw + k_lo + lane * 8;
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    uint4 a[2][2], w[CPI][2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const bool on = ch == 0 ? on0 : (on1 && nch > 1);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) a[r][ch] = on ? *reinterpret_cast<const uint4*>(a_row0 + (size_t)r * p.lda + ch * 512) : zero;
+#pragma unroll
+        for (int c = 0; c < CPI; ++c) w[c][ch] = on ? *reinterpret_cast<const uint4*>(w_col0 + (size_t)c * p.ldw + ch * 512) : zero;
+    }
+    float* const part = reinterpret_cast<float*>(lds);       // [wave][row][column]
+#pragma unroll
+    for (int c = 0; c < CPI; ++c) {
+        float s0 = dot8_bf16(a[0][0], w[c][0], 0.f), s1 = dot8_bf16(a[1][0], w[c][0], 0.f);
+        s0 = dot8_bf16(a[0][1], w[c][1], s0); s1 = dot8_bf16(a[1][1], w[c][1], s1);
+        s0 = wave_sum(s0); s1 = wave_sum(s1);
+        if (lane == 0) { part[(wave * 2 + 0) * CPI + c] = s0; part[(wave * 2 + 1) * CPI + c] = s1; }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 2 * CPI) {
+        const int r = lane / CPI, c = lane - r * CPI;
+        const float v = (part[(0 * 2 + r) * CPI + c] + part[(1 * 2 + r) * CPI + c]) + (part[(2 * 2 + r) * CPI + c] + part[(3 * 2 + r) * CPI + c]);
+        if (p.tail_row0 + r < p.valid_rows) tail_store<EPI>(p, tm0 + r, tn0 + c, v);
+    }
+}
+
 // BN = 128: waves 2(M) x 2(N), each 64 x 64 (2 x 2 accumulators).  BN = 64 (used when N / 128 tiles would not fill the
 // chip, e.g. the N = 1024 projections at batch 1): waves 2 x 2, each 64 x 32 (2 x 1 accumulators), half the LDS.
 template <int EPI, int BN>
@@ -142,6 +211,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     // kernel does -- was measured here and lost: +4..7 us on the N = 1024 GEMMs at batch 1.  Such a block is a chain of L2 round trips
     // (4 waves cannot hold K = 4096 worth of fragments in flight); inside the grid a half-empty tile costs less than that because
     // it overlaps with its CU's other workgroup.
+    if ((int)blockIdx.x >= p.ntiles) {                           // block-uniform: the GEMV items sit BEHIND the tiles in the grid
+        gemv_tail_rows<EPI>(p, lds, (int)blockIdx.x - p.ntiles, wave, lane);
+        return;
+    }
     const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
     // map_mode 0: an XCD's contiguous id range walks tn fastest (A row panels stay in that XCD's L2, W streams through);
     // map_mode 1: tm fastest (a W column panel stays resident, A streams through)
@@ -269,12 +342,22 @@ static void launch_gemm(const GemmParams& p0, int bn, hipStream_t st) {
     p.tiles_n = p.N / bn;
     p.rows_ps = p.rows_per_batch / BM;
     p.full_rows = (p.valid_rows + BM - 1) / BM;               // valid rows are a prefix of every sample
+    // a last tile row with one or two live rows is not a tile row: its 32-column blocks are GEMV items (gemv_tail_rows)
+    const int last_live = p.valid_rows - (p.full_rows - 1) * BM;
+    static const int no_tail = getenv("DGS_GEMM_NO_GEMV_TAIL") ? atoi(getenv("DGS_GEMM_NO_GEMV_TAIL")) : 0;   // measurement aid
+    p.ntail = 0; p.tail_row0 = 0;
+    if (!no_tail && p.full_rows > 1 && last_live <= 2 && p.K % 512 == 0 && p.K <= 4096 && p.k_per_batch == p.K && p.N % 8 == 0 &&
+        !(EPI == DGS_EPI_QKV)) {
+        --p.full_rows;
+        p.tail_row0 = p.full_rows * BM;
+        p.ntail = (p.M / p.rows_per_batch) * (p.N / 8);
+    }
     p.tiles_m = (p.M / p.rows_per_batch) * p.full_rows;
     p.ntiles = p.tiles_m * p.tiles_n;
     static const int map_env = getenv("DGS_GEMM_MAP") ? atoi(getenv("DGS_GEMM_MAP")) : 0;
     p.map_mode = map_env;
-    if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 128>), dim3(p.ntiles), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 64>), dim3(p.ntiles), dim3(256), 0, st, p);
+    if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 128>), dim3(p.ntail + p.ntiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 64>), dim3(p.ntail + p.ntiles), dim3(256), 0, st, p);
 }
 
 extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {

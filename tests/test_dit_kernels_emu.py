@@ -418,3 +418,34 @@ def test_gemm_sliced(ops, N):
         assert torch.allclose(qk.float()[:, Wd:], ref[:, Wd:2 * Wd], atol=3e-2, rtol=1e-2)
         assert torch.allclose(vt.float(), ref[:, 2 * Wd:].reshape(2, 256, Wd).transpose(1, 2), atol=3e-2, rtol=1e-2)
 
+
+
+def test_gemm_128_wide_gemv_tail_rows(ops):
+    """The 128-wide kernel with one or two live rows behind a sample's last full tile (the DiT's learned tokens): those rows are
+    GEMV items of the first workgroups, not a tile row.  Every epilogue the N = 1024 GEMMs use, two samples, K = 512 and a K
+    beyond one 2048-element pass; rows past `valid` in the touched 32-row block are padding (any finite value), the rest untouched."""
+    g = torch.Generator().manual_seed(91)
+    rows, B, N = 256, 2, 128
+    for K, valid in ((512, 130), (1024, 130), (3072, 129), (4096, 130)):
+        A = _bf(torch.randn(B * rows, K, generator=g) * 0.5)
+        W = _bf(torch.randn(N, K, generator=g) * 0.05)
+        bias = torch.randn(N, generator=g)
+        ref = A.float() @ W.float().t() + bias
+        live = (torch.arange(B * rows) % rows) < valid
+        untouched = (torch.arange(B * rows) % rows) >= valid           # the GEMV items write live rows only
+        out = torch.full((B * rows, N), 7.0)
+        ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=rows, valid_rows=valid, algo=_native.GEMM_SIMPLE128)
+        assert torch.allclose(out[live], ref[live], atol=2e-3, rtol=1e-4)
+        assert bool((out[untouched] == 7.0).all())
+        x0 = torch.randn(B * rows, N, generator=g)
+        gate = torch.randn(B, N, generator=g)
+        x, aux = x0.clone(), torch.zeros(B * rows, N, dtype=torch.bfloat16)
+        ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=rows, valid_rows=valid, aux=aux, resid=x0,
+                 algo=_native.GEMM_SIMPLE128)
+        want = x0 + gate.repeat_interleave(rows, 0) * ref
+        assert torch.allclose(x[live], want[live], atol=5e-3, rtol=1e-4)
+        assert torch.allclose(aux.float()[live], ref[live], atol=3e-2, rtol=1e-2)
+        vt = torch.zeros(B, N, rows, dtype=torch.bfloat16)
+        o = ops.gemm(A, W, bias, _native.EPI_BF16, rows_per_batch=rows, valid_rows=valid, vt=vt, algo=_native.GEMM_SIMPLE128)
+        assert torch.allclose(o.float()[live], ref[live], atol=3e-2, rtol=1e-2)
+        assert torch.equal(vt[:, :, :valid], o.reshape(B, rows, N).transpose(1, 2)[:, :, :valid])
