@@ -310,6 +310,20 @@ int dgs_dit_rowlinear_backward(const DgsDitRowLinearBackwardArgs* a, dgs_stream_
 int dgs_dit_gate_mul(const DgsDitGateMulArgs* a, dgs_stream_t stream);
 int dgs_dit_rowlinear(const DgsDitRowLinearArgs* a, dgs_stream_t stream);
 
+/* DGSDenoiser.run_layers(first, last) (denoiser.py:441-447): DiT blocks [first, last) on a token tensor in the reference's
+ * order.  The workspace is the one of dgs_dit_forward for a shape with the same token count (V views of H x W with
+ * n_gaussians + V (H/patch) (W/patch) == L). */
+typedef struct DgsDitRunBlocksArgs {
+    int32_t B, L, V;           /* samples, tokens per sample (n_gaussians + image tokens), views (only used to validate L)    */
+    int32_t first, last;       /* block range [first, last)                                                                  */
+    const float* tokens_in;    /* f32 [B, L, W]: [gaussian tokens, image tokens]                                             */
+    const float* cvec;         /* f32 [B, W]: the timestep embedding c = t_embedder(t)                                       */
+    float* tokens_out;         /* f32 [B, L, W]                                                                              */
+    void* workspace;           /* dgs_dit_workspace_bytes of a shape with L tokens, zero-filled once                         */
+    size_t workspace_bytes;
+} DgsDitRunBlocksArgs;
+int dgs_dit_run_blocks(const DgsDitModel* m, const DgsDitRunBlocksArgs* a, dgs_stream_t stream);
+
 int32_t dgs_dit_lpad(int32_t L);   /* padded rows per sample */
 size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W);
 int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream);

@@ -37,6 +37,23 @@ typedef struct DgsMseArgs {
 
 int dgs_mse_psnr(const DgsMseArgs* args, dgs_stream_t stream);
 
+/* The input path of the LPIPS term (losses.py:304-309): `F.interpolate(x, size=[256, 256], mode='bilinear') * 2.0 - 1.0`
+ * for renderings and targets -- evaluated every step, also when lambda_lpips is 0.  One launch: bilinear resize
+ * (align_corners = False, PyTorch's source-index rule) fused with the affine map; the backward accumulates
+ * d src = mul * W^T d dst (dsrc is zero-filled by the call).  The LPIPS network itself is out of scope. */
+typedef struct DgsResizeArgs {
+    int32_t planes;            /* n * c image planes                                                       */
+    int32_t in_h, in_w, out_h, out_w;
+    const float* src;          /* f32 [planes, in_h, in_w]       (forward)                                 */
+    float* dst;                /* f32 [planes, out_h, out_w]     (forward)                                 */
+    float mul, add;            /* dst = resize(src) * mul + add                                            */
+    const float* ddst;         /* f32 [planes, out_h, out_w]     (backward)                                */
+    float* dsrc;               /* f32 [planes, in_h, in_w]       (backward, written)                       */
+} DgsResizeArgs;
+
+int dgs_resize_bilinear(const DgsResizeArgs* args, dgs_stream_t stream);
+int dgs_resize_bilinear_backward(const DgsResizeArgs* args, dgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

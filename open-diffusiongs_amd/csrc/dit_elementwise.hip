@@ -164,6 +164,16 @@ __global__ void gather_tokens_kernel(const float* x, float* out, int B, int lpad
     out[i] = x[((size_t)b * lpad + src) * width + c];
 }
 
+// reference token order [B, L, width] -> internal rows (inverse of the above; padding rows are not touched)
+__global__ void scatter_tokens_kernel(const float* in, float* x, int B, int lpad, int L, int ng, int width) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * L * width) return;
+    const int c = (int)(i % width);
+    const int tk = (int)((i / width) % L), b = (int)(i / ((size_t)width * L));
+    const int dst = tk < ng ? (L - ng) + tk : tk - ng;
+    x[((size_t)b * lpad + dst) * width + c] = in[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // to_gs + hard pixel alignment.  One thread per Gaussian.
 //   image Gaussians: raw[B*lpad rows][ps*ps*C] f32 (decoder GEMM output), Gaussian (v, hh, ww, ph, pw)
@@ -271,6 +281,12 @@ int launch_pos_embed(const float* pe, float* x, int B, int lpad, int L, int ng, 
 int launch_gather_tokens(const float* x, float* out, int B, int lpad, int L, int ng, int width, hipStream_t st) {
     const size_t n = (size_t)B * L * width;
     hipLaunchKernelGGL(gather_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, out, B, lpad, L, ng, width);
+    return launch_ok();
+}
+
+int launch_scatter_tokens(const float* in, float* x, int B, int lpad, int L, int ng, int width, hipStream_t st) {
+    const size_t n = (size_t)B * L * width;
+    hipLaunchKernelGGL(scatter_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, x, B, lpad, L, ng, width);
     return launch_ok();
 }
 

@@ -81,6 +81,47 @@ struct Prof {
 }  // namespace
 #define DGS_PROF(k, expr) do { prof.before(k); const int rc_ = (expr); prof.after(k); if (rc_ != DGS_OK) { fprintf(stderr, "[dgs] %s:%d: status %d\n", __FILE__, __LINE__, rc_); return rc_; } } while (0)
 
+namespace {
+// DiT blocks [first, last) of the inference sequence on the residual stream ws.x (utils_transformer.py:271-290).
+int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last, int B, int lpad, int L, Prof& prof, dgs_stream_t stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int W = m->width, M = B * lpad, nmod = (6 * m->layers + 4) * W;
+    DgsDitAttentionArgs at{};
+    at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = ws.qk; at.vt = ws.vt; at.out = ws.ao; at.scale = 0.125f; at.q_prescaled = 1;
+    at.tail_ws = ws.attn_tail; at.tail_ws_bytes = ws.attn_tail_bytes;
+    for (int i = first; i < last; ++i) {
+        const DgsDitLayerWeights& lw = m->layer[i];
+        const float* mod = ws.mod + (size_t)i * 6 * W;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        DgsDitLayerNormArgs l1{};
+        l1.rows = M; l1.width = W; l1.x = ws.x; l1.shift = mod; l1.scale = mod + W; l1.mod_stride = nmod; l1.rows_per_batch = lpad;
+        l1.eps = 1e-6f; l1.out = ws.xn;
+        DGS_PROF(5, launch_layernorm(&l1, st));
+        DgsDitGemmArgs q{};
+        q.M = M; q.N = 3 * W; q.K = W; q.A = ws.xn; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_QKV;
+        q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad; q.valid_rows = L;
+        q.q_scale = at.scale * 1.44269504088896341f;       // queries leave the GEMM pre-scaled for the exp2-domain softmax
+        DGS_PROF(2, dgs_dit_gemm(&q, stream));
+        DGS_PROF(1, dgs_dit_attention(&at, stream));
+        DgsDitGemmArgs pr{};
+        pr.M = M; pr.N = W; pr.K = W; pr.A = ws.ao; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
+        pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad; pr.valid_rows = L;
+        DGS_PROF(3, dgs_dit_gemm(&pr, stream));
+        l1.shift = mod + 3 * W; l1.scale = mod + 4 * W;
+        DGS_PROF(5, launch_layernorm(&l1, st));
+        DgsDitGemmArgs f1{};
+        f1.M = M; f1.N = 4 * W; f1.K = W; f1.A = ws.xn; f1.lda = W; f1.W = lw.fc1_w; f1.ldw = W; f1.bias = lw.fc1_b;
+        f1.epilogue = DGS_EPI_GELU_BF16; f1.out = ws.h; f1.ldo = 4 * W; f1.rows_per_batch = lpad; f1.valid_rows = L;
+        DGS_PROF(4, dgs_dit_gemm(&f1, stream));
+        DgsDitGemmArgs f2{};
+        f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = ws.h; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
+        f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.out = ws.x; f2.ldo = W; f2.gate = mod + 5 * W; f2.gate_stride = nmod; f2.rows_per_batch = lpad; f2.valid_rows = L;
+        // (fused split-K for this 64-tile GEMM was built and measured: 66 -> 86 us, see DgsDitGemmArgs.splitk_ws / DESIGN.md section 9)
+        DGS_PROF(3, dgs_dit_gemm(&f2, stream));
+    }
+    return DGS_OK;
+}
+}  // namespace
+
 extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream) {
     if (!m || !a || a->B <= 0 || a->V <= 0 || a->H <= 0 || a->W <= 0) { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
     if (m->width % 256 || m->width != m->heads * 64 || m->layers <= 0 || m->patch <= 0 || a->H % m->patch || a->W % m->patch)
@@ -126,39 +167,8 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     ln.rows = M; ln.width = W; ln.x = ws.x; ln.weight = m->in_ln_w; ln.eps = 1e-5f; ln.out = ws.x; ln.out_f32 = 1; ln.rows_per_batch = lpad;
     DGS_TRY(launch_layernorm(&ln, st));
 
-    // ---- 24 x DiTBlock (utils_transformer.py:271-290) ----
-    DgsDitAttentionArgs at{};
-    at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = ws.qk; at.vt = ws.vt; at.out = ws.ao; at.scale = 0.125f; at.q_prescaled = 1;
-    at.tail_ws = ws.attn_tail; at.tail_ws_bytes = ws.attn_tail_bytes;
-    for (int i = 0; i < m->layers; ++i) {
-        const DgsDitLayerWeights& lw = m->layer[i];
-        const float* mod = ws.mod + (size_t)i * 6 * W;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        DgsDitLayerNormArgs l1{};
-        l1.rows = M; l1.width = W; l1.x = ws.x; l1.shift = mod; l1.scale = mod + W; l1.mod_stride = nmod; l1.rows_per_batch = lpad;
-        l1.eps = 1e-6f; l1.out = ws.xn;
-        DGS_PROF(5, launch_layernorm(&l1, st));
-        DgsDitGemmArgs q{};
-        q.M = M; q.N = 3 * W; q.K = W; q.A = ws.xn; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_QKV;
-        q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad; q.valid_rows = L;
-        q.q_scale = at.scale * 1.44269504088896341f;       // queries leave the GEMM pre-scaled for the exp2-domain softmax
-        DGS_PROF(2, dgs_dit_gemm(&q, stream));
-        DGS_PROF(1, dgs_dit_attention(&at, stream));
-        DgsDitGemmArgs pr{};
-        pr.M = M; pr.N = W; pr.K = W; pr.A = ws.ao; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
-        pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad; pr.valid_rows = L;
-        DGS_PROF(3, dgs_dit_gemm(&pr, stream));
-        l1.shift = mod + 3 * W; l1.scale = mod + 4 * W;
-        DGS_PROF(5, launch_layernorm(&l1, st));
-        DgsDitGemmArgs f1{};
-        f1.M = M; f1.N = 4 * W; f1.K = W; f1.A = ws.xn; f1.lda = W; f1.W = lw.fc1_w; f1.ldw = W; f1.bias = lw.fc1_b;
-        f1.epilogue = DGS_EPI_GELU_BF16; f1.out = ws.h; f1.ldo = 4 * W; f1.rows_per_batch = lpad; f1.valid_rows = L;
-        DGS_PROF(4, dgs_dit_gemm(&f1, stream));
-        DgsDitGemmArgs f2{};
-        f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = ws.h; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
-        f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.out = ws.x; f2.ldo = W; f2.gate = mod + 5 * W; f2.gate_stride = nmod; f2.rows_per_batch = lpad; f2.valid_rows = L;
-        // (fused split-K for this 64-tile GEMM was built and measured: 66 -> 86 us, see DgsDitGemmArgs.splitk_ws / DESIGN.md section 9)
-        DGS_PROF(3, dgs_dit_gemm(&f2, stream));
-    }
+    // ---- 24 x DiTBlock ----
+    DGS_TRY(run_blocks(m, ws, 0, m->layers, B, lpad, L, prof, stream));
     if (a->prof_count) *a->prof_count = prof.n;
     if (a->tokens) DGS_TRY(launch_gather_tokens(ws.x, a->tokens, B, lpad, L, ng, W, st));
 
@@ -194,5 +204,29 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     gp.xyz = a->xyz; gp.features = a->features; gp.scaling = a->scaling; gp.rotation = a->rotation; gp.opacity = a->opacity;
     gp.aligned = a->aligned_xyz;
     DGS_TRY(launch_gaussians(gp, st));
+    return DGS_OK;
+}
+
+// DGSDenoiser.run_layers(first, last) (denoiser.py:441-447): blocks [first, last) applied to a token tensor in the reference's
+// order ([gaussian tokens, image tokens]) under the conditioning vector c = t_embedder(t).  What torch.utils.checkpoint wraps
+// in the reference; here an inference-mode utility (the training path recomputes inside dgs_dit_backward).
+extern "C" int dgs_dit_run_blocks(const DgsDitModel* m, const DgsDitRunBlocksArgs* a, dgs_stream_t stream) {
+    if (!m || !a || a->B <= 0 || a->B > 16 || a->L <= m->n_gaussians || a->first < 0 || a->last > m->layers || a->first > a->last ||
+        !a->tokens_in || !a->tokens_out || !a->cvec || !a->workspace)
+        return DGS_ERR_INVALID_ARGUMENT;
+    if ((a->L - m->n_gaussians) % a->V) return DGS_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int B = a->B, W = m->width, ng = m->n_gaussians, L = a->L, lpad = dgs_dit_lpad(L);
+    const int nmod = (6 * m->layers + 4) * W;
+    size_t need = 0;
+    DitWorkspace ws = DitWorkspace::carve(a->workspace, m, (size_t)B, (size_t)lpad, L, &need);
+    if (a->workspace_bytes < need) return DGS_ERR_ALLOC;
+    DgsDitRowLinearArgs r{};
+    r.M = B; r.N = nmod; r.K = W; r.x = a->cvec; r.silu_input = 1; r.W = m->ada_w; r.bias = m->ada_b; r.out = ws.mod;
+    DGS_TRY(launch_rowlinear(&r, st));
+    DGS_TRY(launch_scatter_tokens(a->tokens_in, ws.x, B, lpad, L, ng, W, st));
+    Prof prof{nullptr, 0, 0, 0, st};
+    DGS_TRY(run_blocks(m, ws, a->first, a->last, B, lpad, L, prof, stream));
+    DGS_TRY(launch_gather_tokens(ws.x, a->tokens_out, B, lpad, L, ng, W, st));
     return DGS_OK;
 }

@@ -39,6 +39,7 @@ int launch_timestep(const int64_t* t, float* emb, int B, hipStream_t st);
 int launch_embed(const EmbedParams& p, hipStream_t st);
 int launch_pos_embed(const float* pe, float* x, int B, int lpad, int L, int ng, int width, hipStream_t st);
 int launch_gather_tokens(const float* x, float* out, int B, int lpad, int L, int ng, int width, hipStream_t st);
+int launch_scatter_tokens(const float* in, float* x, int B, int lpad, int L, int ng, int width, hipStream_t st);
 int launch_gaussians(const GsParams& p, hipStream_t st);
 
 // ---- backward (dit_backward_elementwise.hip) ----

@@ -47,7 +47,70 @@ __global__ void mse_final_kernel(DgsMseArgs a) {
     if (a.psnr) a.psnr[b] = -10.0f * log10f(l2);
 }
 
+// ---- F.interpolate(x, size, mode='bilinear', align_corners=False) * mul + add  (losses.py:304-309: the LPIPS input) ----
+// PyTorch's area_pixel_compute_source_index: src = max(0, (dst + 0.5) * in / out - 0.5); i0 = floor(src), i1 = min(i0 + 1,
+// in - 1), l1 = src - i0, l0 = 1 - l1;  value = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11).
+struct ResizeCoef { int i0, i1; float l0, l1; };
+__device__ __forceinline__ ResizeCoef resize_coef(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    ResizeCoef c;
+    c.i0 = (int)src;
+    c.i1 = c.i0 + (c.i0 < in - 1 ? 1 : 0);
+    c.l1 = src - (float)c.i0;
+    c.l0 = 1.0f - c.l1;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(DgsResizeArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // one output element per thread, x fastest: coalesced stores
+    const long long total = (long long)a.planes * a.out_h * a.out_w;
+    if (i >= total) return;
+    const int ox = (int)(i % a.out_w), oy = (int)((i / a.out_w) % a.out_h);
+    const long long pl = i / ((long long)a.out_w * a.out_h);
+    const ResizeCoef cx = resize_coef(ox, a.in_w, a.out_w), cy = resize_coef(oy, a.in_h, a.out_h);
+    const float* s = a.src + pl * a.in_h * a.in_w;
+    const float v00 = s[(size_t)cy.i0 * a.in_w + cx.i0], v01 = s[(size_t)cy.i0 * a.in_w + cx.i1];
+    const float v10 = s[(size_t)cy.i1 * a.in_w + cx.i0], v11 = s[(size_t)cy.i1 * a.in_w + cx.i1];
+    const float v = cy.l0 * (cx.l0 * v00 + cx.l1 * v01) + cy.l1 * (cx.l0 * v10 + cx.l1 * v11);
+    a.dst[i] = v * a.mul + a.add;
+}
+
+// d src += mul * weights * d dst.  Atomics: for the reference's two cases (same size; 512 -> 256, where every input pixel feeds
+// exactly one output) each address receives one contribution at most per weight, so the result is order-independent.
+__global__ __launch_bounds__(256) void resize_bilinear_backward_kernel(DgsResizeArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.planes * a.out_h * a.out_w;
+    if (i >= total) return;
+    const int ox = (int)(i % a.out_w), oy = (int)((i / a.out_w) % a.out_h);
+    const long long pl = i / ((long long)a.out_w * a.out_h);
+    const ResizeCoef cx = resize_coef(ox, a.in_w, a.out_w), cy = resize_coef(oy, a.in_h, a.out_h);
+    float* s = a.dsrc + pl * a.in_h * a.in_w;
+    const float g = a.ddst[i] * a.mul;
+    atomicAdd(s + (size_t)cy.i0 * a.in_w + cx.i0, cy.l0 * cx.l0 * g);
+    atomicAdd(s + (size_t)cy.i0 * a.in_w + cx.i1, cy.l0 * cx.l1 * g);
+    atomicAdd(s + (size_t)cy.i1 * a.in_w + cx.i0, cy.l1 * cx.l0 * g);
+    atomicAdd(s + (size_t)cy.i1 * a.in_w + cx.i1, cy.l1 * cx.l1 * g);
+}
+
 }  // namespace dgs
+
+extern "C" int dgs_resize_bilinear(const DgsResizeArgs* a, dgs_stream_t stream) {
+    if (!a || a->planes <= 0 || a->in_h <= 0 || a->in_w <= 0 || a->out_h <= 0 || a->out_w <= 0 || !a->src || !a->dst) return DGS_ERR_INVALID_ARGUMENT;
+    const long long total = (long long)a->planes * a->out_h * a->out_w;
+    hipLaunchKernelGGL(dgs::resize_bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+extern "C" int dgs_resize_bilinear_backward(const DgsResizeArgs* a, dgs_stream_t stream) {
+    if (!a || a->planes <= 0 || a->in_h <= 0 || a->in_w <= 0 || a->out_h <= 0 || a->out_w <= 0 || !a->ddst || !a->dsrc) return DGS_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(a->dsrc, 0, sizeof(float) * (size_t)a->planes * a->in_h * a->in_w, st) != hipSuccess) return DGS_ERR_DEVICE;
+    const long long total = (long long)a->planes * a->out_h * a->out_w;
+    hipLaunchKernelGGL(dgs::resize_bilinear_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
 
 extern "C" int dgs_mse_psnr(const DgsMseArgs* a, dgs_stream_t stream) {
     if (!a || a->B <= 0 || a->n <= 0 || a->n % 4 || !a->rendering || !a->target || !a->l2 || !a->partial) return DGS_ERR_INVALID_ARGUMENT;

@@ -240,12 +240,18 @@ class DgsDitBackwardArgs(ctypes.Structure):
 BLOCK_DONE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32)
 
 
+class DgsDitRunBlocksArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("L", ctypes.c_int32), ("V", ctypes.c_int32), ("first", ctypes.c_int32), ("last", ctypes.c_int32),
+                ("tokens_in", ctypes.c_void_p), ("cvec", ctypes.c_void_p), ("tokens_out", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
 # every symbol include/dgs_dit.h declares (checked by tests/test_abi.py)
 DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward", "dgs_dit_layernorm_backward",
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes", "dgs_dit_gemm_fused_splitk_bytes",
-               "dgs_dit_attention_tail_bytes"]
+               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks"]
 
 
 def _declare_dit(L):
@@ -271,6 +277,8 @@ def _declare_dit(L):
         fn.restype = ctypes.c_size_t
         fn.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
     L.dgs_dit_saved_bytes.argtypes = L.dgs_dit_saved_bytes.argtypes + [ctypes.c_int32]
+    L.dgs_dit_run_blocks.restype = ctypes.c_int
+    L.dgs_dit_run_blocks.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitRunBlocksArgs), ctypes.c_void_p]
     L.dgs_dit_forward_train.restype = ctypes.c_int
     L.dgs_dit_forward_train.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitForwardArgs), ctypes.c_void_p,
                                         ctypes.c_size_t, ctypes.c_void_p]
@@ -307,12 +315,21 @@ class DgsMseArgs(ctypes.Structure):
 
 LOSS_CHUNKS = 64
 # every symbol include/dgs_loss.h declares (checked by tests/test_abi.py)
-LOSS_SYMBOLS = ["dgs_mse_psnr"]
+class DgsResizeArgs(ctypes.Structure):
+    _fields_ = [("planes", ctypes.c_int32), ("in_h", ctypes.c_int32), ("in_w", ctypes.c_int32), ("out_h", ctypes.c_int32),
+                ("out_w", ctypes.c_int32), ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("mul", ctypes.c_float),
+                ("add", ctypes.c_float), ("ddst", ctypes.c_void_p), ("dsrc", ctypes.c_void_p)]
+
+
+LOSS_SYMBOLS = ["dgs_mse_psnr", "dgs_resize_bilinear", "dgs_resize_bilinear_backward"]
 
 
 def _declare_loss(L):
     L.dgs_mse_psnr.restype = ctypes.c_int
     L.dgs_mse_psnr.argtypes = [ctypes.POINTER(DgsMseArgs), ctypes.c_void_p]
+    for fn in (L.dgs_resize_bilinear, L.dgs_resize_bilinear_backward):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(DgsResizeArgs), ctypes.c_void_p]
     return L
 
 

@@ -4,6 +4,7 @@ Mirrors diffusionGS/models/gsrenderer/gs_core.py:
     get_turntable_cameras                      :50-85
     render_turntable                           :1203-1219   (reference: one rasterizer call + ~15 camera ops + syncs PER VIEW;
                                                              here all views are one batched launch sequence of the HIP rasterizer)
+    render_generic                             :1300-1316   (same, for caller-supplied cameras; [v, h, w, 3] uint8)
     GaussianModel.construct_dtypes / save_ply / load_ply   :578-760   (the layout 3DGS viewers read: x y z, red green blue,
                                                              f_dc_*, f_rest_* padded to SH degree 3, opacity, scale_*, rot_*)
 The reference writes / reads the file through the `plyfile` package (binary_little_endian 1.0, one "vertex" element, scalar
@@ -52,6 +53,21 @@ def render_turntable(pc, rendering_resolution=384, num_views=8, backend=None):
                         h, w, c, k)[0]                                   # [v, 3, h, w]
     r = (r.detach().cpu().numpy() * 255).clip(0, 255).astype(np.uint8)
     return np.ascontiguousarray(r.transpose(2, 0, 3, 1).reshape(h, v * w, 3))       # "v c h w -> h (v w) c"
+
+
+def render_generic(pc, c2ws, fxfycxcy, h=512, w=512, backend=None):
+    """gs_core.py:1300-1316: `pc` a GaussianModel, c2ws [v, 4, 4], fxfycxcy [v, 4] -> uint8 [v, h, w, 3].  The reference loops
+    render_opencv_cam over the views; here they are one batched launch sequence."""
+    from .raster import default_backend
+    dev = pc._xyz.device
+    c = torch.as_tensor(c2ws).float().to(dev)[None]
+    k = torch.as_tensor(fxfycxcy).float().to(dev)[None]
+    be = backend if backend is not None else default_backend()
+    with torch.no_grad():
+        r = be.render_views(pc._xyz.float()[None], pc.get_features.float()[None], pc._scaling.float()[None], pc._rotation.float()[None],
+                            pc._opacity.float()[None], h, w, c, k)[0]                       # [v, 3, h, w]
+    r = (r.detach().cpu().numpy() * 255).clip(0, 255).astype(np.uint8)
+    return np.ascontiguousarray(r.transpose(0, 2, 3, 1))                                   # "v c h w -> v h w c"
 
 
 def construct_dtypes(pc, enable_gs_viewer=True):

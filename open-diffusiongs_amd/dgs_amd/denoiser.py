@@ -386,6 +386,15 @@ class DGSDenoiser(nn.Module):
     def dtype(self):
         return next(self.parameters()).dtype
 
+    def run_layers(self, start, end, views=4):   # denoiser.py:441-447
+        """-> custom_forward(concat_nerf_img_tokens [b, L, d], t = t_embedder(timesteps) [b, d]) running blocks [start, end).
+        The reference hands this closure to torch.utils.checkpoint; here checkpointing lives inside the training path
+        (`recompute_policy`), and the closure is an inference-mode utility on the same kernels."""
+        def custom_forward(concat_nerf_img_tokens, t):
+            with torch.no_grad():
+                return self.engine().run_blocks(concat_nerf_img_tokens, t, start, min(end, self.cfg.num_layers), views=views)
+        return custom_forward
+
 
 @register("diffusion-gs-model-scene")
 class DGSDenoiserScene(DGSDenoiser):

@@ -262,6 +262,26 @@ class DitEngine:
         return out, aligned
 
 
+    def run_blocks(self, tokens, cvec, first, last, views=4):
+        """DiT blocks [first, last) on tokens [B, L, W] (reference order: gaussian tokens first) under cvec [B, W] = t_embedder(t):
+        DGSDenoiser.run_layers (denoiser.py:441-447).  Inference-mode utility."""
+        dev = self.device
+        B, L, W = tokens.shape
+        n_img = (L - self.ng) // views
+        side = int(round(n_img ** 0.5))
+        assert self.ng + views * side * side == L, "token count is not n_gaussians + views * (side / patch)^2"
+        ws = self._workspace(B, views, side * self.patch, side * self.patch)
+        tin = tokens.to(dev, torch.float32).contiguous()
+        c = cvec.to(dev, torch.float32).contiguous()
+        out = torch.empty_like(tin)
+        a = _native.DgsDitRunBlocksArgs()
+        a.B, a.L, a.V, a.first, a.last = B, L, views, int(first), int(last)
+        a.tokens_in, a.cvec, a.tokens_out, a.workspace, a.workspace_bytes = _p(tin), _p(c), _p(out), _p(ws), ws.numel()
+        rc = self.lib.dgs_dit_run_blocks(ctypes.byref(self.model), ctypes.byref(a), _stream(dev))
+        if rc != 0:
+            raise RuntimeError(f"dgs dit run_blocks: {_native.status_string(self.lib, rc)} (status {rc})")
+        return out
+
     # ------------------------------------------------------------------------------------------------------------
     # training: forward that saves activations + backward (include/dgs_dit.h "training")
     # ------------------------------------------------------------------------------------------------------------

@@ -57,3 +57,47 @@ def mse_psnr(rendering, target, lib=None):
     """rendering / target [b, v, 3, h, w] -> (loss = mean_b l2_b, l2 [b], psnr [b]); loss and l2 are differentiable w.r.t.
     `rendering` (the gradient was produced by the same pass that formed the sums)."""
     return _Mse.apply(rendering, target, lib)
+
+
+def _resize_args(x_shape, size, lib):
+    a = _native.DgsResizeArgs()
+    a.planes = 1
+    for d in x_shape[:-2]:
+        a.planes *= int(d)
+    a.in_h, a.in_w, a.out_h, a.out_w = int(x_shape[-2]), int(x_shape[-1]), int(size[0]), int(size[1])
+    return a, (lib or _native.lib())
+
+
+class _LpipsInput(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, mul, add, lib):
+        x = x.contiguous().float()
+        out = torch.empty(tuple(x.shape[:-2]) + tuple(size), dtype=torch.float32, device=x.device)
+        a, L = _resize_args(x.shape, size, lib)
+        a.src, a.dst, a.mul, a.add = ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), float(mul), float(add)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream) if x.is_cuda else None
+        rc = L.dgs_resize_bilinear(ctypes.byref(a), stream)
+        if rc != 0:
+            raise RuntimeError(f"dgs_resize_bilinear failed: {rc}")
+        ctx.meta = (tuple(x.shape), tuple(size), float(mul), lib)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, size, mul, lib = ctx.meta
+        g = g.contiguous().float()
+        dx = torch.empty(shape, dtype=torch.float32, device=g.device)
+        a, L = _resize_args(shape, size, lib)
+        a.ddst, a.dsrc, a.mul = ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(dx.data_ptr()), mul
+        stream = ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream) if g.is_cuda else None
+        rc = L.dgs_resize_bilinear_backward(ctypes.byref(a), stream)
+        if rc != 0:
+            raise RuntimeError(f"dgs_resize_bilinear_backward failed: {rc}")
+        return dx, None, None, None, None
+
+
+def lpips_input(images, size=(256, 256), lib=None):
+    """losses.py:304-309: `F.interpolate(images, size=[256, 256], mode='bilinear') * 2.0 - 1.0` -- what the reference feeds its
+    LPIPS module for renderings and targets ([n, 3, h, w] in (0, 1) -> [n, 3, 256, 256] in (-1, 1)), one fused launch,
+    differentiable.  The network behind it is out of scope."""
+    return _LpipsInput.apply(images, tuple(size), 2.0, -1.0, lib)

@@ -194,3 +194,30 @@ def test_engine_survives_optimizer_steps_in_place():
     with torch.no_grad():
         p3, _ = m.image_to_gaussians(images, ray_o, ray_d, t)
     assert not torch.equal(p3.xyz, p1.xyz)
+
+
+def test_run_layers_matches_oracle_blocks():
+    """DGSDenoiser.run_layers(start, end) (denoiser.py:441-447): blocks [start, end) on a token tensor in the reference's order
+    (gaussian tokens first) under c = t_embedder(t), vs the oracle's DiTBlock restatement; composing two ranges == one."""
+    m = dn.DGSDenoiser(dict(OBJ_CFG, num_layers=3), device="cpu", lib=emu_lib())
+    m.reset_parameters(seed=12)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith(".bias"):
+                p_.copy_(torch.randn_like(p_) * 0.05)
+            if p_.dim() == 2:
+                p_.copy_(p_.to(torch.bfloat16).float())
+    sd = {k_: v.detach().clone() for k_, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    B, V, side = 2, 2, 2                       # L = 2 + 2 * 2 * 2 = 10 tokens
+    L = 2 + V * side * side
+    tokens = torch.randn(B, L, 256, generator=g)
+    c = D.t_embed(sd, torch.tensor([17, 801]))
+    ref = tokens
+    for i in range(1, 3):
+        ref = D.dit_block(ref, c, sd, f"transformer.{i}.", 4)
+    out = m.run_layers(1, 3, views=V)(tokens, c)
+    assert out.shape == tokens.shape and rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
+    two = m.run_layers(2, 3, views=V)(m.run_layers(1, 2, views=V)(tokens, c), c)
+    assert torch.equal(two, out)
+    assert torch.equal(m.run_layers(1, 1, views=V)(tokens, c), tokens)          # empty range: identity

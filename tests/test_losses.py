@@ -37,6 +37,34 @@ def _check(lib, device):
     assert torch.equal(losses.mse_psnr(render.detach(), target, lib=lib)[1], l2.detach())
 
 
+def _check_resize(lib, device, planes=(3, 3), sizes=((256, 256), (512, 512), (64, 96), (300, 200))):
+    """The LPIPS input path (losses.py:304-309) vs F.interpolate: the reference's two cases (256 -> 256, 512 -> 256) and odd
+    up / down factors; values and the gradient w.r.t. the rendering."""
+    from dgs_amd import losses
+    g = torch.Generator().manual_seed(9)
+    for (h, w) in sizes:
+        x = torch.rand(*planes, h, w, generator=g).to(device).requires_grad_(True)
+        y = losses.lpips_input(x, lib=lib)
+        xr = x.detach().cpu().clone().requires_grad_(True)
+        ref = F.interpolate(xr, size=[256, 256], mode="bilinear") * 2.0 - 1.0
+        assert y.shape == (*planes, 256, 256)
+        assert torch.allclose(y.detach().cpu(), ref.detach(), rtol=0, atol=2e-6), (h, w, float((y.detach().cpu() - ref.detach()).abs().max()))
+        wgt = torch.randn(ref.shape, generator=g)
+        (y * wgt.to(device)).sum().backward()
+        (ref * wgt).sum().backward()
+        assert torch.allclose(x.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5 * float(xr.grad.abs().max())), (h, w)     # sums of up to ~16 fp32 terms, order differs
+
+
+def test_resize_on_emulator():
+    from emu_util import emu_lib
+    _check_resize(emu_lib(), "cpu", planes=(1, 2), sizes=((256, 256), (512, 512), (64, 96)))
+
+
+@pytest.mark.gpu
+def test_resize_on_gpu():
+    _check_resize(None, "cuda:0")
+
+
 def test_on_emulator():
     from emu_util import emu_lib
     _check(emu_lib(), "cpu")
