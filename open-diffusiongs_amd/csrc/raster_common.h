@@ -34,6 +34,32 @@ __device__ __forceinline__ M3 m3_t(const M3& A) {
 }
 
 
+// Which of a tile's four 16 x 4 pixel strips (rows 4g .. 4g+3 of the tile at pixel (tx0, ty0)) can a Gaussian touch at all?
+// A (pixel, Gaussian) pair contributes only if cut <= power <= 0 with power = -0.5 (A dx^2 + C dy^2) - B dx dy, i.e. inside
+// the ellipse A dx^2 + 2 B dx dy + C dy^2 <= -2 cut, whose bounding box has half extents sqrt(q C / det), sqrt(q A / det).
+// The box is inflated (1 % of q, 0.1 % + 0.01 px of the extents) against the rounding of the fp32 `power`; conics that are
+// not comfortably positive definite (condition number above 1e4, non-finite values) get all four bits.  CONSERVATIVE by
+// construction: a strip without its bit holds no pixel that passes the exact per-pixel test, so skipping it changes no
+// result bit.  (The per-tile LIST still is the reference's -- radius = ceil(3 sigma_max) rectangles; a small Gaussian is in
+// the lists of tiles its ellipse never reaches.)
+__device__ __forceinline__ unsigned strip_mask(float2 xy, float4 co, float cut, float tx0, float ty0) {
+    const float A = co.x, B = co.y, C = co.z;
+    if (cut > 0.0f) return 0u;                                   // alpha < 1/255 everywhere
+    const float det = A * C - B * B, tr = A + C;
+    const float q = -2.0f * cut * 1.01f + 0.01f;
+    if (!(det > 0.0f) || !(A > 0.0f) || !(C > 0.0f) || !(tr * tr < 1.0e4f * det) || !(q < 1.0e30f)) return 0xFu;   // NaN-safe
+    const float hx = sqrtf(q * C / det) * 1.001f + 0.01f, hy = sqrtf(q * A / det) * 1.001f + 0.01f;
+    if (!(hx < 1.0e30f) || !(hy < 1.0e30f) || !(xy.x == xy.x) || !(xy.y == xy.y)) return 0xFu;
+    if (xy.x + hx < tx0 || xy.x - hx > tx0 + 15.0f) return 0u;
+    unsigned m = 0u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float ys = ty0 + 4.0f * (float)g;
+        if (!(xy.y + hy < ys) && !(xy.y - hy > ys + 3.0f)) m |= 1u << g;
+    }
+    return m;
+}
+
 // Sum over the 64 lanes of a wave; the total is valid in lane 63 only.  Six v_add_f32_dpp (row shifts inside the 16-lane
 // rows, then row broadcasts) instead of six ds_bpermute round trips.
 #ifdef HIPEMU

@@ -562,62 +562,81 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups
 }
 
 // grid (gx, gy, V), block 16x16 = 4 wave64, each wave a 16x4 pixel strip.  forward.cu:261-374.
+// A batch of 256 list entries is staged in LDS; while staging, every thread also works out which strips ITS Gaussian can
+// reach (strip_mask) and four ballots per staging wave turn that into one 256-bit set per strip.  A wave then walks the
+// set bits of its strip only: in the trained-like regime the lists hold ~3,000 Gaussians per tile of
+// which a strip meets a fraction -- the list is the reference's rectangle-overlap list, the ellipse is much smaller.
 __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
     __shared__ float4 s_rgbc[256];
+    __shared__ unsigned long long s_set[4][4];            // [strip][staging wave]
     const int v = blockIdx.z;
-    const int tid = threadIdx.y * 16 + threadIdx.x;
+    const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pxi = blockIdx.x * kTile + threadIdx.x, pyi = blockIdx.y * kTile + threadIdx.y;
     const bool inside = pxi < p.W && pyi < p.H;
     const float pfx = (float)pxi, pfy = (float)pyi;
+    const float tx0 = (float)(blockIdx.x * kTile), ty0 = (float)(blockIdx.y * kTile);
     const bool ok = p.im.totals[1] == 0;
     uint2 rg = p.im.ranges[(size_t)v * p.T + blockIdx.y * p.gx + blockIdx.x];
     if (!ok) rg.y = rg.x;
     const int rounds = (int)((rg.y - rg.x + 255u) / 256u);
-    int todo = (int)(rg.y - rg.x);
     const size_t vo = (size_t)v * p.P;
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
-    for (int i = 0; i < rounds; ++i, todo -= 256) {
+    for (int i = 0; i < rounds; ++i) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t pos = rg.x + (uint32_t)i * 256u + (uint32_t)tid;
+        unsigned m4 = 0u;
         if (pos < rg.y) {
             const uint32_t id = p.bn.point_list[pos];
-            s_xy[tid] = p.g.means2D[vo + id];
-            s_co[tid] = p.g.conic_opacity[vo + id];
-            s_rgbc[tid] = p.g.rgb_cut[vo + id];
+            const float2 xy = p.g.means2D[vo + id];
+            const float4 co = p.g.conic_opacity[vo + id];
+            const float4 rc = p.g.rgb_cut[vo + id];
+            s_xy[tid] = xy; s_co[tid] = co; s_rgbc[tid] = rc;
+            m4 = strip_mask(xy, co, rc.w, tx0, ty0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned long long bal = __ballot((m4 >> g) & 1u);
+            if (lane == 0) s_set[g][wave] = bal;
         }
         __syncthreads();
-        const int nb = todo < 256 ? todo : 256;
-        // Per (pixel, Gaussian) the common case is a reject (power > 0, or below the Gaussian's alpha cut-off): the loop is kept
+        // Per (pixel, Gaussian) the common case is still a reject (power > 0, or below the Gaussian's alpha cut-off): the body is
         // free of per-lane branches up to that test and leaves with ONE wave-uniform branch when no lane of the wave passes;
         // the arithmetic of every lane is the reference's, in the reference's order (forward.cu:332-358).
         const uint32_t base = (uint32_t)i * 256u;
-        const int nbw = __ballot(!done) == 0ull ? 0 : nb;          // a wave whose 64 pixels are all finished only keeps the barriers
-#pragma unroll 4
-        for (int j = 0; j < nbw; ++j) {
-            const float2 xy = s_xy[j];
-            const float4 co = s_co[j];
-            const float cut = s_rgbc[j].w;
-            const float dx = xy.x - pfx, dy = xy.y - pfy;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            const bool pass = !done && !(power > 0.0f) && !(power < cut);      // alpha < 1/255 guaranteed below `cut` (preprocess_one)
-            if (__ballot(pass) == 0ull) continue;
-            if (pass) {
-                const float alpha = fminf(0.99f, co.w * det_expf(power));
-                if (!(alpha < 1.0f / 255.0f)) {
-                    const float test_T = T * (1 - alpha);
-                    if (test_T < 0.0001f) {
-                        done = true;
-                    } else {
-                        const float4 rc = s_rgbc[j];
-                        C0 += rc.x * alpha * T;
-                        C1 += rc.y * alpha * T;
-                        C2 += rc.z * alpha * T;
-                        T = test_T;
-                        last_contributor = base + (uint32_t)j + 1u;
+        if (__ballot(!done) != 0ull) {                         // a wave whose 64 pixels are all finished only keeps the barriers
+            for (int sw = 0; sw < 4; ++sw) {
+                unsigned long long m = s_set[wave][sw];
+                m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+                while (m) {
+                    const int j = sw * 64 + (__ffsll((long long)m) - 1);
+                    m &= m - 1;
+                    const float2 xy = s_xy[j];
+                    const float4 co = s_co[j];
+                    const float cut = s_rgbc[j].w;
+                    const float dx = xy.x - pfx, dy = xy.y - pfy;
+                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                    const bool pass = !done && !(power > 0.0f) && !(power < cut);      // alpha < 1/255 guaranteed below `cut` (preprocess_one)
+                    if (__ballot(pass) == 0ull) continue;
+                    if (pass) {
+                        const float alpha = fminf(0.99f, co.w * det_expf(power));
+                        if (!(alpha < 1.0f / 255.0f)) {
+                            const float test_T = T * (1 - alpha);
+                            if (test_T < 0.0001f) {
+                                done = true;
+                            } else {
+                                const float4 rc = s_rgbc[j];
+                                C0 += rc.x * alpha * T;
+                                C1 += rc.y * alpha * T;
+                                C2 += rc.z * alpha * T;
+                                T = test_T;
+                                last_contributor = base + (uint32_t)j + 1u;
+                            }
+                        }
                     }
                 }
             }
