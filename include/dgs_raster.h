@@ -94,6 +94,10 @@ typedef struct DgsRasterForwardArgs {
     int32_t* num_rendered_dev;   /* device int64-compatible pair: [0]=num_rendered (low 32 bits), [1]=status; may be NULL in sync mode */
     /* ---- result ---- */
     int64_t num_rendered;        /* host, OUT (sync mode); -1 in async mode             */
+    int32_t binning_form;        /* per-tile ordering algorithm. 0: chosen from the instance statistics (default);
+                                    tests / measurement: 1 instance list + depth-rank bitmap sort, 2 per-tile scan of the
+                                    depth-ordered Gaussians, 3 instance list + per-tile bitonic sort in LDS.  All forms
+                                    produce the reference's lists bit for bit.                                       */
 } DgsRasterForwardArgs;
 
 typedef struct DgsRasterBackwardArgs {

@@ -29,7 +29,9 @@ struct FwdParams {
     const float *bg, *means3D, *shs, *colors_pre, *opac, *scales, *rots, *cov_pre, *viewm, *projm, *campos, *tanfov;
     float tanfovx, tanfovy, scale_mod;
     int prefiltered, raw_act;
-    int bin_mode;            // binning form: 0 by instance density (on the device), 1 instance list + per-tile sort, 2 per-tile scan
+    int bin_mode;            // binning form: 0 chosen from the instance statistics (binning_form), else forced: 1 instance list + rank
+                             // bitmap sort, 2 per-tile scan, 3 instance list + per-tile bitonic sort in LDS
+    int bitonic_cap;         // longest tile list the bitonic form is launched for (LDS entries), 0: form not available
     int* radii;
     float* out_color;
     GeomState g;
@@ -304,38 +306,58 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* count, uint2* ranges, uint32_t* cursor, int n,
                                                          int32_t* totals, long long capacity) {
     __shared__ uint32_t scratch[20];
-    uint32_t carry = 0;
+    __shared__ uint32_t smax;
+    uint32_t carry = 0, mx = 0;
+    if (threadIdx.x == 0) smax = 0;
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
         const uint32_t c = (i < n) ? count[i] : 0u;
+        mx = max(mx, c);
         uint32_t tot;
         const uint32_t ex = block_exclusive_scan<1024>(c, scratch, &tot);
         if (i < n) { ranges[i] = make_uint2(carry + ex, carry + ex + c); cursor[i] = 0; }
         carry += tot;
     }
+    __syncthreads();
+    atomicMax(&smax, mx);
+    __syncthreads();
     if (threadIdx.x == 0) {
         totals[0] = (int32_t)carry;
+        totals[2] = (int32_t)smax;
         if (capacity >= 0 && (long long)carry > capacity) totals[1] = DGS_ERR_BINNING_OVERFLOW;
     }
 }
 
-// Which binning form runs (both are launched when the host cannot know the instance count, i.e. in the async mode; the one
-// whose turn it is not returns at once).  bin_mode 1: instance list + per-tile sort, 2: per-tile scan, 0: scan when at least a
-// tenth of all (tile, Gaussian) pairs are instances -- measured crossover at 256^2, 4 views: the scan is 0.17 ms faster at a
-// density of 0.2 (random-init weights) and 0.15 ms slower at 0.012 (trained-like scenes).
-__device__ __forceinline__ bool binning_is_scan(const FwdParams& p) {
-    if (p.bin_mode) return p.bin_mode == 2;
-    return (long long)(uint32_t)p.im.totals[0] * 10 >= (long long)p.T * p.P * p.V;
+// Which binning form runs.  In the sync mode the host has read {num_rendered, longest tile list} back and launches one form
+// only; in the async mode every form is launched and the ones whose turn it is not return at once -- both sides evaluate
+// THIS function.  scan: at least a tenth of all (tile, Gaussian) pairs are instances (measured crossover at 256^2, 4 views:
+// the scan is 0.17 ms faster at a density of 0.2 -- random-init weights -- and slower at 0.012 -- trained-like scenes);
+// bitonic: sparse scenes whose longest tile list fits the LDS the kernel was launched with; rank sort: the rest.
+enum { kFormRankSort = 1, kFormScan = 2, kFormBitonic = 3 };
+__host__ __device__ __forceinline__ int binning_form_of(int bin_mode, int bitonic_cap, long long num_rendered, long long longest,
+                                                        long long T, long long P, long long V) {
+    const bool fits = bitonic_cap > 0 && longest <= bitonic_cap;
+    if (bin_mode == kFormScan || bin_mode == kFormRankSort) return bin_mode;
+    if (bin_mode == kFormBitonic) return fits ? kFormBitonic : kFormRankSort;
+    if (num_rendered * 10 >= T * P * V) return kFormScan;
+    return fits ? kFormBitonic : kFormRankSort;
 }
+__device__ __forceinline__ int binning_form(const FwdParams& p) {
+    return binning_form_of(p.bin_mode, p.bitonic_cap, (long long)(uint32_t)p.im.totals[0], (long long)(uint32_t)p.im.totals[2], p.T, p.P, p.V);
+}
+__device__ __forceinline__ bool binning_is_scan(const FwdParams& p) { return binning_form(p) == kFormScan; }
 
-// grid (ceil(P/256), V).  Writes, for every (Gaussian, touched tile), the Gaussian's depth rank into that tile's segment.
-// Slot order inside a segment is arbitrary (tile_sort_kernel is order-independent).
+// grid (ceil(P/256), V).  Writes, for every (Gaussian, touched tile), the Gaussian's sort key into that tile's segment: its depth
+// rank (rank-sort form) or (depth bits << 32 | index) (bitonic form).  Slot order inside a segment is arbitrary (both per-tile
+// sorts are order-independent: the keys of a tile are distinct).
 template <bool LDS_AGG>
 __global__ __launch_bounds__(256) void emit_instances_kernel(FwdParams p) {
     DGS_DYNAMIC_LDS(smem);
     uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem);
     uint32_t* lbase = lcnt + p.T;
-    if (p.im.totals[1] != 0 || binning_is_scan(p)) return;
+    const int form = binning_form(p);
+    if (p.im.totals[1] != 0 || form == kFormScan) return;
+    const bool wide = form == kFormBitonic;
     const int v = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const size_t gi = (size_t)v * p.P + idx;
@@ -346,7 +368,9 @@ __global__ __launch_bounds__(256) void emit_instances_kernel(FwdParams p) {
         tile_rect(m.x, m.y, p.radii[gi], p.gx, p.gy, &x0, &y0, &x1, &y1);
         vis = true;
     }
-    const uint32_t rank = vis ? p.g.rank_of[gi] : 0u;
+    const uint32_t rank = (vis && !wide) ? p.g.rank_of[gi] : 0u;
+    // the reference's sort key without the tile id (rasterizer_impl.cu:98-109): depth bits, ties by Gaussian index
+    const uint64_t key = (vis && wide) ? (((uint64_t)__float_as_uint(p.g.depths[gi]) << 32) | (uint32_t)idx) : 0ull;
     const uint2* ranges = p.im.ranges + (size_t)v * p.T;
     uint32_t* cursor = p.im.tile_cursor + (size_t)v * p.T;
     if (LDS_AGG) {
@@ -366,13 +390,14 @@ __global__ __launch_bounds__(256) void emit_instances_kernel(FwdParams p) {
                 for (int x = x0; x < x1; ++x) {
                     const int t = y * p.gx + x;
                     const uint32_t slot = ranges[t].x + lbase[t] + atomicAdd(&lcnt[t], 1u);
-                    p.bn.inst_rank[slot] = rank;
+                    if (wide) p.bn.inst_key[slot] = key; else p.bn.inst_rank[slot] = rank;
                 }
     } else if (vis) {
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
                 const int t = y * p.gx + x;
-                p.bn.inst_rank[ranges[t].x + atomicAdd(&cursor[t], 1u)] = rank;
+                const uint32_t slot = ranges[t].x + atomicAdd(&cursor[t], 1u);
+                if (wide) p.bn.inst_key[slot] = key; else p.bn.inst_rank[slot] = rank;
             }
     }
 }
@@ -384,7 +409,7 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
     DGS_DYNAMIC_LDS(smem);
     uint32_t* bm = reinterpret_cast<uint32_t*>(smem);
     __shared__ uint32_t scratch[8];
-    if (p.im.totals[1] != 0 || binning_is_scan(p)) return;
+    if (p.im.totals[1] != 0 || binning_form(p) != kFormRankSort) return;
     const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
     const uint2 rg = p.im.ranges[(size_t)v * p.T + t];
     if (rg.x == rg.y) return;
@@ -450,6 +475,139 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
         emitted += total;
         __syncthreads();
     }
+}
+
+// grid (T, V), 256 threads, dynamic LDS = cap * 8 + 2 * kBuckets * 4 bytes.  Sparse scenes: a tile's list is a few thousand
+// entries, and the rank-sort form above pays O(P / 32) per tile (it expands a bitmap over ALL depth ranks) plus a 12-launch
+// radix sort of the P depth keys first.  Here a tile sorts ITS OWN (depth bits << 32 | index) keys in LDS -- O(n) for n = the
+// tile's list, no global sort at all, and the keys' order IS the reference's (tile, depth bits, Gaussian index):
+//   1. min / max of the tile's depth bits;  2. histogram over B ~ n / 4 buckets under the monotone map
+//   b = floor((bits - min) * B / (max - min + 1)) (LDS atomics);  3. exclusive scan -> bucket starts;  4. keys scattered into
+//   their buckets in LDS (arrival order inside a bucket is arbitrary);  5. every bucket -- ~4 keys -- finished by ONE thread
+//   with an insertion sort on the full 64-bit keys.  The map is monotone, so bucket order + in-bucket order is the total order;
+//   the keys of a tile are distinct, so the result does not depend on the order atomics happened to arrive in.
+// A tile whose depths pile up (a bucket above kBucketLimit keys: insertion sort is quadratic) takes the bitonic network over
+// the whole list instead -- O(n log^2 n), data-independent.  (The network alone was measured first: 0.34 ms per 4 views at
+// 256^2 and 3.7 ms at 512^2, where 8 k-key tiles need 91 LDS round trips each.)
+constexpr int kBuckets = 2048, kBucketLimit = 40;
+__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b, bool up) {
+    const bool sw = (a > b) == up;
+    const uint64_t t = sw ? b : a;
+    b = sw ? a : b;
+    a = t;
+}
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t m, int tid) {      // m: power of two >= 8 * NT
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        uint32_t j = k >> 1;
+        for (; j > 4; j >>= 1) {                               // partners further than 4 apart: one compare-exchange per LDS round trip
+            for (uint32_t i = tid; i < m / 2; i += NT) {
+                const uint32_t lo = ((i / j) * 2 * j) + (i % j), hi = lo + j;
+                uint64_t a = keys[lo], b = keys[hi];
+                cswap(a, b, (lo & k) == 0);
+                keys[lo] = a; keys[hi] = b;
+            }
+            __syncthreads();
+        }
+        // strides 4, 2, 1 (those that remain): 8 consecutive keys per thread, in registers
+        for (uint32_t c = tid; c < m / 8; c += NT) {
+            uint64_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = keys[8 * c + u];
+            const bool up = ((8 * c) & k) == 0;
+            if (k >= 8) {
+                if (j >= 4) { cswap(r[0], r[4], up); cswap(r[1], r[5], up); cswap(r[2], r[6], up); cswap(r[3], r[7], up); }
+                if (j >= 2) { cswap(r[0], r[2], up); cswap(r[1], r[3], up); cswap(r[4], r[6], up); cswap(r[5], r[7], up); }
+                cswap(r[0], r[1], up); cswap(r[2], r[3], up); cswap(r[4], r[5], up); cswap(r[6], r[7], up);
+            } else if (k == 2) {
+                cswap(r[0], r[1], true); cswap(r[2], r[3], false); cswap(r[4], r[5], true); cswap(r[6], r[7], false);
+            } else {   // k == 4: strides 2, 1, direction per group of 4
+                cswap(r[0], r[2], true); cswap(r[1], r[3], true); cswap(r[4], r[6], false); cswap(r[5], r[7], false);
+                cswap(r[0], r[1], true); cswap(r[2], r[3], true); cswap(r[4], r[5], false); cswap(r[6], r[7], false);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) keys[8 * c + u] = r[u];
+        }
+        __syncthreads();
+    }
+}
+
+// NT threads per tile: 256 while two or more tiles fit a CU's LDS, 1024 for the long lists that own a CU each (512^2 scenes).
+template <int NT>
+__global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
+    DGS_DYNAMIC_LDS(smem);
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + (size_t)p.bitonic_cap * 8);
+    uint32_t* cur = cnt + kBuckets;
+    constexpr int NWV = NT / 64;
+    __shared__ uint32_t s_red[3][NWV];
+    __shared__ uint32_t scratch[NWV + 4];
+    if (p.im.totals[1] != 0 || binning_form(p) != kFormBitonic) return;
+    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint2 rg = p.im.ranges[(size_t)v * p.T + t];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0) return;
+    const uint64_t* src = p.bn.inst_key + rg.x;
+    // 1. range of the depth bits
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t i = tid; i < n; i += NT) {
+        const uint32_t d = (uint32_t)(src[i] >> 32);
+        lo = min(lo, d); hi = max(hi, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+    if (lane == 0) { s_red[0][wave] = lo; s_red[1][wave] = hi; }
+    uint32_t B = 256;
+    while (B * 4 < n && B < (uint32_t)kBuckets) B <<= 1;
+    for (uint32_t i = tid; i < (uint32_t)kBuckets; i += NT) cnt[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) { lo = min(lo, s_red[0][w]); hi = max(hi, s_red[1][w]); }
+    // monotone map of the depth bits onto [0, B): float conversion and the multiplication by a positive constant are monotone
+    const float scale = (float)B / ((float)(hi - lo) + 1.0f);
+    auto bucket = [&](uint32_t d) { return min((uint32_t)((float)(d - lo) * scale), B - 1u); };
+    // 2. histogram
+    for (uint32_t i = tid; i < n; i += NT) atomicAdd(&cnt[bucket((uint32_t)(src[i] >> 32))], 1u);
+    __syncthreads();
+    // 3. exclusive scan of the counts (kBuckets / NT consecutive buckets per thread; buckets >= B are empty) and the largest bucket
+    const uint32_t per = kBuckets / NT;
+    uint32_t local = 0, big = 0;
+    for (uint32_t u = 0; u < per; ++u) { const uint32_t c = cnt[tid * per + u]; local += c; big = max(big, c); }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan<NT>(local, scratch, &tot);
+    for (uint32_t u = 0; u < per; ++u) { const uint32_t c = cnt[tid * per + u]; cur[tid * per + u] = ex; cnt[tid * per + u] = ex; ex += c; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, o));
+    if (lane == 0) s_red[2][wave] = big;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) big = max(big, s_red[2][w]);
+    // 4. scatter into the buckets (cnt[] keeps the bucket starts, cur[] are the cursors)
+    for (uint32_t i = tid; i < n; i += NT) {
+        const uint64_t k = src[i];
+        keys[atomicAdd(&cur[bucket((uint32_t)(k >> 32))], 1u)] = k;
+    }
+    __syncthreads();
+    if (big <= (uint32_t)kBucketLimit) {
+        // 5. one thread per bucket: insertion sort on the full keys (cur[b] is now the bucket's end)
+        for (uint32_t b = tid; b < B; b += NT) {
+            const uint32_t s0 = cnt[b], e0 = cur[b];
+            for (uint32_t i = s0 + 1; i < e0; ++i) {
+                const uint64_t x = keys[i];
+                uint32_t j = i;
+                while (j > s0 && keys[j - 1] > x) { keys[j] = keys[j - 1]; --j; }
+                keys[j] = x;
+            }
+        }
+    } else {
+        uint32_t m = 8 * NT;
+        while (m < n) m <<= 1;                                 // <= bitonic_cap (the host sized the LDS for it)
+        for (uint32_t i = n + tid; i < m; i += NT) keys[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_lds<NT>(keys, m, tid);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += NT) p.bn.point_list[rg.x + i] = (uint32_t)keys[i];
 }
 
 // ---- binning, dense form ("scan") -------------------------------------------------------------------------------------
@@ -750,21 +908,36 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     int rc = check(st, a->debug);
     if (rc) return rc;
 
-    // depth sort of the P Gaussians of each view
-    const int NB = sort_blocks(P);
-    for (int pass = 0; pass < 4; ++pass) {
-        const int in = pass & 1, out = in ^ 1;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], p.g.radix_hist, P, NB, 8 * pass);
-        hipLaunchKernelGGL(radix_colscan_kernel, dim3(1, V), dim3(256), 0, st, p.g.radix_hist, p.g.radix_base, NB);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], pass == 0 ? (const uint32_t*)nullptr : p.g.vals[in],
-                           p.g.keys[out], p.g.vals[out], pass == 3 ? p.g.rank_of : (uint32_t*)nullptr, p.g.radix_hist, p.g.radix_base, P, NB, 8 * pass);
-    }
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, p.im.ranges, p.im.tile_cursor, VT, p.im.totals,
                        async ? (long long)a->binning_capacity : -1LL);
     rc = check(st, a->debug);
     if (rc) return rc;
 
-    if (!async) {   // the reference's blocking read of num_rendered (rasterizer_impl.cu:281)
+    // binning form (binning_form_of): the host only rules forms out; the choice itself is made from the instance statistics --
+    // on the host in the sync mode (it has just read them back), on the device in the async mode
+    const bool can_scan = p.gx <= 255 && p.gy <= 255 && (long long)p.T * P <= (1ll << 27);
+    p.bin_mode = a->binning_form;
+    if (p.bin_mode < 0 || p.bin_mode > 3 || (p.bin_mode == 0 && !can_scan) || (p.bin_mode == kFormScan && !can_scan)) p.bin_mode = can_scan ? 0 : kFormBitonic;
+    constexpr int kBitonicMax = 16384;                             // 128 KiB of LDS
+    int forms = 0;                                                 // bit f set: form f has to be launched
+    // The forms that work on depth ranks need the radix sort of the P depth keys (12 launches, ~0.17 ms at 256^2 x 4 views).  In
+    // the sync mode it is worth having it in flight while the host waits for the statistics -- but only if it will be needed:
+    // the previous call's form is the (performance-only) guess.
+    static thread_local int last_form = 0;
+    bool radix_done = false;
+    auto radix_sort = [&]() {
+        const int NB = sort_blocks(P);
+        for (int pass = 0; pass < 4; ++pass) {
+            const int in = pass & 1, out = in ^ 1;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], p.g.radix_hist, P, NB, 8 * pass);
+            hipLaunchKernelGGL(radix_colscan_kernel, dim3(1, V), dim3(256), 0, st, p.g.radix_hist, p.g.radix_base, NB);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], pass == 0 ? (const uint32_t*)nullptr : p.g.vals[in],
+                               p.g.keys[out], p.g.vals[out], pass == 3 ? p.g.rank_of : (uint32_t*)nullptr, p.g.radix_hist, p.g.radix_base, P, NB, 8 * pass);
+        }
+        radix_done = true;
+    };
+    if (!async) {   // the reference's blocking read of num_rendered (rasterizer_impl.cu:281), plus the longest tile list
+        if (last_form != kFormBitonic && p.bin_mode != kFormBitonic) radix_sort();
         int32_t tot[4] = {0, 0, 0, 0};
         if (hipMemcpyAsync(tot, p.im.totals, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return DGS_ERR_DEVICE;
         if (hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
@@ -773,29 +946,45 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         bbuf = a->binning_alloc(dgs_raster_binning_bytes(a->num_rendered), a->binning_user);
         if (!bbuf) return DGS_ERR_ALLOC;
         p.bn = BinningState::carve(bbuf, (size_t)(a->num_rendered < 1 ? 1 : a->num_rendered), nullptr);
+        int cap = 2048;
+        while (cap < tot[2] && cap < kBitonicMax) cap <<= 1;
+        p.bitonic_cap = cap;
+        last_form = binning_form_of(p.bin_mode, p.bitonic_cap, a->num_rendered, (uint32_t)tot[2], p.T, P, V);
+        forms = 1 << last_form;
     } else {
         a->num_rendered = -1;
         if (a->num_rendered_dev)
             hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        p.bitonic_cap = kBitonicMax;
+        forms = p.bin_mode ? (1 << p.bin_mode) | (p.bin_mode == kFormBitonic ? 1 << kFormRankSort : 0)
+                           : (1 << kFormRankSort) | (1 << kFormScan) | (1 << kFormBitonic);
     }
 
-    // binning: per tile, either filter the depth-ordered Gaussians (dense scenes, T x P small) or list the instances and sort
-    // them; the kernels pick by instance density on the device (binning_is_scan), the host only rules forms out
-    const char* bin_s = getenv("DGS_RASTER_BIN");                   // 1: sort, 2: scan (tests and measurement)
-    const bool can_scan = p.gx <= 255 && p.gy <= 255 && (long long)p.T * P <= (1ll << 27);
-    p.bin_mode = bin_s ? atoi(bin_s) : 0;
-    if (!can_scan || p.bin_mode < 0 || p.bin_mode > 2) p.bin_mode = 1;
-    if (p.bin_mode != 1) {
+    if ((forms & ((1 << kFormRankSort) | (1 << kFormScan))) && !radix_done) radix_sort();
+    if (forms & (1 << kFormScan)) {
         int wgroups = ((P + 63) / 64 + 7) / 8 * 8;
         if (wgroups > 7680) wgroups = 7680;                      // 60 KiB of masks per workgroup
         hipLaunchKernelGGL(rank_rects_kernel, gridP, dim3(256), 0, st, p);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(p.T, V), dim3(256), (size_t)wgroups * 8, st, p, wgroups);
     }
-    if (p.bin_mode != 2) {
+    if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) {
         if (lds_tiles) hipLaunchKernelGGL((emit_instances_kernel<true>), gridP, dim3(256), (size_t)p.T * 8, st, p);
         else hipLaunchKernelGGL((emit_instances_kernel<false>), gridP, dim3(256), 0, st, p);
+    }
+    if (forms & (1 << kFormRankSort)) {
         const int wwords = pick_window_words(P);
         hipLaunchKernelGGL(tile_sort_kernel, dim3(p.T, V), dim3(256), (size_t)wwords * 4, st, p, wwords);
+    }
+    if (forms & (1 << kFormBitonic)) {
+        static const bool lds_ok =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
+        if (!lds_ok) return DGS_ERR_DEVICE;
+        const size_t lds = (size_t)p.bitonic_cap * 8 + 2 * kBuckets * 4;
+        if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(p.T, V), dim3(1024), lds, st, p);
+        else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(p.T, V), dim3(256), lds, st, p);
     }
     hipLaunchKernelGGL(blend_forward_kernel, dim3(p.gx, p.gy, V), dim3(kTile, kTile), 0, st, p);
     return check(st, a->debug);

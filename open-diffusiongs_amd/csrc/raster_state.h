@@ -78,7 +78,7 @@ struct ImageState {
     uint32_t* tile_count;          // [V*T]   instances per tile
     uint32_t* tile_cursor;         // [V*T]   scatter cursors
     uint2* ranges;                 // [V*T]   [start,end) into the packed instance list
-    int32_t* totals;               // [4]     {num_rendered, status, -, -}
+    int32_t* totals;               // [4]     {num_rendered, status, longest tile list, -}
     static ImageState carve(void* buf, size_t W, size_t H, size_t V, size_t* bytes) {
         Carver c(buf);
         ImageState s;
@@ -95,12 +95,14 @@ struct ImageState {
 };
 
 struct BinningState {
-    uint32_t* inst_rank;           // [N] unsorted: depth rank of the instance's Gaussian, grouped by tile
+    uint64_t* inst_key;            // [N] unsorted, grouped by tile: (depth bits << 32) | Gaussian index   (bitonic form)
+    uint32_t* inst_rank;           //     the same storage as 32-bit depth ranks                           (rank-sort form)
     uint32_t* point_list;          // [N] per tile, front to back: Gaussian index
     static BinningState carve(void* buf, size_t N, size_t* bytes) {
         Carver c(buf);
         BinningState b;
-        b.inst_rank = c.take<uint32_t>(N);
+        b.inst_key = c.take<uint64_t>(N);
+        b.inst_rank = reinterpret_cast<uint32_t*>(b.inst_key);
         b.point_list = c.take<uint32_t>(N);
         if (bytes) *bytes = c.bytes();
         return b;

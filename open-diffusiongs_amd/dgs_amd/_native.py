@@ -29,7 +29,7 @@ class DgsRasterForwardArgs(ctypes.Structure):
         ("img_alloc", ALLOC_FN), ("img_user", ctypes.c_void_p),
         ("binning_alloc", ALLOC_FN), ("binning_user", ctypes.c_void_p),
         ("binning_capacity", ctypes.c_int64), ("num_rendered_dev", ctypes.c_void_p),
-        ("num_rendered", ctypes.c_int64),
+        ("num_rendered", ctypes.c_int64), ("binning_form", ctypes.c_int32),
     ]
 
 

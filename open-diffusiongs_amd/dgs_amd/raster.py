@@ -7,6 +7,7 @@ diff_gaussian_rasterization/__init__.py can stay a verbatim mirror of the refere
 PyTorch only provides device memory and the current HIP stream here.
 """
 import ctypes
+import os
 
 import torch
 
@@ -103,6 +104,7 @@ class RasterBackend:
         cbs = [self._allocator(holder, k, device) for k in ("geom", "img", "binning")]
         a.geom_alloc, a.img_alloc, a.binning_alloc = cbs
         a.binning_capacity = int(binning_capacity)
+        a.binning_form = int(os.environ.get("DGS_RASTER_BIN", "0") or 0)     # tests / measurement only (dgs_raster.h)
         ndev = None
         if binning_capacity > 0:
             ndev = torch.zeros(2, dtype=torch.int32, device=device)

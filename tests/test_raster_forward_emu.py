@@ -12,11 +12,12 @@ from util_scene import small_scene
 CPU = torch.device("cpu")
 
 
-@pytest.fixture(params=["scan", "sort"], autouse=True)
+@pytest.fixture(params=["scan", "sort", "bitonic"], autouse=True)
 def binning_form(request, monkeypatch):
     """Both binning forms of raster_forward.hip (per-tile scan of the depth-ordered Gaussians / instance list + per-tile bitmap
-    sort) must give the reference's per-tile lists: every test runs with each forced (DGS_RASTER_BIN)."""
-    monkeypatch.setenv("DGS_RASTER_BIN", {"sort": "1", "scan": "2"}[request.param])
+    sort / instance list + per-tile bitonic sort in LDS) must give the reference's per-tile lists: every test runs with each forced
+    (DGS_RASTER_BIN -> DgsRasterForwardArgs.binning_form)."""
+    monkeypatch.setenv("DGS_RASTER_BIN", {"sort": "1", "scan": "2", "bitonic": "3"}[request.param])
 
 
 @pytest.mark.parametrize("deg,seed,H,W", [(0, 1, 40, 56), (3, 3, 33, 17), (1, 5, 64, 64)])

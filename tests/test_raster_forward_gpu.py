@@ -12,12 +12,12 @@ from util_scene import small_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["scan", "sort", "auto"], autouse=True)
+@pytest.fixture(params=["scan", "sort", "bitonic", "auto"], autouse=True)
 def binning_form(request, monkeypatch):
     """Both binning forms of raster_forward.hip (per-tile scan of the depth-ordered Gaussians / instance list + per-tile bitmap
     sort) must give the reference's per-tile lists: every test runs with each forced (DGS_RASTER_BIN) and with the device-side
     choice by instance density."""
-    monkeypatch.setenv("DGS_RASTER_BIN", {"sort": "1", "scan": "2", "auto": "0"}[request.param])
+    monkeypatch.setenv("DGS_RASTER_BIN", {"sort": "1", "scan": "2", "bitonic": "3", "auto": "0"}[request.param])
 
 
 def _backend():
