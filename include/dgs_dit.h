@@ -53,8 +53,6 @@ typedef enum DgsGemmEpilogue {
 typedef enum DgsGemmAlgo {
     DGS_GEMM_AUTO = 0,
     DGS_GEMM_SIMPLE128 = 1,    /* 128 x 128|64 tiles, two LDS stages, 2 workgroups / CU (AUTO: the N = 1024 GEMMs at 1 sample) */
-    DGS_GEMM_DEEP = 2,         /* 128 x N/8 tiles, NS-stage LDS-DMA ring, counted vmcnt + raw barrier                  */
-    DGS_GEMM_BIG256 = 3,       /* 256 x 256 tiles, two stages (N >= 3072)                                              */
     DGS_GEMM_SLICED = 4,       /* 256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring, explicit MFMA / LDS issue slices (AUTO: QKV and
                                   fc1 at 1 sample, every eligible shape above 8192 rows)                               */
     DGS_GEMM_QUAD = 5          /* the same with 4 waves of 128 x 128 (256 x 256 tiles only; else as SLICED)              */
@@ -87,8 +85,7 @@ typedef struct DgsDitGemmArgs {
     float q_scale;             /* DGS_EPI_QKV: the q features (n < N/3) are multiplied by q_scale before the bf16 rounding
                                   (0 -> 1).  The denoiser passes scale * log2(e) so that the attention kernel gets its
                                   pre-scaled queries with a single rounding (DgsDitAttentionArgs.q_prescaled).        */
-    float* splitk_ws;          /* optional f32 scratch of dgs_dit_gemm_splitk_bytes(M, N, K, k_per_batch) bytes (or of
-                                  dgs_dit_gemm_fused_splitk_bytes, below).  When set,
+    float* splitk_ws;          /* optional f32 scratch of dgs_dit_gemm_splitk_bytes(M, N, K, k_per_batch) bytes.  When set,
                                   DGS_EPI_F32 without bias and that size is non-zero, the reduction is split over
                                   workgroups (256 x 256 tiles, one partial product per split, summed by a second kernel
                                   into `out`): weight gradients have few output tiles and a very long K.              */
@@ -96,14 +93,6 @@ typedef struct DgsDitGemmArgs {
 
 /* Bytes of DgsDitGemmArgs.splitk_ws for this shape; 0 when the split-K path does not apply to it. */
 size_t dgs_dit_gemm_splitk_bytes(int32_t M, int32_t N, int32_t K, int32_t k_per_batch);
-/* The other use of splitk_ws: GEMMs with few 256 x 256 output tiles and a long K (the fc2 GEMM at one sample: 64 tiles,
- * K = 4096) and a BF16 / F32 / GATE_RESIDUAL epilogue run split-K with the reduction INSIDE the kernel: several workgroups
- * share an output tile, leave fp32 partial tiles in the scratch, the last one to arrive sums them in split order
- * (deterministic) and applies the epilogue.  Bytes of scratch for the shape, 0 when that path does not apply.  Opt-in: the
- * denoiser's launch sequence does not use it -- on MI355X the 64 MiB of partial tiles of the fc2 GEMM spill from L2 to HBM
- * and the exchange costs more (86 us) than the under-filled grid it replaces (66 us).  The arrival
- * counters are library-owned: launches that use this path must not run concurrently on different streams. */
-size_t dgs_dit_gemm_fused_splitk_bytes(int32_t M, int32_t N, int32_t K, int32_t rows_per_batch, int32_t valid_rows);
 
 typedef struct DgsDitAttentionArgs {
     int32_t B, heads, L, lpad; /* head dim is 64; L valid tokens per sample, lpad padded rows         */

@@ -321,16 +321,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
-int deep_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);   // dit_gemm_deep.hip
-int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
-bool big_gemm_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch);
-int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows, hipStream_t st);
-int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);
+int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);   // dit_gemm_deep.hip
 int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad);
 int splitk_plan(int M, int N, int K, int k_per_batch, int* splits_per_batch);
 int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st);
-int fused_splitk_plan(int M, int N, int K, int k_per_batch, int rows_per_batch, int valid_rows, int* bn);
-int launch_fused_splitk_gemm(const DgsDitGemmArgs* a, int nsplit, int bn, int rows_per_batch, int valid_rows, hipStream_t st);
 
 }  // namespace dgs
 
@@ -380,24 +374,14 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
     hipStream_t st0 = static_cast<hipStream_t>(stream);
     // Kernel choice.  The default is the 128-wide two-stage kernel below; the sliced 256-row kernel (dit_gemm_deep.hip) takes over
-    // where its tile count fits the chip (see AUTO); the deep-ring and two-stage 256 x 256 kernels are selectable for experiments
-    // and covered by the tests.
+    // where its tile count fits the chip (see AUTO).
     static const int env_algo = getenv("DGS_GEMM_ALGO") ? atoi(getenv("DGS_GEMM_ALGO")) : 0;
     const int algo = a->algo ? a->algo : env_algo;
-    if (algo == DGS_GEMM_BIG256 && big_gemm_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
-        return launch_big_gemm(a, p.rows_per_batch, p.valid_rows, st0);
-    // weight-gradient shapes with a scratch buffer: split-K on the sliced kernel (any algo but an explicit SIMPLE128 / DEEP / BIG256)
+    // weight-gradient shapes with a scratch buffer: split-K on the sliced kernel (any algo but an explicit SIMPLE128)
     if ((algo == DGS_GEMM_AUTO || algo == DGS_GEMM_SLICED) && a->splitk_ws && a->epilogue == DGS_EPI_F32 && !a->bias && a->ldo % 4 == 0 &&
         p.rows_per_batch == a->M && p.valid_rows == a->M) {
         int spb = 0;
         if (splitk_plan(a->M, a->N, a->K, kpb, &spb)) return launch_splitk_gemm(a, kpb, st0);
-    }
-    // few output tiles, long K, a scratch buffer: split-K with the reduction inside the sliced kernel (fc2 at one sample)
-    if ((algo == DGS_GEMM_AUTO || algo == DGS_GEMM_SLICED) && a->splitk_ws &&
-        (a->epilogue == DGS_EPI_GATE_RESIDUAL || a->epilogue == DGS_EPI_BF16 || a->epilogue == DGS_EPI_F32) && (a->epilogue == DGS_EPI_F32 || !a->vt)) {
-        int fbn = 0;
-        const int fs = fused_splitk_plan(a->M, a->N, a->K, kpb, p.rows_per_batch, p.valid_rows, &fbn);
-        if (fs) return launch_fused_splitk_gemm(a, fs, fbn, p.rows_per_batch, p.valid_rows, st0);
     }
     // AUTO (measured on MI355X, tools/gemm_check.py; 128-wide kernel -> sliced kernel):
     //   1 sample  (M = 4352):  QKV 41 -> 39 us, fc1 + GELU 58 -> 44 us on 256 x 256 tiles (one round of the chip); the N = 1024
@@ -409,10 +393,6 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     if (algo == DGS_GEMM_SLICED || algo == DGS_GEMM_QUAD || auto_sliced) {
         const int sbn = sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
         if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0, algo == DGS_GEMM_QUAD);
-    }
-    if (algo == DGS_GEMM_DEEP) {
-        const int dbn = deep_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
-        if (dbn) return launch_deep_gemm(a, dbn, p.rows_per_batch, p.valid_rows, st0);
     }
     // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each
     if (a->epilogue == DGS_EPI_QKV && a->N % 128) return DGS_ERR_INVALID_ARGUMENT;
@@ -439,13 +419,3 @@ extern "C" size_t dgs_dit_gemm_splitk_bytes(int32_t M, int32_t N, int32_t K, int
     return (size_t)nsplit * M * N * sizeof(float);
 }
 
-extern "C" size_t dgs_dit_gemm_fused_splitk_bytes(int32_t M, int32_t N, int32_t K, int32_t rows_per_batch, int32_t valid_rows) {
-    const int rpb = rows_per_batch > 0 ? rows_per_batch : M, vr = (valid_rows > 0 && valid_rows < rpb) ? valid_rows : rpb;
-    int bn = 0;
-    const int s = dgs::fused_splitk_plan(M, N, K, K, rpb, vr, &bn);
-    if (!s) return 0;
-    int full_rows = 0;
-    for (int i = 0; i < rpb / 256; ++i)
-        if ((vr - i * 256 + 31) / 32 > 1) ++full_rows;
-    return (size_t)(M / rpb) * full_rows * (N / bn) * s * 256 * bn * sizeof(float);
-}

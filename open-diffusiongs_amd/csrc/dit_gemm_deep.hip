@@ -1,19 +1,14 @@
-// dit_gemm_deep.hip -- deep-pipelined variant of the DiT GEMM (same contract and epilogues as dit_gemm.hip).
+// dit_gemm_deep.hip -- the "sliced" DiT GEMM: 256-row tiles on a 4-stage LDS-DMA ring with an explicit issue schedule (same
+// contract and epilogues as dit_gemm.hip), its split-K form for the weight gradients, and the side jobs for tile rows with a
+// single live 32-row block (the DiT's two learned-token rows).
 //
-// Why a second kernel: rocprofv3 on the 128x128 / two-stage kernel shows ~3.5k cycles per K slab per workgroup against 512
-// cycles of MFMA issue -- every slab pays a full LDS-DMA round trip (L2 -> LDS, ~1.4 us under load) because only ONE slab
-// is in flight per workgroup and `__syncthreads()` drains it (vmcnt(0)) before anyone may continue.  Little's law: with
-// 64 KiB in flight per CU the chip streams ~12 TB/s into LDS, a third of what the L2 delivers.  This kernel
-//   * keeps NS-1 slabs in flight per workgroup (LDS ring of NS stages, 120-128 KiB, one 8-wave workgroup per CU),
-//     released by COUNTED `s_waitcnt vmcnt(N)` + a raw `s_barrier` (a `__syncthreads()` would drain the ring), one barrier
-//     per slab:   wait own DMAs of slab t -> barrier -> refill the stage read in iteration t-1 -> MFMAs on slab t;
-//   * uses 128 x BN tiles with BN = N / 8 where that makes the tile count a multiple of the CU count (batch 1:
-//     32 x 8 = 256 tiles for N = 1024 / 3072 / 4096), which also cuts the L2 -> LDS traffic per flop (128 x 384:
-//     96 flop/B, 128 x 512: 102, vs 64 for 128 x 128; the L2 needs 72 to keep the MFMAs fed);
-//   * gives the mostly-padding last M tile of a sample (L = 4098: two live rows) its own path: the eight waves split the BN
-//     columns and read fragments straight from L2 into registers -- no ring, no barriers -- because a tile that streams W
-//     through the ring costs a full tile's latency no matter how few rows are live.
-// Waves: 2 (M) x 4 (N); a wave owns 64 x BN/4 of the tile = 2 x (BN/128) accumulators of v_mfma_f32_32x32x16_bf16.
+// Why a second kernel: the 128-wide two-stage kernel of dit_gemm.hip drains its one slab in flight (`__syncthreads()` =
+// vmcnt(0) + barrier) every K slab and stages 0.5-0.75 KiB per MFMA; it runs at 0.4-0.65 PFLOP/s.  This one keeps three slabs
+// in flight per workgroup (COUNTED `s_waitcnt vmcnt(N)` + ONE raw `s_barrier` per slab), gives a wave 64 x 128 (or 128 x 128)
+// of a 256 x 256 tile so that one staged KiB feeds 4 MFMAs, and fixes the issue order by hand.
+// History (measured on MI355X, removed because they lost to the kernels kept): a 128 x N/8-tile deep-ring kernel, a two-stage
+// 256 x 256 kernel, and split-K with the reduction inside the kernel for the few-tile / long-K shapes (fc2 at one sample:
+// 66 -> 86 us, the partial tiles do not stay in L2).
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -30,9 +25,6 @@ struct DeepParams {
     int ntail, tail_mode;                                       // sliced kernel: side jobs of the single-live-block tile rows (1: MFMA items, 2: two-row GEMV items)
     int nsplit, splits_per_batch;                               // sliced kernel, split-K: items = nsplit x tiles, K = k_per_batch
     long long a_batch_stride, w_batch_stride, out_split_stride;
-    int fused;                                                  // split-K with the reduction in the kernel (last arriver), any epilogue
-    float* ws;                                                  // fused: [tile][split][256 x 256] f32 partial tiles, fragment order
-    int* cnt;                                                   // fused: arrival counter per tile (library-owned, zero between launches)
     const bf16_t* A;
     const bf16_t* W;
     const float* bias;
@@ -138,224 +130,6 @@ __device__ __forceinline__ void store_block(const DeepParams& p, const f32x16 (&
             }
             if (tdst) *reinterpret_cast<uint2*>(tdst + 8 * g) = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
         }
-    }
-}
-
-template <int EPI, int BN, int BK, int NS>
-__global__ __launch_bounds__(512, 2) void gemm_deep_kernel(DeepParams p) {
-    constexpr int NI = BN / 128;                                  // 32-column accumulator blocks per wave
-    constexpr int A_BYTES = 128 * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
-    static_assert((128 * 2 * BK / 1024) % 8 == 0 && (BN * 2 * BK / 1024) % 8 == 0, "every wave must issue the same number of DMAs per slab");
-    constexpr int G = (128 * 2 * BK / 1024) / 8 + (BN * 2 * BK / 1024) / 8;   // LDS-DMA instructions per wave per slab (vmcnt bookkeeping)
-    DGS_DYNAMIC_LDS(lds);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
-    const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
-    const int m0 = tm * 128, n0 = tn * BN;
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const int mrow_tile = m0 - (m0 / p.rows_per_batch) * p.rows_per_batch;
-    const int live_blocks = (p.valid_rows - mrow_tile + 31) / 32;            // 32-row blocks of this tile with live rows
-    const int nk = p.K / BK;
-
-    if (live_blocks <= 1) {
-        // ---- mostly-padding tile: at most one live 32-row block.  No ring, no barriers: the 8 waves split the BN / 32
-        //      column blocks, fragments come straight from global memory (L2). ----
-        if (live_blocks <= 0) return;
-        const bf16_t* arow = p.A + (size_t)(m0 + frow) * p.lda + fhalf * 8;
-        for (int cb = wave; cb < BN / 32; cb += 8) {
-            const bf16_t* wrow = p.W + (size_t)(n0 + cb * 32 + frow) * p.ldw + fhalf * 8;
-            f32x16 acc1[1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-            for (int k = 0; k < p.K; k += BK) direct_block_mfma<BK / 16>(arow + k, wrow + k, acc1[0]);
-            store_block<EPI, 1>(p, acc1, m0 + 4 * fhalf, n0 + cb * 32, lane);
-        }
-        return;
-    }
-
-    f32x16 acc[2][NI];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // ---- prologue: NS - 1 slabs in flight ----
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) {
-        if (s < nk) {
-            stage_slab<128, BK>(p.A, p.lda, m0, s * BK, lds + s * STAGE, wave, lane);
-            stage_slab<BN, BK>(p.W, p.ldw, n0, s * BK, lds + s * STAGE + A_BYTES, wave, lane);
-        }
-    }
-    for (int t = 0; t < nk; ++t) {
-        // slab t has landed once at most (slabs issued after it) * G of this wave's DMAs are still outstanding
-        const int after = min(nk - 1 - t, NS - 2);
-#ifndef HIPEMU
-        if (after >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ring is draining (last NS - 2 slabs)
-        __builtin_amdgcn_s_barrier();   // everybody's share of slab t landed; everybody finished reading slab t - 1
-#else
-        (void)after;
-        __syncthreads();
-#endif
-        if (t + NS - 1 < nk) {          // refill the stage that held slab t - 1
-            char* dst = lds + ((t + NS - 1) % NS) * STAGE;
-            stage_slab<128, BK>(p.A, p.lda, m0, (t + NS - 1) * BK, dst, wave, lane);
-            stage_slab<BN, BK>(p.W, p.ldw, n0, (t + NS - 1) * BK, dst + A_BYTES, wave, lane);
-        }
-        const char* cur = lds + (t % NS) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int c = 2 * ks + fhalf;
-            bf16x8 b[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                b[j] = *reinterpret_cast<const bf16x8*>(cur + A_BYTES + slab_off<BK>(wn * (BN / 4) + j * 32 + frow, c));
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(cur + slab_off<BK>(wm * 64 + frow, c));
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(cur + slab_off<BK>(wm * 64 + 32 + frow, c));
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[j], acc[0][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[j], acc[1][j], 0, 0, 0);
-        }
-    }
-    // (a tile with >= 2 live blocks is computed and stored completely: rows that are padding hold finite values in the
-    // forward and exact zeros in the backward either way)
-    store_block<EPI, NI>(p, acc[0], m0 + wm * 64 + 4 * fhalf, n0 + wn * (BN / 4), lane);
-    store_block<EPI, NI>(p, acc[1], m0 + wm * 64 + 32 + 4 * fhalf, n0 + wn * (BN / 4), lane);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// 256 x 256 x 64 tiles, 8 waves (2 x 4, each 128 x 64 = 4 x 2 accumulators), two 64 KiB stages, plain __syncthreads().
-// Measurements on MI355X (profiles/): every variant of the 128-wide kernels moves ~37-40 GB/s per CU from L2 into LDS
-// (~10 TB/s chip-wide) whatever the ring depth or tile order -- the GEMMs are bound by that stream, so throughput is
-// proportional to the tile's flop per staged byte: 64 for 128 x 128, 128 for 256 x 256.  Used where 256-wide tiles still
-// cover the chip (N >= 3072: QKV, fc1 and the fc2 input-gradient GEMM); at batch 1, M = 4224 gives 16 full tile rows
-// (16 x 16 = 256 tiles for N = 4096) plus one mostly-padding row that takes the direct-from-L2 path.
-// ------------------------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(DeepParams p) {
-    constexpr int BMB = 256, BNB = 256, BK = 64;
-    constexpr int OP_BYTES = BMB * BK * 2, STAGE = 2 * OP_BYTES;       // 32 KiB per operand, 64 KiB per stage
-    DGS_DYNAMIC_LDS(lds);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int logical = xcd_remap((int)blockIdx.x, p.ntiles);
-    const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
-    const int m0 = tm * BMB, n0 = tn * BNB;
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const int mrow_tile = m0 - (m0 / p.rows_per_batch) * p.rows_per_batch;
-    const int live_blocks = (p.valid_rows - mrow_tile + 31) / 32;
-    if (live_blocks <= 1) {            // mostly-padding tile: no staging, fragments straight from L2
-        if (live_blocks <= 0) return;
-        const bf16_t* arow = p.A + (size_t)(m0 + frow) * p.lda + fhalf * 8;
-        for (int cb = wave; cb < BNB / 32; cb += 8) {
-            const bf16_t* wrow = p.W + (size_t)(n0 + cb * 32 + frow) * p.ldw + fhalf * 8;
-            f32x16 acc1[1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < p.K; k += 16)
-                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + k),
-                                                                  *reinterpret_cast<const bf16x8*>(wrow + k), acc1[0], 0, 0, 0);
-            store_block<EPI, 1>(p, acc1, m0 + 4 * fhalf, n0 + cb * 32, lane);
-        }
-        return;
-    }
-    // rows of this tile that exist in memory (the last tile row of a sample may reach past M): staging clamps, stores skip
-    const int rows_here = min(BMB, p.M - m0);
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    auto stage = [&](int k0, char* dst) {
-        // A: 32 wave-instructions of 1 KiB (8 rows each), 4 per wave; rows past the end of A are clamped (never stored)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int piece = wave + 8 * q;
-            const int row = piece * 8 + (lane >> 3), slot = lane & 7;
-            const int chunk = slot ^ ((row >> 1) & 7);
-            const int ar = row < rows_here ? row : rows_here - 1;
-            glds16(p.A + (size_t)(m0 + ar) * p.lda + k0 + chunk * 8, dst + piece * 1024);
-            glds16(p.W + (size_t)(n0 + row) * p.ldw + k0 + chunk * 8, dst + OP_BYTES + piece * 1024);
-        }
-    };
-    const int nk = p.K / BK;
-    stage(0, lds);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const char* cur = lds + (t & 1) * STAGE;
-        if (t + 1 < nk) stage((t + 1) * BK, lds + ((t + 1) & 1) * STAGE);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = 2 * ks + fhalf;
-            bf16x8 b[2], a[4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(cur + OP_BYTES + slab_off<64>(wn * 64 + j * 32 + frow, c));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cur + slab_off<64>(wm * 128 + i * 32 + frow, c));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int mb = wm * 128 + i * 32;
-        if (mb < rows_here) store_block<EPI, 2>(p, acc[i], m0 + mb + 4 * fhalf, n0 + wn * 64, lane);
-    }
-}
-
-template <int EPI>
-static int launch_big(DeepParams p, hipStream_t st) {
-    constexpr int LDS = 2 * 2 * 256 * 64 * 2;      // 128 KiB
-    p.tiles_n = p.N / 256;
-    p.ntiles = p.tiles_n * ((p.M + 255) / 256);
-    auto kern = gemm_big_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DGS_ERR_DEVICE;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(512), LDS, st, p);
-    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
-}
-
-// 256 x 256 tiles are used when they still give every CU work: N a multiple of 256 and >= 3072, plain (non-batched) reduction.
-bool big_gemm_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch) {
-    if (k_per_batch != K || K % 64 || N % 256 || N < 3072 || M < 2048) return false;
-    if (rows_per_batch % 128) return false;
-    if (epilogue == DGS_EPI_QKV && N % 3) return false;
-    // a 256-row tile must not straddle two samples' live rows in a way the padding logic cannot express: require that every
-    // sample starts on a tile boundary or that there is a single sample
-    return rows_per_batch % 256 == 0 || M == rows_per_batch;
-}
-
-int launch_big_gemm(const DgsDitGemmArgs* a, int rows_per_batch, int valid_rows, hipStream_t st) {
-    DeepParams p;
-    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
-    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0;
-    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
-    p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
-    p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
-    switch (a->epilogue) {
-        case DGS_EPI_BF16: return launch_big<DGS_EPI_BF16>(p, st);
-        case DGS_EPI_GELU_BF16: return launch_big<DGS_EPI_GELU_BF16>(p, st);
-        case DGS_EPI_GATE_RESIDUAL: return launch_big<DGS_EPI_GATE_RESIDUAL>(p, st);
-        case DGS_EPI_F32: return launch_big<DGS_EPI_F32>(p, st);
-        case DGS_EPI_QKV: return launch_big<DGS_EPI_QKV>(p, st);
-        case DGS_EPI_DGELU_BF16: return launch_big<DGS_EPI_DGELU_BF16>(p, st);
-        default: return DGS_ERR_INVALID_ARGUMENT;
     }
 }
 
@@ -466,7 +240,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
             }
             return;
         }
-        for (int j = (p.nsplit > 1 && !p.fused) ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
+        for (int j = p.nsplit > 1 ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
             constexpr int CBW = BN == 256 ? 1 : 2, KQ = NW / CBW, TPC = BN / (32 * CBW);   // column blocks, K ranges per item; items per tile column
             const int sub = j % TPC, ttn = (j / TPC) % p.tiles_n, trr = j / (TPC * p.tiles_n);
             const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = ttn * BN + sub * 32 * CBW;
@@ -496,18 +270,8 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         }
     };
     if (p.nfull_items == 0) { side_jobs(); return; }           // no full tile at all (<= 32 valid rows per sample)
-    int tile, fsp = 0;
-    if (p.fused) {
-        // fused split-K (few output tiles, long K: fc2 at one sample): nsplit workgroups share an output tile, each a range of
-        // 128-wide K units; they sit on the same XCD (block id mod 8), so their partial tiles meet in that XCD's L2
-        const int x = bid & 7, q = bid >> 3;
-        fsp = q % p.nsplit;
-        tile = (q / p.nsplit) * 8 + x;
-        const int units = p.K / 128, u0 = fsp * units / p.nsplit, u1 = (fsp + 1) * units / p.nsplit;
-        p.A += u0 * 128;
-        p.W += u0 * 128;
-        p.K = (u1 - u0) * 128;
-    } else if (p.nsplit > 1) {
+    int tile;
+    if (p.nsplit > 1) {
         // split-K (weight gradients): item = (split, tile), split-major so that an XCD's tiles share operand panels; a split is
         // a range of 128-wide K units of one sample; its partial product goes to its own [M, N] f32 plane
         const int all = xcd_remap(bid, p.nfull_items * p.nsplit);
@@ -620,52 +384,6 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #ifndef HIPEMU
     const long long dbg_t1 = p.dbg == 1 ? clock64() : 0;
 #endif
-    if (p.fused) {
-        // every workgroup leaves its partial tile in fragment order (coalesced 16-byte stores); the LAST one to arrive sums all
-        // nsplit partials in split order -- its own included, read back: the result does not depend on who is last -- and runs
-        // the epilogue.  No release fence (an agent-scope release writes the whole L2 back: 15 us): the stores are complete in
-        // the XCD's L2 once vmcnt reaches 0, the counter is an L2 atomic, the reader invalidates its L1 (acquire) first.
-        float* const mine = p.ws + ((size_t)tile * p.nsplit + fsp) * (BM * BN) + ((size_t)wave * WMB * NI * 4) * 256 + lane * 4;
-#pragma unroll
-        for (int i = 0; i < WMB; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(mine + ((i * NI + j) * 4 + g) * 256) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-#ifndef HIPEMU
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        __syncthreads();
-        int* const flag = reinterpret_cast<int*>(lds);
-        if (tid == 0) {
-            const int old = atomicAdd(p.cnt + tile, 1);          // relaxed, agent scope: executes in L2
-            *flag = old == p.nsplit - 1;
-            if (old == p.nsplit - 1) atomicExch(p.cnt + tile, 0);
-        }
-        __syncthreads();
-        if (!*flag) return;
-        __syncthreads();                                            // `flag` lives in the first epilogue patch
-#ifndef HIPEMU
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-        // two splits: own + other is the same sum whoever is last, the own partial stays in registers; more: all of them, in order
-        for (int sq = 0; sq < p.nsplit; ++sq) {
-            if (p.nsplit == 2 && sq == fsp) continue;
-            const bool first = p.nsplit > 2 && sq == 0;
-            const float* src = p.ws + ((size_t)tile * p.nsplit + sq) * (BM * BN) + ((size_t)wave * WMB * NI * 4) * 256 + lane * 4;
-#pragma unroll
-            for (int i = 0; i < WMB; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 v = *reinterpret_cast<const float4*>(src + ((i * NI + j) * 4 + g) * 256);
-                        if (first) { acc[i][j][4 * g] = v.x; acc[i][j][4 * g + 1] = v.y; acc[i][j][4 * g + 2] = v.z; acc[i][j][4 * g + 3] = v.w; }
-                        else { acc[i][j][4 * g] += v.x; acc[i][j][4 * g + 1] += v.y; acc[i][j][4 * g + 2] += v.z; acc[i][j][4 * g + 3] += v.w; }
-                    }
-        }
-    }
     if (epi_staged<EPI>(p)) {          // the ring is idle now (everybody passed the last barrier): a private LDS patch per wave
         char* patch = lds + wave * epi_strip_bytes(2);
 #pragma unroll
@@ -715,10 +433,7 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
     p.tail_mode = gemv_ok ? 2 : 1;
     p.ntail = samples * p.tail_rows * (gemv_ok ? p.N / 32 : p.tiles_n * (BN == 256 ? 8 : 2));
     p.ntiles = p.nfull_items ? p.nfull_items : p.ntail;
-    if (p.fused) {
-        if (p.nfull_items % 8 || p.nfull_items * p.nsplit > 65536) return DGS_ERR_INVALID_ARGUMENT;
-        p.ntiles = p.nfull_items * p.nsplit;
-    } else if (p.nsplit > 1) {
+    if (p.nsplit > 1) {
         if (p.tail_rows || samples != 1) return DGS_ERR_INVALID_ARGUMENT;
         p.ntiles = p.nfull_items * p.nsplit;
     }
@@ -771,7 +486,7 @@ int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int 
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
     p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0; p.nsplit = 1; p.splits_per_batch = 1;
-    p.a_batch_stride = p.w_batch_stride = p.out_split_stride = 0; p.fused = 0; p.ws = nullptr; p.cnt = nullptr;
+    p.a_batch_stride = p.w_batch_stride = p.out_split_stride = 0;
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
@@ -828,7 +543,7 @@ int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st)
     if (!nsplit || a->epilogue != DGS_EPI_F32 || a->bias || !a->splitk_ws || a->ldo % 4) return DGS_ERR_INVALID_ARGUMENT;
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = k_per_batch; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->N; p.gate_stride = 0;
-    p.rows_per_batch = a->M; p.valid_rows = a->M; p.dbg = 0; p.nsplit = nsplit; p.splits_per_batch = spb; p.fused = 0; p.ws = nullptr; p.cnt = nullptr;
+    p.rows_per_batch = a->M; p.valid_rows = a->M; p.dbg = 0; p.nsplit = nsplit; p.splits_per_batch = spb;
     p.a_batch_stride = a->a_batch_stride; p.w_batch_stride = a->w_batch_stride; p.out_split_stride = (long long)a->M * a->N;
     p.A = a->A; p.W = a->W; p.bias = nullptr; p.out = a->splitk_ws; p.gate = nullptr; p.vt = nullptr; p.aux = nullptr; p.q_scale = 1.0f;
     p.resid = nullptr;
@@ -838,119 +553,6 @@ int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((plane / 4 + 255) / 256)), dim3(256), 0, st, a->splitk_ws, static_cast<float*>(a->out), nsplit,
                        a->N, a->ldo, plane);
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
-}
-
-// ---- fused split-K: few 256 x 256 output tiles, long K, any epilogue (the fc2 GEMM at one sample: 64 tiles, K = 4096) ----
-// nsplit workgroups per tile so that one round covers the chip; 0 when the shape does not qualify.
-int fused_splitk_plan(int M, int N, int K, int k_per_batch, int rows_per_batch, int valid_rows, int* bn) {
-    if (k_per_batch != K || M % 256 || N % 256 || rows_per_batch % 256 || K % 1024) return 0;
-    int full_rows = 0;
-    for (int i = 0; i < rows_per_batch / 256; ++i)
-        if ((valid_rows - i * 256 + 31) / 32 > 1) ++full_rows;
-    // 256 x 128 tiles with two splits when that fills the chip: one 128 KiB partial per tile travels, and it stays in L2;
-    // otherwise 256 x 256 tiles with up to 8 splits (their partials spill to HBM: only worth it for very few tiles)
-    static const int force_bn = getenv("DGS_GEMM_FUSED_BN") ? atoi(getenv("DGS_GEMM_FUSED_BN")) : 0;   // measurement aid
-    for (int w = 128; w <= 256; w += 128) {
-        if (force_bn && force_bn != w) continue;
-        const int tiles = (M / rows_per_batch) * full_rows * (N / w);
-        if (tiles <= 0 || tiles % 8 || tiles > 128) continue;
-        int s = 256 / tiles;
-        if (s > 8) s = 8;
-        if (s > K / 1024) s = K / 1024;                           // a split is at least 32 slabs: shorter ones are all prologue and fix-up
-        if (w == 128 && s != 2) continue;
-        if (s >= 2) { *bn = w; return s; }
-    }
-    return 0;
-}
-
-int launch_fused_splitk_gemm(const DgsDitGemmArgs* a, int nsplit, int bn, int rows_per_batch, int valid_rows, hipStream_t st) {
-    static int* counters = nullptr;                               // one per tile; every launch leaves them zero
-    if (!counters) {
-        if (hipMalloc(&counters, 256 * sizeof(int)) != hipSuccess || hipMemset(counters, 0, 256 * sizeof(int)) != hipSuccess) return DGS_ERR_ALLOC;
-    }
-    DeepParams p;
-    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
-    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0; p.nsplit = nsplit; p.splits_per_batch = nsplit;
-    p.a_batch_stride = p.w_batch_stride = p.out_split_stride = 0; p.fused = 1; p.ws = a->splitk_ws; p.cnt = counters;
-    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
-    p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
-    p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
-    switch (a->epilogue) {
-        case DGS_EPI_BF16: return bn == 256 ? launch_sliced<DGS_EPI_BF16, 256>(p, st) : launch_sliced<DGS_EPI_BF16, 128>(p, st);
-        case DGS_EPI_GATE_RESIDUAL: return bn == 256 ? launch_sliced<DGS_EPI_GATE_RESIDUAL, 256>(p, st) : launch_sliced<DGS_EPI_GATE_RESIDUAL, 128>(p, st);
-        case DGS_EPI_F32: return bn == 256 ? launch_sliced<DGS_EPI_F32, 256>(p, st) : launch_sliced<DGS_EPI_F32, 128>(p, st);
-        default: return DGS_ERR_INVALID_ARGUMENT;
-    }
-}
-
-template <int EPI, int BN, int BK, int NS>
-static int launch_deep(DeepParams p, hipStream_t st) {
-    constexpr int STAGE = 128 * BK * 2 + BN * BK * 2;
-    constexpr int LDS = NS * STAGE;
-    static_assert(LDS <= 160 * 1024, "LDS ring too large");
-    p.tiles_n = p.N / BN;
-    p.ntiles = p.tiles_n * (p.M / 128);
-    auto kern = gemm_deep_kernel<EPI, BN, BK, NS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DGS_ERR_DEVICE;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(512), LDS, st, p);
-    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
-}
-
-template <int EPI>
-static int dispatch_deep(const DeepParams& p, int bn, hipStream_t st) {
-    switch (bn) {
-        case 128: return launch_deep<EPI, 128, 64, 4>(p, st);      // stage 32 KiB, ring 128 KiB
-        case 256: return launch_deep<EPI, 256, 32, 5>(p, st);      // stage 24 KiB, ring 120 KiB
-        case 384: return launch_deep<EPI, 384, 32, 4>(p, st);      // stage 32 KiB, ring 128 KiB
-        case 512: return launch_deep<EPI, 512, 32, 3>(p, st);      // stage 40 KiB, ring 120 KiB
-        default: return DGS_ERR_INVALID_ARGUMENT;
-    }
-}
-
-// Tile width for the deep kernel, or 0 when the shape is not eligible (then dit_gemm.hip's kernel runs).
-int deep_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows) {
-    if (k_per_batch != K || K % 64 || M % 128) return 0;     // batched-reduction (weight-gradient) GEMMs stay on the simple kernel
-    if (epilogue == DGS_EPI_QKV && N % 3) return 0;
-    // M tiles that run the ring (>= 2 live 32-row blocks); mostly-padding tiles take the cheap path and are not counted
-    const int tiles_per_sample = rows_per_batch / 128;
-    int full_per_sample = 0;
-    for (int i = 0; i < tiles_per_sample; ++i)
-        if (valid_rows - i * 128 > 32) ++full_per_sample;
-    const int mt = (M / rows_per_batch) * full_per_sample;
-    const int cand[4] = {512, 384, 256, 128};
-    int best = 0;
-    double best_cost = 1e30;
-    for (int i = 0; i < 4; ++i) {
-        const int bn = cand[i];
-        if (N % bn) continue;
-        const int tiles = mt * (N / bn);
-        const int rounds = (tiles + 255) / 256;
-        const double cost = (double)rounds * bn * (1.0 + 16.0 / bn);    // work per tile ~ bn; wider tiles move fewer L2 bytes per flop
-        if (cost < best_cost) { best_cost = cost; best = bn; }
-    }
-    return best;
-}
-
-int launch_deep_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st) {
-    DeepParams p;
-    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
-    p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0;
-    p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
-    p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
-    p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
-    switch (a->epilogue) {
-        case DGS_EPI_BF16: return dispatch_deep<DGS_EPI_BF16>(p, bn, st);
-        case DGS_EPI_GELU_BF16: return dispatch_deep<DGS_EPI_GELU_BF16>(p, bn, st);
-        case DGS_EPI_GATE_RESIDUAL: return dispatch_deep<DGS_EPI_GATE_RESIDUAL>(p, bn, st);
-        case DGS_EPI_F32: return dispatch_deep<DGS_EPI_F32>(p, bn, st);
-        case DGS_EPI_QKV: return dispatch_deep<DGS_EPI_QKV>(p, bn, st);
-        case DGS_EPI_DGELU_BF16: return dispatch_deep<DGS_EPI_DGELU_BF16>(p, bn, st);
-        default: return DGS_ERR_INVALID_ARGUMENT;
-    }
 }
 
 }  // namespace dgs

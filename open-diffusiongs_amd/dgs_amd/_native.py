@@ -120,7 +120,7 @@ def status_string(L, code):
 # include/dgs_dit.h
 # ---------------------------------------------------------------------------------------------------
 EPI_BF16, EPI_GELU_BF16, EPI_GATE_RESIDUAL, EPI_F32, EPI_QKV, EPI_DGELU_BF16 = range(6)
-GEMM_AUTO, GEMM_SIMPLE128, GEMM_DEEP, GEMM_BIG256, GEMM_SLICED, GEMM_QUAD = range(6)
+GEMM_AUTO, GEMM_SIMPLE128, GEMM_SLICED, GEMM_QUAD = 0, 1, 4, 5
 
 
 class DgsDitGemmArgs(ctypes.Structure):
@@ -250,7 +250,7 @@ class DgsDitRunBlocksArgs(ctypes.Structure):
 DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward", "dgs_dit_layernorm_backward",
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
-               "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes", "dgs_dit_gemm_fused_splitk_bytes",
+               "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
                "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks"]
 
 
@@ -265,8 +265,6 @@ def _declare_dit(L):
         fn.argtypes = [ctypes.POINTER(argt), ctypes.c_void_p]
     L.dgs_dit_gemm_splitk_bytes.restype = ctypes.c_size_t
     L.dgs_dit_gemm_splitk_bytes.argtypes = [ctypes.c_int32] * 4
-    L.dgs_dit_gemm_fused_splitk_bytes.restype = ctypes.c_size_t
-    L.dgs_dit_gemm_fused_splitk_bytes.argtypes = [ctypes.c_int32] * 5
     L.dgs_dit_attention_tail_bytes.restype = ctypes.c_size_t
     L.dgs_dit_attention_tail_bytes.argtypes = [ctypes.c_int32] * 3
     L.dgs_dit_lpad.restype = ctypes.c_int32

@@ -38,7 +38,7 @@ class DitOps:
              resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None, algo=0,
              q_scale=0.0, splitk=False):
         """A bf16 [M,K], W bf16 [N,K] -> per epilogue (see dgs_dit.h).  `out` is required for GATE_RESIDUAL (in-place).
-        splitk: hand the library its split-K scratch (weight-gradient shapes, or few-tile / long-K shapes; a no-op where no split applies)."""
+        splitk: hand the library its split-K scratch (weight-gradient shapes; a no-op where no split applies)."""
         if shape is not None:          # batched-reduction form (weight gradients): operands are [batch, rows, tokens]
             M, N, K = shape
         else:
@@ -69,8 +69,6 @@ class DitOps:
         a.valid_rows, a.algo, a.q_scale = valid_rows, algo, q_scale
         if splitk:
             nbytes = self.lib.dgs_dit_gemm_splitk_bytes(M, N, K, k_per_batch)
-            if not nbytes and not k_per_batch:           # few output tiles, long K: reduction inside the kernel
-                nbytes = self.lib.dgs_dit_gemm_fused_splitk_bytes(M, N, K, rows_per_batch, valid_rows)
             ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dev)
             a.splitk_ws = _p(ws) if nbytes else None
         self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))

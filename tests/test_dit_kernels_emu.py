@@ -291,42 +291,6 @@ def test_rowlinear_backward_and_gate_mul(ops):
     assert torch.allclose(dgate[:, Wd:], (dxr * y.float()).reshape(B, rows, Wd).sum(1), atol=1e-3, rtol=1e-4)
 
 
-def test_gemm_deep_ring_kernel(ops):
-    """Opt-in deep-ring kernel: same results as the default kernel on every tile width it can pick."""
-    g = torch.Generator().manual_seed(32)
-    for (M, N, K) in ((256, 384, 192), (256, 512, 128), (384, 256, 128), (256, 128, 256)):
-        A = _bf(torch.randn(M, K, generator=g))
-        W = _bf(torch.randn(N, K, generator=g) * 0.2)
-        bias = torch.randn(N, generator=g)
-        ref = A.float() @ W.float().t() + bias
-        out = ops.gemm(A, W, bias, _native.EPI_F32, algo=_native.GEMM_DEEP)
-        assert torch.allclose(out, ref, atol=2e-3, rtol=1e-4), (M, N, K)
-    out = torch.full((256, 384), 7.0)
-    A = _bf(torch.randn(256, 64, generator=g)); W = _bf(torch.randn(384, 64, generator=g))
-    ops.gemm(A, W, None, _native.EPI_F32, out=out, rows_per_batch=256, valid_rows=130, algo=_native.GEMM_DEEP)
-    ref = A.float() @ W.float().t()
-    assert torch.allclose(out[:160], ref[:160], atol=2e-3, rtol=1e-4) and bool((out[160:] == 7.0).all())
-
-
-def test_gemm_256_tiles(ops):
-    """256 x 256 tile kernel (N >= 3072): ragged last tile row (rows past M are clamped on load, never stored), padding path."""
-    g = torch.Generator().manual_seed(31)
-    M, N, K = 2176, 3072, 64                       # 8.5 tile rows
-    A = _bf(torch.randn(M, K, generator=g))
-    W = _bf(torch.randn(N, K, generator=g) * 0.2)
-    bias = torch.randn(N, generator=g)
-    ref = A.float() @ W.float().t() + bias
-    big = _native.GEMM_BIG256
-    out = ops.gemm(A, W, bias, _native.EPI_F32, algo=big)
-    assert torch.allclose(out, ref, atol=2e-3, rtol=1e-4)
-    out = torch.full((M, N), 7.0)
-    ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=M, valid_rows=2050, algo=big)   # last tile row: one live block
-    assert torch.allclose(out[:2080], ref[:2080], atol=2e-3, rtol=1e-4) and bool((out[2080:] == 7.0).all())
-    qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=M, algo=big)
-    assert torch.allclose(qk.float(), ref[:, :2048], atol=3e-2, rtol=1e-2)
-    assert torch.allclose(vt.float()[0], ref[:, 2048:].t(), atol=3e-2, rtol=1e-2)
-
-
 def test_gemm_split_k_weight_gradient(ops, monkeypatch):
     """Split-K form of the weight-gradient GEMM: per-sample operands, uneven K ranges (9 units of 128 over 2 splits), partial planes
     summed into a strided output; the scratch size query says when the path applies."""
@@ -346,38 +310,6 @@ def test_gemm_split_k_weight_gradient(ops, monkeypatch):
     plain = ops.gemm(dyT, xT, None, _native.EPI_F32, shape=(N, K, B * T), k_per_batch=T, a_batch_stride=N * T, w_batch_stride=K * T,
                      lda=T, ldw=T)
     assert torch.allclose(out, plain, atol=2e-3, rtol=1e-4)
-
-
-def test_gemm_fused_split_k(ops):
-    """Few output tiles, long K: several workgroups share a 256 x 256 tile, the last arriver sums the partial tiles in split
-    order and applies the epilogue (gated residual in place; bf16).  16 tiles of 256 x 128, 2 splits each; then with 258 valid rows:
-    8 tiles, the 2 rows past the last full tile ride as side jobs."""
-    g = torch.Generator().manual_seed(77)
-    rows, B, N, K, valid = 512, 1, 1024, 2048, 258
-    A = _bf(torch.randn(B * rows, K, generator=g) * 0.5)
-    W = _bf(torch.randn(N, K, generator=g) * 0.05)
-    bias = torch.randn(N, generator=g)
-    ref = A.float() @ W.float().t() + bias
-    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, K, rows, 0) == 16 * 2 * 256 * 128 * 4          # 16 tiles of 256 x 128, 2 splits
-    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, K, rows, valid) == 8 * 2 * 256 * 128 * 4      # one full tile row of 256 x 128 tiles
-    assert ops.lib.dgs_dit_gemm_fused_splitk_bytes(B * rows, N, 1024, rows, 0) == 0                       # K too short to split
-    x0 = torch.randn(B * rows, N, generator=g)
-    gate = torch.randn(B, N, generator=g)
-    x = x0.clone()
-    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=rows, splitk=True)
-    assert torch.allclose(x, x0 + gate.repeat_interleave(rows, 0) * ref, atol=5e-3, rtol=1e-4)
-    plain = x0.clone()
-    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=plain, gate=gate, rows_per_batch=rows)
-    assert torch.allclose(x, plain, atol=5e-3, rtol=1e-4)
-    out = ops.gemm(A, W, bias, _native.EPI_BF16, rows_per_batch=rows, splitk=True)
-    assert torch.allclose(out.float(), ref, atol=3e-2, rtol=1e-2)
-    x2 = x0.clone()                                 # a second launch finds the arrival counters at zero again
-    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x2, gate=gate, rows_per_batch=rows, splitk=True)
-    assert torch.equal(x2, x)
-    x3 = x0.clone()
-    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x3, gate=gate, rows_per_batch=rows, valid_rows=valid, splitk=True)
-    assert torch.equal(x3[:256], x[:256]) and torch.equal(x3[288:], x0[288:])        # full tile: same arithmetic; padding untouched
-    assert torch.allclose(x3[256:valid], x[256:valid], atol=5e-3, rtol=1e-4)           # side jobs: K summed in 4 ranges
 
 
 @pytest.mark.parametrize("N", [256, 128, -256])

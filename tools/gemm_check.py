@@ -27,10 +27,9 @@ cases = {
     "fc1": lambda al: ops.gemm(xn, w1, None, _native.EPI_GELU_BF16, rows_per_batch=lpad, valid_rows=L, algo=al),
     "fc2": lambda al: ops.gemm(h, w2, None, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=lpad, valid_rows=L, algo=al),
     "f32": lambda al: ops.gemm(xn, w1, None, _native.EPI_F32, rows_per_batch=lpad, valid_rows=L, algo=al),
-    "fc2_fused": lambda al: ops.gemm(h, w2, None, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=lpad, valid_rows=L, algo=al, splitk=True),
     "proj": lambda al: ops.gemm(xn, wp, None, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=lpad, valid_rows=L, algo=al),
 }
-flops = {"fc2_fused": 2 * B * L * 4 * W * W, "f32": 2 * B * L * 4 * W * W, "qkv": 2 * B * L * 3 * W * W, "fc1": 2 * B * L * 4 * W * W, "fc2": 2 * B * L * 4 * W * W, "proj": 2 * B * L * W * W}
+flops = {"f32": 2 * B * L * 4 * W * W, "qkv": 2 * B * L * 3 * W * W, "fc1": 2 * B * L * 4 * W * W, "fc2": 2 * B * L * 4 * W * W, "proj": 2 * B * L * W * W}
 only = os.environ.get("GEMM_CASES")
 for name, fn in cases.items():
     if only and name not in only.split(","):
