@@ -55,7 +55,9 @@ typedef enum DgsGemmAlgo {
     DGS_GEMM_SIMPLE128 = 1,    /* 128 x 128|64 tiles, two LDS stages, 2 workgroups / CU (AUTO: the N = 1024 GEMMs at 1 sample) */
     DGS_GEMM_SLICED = 4,       /* 256 x 256|128 x 32 tiles, 4-stage LDS-DMA ring, explicit MFMA / LDS issue slices (AUTO: QKV and
                                   fc1 at 1 sample, every eligible shape above 8192 rows)                               */
-    DGS_GEMM_QUAD = 5          /* the same with 4 waves of 128 x 128 (256 x 256 tiles only; else as SLICED)              */
+    DGS_GEMM_QUAD = 5,         /* the same with 4 waves of 128 x 128 (256 x 256 tiles only; else as SLICED)              */
+    DGS_GEMM_SLICED128 = 6     /* the same ring and schedule on 128 x 128 tiles, 4 waves of 64 x 64 (AUTO: shapes with few tiles, e.g.
+                                  the N = 1024 GEMMs at one sample: 256 tiles, one per CU)                                */
 } DgsGemmAlgo;
 
 typedef struct DgsDitGemmArgs {

@@ -54,6 +54,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 #endif
 }
 
+// Sum over the 64 lanes, valid in lane 63 only: six v_add_f32_dpp (row shifts inside the 16-lane rows, then row broadcasts) instead
+// of six dependent ds_bpermute round trips (wave_sum below: ~400 cycles per sum; the GEMV side jobs do 16 of them).
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+#ifdef HIPEMU
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+#else
+#define DGS_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+    DGS_DPP_ADD(0x111);   // row_shr:1
+    DGS_DPP_ADD(0x112);   // row_shr:2
+    DGS_DPP_ADD(0x114);   // row_shr:4
+    DGS_DPP_ADD(0x118);   // row_shr:8    -> lane 15 of every 16-lane row holds the row sum
+    DGS_DPP_ADD(0x142);   // row_bcast:15 -> lanes 31 / 63 hold the sum of their row pair
+    DGS_DPP_ADD(0x143);   // row_bcast:31 -> lane 63 holds the wave sum
+#undef DGS_DPP_ADD
+    return v;
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -139,28 +139,6 @@ __device__ __forceinline__ void main_loop(const GemmParams& p, char* lds, int m0
 // issues all of its loads (8 columns x its K quarter, 16 bytes per lane) before the first v_dot2c_f32_bf16; the partial
 // sums meet in LDS and 16 lanes apply the epilogue element-wise (same arithmetic as store_strip).
 template <int EPI>
-__device__ __forceinline__ void tail_store(const GemmParams& p, int m, int n, float v) {
-    v += p.bias ? p.bias[n] : 0.0f;
-    const int b = m / p.rows_per_batch;
-    const size_t o = (size_t)m * p.ldo + n;
-    auto bf1 = [](float x) { return (bf16_t)(pack_bf2(x, 0.0f) & 0xffffu); };
-    if (EPI == DGS_EPI_F32) { reinterpret_cast<float*>(p.out)[o] = v; return; }
-    if (EPI == DGS_EPI_GATE_RESIDUAL) {
-        reinterpret_cast<float*>(p.out)[o] = p.resid[o] + p.gate[(size_t)b * p.gate_stride + n] * v;
-        if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = bf1(v);
-        return;
-    }
-    if (EPI == DGS_EPI_GELU_BF16) {
-        if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = bf1(v);
-        v = epi_gelu_tanh(v);
-    } else if (EPI == DGS_EPI_DGELU_BF16) {
-        v *= epi_dgelu_tanh(__uint_as_float((unsigned)reinterpret_cast<const bf16_t*>(p.aux)[o] << 16));
-    }
-    reinterpret_cast<bf16_t*>(p.out)[o] = bf1(v);
-    if (p.vt) p.vt[((size_t)b * p.N + n) * p.rows_per_batch + (m - b * p.rows_per_batch)] = bf1(v);
-}
-
-template <int EPI>
 __device__ __forceinline__ void gemv_tail_rows(const GemmParams& p, char* lds, int item, int wave, int lane) {
     constexpr int CPI = 8;                                   // columns per item
     const int nblk = p.N / CPI, b = item / nblk, tn0 = (item - b * nblk) * CPI;
@@ -171,6 +149,10 @@ __device__ __forceinline__ void gemv_tail_rows(const GemmParams& p, char* lds, i
     const bf16_t* a_row0 = p.A + (size_t)tm0 * p.lda + k_lo + lane * 8;
     const bf16_t* w_col0 = p.W + (size_t)tn0 * p.ldw + k_lo + lane * 8;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    const int er = lane / CPI, ec = lane - er * CPI;         // the element lane `lane` of wave 0 finishes (lanes 0 .. 2 CPI - 1)
+    const bool finisher = wave == 0 && lane < 2 * CPI && p.tail_row0 + er < p.valid_rows;
+    TailOperands ops{0.f, 0.f, 0.f};
+    if (finisher) ops = tail_prefetch<EPI>(p, tm0 + er, tn0 + ec);
     uint4 a[2][2], w[CPI][2];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
@@ -185,14 +167,14 @@ __device__ __forceinline__ void gemv_tail_rows(const GemmParams& p, char* lds, i
     for (int c = 0; c < CPI; ++c) {
         float s0 = dot8_bf16(a[0][0], w[c][0], 0.f), s1 = dot8_bf16(a[1][0], w[c][0], 0.f);
         s0 = dot8_bf16(a[0][1], w[c][1], s0); s1 = dot8_bf16(a[1][1], w[c][1], s1);
-        s0 = wave_sum(s0); s1 = wave_sum(s1);
-        if (lane == 0) { part[(wave * 2 + 0) * CPI + c] = s0; part[(wave * 2 + 1) * CPI + c] = s1; }
+        s0 = wave_sum_lane63(s0); s1 = wave_sum_lane63(s1);
+        if (lane == 63) { part[(wave * 2 + 0) * CPI + c] = s0; part[(wave * 2 + 1) * CPI + c] = s1; }
     }
     __syncthreads();
-    if (wave == 0 && lane < 2 * CPI) {
-        const int r = lane / CPI, c = lane - r * CPI;
+    if (finisher) {
+        const int r = er, c = ec;
         const float v = (part[(0 * 2 + r) * CPI + c] + part[(1 * 2 + r) * CPI + c]) + (part[(2 * 2 + r) * CPI + c] + part[(3 * 2 + r) * CPI + c]);
-        if (p.tail_row0 + r < p.valid_rows) tail_store<EPI>(p, tm0 + r, tn0 + c, v);
+        tail_store<EPI>(p, tm0 + r, tn0 + c, v, ops);
     }
 }
 
@@ -323,6 +305,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
 int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);   // dit_gemm_deep.hip
 int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad);
+bool sliced128_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch);
 int splitk_plan(int M, int N, int K, int k_per_batch, int* splits_per_batch);
 int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st);
 
@@ -394,6 +377,13 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
         const int sbn = sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
         if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0, algo == DGS_GEMM_QUAD);
     }
+    // few tiles and a long reduction (fc2 at one sample: N = 1024, K = 4096): 128 x 128 tiles on the sliced kernel's ring, one per
+    // CU -- 56 vs 60 us; at K = 1024 (proj) its prologue and epilogue weigh more and the 128-wide kernel below wins, 21 vs 23 us
+    static const int no_s128 = getenv("DGS_GEMM_NO_SLICED128") ? atoi(getenv("DGS_GEMM_NO_SLICED128")) : 0;   // measurement aid
+    const bool few_tiles = (a->M / BM) * (a->N / 128) < 512 && a->N % 128 == 0;
+    if ((algo == DGS_GEMM_SLICED128 || (algo == DGS_GEMM_AUTO && few_tiles && !no_s128 && a->K >= 2048)) &&
+        sliced128_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
+        return launch_sliced_gemm(a, -128, p.rows_per_batch, p.valid_rows, st0, false);
     // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each
     if (a->epilogue == DGS_EPI_QKV && a->N % 128) return DGS_ERR_INVALID_ARGUMENT;
     static const int env_bn = getenv("DGS_GEMM_BN") ? atoi(getenv("DGS_GEMM_BN")) : 0;      // measurement aid

@@ -159,15 +159,20 @@ __device__ long long dgs_gemm_dbg[16];   // DGS_GEMM_DBG: cycle stamps of workgr
 // fragments; four SIMDs at full MFMA rate therefore pull 128 (I + J) / (I J) B/clk from a 128 B/clk LDS that also absorbs the
 // DMA writes:   2 x 1 (the 128 x 64 tile): 192 + 48,   2 x 2: 128 + 32,   2 x 4 (NW = 8): 96 + 32,   4 x 4 (NW = 4): 64 + 32.
 // EXP (measurement only, wrong results): 1 = no DMA refills in the loop, 2 = no fragment reads in the loop
-template <int EPI, int BN, int NW, int EXP = 0>
+// BM = 128 (NW = 4, BN = 128: a wave owns 64 x 64): the N = 1024 GEMMs at one sample.  256-row tiles give 64-128 of them for 256
+// CUs and the two-stage 128-wide kernel of dit_gemm.hip runs them at 0.4-0.57 PFLOP/s; 128 x 128 tiles are 32 x 8 = 256, one
+// per CU, on this kernel's ring and schedule (0.5 DMA pieces per MFMA instead of 0.25: the loop is DMA-issue-bound, but with
+// three slabs in flight and one barrier per slab).
+template <int EPI, int BN, int NW, int EXP = 0, int BM = 256>
 __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepParams p) {
-    constexpr int BM = 256, BK = 32, NS = 4;
-    constexpr int WMB = NW == 8 ? 2 : 4, WROWS = 32 * WMB;        // A blocks per wave
+    constexpr int BK = 32, NS = BM == 128 ? 8 : 4;                // ring depth (LDS: 128 KiB for every tile shape)
+    constexpr int WMB = BM / (16 * NW), WROWS = 32 * WMB;         // A blocks per wave: waves are (NW / 2) x 2
     constexpr int WN = BN / 2, NI = WN / 32;                      // wave tile WROWS x WN: WMB x NI accumulators
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int G = (A_BYTES / 1024 + W_BYTES / 1024) / NW;     // LDS-DMA instructions per wave per slab
     constexpr int NF = WMB + NI, MF = WMB * NI;                   // per k-substep: fragments (WMB of A, NI of W), MFMAs
-    static_assert(NW == 8 || BN == 256, "quad layout: 256 x 256 tiles");
+    static_assert(NW == 8 || BN == 256 || (BM == 128 && BN == 128), "4 waves: 256 x 256 tiles (128 x 128 per wave) or 128 x 128 tiles (64 x 64)");
+    static_assert(WMB * NI >= G, "one DMA piece behind each MFMA of the spread half");
     DGS_DYNAMIC_LDS(lds);
 #ifndef HIPEMU
     const long long dbg_k0 = p.dbg == 1 ? clock64() : 0;
@@ -185,56 +190,52 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const int K_all = p.K;
     auto side_jobs = [&]() {
         if (p.tail_mode == 2) {
-            // At most two live rows behind the last full tile row (the DiT's learned tokens): a 2-row GEMV per 32-column block, on
-            // the vector pipe.  A wave takes 32 / NW columns; its lanes span K with 16-byte loads (a wave-instruction = 1 KiB of one
-            // row = 8 cache lines, against the 32 lines of a fragment-layout gather), v_dot2c_f32_bf16 into fp32, a wave reduction
-            // per (row, column).  The 2 x 32 results go through LDS into the accumulator layout and out through the epilogue.
-            constexpr int CPW = 32 / NW;
-            const int nblk = p.N / 32, nch = K_all / 512;               // K_all % 512 == 0, nch <= 8 (launch_sliced)
-            float* const tile2 = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);
+            // At most two live rows behind the last full tile row (the DiT's learned tokens): a 2-row GEMV on the vector pipe.  An
+            // item is 8 output columns of one sample and ONE memory round trip: the NW waves split K, every wave issues all of its
+            // loads (8 columns x its K range, 16 bytes per lane; a wave-instruction = 1 KiB of one row = 8 cache lines, against the
+            // 32 lines of a fragment-layout gather) before the first v_dot2c_f32_bf16; the partial sums meet in LDS and 16 lanes
+            // apply the epilogue element-wise (tail_store).  While the chip streams GEMM tiles a round trip costs microseconds:
+            // the earlier form (a wave per 32 / NW columns, all of K, two columns per trip) held its workgroup back by 13 us at K = 4096.
+            // The NW waves are KS ranges of K x CS groups of 8 columns: KS = min(NW, K / 512) keeps every lane of a wave busy
+            // (a range is 512 or 1024 elements = one or two 16-byte loads per lane and row).
+            const int KS = min(NW, K_all / 512), CS = NW / KS, CPI = 8 * CS;     // p.tail_cpi == CPI (launch_sliced)
+            const int nblk = p.N / CPI;
+            const int kq = wave % KS, cq = wave / KS;
+            const int kw = K_all / KS, k_lo = kq * kw;                   // 512 or 1024
+            const bool two = kw > 512;
+            float* const part = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);     // [k range][row][column of the item]
+            const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
             for (int j = bid; j < p.ntail; j += (int)gridDim.x) {
                 const int blk = j % nblk, trr = j / nblk;
-                const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = blk * 32;
-                uint4 a0[8], a1[8];
+                const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = blk * CPI + cq * 8;
+                const bf16_t* a_row0 = A_all + (size_t)tm0 * p.lda + k_lo + lane * 8;
+                const bf16_t* w_col0 = W_all + (size_t)tn0 * p.ldw + k_lo + lane * 8;
+                const int er = tid / CPI, ec = tid - er * CPI;           // the element thread `tid` finishes (tid < 2 CPI)
+                const int erow = tm0 + er;
+                const bool finisher = tid < 2 * CPI && erow - (erow / p.rows_per_batch) * p.rows_per_batch < p.valid_rows;
+                TailOperands ops{0.f, 0.f, 0.f};
+                if (finisher) ops = tail_prefetch<EPI>(p, erow, blk * CPI + ec);
+                uint4 a[2][2], w[8][2];
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch)
-                    if (ch < nch) {
-                        a0[ch] = *reinterpret_cast<const uint4*>(A_all + (size_t)tm0 * p.lda + ch * 512 + lane * 8);
-                        a1[ch] = *reinterpret_cast<const uint4*>(A_all + (size_t)(tm0 + 1) * p.lda + ch * 512 + lane * 8);
-                    }
-                // all loads of a group of columns go out before the first dot product (one L2 round trip per group): every column of
-                // the wave at once for K <= 1024, two at a time beyond (register budget)
-                auto columns = [&](auto gtag, auto ctag) {
-                    constexpr int GC = decltype(gtag)::value, NCH = decltype(ctag)::value;
+                for (int ch = 0; ch < 2; ++ch) {
+                    const bool on = ch == 0 || two;
 #pragma unroll
-                    for (int c0 = 0; c0 < CPW; c0 += GC) {
-                        uint4 w[GC][NCH];
+                    for (int r = 0; r < 2; ++r) a[r][ch] = on ? *reinterpret_cast<const uint4*>(a_row0 + (size_t)r * p.lda + ch * 512) : zero;
 #pragma unroll
-                        for (int c = 0; c < GC; ++c)
+                    for (int c = 0; c < 8; ++c) w[c][ch] = on ? *reinterpret_cast<const uint4*>(w_col0 + (size_t)c * p.ldw + ch * 512) : zero;
+                }
 #pragma unroll
-                            for (int ch = 0; ch < NCH; ++ch)
-                                if (ch < nch) w[c][ch] = *reinterpret_cast<const uint4*>(W_all + (size_t)(tn0 + wave * CPW + c0 + c) * p.ldw + ch * 512 + lane * 8);
-#pragma unroll
-                        for (int c = 0; c < GC; ++c) {
-                            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                            for (int ch = 0; ch < NCH; ++ch)
-                                if (ch < nch) { s0 = dot8_bf16(a0[ch], w[c][ch], s0); s1 = dot8_bf16(a1[ch], w[c][ch], s1); }
-                            s0 = wave_sum(s0);
-                            s1 = wave_sum(s1);
-                            if (lane == 0) { tile2[wave * CPW + c0 + c] = s0; tile2[32 + wave * CPW + c0 + c] = s1; }
-                        }
-                    }
-                };
-                if (nch <= 2) columns(SIC<CPW>{}, SIC<2>{});
-                else columns(SIC<(CPW < 2 ? CPW : 2)>{}, SIC<8>{});
+                for (int c = 0; c < 8; ++c) {
+                    float s0 = dot8_bf16(a[0][0], w[c][0], 0.f), s1 = dot8_bf16(a[1][0], w[c][0], 0.f);
+                    s0 = dot8_bf16(a[0][1], w[c][1], s0); s1 = dot8_bf16(a[1][1], w[c][1], s1);
+                    s0 = wave_sum_lane63(s0); s1 = wave_sum_lane63(s1);
+                    if (lane == 63) { part[(kq * 2 + 0) * CPI + cq * 8 + c] = s0; part[(kq * 2 + 1) * CPI + cq * 8 + c] = s1; }
+                }
                 __syncthreads();
-                if (wave == 0) {
-                    f32x16 acc1[1];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-                    if (fhalf == 0) { acc1[0][0] = tile2[frow]; acc1[0][1] = tile2[32 + frow]; }      // rows 0, 1 of the block: registers 0, 1 of lanes 0..31
-                    store_block<EPI, 1>(p, acc1, tm0 + 4 * fhalf, tn0, lane);
+                if (finisher) {
+                    float v = 0.f;
+                    for (int q = 0; q < KS; ++q) v += part[(q * 2 + er) * CPI + ec];
+                    tail_store<EPI>(p, erow, blk * CPI + ec, v, ops);
                 }
                 __syncthreads();
             }
@@ -320,7 +321,12 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     // column block, and still 14 us in this one-trip form.
     side_jobs();
 #ifndef HIPEMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the slabs, and the stores above (the counted waits of the loop see DMAs only)
+    // Slabs 0 and 1 have to be there before iteration 0 (its second half prefetches fragments of slab 1); slabs 2 .. NS-2 may stay
+    // in flight -- with the 8-stage ring of the 128 x 128 tiles, waiting for all seven (112 KiB per CU, every CU at once) cost
+    // ~10 k cycles of every tile.  A workgroup that ran a side job has stores in flight too, and the counted waits of the loop
+    // must see DMAs only: it drains completely.
+    if (bid < p.ntail && p.nsplit == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
     __builtin_amdgcn_s_barrier();
 #else
     __syncthreads();
@@ -358,7 +364,11 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #ifndef HIPEMU
         long long w0 = 0;
         if (p.dbg == 1) w0 = clock64();
-        if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        // The second half of iteration t+1 already prefetches fragments of slab t+2, so slabs <= t+2 must have landed by the end of
+        // iteration t: slabs t+3 .. t+NS-1 stay in flight across the barrier (DMAs complete in issue order).  NS = 4: only the slab
+        // issued in this iteration; NS = 8 (128 x 128 tiles, whose A operand streams from beyond L2): five slabs, ~3 k cycles of
+        // latency tolerance.
+        if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long w1 = 0;
         if (p.dbg == 1) w1 = clock64();
@@ -371,16 +381,12 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #ifndef HIPEMU
     const long long dbg_t0 = p.dbg == 1 ? clock64() : 0;
 #endif
-    for (int t = 0; t < nk - NS; t += NS) {
-        iteration(t, 0, std::true_type{});
-        iteration(t + 1, 1, std::true_type{});
-        iteration(t + 2, 2, std::true_type{});
-        iteration(t + 3, 3, std::true_type{});
-    }
-    iteration(nk - 4, 0, std::true_type{});                       // the last slab goes out here
-    iteration(nk - 3, 1, std::false_type{});
-    iteration(nk - 2, 2, std::false_type{});
-    iteration(nk - 1, 3, std::false_type{});
+    for (int t = 0; t < nk - NS; t += NS)                          // unrolled by the ring depth: slots are literals
+        sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, decltype(sc)::value, std::true_type{}); });
+    sliced_for<0, NS>([&](auto sc) {                               // the last slab goes out in the first of the last NS iterations
+        constexpr int S = decltype(sc)::value;
+        iteration(nk - NS + S, S, std::integral_constant<bool, S == 0>{});
+    });
 #ifndef HIPEMU
     const long long dbg_t1 = p.dbg == 1 ? clock64() : 0;
 #endif
@@ -412,33 +418,34 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #endif
 }
 
-template <int EPI, int BN, int NW = 8>
+template <int EPI, int BN, int NW = 8, int BM = 256>
 static int launch_sliced(DeepParams p, hipStream_t st) {
-    constexpr int LDS = 4 * (256 * 32 * 2 + BN * 32 * 2);          // 128 KiB (BN 256) / 96 KiB (BN 128)
+    constexpr int LDS = (BM == 128 ? 8 : 4) * (BM * 32 * 2 + BN * 32 * 2);   // 128 KiB (256 x 256) / 96 KiB (256 x 128) / 128 KiB (128 x 128, 8 stages)
     p.tiles_n = p.N / BN;
-    p.rows_ps = p.rows_per_batch / 256;
+    p.rows_ps = p.rows_per_batch / BM;
     p.full_rows = 0; p.tail_rows = 0;
     // A tile row with a single live 32-row block is not a tile: its blocks are side jobs of the first workgroups -- a two-row
     // GEMV on the vector pipe when at most 2 rows are live (the DiT's learned tokens), MFMA items otherwise; if the shape fits
     // neither, it runs the ring like a full row.
-    const int last_live = p.valid_rows - (p.valid_rows - 1) / 256 * 256;                     // live rows of the last tile row that has any
-    const bool gemv_ok = last_live <= 2 && p.K % 512 == 0 && p.K <= 4096;
+    const int last_live = p.valid_rows - (p.valid_rows - 1) / BM * BM;                       // live rows of the last tile row that has any
+    const bool gemv_ok = last_live <= 2 && p.K >= 512 && p.K <= 4096 && (p.K & (p.K - 1)) == 0 && p.N % 64 == 0;
     const bool mfma_ok = p.K % (NW / (BN == 256 ? 1 : 2) * 128) == 0;
     for (int i = 0; i < p.rows_ps; ++i) {                          // per sample: tile rows with >= 2 / exactly 1 live 32-row blocks
-        const int live = (p.valid_rows - i * 256 + 31) / 32;
+        const int live = (p.valid_rows - i * BM + 31) / 32;
         if (live > 1 || (live == 1 && !gemv_ok && !mfma_ok)) ++p.full_rows; else if (live == 1) ++p.tail_rows;
     }
     const int samples = p.M / p.rows_per_batch;
     p.nfull_items = samples * p.full_rows * p.tiles_n;
     p.tail_mode = gemv_ok ? 2 : 1;
-    p.ntail = samples * p.tail_rows * (gemv_ok ? p.N / 32 : p.tiles_n * (BN == 256 ? 8 : 2));
+    const int gemv_ks = NW < p.K / 512 ? NW : p.K / 512, gemv_cpi = 8 * (NW / (gemv_ks > 0 ? gemv_ks : 1));
+    p.ntail = samples * p.tail_rows * (gemv_ok ? p.N / gemv_cpi : p.tiles_n * (BN == 256 ? 8 : 2));
     p.ntiles = p.nfull_items ? p.nfull_items : p.ntail;
     if (p.nsplit > 1) {
         if (p.tail_rows || samples != 1) return DGS_ERR_INVALID_ARGUMENT;
         p.ntiles = p.nfull_items * p.nsplit;
     }
-    auto kern = gemm_sliced_kernel<EPI, BN, NW>;
-    if constexpr (EPI == DGS_EPI_F32 && BN == 256) {              // DGS_GEMM_EXP=1|2: the measurement variants
+    auto kern = gemm_sliced_kernel<EPI, BN, NW, 0, BM>;
+    if constexpr (EPI == DGS_EPI_F32 && BN == 256 && BM == 256) {              // DGS_GEMM_EXP=1|2: the measurement variants
         static const int exp = getenv("DGS_GEMM_EXP") ? atoi(getenv("DGS_GEMM_EXP")) : 0;
         if (exp == 1) kern = gemm_sliced_kernel<EPI, BN, NW, 1>;
         if (exp == 2) kern = gemm_sliced_kernel<EPI, BN, NW, 2>;
@@ -482,6 +489,11 @@ int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int row
     return N % 128 ? 0 : 128;
 }
 
+// 128 x 128 tiles (bn = -128 in launch_sliced_gemm): eligibility
+bool sliced128_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch) {
+    return k_per_batch == K && K % 256 == 0 && M % 128 == 0 && rows_per_batch % 128 == 0 && N % 128 == 0 && epilogue != DGS_EPI_QKV;
+}
+
 int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad) {
     DeepParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
@@ -490,7 +502,8 @@ int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int 
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
-#define DGS_SLICED_CASE(E) case E: return bn == 256 ? (quad ? launch_sliced<E, 256, 4>(p, st) : launch_sliced<E, 256>(p, st)) : launch_sliced<E, 128>(p, st)
+#define DGS_SLICED_CASE(E) case E: return bn == 256 ? (quad ? launch_sliced<E, 256, 4>(p, st) : launch_sliced<E, 256>(p, st)) : \
+                                   bn == 128 ? launch_sliced<E, 128>(p, st) : launch_sliced<E, 128, 4, 128>(p, st)
     switch (a->epilogue) {
         DGS_SLICED_CASE(DGS_EPI_BF16);
         DGS_SLICED_CASE(DGS_EPI_GELU_BF16);

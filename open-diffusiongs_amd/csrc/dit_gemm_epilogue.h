@@ -74,6 +74,7 @@ __device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b, float
 
 constexpr int epi_strip_bytes(int nb) { return 32 * (32 * nb + 4) * 4; }     // LDS per wave
 
+
 // Which (epilogue, arguments) take the staged path: all of them.  (The training epilogues -- DGELU and the transposed `vt`
 // copies of BF16 / GELU / DGELU -- used to keep the per-register path of their kernel: 16 two-byte loads and stores per block
 // per lane made the fc2 input-gradient GEMM 489 us at 4 samples, 175 us more than the forward fc1 of the same shape.)
@@ -181,5 +182,47 @@ __device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m
     }
     __builtin_amdgcn_wave_barrier();       // the patch is rewritten by the next strip
 }
+
+// One output element (row m, column n) through epilogue EPI: the scalar twin of store_strip, same arithmetic and roundings.
+// Used by the GEMV items that compute the one or two live rows behind a sample's last full tile.
+struct TailOperands { float bias, resid, gate; };           // what a GEMV item can load BEFORE its dot products: no second round trip
+template <int EPI, class P>
+__device__ __forceinline__ TailOperands tail_prefetch(const P& p, int m, int n) {
+    TailOperands t{0.f, 0.f, 0.f};
+    if (p.bias) t.bias = p.bias[n];
+    if (EPI == DGS_EPI_GATE_RESIDUAL) {
+        t.resid = p.resid[(size_t)m * p.ldo + n];
+        t.gate = p.gate[(size_t)(m / p.rows_per_batch) * p.gate_stride + n];
+    }
+    return t;
+}
+template <int EPI, class P>
+__device__ __forceinline__ void tail_store(const P& p, int m, int n, float v, const TailOperands& t) {
+    v += t.bias;
+    const int b = m / p.rows_per_batch;
+    const size_t o = (size_t)m * p.ldo + n;
+    auto bf1 = [](float x) { return (bf16_t)(pack_bf2(x, 0.0f) & 0xffffu); };
+    if (EPI == DGS_EPI_F32) { reinterpret_cast<float*>(p.out)[o] = v; return; }
+    if (EPI == DGS_EPI_QKV) {                                   // q (pre-scaled) | k row-major, V only as V^T[b][feature][token]
+        const int third = p.N / 3;
+        if (n >= 2 * third) p.vt[((size_t)b * third + (n - 2 * third)) * p.rows_per_batch + (m - b * p.rows_per_batch)] = bf1(v);
+        else reinterpret_cast<bf16_t*>(p.out)[o] = bf1(n < third ? v * p.q_scale : v);
+        return;
+    }
+    if (EPI == DGS_EPI_GATE_RESIDUAL) {
+        reinterpret_cast<float*>(p.out)[o] = t.resid + t.gate * v;
+        if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = bf1(v);
+        return;
+    }
+    if (EPI == DGS_EPI_GELU_BF16) {
+        if (p.aux) reinterpret_cast<bf16_t*>(p.aux)[o] = bf1(v);
+        v = epi_gelu_tanh(v);
+    } else if (EPI == DGS_EPI_DGELU_BF16) {
+        v *= epi_dgelu_tanh(__uint_as_float((unsigned)reinterpret_cast<const bf16_t*>(p.aux)[o] << 16));
+    }
+    reinterpret_cast<bf16_t*>(p.out)[o] = bf1(v);
+    if (p.vt) p.vt[((size_t)b * p.N + n) * p.rows_per_batch + (m - b * p.rows_per_batch)] = bf1(v);
+}
+
 
 }  // namespace dgs

@@ -120,7 +120,7 @@ def status_string(L, code):
 # include/dgs_dit.h
 # ---------------------------------------------------------------------------------------------------
 EPI_BF16, EPI_GELU_BF16, EPI_GATE_RESIDUAL, EPI_F32, EPI_QKV, EPI_DGELU_BF16 = range(6)
-GEMM_AUTO, GEMM_SIMPLE128, GEMM_SLICED, GEMM_QUAD = 0, 1, 4, 5
+GEMM_AUTO, GEMM_SIMPLE128, GEMM_SLICED, GEMM_QUAD, GEMM_SLICED128 = 0, 1, 4, 5, 6
 
 
 class DgsDitGemmArgs(ctypes.Structure):

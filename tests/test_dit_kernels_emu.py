@@ -381,3 +381,35 @@ def test_gemm_128_wide_gemv_tail_rows(ops):
         o = ops.gemm(A, W, bias, _native.EPI_BF16, rows_per_batch=rows, valid_rows=valid, vt=vt, algo=_native.GEMM_SIMPLE128)
         assert torch.allclose(o.float()[live], ref[live], atol=3e-2, rtol=1e-2)
         assert torch.equal(vt[:, :, :valid], o.reshape(B, rows, N).transpose(1, 2)[:, :, :valid])
+
+
+def test_gemm_sliced_128_tiles(ops):
+    """The sliced ring on 128 x 128 tiles, 4 waves of 64 x 64 (the N = 1024 GEMMs at one sample: one tile per CU): several trips
+    round the ring, padding rows, the two-live-row GEMV side job, a live-block MFMA side job, and the epilogues those GEMMs use."""
+    sl = _native.GEMM_SLICED128
+    g = torch.Generator().manual_seed(47)
+    M, N, K = 512, 256, 1024
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.2)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    out = ops.gemm(A, W, bias, _native.EPI_F32, algo=sl)
+    assert torch.allclose(out, ref, atol=3e-3, rtol=1e-4)
+    for valid in (130, 150, 2):                      # 2 rows past a full tile (GEMV items) / 22 rows (MFMA items) / no full tile at all
+        out = torch.full((M, N), 7.0)
+        ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=256, valid_rows=valid, algo=sl)
+        for b in range(2):
+            assert torch.allclose(out[b * 256:b * 256 + valid], ref[b * 256:b * 256 + valid], atol=3e-3, rtol=1e-4), valid
+            assert bool((out[b * 256 + 160:(b + 1) * 256] == 7.0).all()), valid
+    x0 = torch.randn(M, N, generator=g)
+    gate = torch.randn(2, N, generator=g)
+    x, aux = x0.clone(), torch.zeros(M, N, dtype=torch.bfloat16)
+    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=256, valid_rows=130, aux=aux, resid=x0, algo=sl)
+    live = (torch.arange(M) % 256) < 130
+    want = x0 + gate.repeat_interleave(256, 0) * ref
+    assert torch.allclose(x[live], want[live], atol=5e-3, rtol=1e-4)
+    assert torch.allclose(aux.float()[live], ref[live], atol=3e-2, rtol=1e-2)
+    vt = torch.zeros(2, N, 256, dtype=torch.bfloat16)
+    o = ops.gemm(A, W, bias, _native.EPI_BF16, rows_per_batch=256, valid_rows=130, vt=vt, algo=sl)
+    assert torch.allclose(o.float()[live], ref[live], atol=3e-2, rtol=1e-2)
+    assert torch.equal(vt[:, :, :130], o.reshape(2, 256, N).transpose(1, 2)[:, :, :130])
