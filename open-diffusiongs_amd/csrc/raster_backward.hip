@@ -433,6 +433,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
 using namespace dgs;
 
 extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t stream) {
+    (void)hipGetLastError();       // sticky per-thread error state of unrelated earlier calls is not ours to report
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!a || a->P < 0 || a->width <= 0 || a->height <= 0 || a->V < 1 || a->views_per_set < 1) return DGS_ERR_INVALID_ARGUMENT;
     const int P = a->P, V = a->V, W = a->width, H = a->height;

@@ -821,8 +821,10 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* vm, 
 }
 
 static int check(hipStream_t st, int debug) {
-    if (debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
-    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+    hipError_t e = debug ? hipStreamSynchronize(st) : hipSuccess;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { fprintf(stderr, "[dgs] rasterizer: HIP error %d (%s)\n", (int)e, hipGetErrorString(e)); return DGS_ERR_DEVICE; }
+    return DGS_OK;
 }
 
 static int pick_window_words(int P) {
@@ -863,6 +865,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     if (!a || a->P < 0 || a->width <= 0 || a->height <= 0 || a->V < 1 || a->views_per_set < 1) return DGS_ERR_INVALID_ARGUMENT;
     const int P = a->P, V = a->V, W = a->width, H = a->height;
     a->num_rendered = 0;
+    (void)hipGetLastError();       // hipGetLastError is sticky per thread: an unrelated earlier failure (another library's probing) must
+                                   // not be reported as ours by the checks below
     if (!a->out_color || !a->geom_alloc || !a->img_alloc || !a->binning_alloc) return DGS_ERR_INVALID_ARGUMENT;
     const size_t HW = (size_t)W * H;
     if (P == 0) {   // rasterize_points.cu:68: outputs stay zero-initialised
@@ -981,7 +985,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
                                 kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
-        if (!lds_ok) return DGS_ERR_DEVICE;
+        if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
         const size_t lds = (size_t)p.bitonic_cap * 8 + 2 * kBuckets * 4;
         if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(p.T, V), dim3(1024), lds, st, p);
         else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(p.T, V), dim3(256), lds, st, p);

@@ -106,6 +106,10 @@ def lib():
             raise RuntimeError(
                 f"dgs_amd: HIP library {LIB_PATH} is missing. Build it with `python -m dgs_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm ships its own copy of the HIP runtime (torch/lib/libamdhip64.so); the device pointers and streams this
+        # library is handed come from it.  It has to be in the process FIRST, so that libdgs_hip.so's libamdhip64.so.7 resolves to
+        # that copy: loaded the other way round the process holds two runtimes and every launch fails with hipErrorNoDevice.
+        import torch  # noqa: F401
         _lib = open_library(LIB_PATH)
         if _lib.dgs_abi_version() != 1:
             raise RuntimeError("dgs_amd: ABI version mismatch between Python binding and libdgs_hip.so")
