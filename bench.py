@@ -17,6 +17,7 @@ Prints ONE JSON line (rank 0).  Extra objects next to the contract keys:
                 tools/pmc_traffic.py IF they were taken on exactly these kernel sources (else null)
   raster        the rasterizer on its HBM roofline, forward and forward+backward, in the regime the step renders (random-init
                 Gaussians) and the trained-like regime, algorithmic bytes 104 P + 84 N + 20 HW per view
+  scene_512     BASELINE configs[4] at inference: the scene model's sampling step at 512^2 (L = 16,386, P = 1,048,578), informational
   train_step    BASELINE configs[3]: B = 4 samples / GPU, 10 rendered views, forward + backward + gradient all-reduce
                 (overlapped, RCCL) + AdamW step + weight refresh, `DataParallelTrainer.step` end to end
   cpu_baseline  the CPU oracle on the host cores on ONE sample of the same workload (N = 1 only)
@@ -188,6 +189,42 @@ def raster_roofline(dev, res, V, iters=10):
                 rec[name]["traffic"] = traffic["raster"][regime][name]
         out[regime] = rec
     return out
+
+
+def scene_512(dev, steps=5):
+    """BASELINE configs[4] at inference: the scene model (`diffusion-gs-model-scene`, plk ray embedding) at 512^2, one sample, 4 views:
+    L = 16,386 tokens, 36.3 TFLOP per DiT step, P = 1,048,578 Gaussians rendered into 4 views.  Informational, not part of `value`."""
+    import torch
+    from dgs_amd import denoiser as dn, synth
+    model = dn.DGSDenoiserScene(dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="plk"), device=dev)
+    model.reset_parameters(seed=0)
+    batch, t = synth.make_batch(1, 512, V=4, device=dev, seed=0, with_t=True)
+    eng = model.engine()
+    L = eng.num_tokens(4, 512, 512)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * 24)]
+    for e in ev:
+        e.record()
+
+    def step(prof=None):
+        with torch.no_grad():
+            params, _ = eng.image_to_gaussians(batch["image"], batch["ray_o"], batch["ray_d"], t, prof=prof)
+            params.pop("prof_count", 0)
+            return model.render_gaussians(dn.AttrDict(params), batch["c2w"], batch["fxfycxcy"], 512, 512)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(prof=(PROF_KINDS["attention"], ev) if i == steps - 1 else None)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    attn_ms = sum(ev[2 * j].elapsed_time(ev[2 * j + 1]) for j in range(24)) / 24
+    return {"workload": "scene-512 sampling step (BASELINE.json configs[4] at inference): DiT L=%d + 4 rasterizations of P=%d Gaussians at 512^2" % (L, 2 + 4 * 512 * 512),
+            "ms_per_step": round(ms, 2), "renders_per_s": round(4 / (ms * 1e-3), 1), "dit_tflop_per_sample": round(dit_flops(L) / 1e12, 2),
+            "step_frac_of_peak": round(dit_flops(L) / (ms * 1e-3) / PEAK_BF16_MFMA, 4),
+            "attention": {"avg_launch_us": round(attn_ms * 1e3, 1), "achieved_tflops": round(4.0 * L * L * 1024 / (attn_ms * 1e-3) / 1e12, 1),
+                          "frac": round(4.0 * L * L * 1024 / (attn_ms * 1e-3) / PEAK_BF16_MFMA, 4)}}
 
 
 def train_bench(a, dev, rank, world, steps, warmup):
@@ -378,11 +415,13 @@ def main():
                                              "note": "per GPU; informational, not part of value"}
     if not a.no_extras:
         rr = raster_roofline(dev, res, V) if rank == 0 else None
+        s512 = scene_512(dev) if rank == 0 else None
         del model, eng
         torch.cuda.empty_cache()
         tb = train_bench(a, dev, rank, world, a.train_steps, 2)      # every rank: the step has a collective
         if rank == 0:
             out["raster"] = rr
+            out["scene_512"] = s512
             out["train_step"] = tb
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not a.no_extras:
