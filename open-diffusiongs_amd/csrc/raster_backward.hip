@@ -33,7 +33,7 @@ struct BwdParams {
     float *dL_dmean2D, *dL_dconic, *dL_dcolors, *dL_dcov3D, *dL_dopacity, *dL_dmeans3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 
-// grid (gx, gy, V), block 16x16 = 4 wave64 (each a 16x4 pixel strip).  backward.cu:399-557.
+// grid V*T (workgroup b takes tile tile_order[b], like the forward), block 16x16 = 4 wave64 (each a 16x4 pixel strip).  backward.cu:399-557.
 //
 // Per (tile, Gaussian) the nine sums have to be reduced over up to 256 pixels.  A wave reduces its strip with DPP adds and
 // parks the nine partial sums in LDS (one slot per (wave, batch entry), plus a 256-bit "touched" set per wave); when the batch
@@ -54,15 +54,17 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     __shared__ unsigned long long s_set[4][4];            // [strip][staging wave]: entries the strip may touch (strip_mask)
     __shared__ unsigned long long s_hit[4][4];            // [strip][staging wave]: entries the strip did touch
     __shared__ float s_part[4][9][256];                   // [strip][value][entry]
-    const int v = blockIdx.z, s = v / p.vps;
+    const uint32_t vt = p.im.tile_order[blockIdx.x];           // order_tiles_kernel: most replayed entries first
+    const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T), s = v / p.vps;
+    const int bx = tile % p.gx, by = tile / p.gx;
     const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pxi = blockIdx.x * kTile + threadIdx.x, pyi = blockIdx.y * kTile + threadIdx.y;
+    const int pxi = bx * kTile + threadIdx.x, pyi = by * kTile + threadIdx.y;
     const bool inside = pxi < p.W && pyi < p.H;
     const float pfx = (float)pxi, pfy = (float)pyi;
-    const float tx0 = (float)(blockIdx.x * kTile), ty0 = (float)(blockIdx.y * kTile);
+    const float tx0 = (float)(bx * kTile), ty0 = (float)(by * kTile);
     const size_t HW = (size_t)p.H * p.W, pid = (size_t)p.W * pyi + pxi;
-    const uint2 rg = p.im.ranges[(size_t)v * p.T + blockIdx.y * p.gx + blockIdx.x];
+    const uint2 rg = p.im.ranges[vt];
     const size_t vo = (size_t)v * p.P;
 
     const float T_final = inside ? p.im.final_T[(size_t)v * HW + pid] : 0.0f;
@@ -266,6 +268,20 @@ __device__ __forceinline__ void sh_backward(int deg, const float* sh, float ox, 
 }
 
 // grid ceil(S*P / 256).  One thread per (set, Gaussian); loops over the views of the set.
+// The backward of a tile replays exactly the entries its forward walked (tile_work): its launch order is dealt by that.
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* work, int n, uint32_t* order) {
+    __shared__ uint32_t scratch[20];
+    __shared__ uint32_t smax;
+    __shared__ uint32_t s_class[1024];
+    if (threadIdx.x == 0) smax = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) mx = max(mx, work[i]);
+    atomicMax(&smax, mx);
+    __syncthreads();
+    deal_tiles(work, n, smax, order, s_class, scratch);
+}
+
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, int S) {
     const size_t si = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (si >= (size_t)S * p.P) return;
@@ -470,7 +486,8 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
     hipMemsetAsync(p.dL_dcolors, 0, (a->colors_precomp ? ns : nv) * 3 * sizeof(float), st);
     hipMemsetAsync(p.dL_dcov3D, 0, nv * 6 * sizeof(float), st);
     hipMemsetAsync(p.dL_dopacity, 0, ns * sizeof(float), st);
-    if (a->num_rendered != 0) hipLaunchKernelGGL(blend_backward_kernel, dim3(p.gx, p.gy, V), dim3(kTile, kTile), 0, st, p);
+    if (a->num_rendered != 0) hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_work, V * p.T, p.im.tile_order);
+    if (a->num_rendered != 0) hipLaunchKernelGGL(blend_backward_kernel, dim3((unsigned)(V * p.T)), dim3(kTile, kTile), 0, st, p);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;

@@ -84,4 +84,29 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 }
 #endif
 
+// Launch order of the per-tile kernels, by one workgroup of 1,024 threads: order[b] = the (view, tile) workgroup b takes.
+// The blend / sort kernels of a call are all resident at once at 4 views of 256^2 (1,024 workgroups, 4 per CU) and workgroup
+// b lands on CU b mod 256: in tile order every CU would get the SAME tile of all four views -- the image centre four times on
+// one CU, a corner four times on another (longest CU 1.6x the mean in the trained-like regime).  Tiles are ranked by `work`
+// instead (counting sort on 1,024 classes, most work first) and dealt out boustrophedon, 256 at a time: under the same
+// placement the longest CU is 1.02x the mean; with more workgroups than slots most-work-first is the usual greedy order.
+// Only the schedule depends on it, never a result.  s_class: 1,024 words of LDS, scratch: 17.
+__device__ __forceinline__ void deal_tiles(const uint32_t* work, int n, uint32_t most, uint32_t* order, uint32_t* s_class, uint32_t* scratch) {
+    const unsigned long long top = most ? most : 1u;
+    s_class[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_class[1023u - (uint32_t)(min((unsigned long long)work[i], top) * 1023ull / top)], 1u);
+    __syncthreads();
+    uint32_t tot;
+    const uint32_t first = block_exclusive_scan<1024>(s_class[threadIdx.x], scratch, &tot);
+    __syncthreads();
+    s_class[threadIdx.x] = first;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t r = atomicAdd(&s_class[1023u - (uint32_t)(min((unsigned long long)work[i], top) * 1023ull / top)], 1u);
+        const uint32_t q = r >> 8, j = r & 255u, m = min(256u, (uint32_t)n - (q << 8));
+        order[(q << 8) + ((q & 1u) ? m - 1u - j : j)] = (uint32_t)i;
+    }
+}
+
 }  // namespace dgs

@@ -302,11 +302,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys
     }
 }
 
-// Exclusive scan of the V*T tile counts -> [start,end) ranges into the packed instance list (one workgroup).
+// Exclusive scan of the V*T tile counts -> [start,end) ranges into the packed instance list (one workgroup), and the launch
+// order of the per-tile kernels (deal_tiles, by list length).
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* count, uint2* ranges, uint32_t* cursor, int n,
-                                                         int32_t* totals, long long capacity) {
+                                                         int32_t* totals, long long capacity, uint32_t* order) {
     __shared__ uint32_t scratch[20];
     __shared__ uint32_t smax;
+    __shared__ uint32_t s_class[1024];
     uint32_t carry = 0, mx = 0;
     if (threadIdx.x == 0) smax = 0;
     for (int base = 0; base < n; base += 1024) {
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* count,
         totals[2] = (int32_t)smax;
         if (capacity >= 0 && (long long)carry > capacity) totals[1] = DGS_ERR_BINNING_OVERFLOW;
     }
+    deal_tiles(count, n, smax, order, s_class, scratch);
 }
 
 // Which binning form runs.  In the sync mode the host has read {num_rendered, longest tile list} back and launches one form
@@ -543,8 +546,8 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
     __shared__ uint32_t s_red[3][NWV];
     __shared__ uint32_t scratch[NWV + 4];
     if (p.im.totals[1] != 0 || binning_form(p) != kFormBitonic) return;
-    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint2 rg = p.im.ranges[(size_t)v * p.T + t];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint2 rg = p.im.ranges[p.im.tile_order[blockIdx.x]];
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
     const uint64_t* src = p.bn.inst_key + rg.x;
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups
     }
 }
 
-// grid (gx, gy, V), block 16x16 = 4 wave64, each wave a 16x4 pixel strip.  forward.cu:261-374.
+// grid V*T (tile_order picks the tile), block 16x16 = 4 wave64, each wave a 16x4 pixel strip.  forward.cu:261-374.
 // A batch of 256 list entries is staged in LDS; while staging, every thread also works out which strips ITS Gaussian can
 // reach (strip_mask) and four ballots per staging wave turn that into one 256-bit set per strip.  A wave then walks the
 // set bits of its strip only: in the trained-like regime the lists hold ~3,000 Gaussians per tile of
@@ -729,15 +732,18 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ float4 s_co[256];
     __shared__ float4 s_rgbc[256];
     __shared__ unsigned long long s_set[4][4];            // [strip][staging wave]
-    const int v = blockIdx.z;
+    __shared__ uint32_t s_walk[4];
+    const uint32_t vt = p.im.tile_order[blockIdx.x];           // (view, tile) this workgroup works on: scan_tiles_kernel
+    const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T);
+    const int bx = tile % p.gx, by = tile / p.gx;
     const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pxi = blockIdx.x * kTile + threadIdx.x, pyi = blockIdx.y * kTile + threadIdx.y;
+    const int pxi = bx * kTile + threadIdx.x, pyi = by * kTile + threadIdx.y;
     const bool inside = pxi < p.W && pyi < p.H;
     const float pfx = (float)pxi, pfy = (float)pyi;
-    const float tx0 = (float)(blockIdx.x * kTile), ty0 = (float)(blockIdx.y * kTile);
+    const float tx0 = (float)(bx * kTile), ty0 = (float)(by * kTile);
     const bool ok = p.im.totals[1] == 0;
-    uint2 rg = p.im.ranges[(size_t)v * p.T + blockIdx.y * p.gx + blockIdx.x];
+    uint2 rg = p.im.ranges[vt];
     if (!ok) rg.y = rg.x;
     const int rounds = (int)((rg.y - rg.x + 255u) / 256u);
     const size_t vo = (size_t)v * p.P;
@@ -810,6 +816,13 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
         out[HW + pid] = C1 + T * p.bg[1];
         out[2 * HW + pid] = C2 + T * p.bg[2];
     }
+    // how far into its list the tile got: what the backward replays, and what it ranks its launch order by
+    uint32_t walked = last_contributor;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) walked = max(walked, (uint32_t)__shfl_xor((int)walked, o));
+    if (lane == 0) s_walk[wave] = walked;
+    __syncthreads();
+    if (tid == 0) p.im.tile_work[vt] = max(max(s_walk[0], s_walk[1]), max(s_walk[2], s_walk[3]));
 }
 
 __global__ void mark_visible_kernel(int P, const float* means, const float* vm, uint8_t* present) {
@@ -913,7 +926,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     if (rc) return rc;
 
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, p.im.ranges, p.im.tile_cursor, VT, p.im.totals,
-                       async ? (long long)a->binning_capacity : -1LL);
+                       async ? (long long)a->binning_capacity : -1LL, p.im.tile_order);
     rc = check(st, a->debug);
     if (rc) return rc;
 
@@ -987,10 +1000,10 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
                                 kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
         if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
         const size_t lds = (size_t)p.bitonic_cap * 8 + 2 * kBuckets * 4;
-        if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(p.T, V), dim3(1024), lds, st, p);
-        else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(p.T, V), dim3(256), lds, st, p);
+        if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(VT), dim3(1024), lds, st, p);
+        else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(VT), dim3(256), lds, st, p);
     }
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(p.gx, p.gy, V), dim3(kTile, kTile), 0, st, p);
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(VT), dim3(kTile, kTile), 0, st, p);
     return check(st, a->debug);
 }
 

@@ -79,6 +79,8 @@ struct ImageState {
     uint32_t* tile_cursor;         // [V*T]   scatter cursors
     uint2* ranges;                 // [V*T]   [start,end) into the packed instance list
     int32_t* totals;               // [4]     {num_rendered, status, longest tile list, -}
+    uint32_t* tile_order;          // [V*T]   launch order of the per-tile kernels (workgroup b works on tile tile_order[b])
+    uint32_t* tile_work;           // [V*T]   list entries the forward blend walked before the tile was finished
     static ImageState carve(void* buf, size_t W, size_t H, size_t V, size_t* bytes) {
         Carver c(buf);
         ImageState s;
@@ -89,6 +91,8 @@ struct ImageState {
         s.tile_cursor = c.take<uint32_t>(V * T);
         s.ranges = c.take<uint2>(V * T);
         s.totals = c.take<int32_t>(4);
+        s.tile_order = c.take<uint32_t>(V * T);
+        s.tile_work = c.take<uint32_t>(V * T);
         if (bytes) *bytes = c.bytes();
         return s;
     }
