@@ -49,6 +49,24 @@ __device__ __forceinline__ float det_expf(float x) {
     return __builtin_ldexpf(y, (int)n);
 }
 
+// det_expf without its three range checks, for callers that know x is a number in [-87, 88] (the blend kernels: a pair that
+// passes the alpha cut-off has -5.6 < power <= 0): the same instructions, the same bits.
+__device__ __forceinline__ float det_expf_core(float x) {
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r);
+    y = y + 1.0f;
+    return __builtin_ldexpf(y, (int)n);
+}
+
 // Exclusive scan of one value per thread over a block of `NT` threads (NT multiple of 64, <= 1024).
 // `scratch` needs NT/64 + 1 uint32 of LDS.  Returns the exclusive prefix; *total receives the block sum.
 template <int NT>

@@ -33,36 +33,40 @@ struct BwdParams {
     float *dL_dmean2D, *dL_dconic, *dL_dcolors, *dL_dcov3D, *dL_dopacity, *dL_dmeans3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 
-// grid V*T (workgroup b takes tile tile_order[b], like the forward), block 16x16 = 4 wave64 (each a 16x4 pixel strip).  backward.cu:399-557.
+// grid V*T (workgroup b takes tile tile_order[b]), 256 threads = 4 wave64.  backward.cu:399-557.
 //
-// Per (tile, Gaussian) the nine sums have to be reduced over up to 256 pixels.  A wave reduces its strip with DPP adds and
-// parks the nine partial sums in LDS (one slot per (wave, batch entry), plus a 256-bit "touched" set per wave); when the batch
-// of 256 entries is done, thread j adds the up to four partials of entry j and issues ONE atomic per value -- 256 Gaussians'
-// atomics in flight at once instead of one lane's, and a quarter of them.  Strips the Gaussian's ellipse cannot reach
-// (strip_mask, shared with the forward) are skipped on a scalar bit test.  Measured per 4 views at 256^2, trained-like /
-// random-init regime, forward + backward: 4.14 / 2.49 ms before; strip masks + per-wave atomics 3.45 / 2.11; + this LDS
-// combine 3.00 / 1.88.  (One wave per tile with four pixels per lane -- a single reduction per (tile, Gaussian) -- lost: 5.3 /
-// 2.7 ms at 4 views, where 1024 tiles are one wave per SIMD and the replay is a latency chain, and still 22.2 vs 19.9 ms at
-// 40 views.)
+// Lanes, pixels and lists as in the forward (blend_forward_kernel): wave g owns strip g, its four 16-lane rows own the strip's
+// four 4 x 4 cells; a batch of 256 list entries is staged in LDS back to front, compacted into one index list per cell
+// (cell_mask: the cells the Gaussian's ellipse can reach), and the four rows of a wave walk their lists in lockstep.
+//
+// Per (tile, Gaussian) the nine sums have to be reduced over up to 256 pixels.  A 16-lane row reduces its cell with four DPP
+// adds per value; lane 15 of the row adds the nine partial sums into the batch entry's accumulators in LDS (ds_add_f32: up
+// to sixteen cells meet there); when the batch is done, thread j reads entry j's nine sums and issues ONE global atomic per
+// value -- 256 Gaussians' atomics in flight at once, a sixteenth (at most) of the per-cell count.  The body has no per-lane
+// branches: two wave-uniform exits (no lane inside the ellipse / above the alpha cut-off), selects behind them.
+// Measured per 4 views at 256^2, trained-like / random-init regime, forward + backward: one atomic per wave per value 4.14 /
+// 2.49 ms; 16 x 4 strip masks 3.45 / 2.11; + combining a tile's four strips in LDS 3.00 / 1.88; + launch order by work 2.33 /
+// 1.70; cells: see DESIGN.md.  (One wave per tile with four pixels per lane lost: a latency chain.)
 __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     __shared__ uint32_t s_id[256];
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
-    __shared__ float4 s_rgb[256];
-    __shared__ float s_cut[256];
+    __shared__ float4 s_rgbc[256];                        // colour, alpha cut-off on `power`
     __shared__ uint32_t s_max[4];
-    __shared__ unsigned long long s_set[4][4];            // [strip][staging wave]: entries the strip may touch (strip_mask)
-    __shared__ unsigned long long s_hit[4][4];            // [strip][staging wave]: entries the strip did touch
-    __shared__ float s_part[4][9][256];                   // [strip][value][entry]
+    __shared__ uint4 s_cnt[16];                           // [cell] entries of the batch the cell keeps, per staging wave
+    __shared__ uint8_t s_list[17][256];                   // [cell] their batch indices, back to front (+ one row: read-ahead)
+    __shared__ float s_acc[9][256];                       // [value][entry] sums over the tile's pixels
     const uint32_t vt = p.im.tile_order[blockIdx.x];           // order_tiles_kernel: most replayed entries first
     const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T), s = v / p.vps;
     const int bx = tile % p.gx, by = tile / p.gx;
-    const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, row = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pxi = bx * kTile + threadIdx.x, pyi = by * kTile + threadIdx.y;
+    const int cell = wave * 4 + row;
+    const int pxi = bx * kTile + 4 * row + (lane & 3), pyi = by * kTile + 4 * wave + ((lane >> 2) & 3);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pfx = (float)pxi, pfy = (float)pyi;
     const float tx0 = (float)(bx * kTile), ty0 = (float)(by * kTile);
+    const unsigned long long lanes_before = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const size_t HW = (size_t)p.H * p.W, pid = (size_t)p.W * pyi + pxi;
     const uint2 rg = p.im.ranges[vt];
     const size_t vo = (size_t)v * p.P;
@@ -86,113 +90,122 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
     if (lane == 0) s_max[wave] = mc;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_acc[k][tid] = 0.f;
     __syncthreads();
     const uint32_t todo = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));   // <= rg.y - rg.x
     const int rounds = (int)((todo + 255u) / 256u);
     const bool colors_per_set = p.colors_pre != nullptr;
     for (int i = 0; i < rounds; ++i) {
-        __syncthreads();
         // batch entry e (0..255) = 1-based list index contributor = todo - (i * 256 + e), list position rg.x + contributor - 1
         const int idx = (int)todo - 1 - (i * 256 + tid);
-        unsigned m4 = 0u;
+        unsigned m16 = 0u;
         if (idx >= 0) {
             const uint32_t id = p.bn.point_list[rg.x + (uint32_t)idx];
             const float2 xy = p.g.means2D[vo + id];
             const float4 co = p.g.conic_opacity[vo + id];
-            const float4 rc = p.g.rgb_cut[vo + id];
-            s_id[tid] = id; s_xy[tid] = xy; s_co[tid] = co; s_cut[tid] = rc.w;
-            m4 = strip_mask(xy, co, rc.w, tx0, ty0);
+            float4 rc = p.g.rgb_cut[vo + id];
+            m16 = cell_mask(xy, co, rc.w, tx0, ty0);
             if (colors_per_set) {
                 const float* c = p.colors_pre + 3 * ((size_t)s * p.P + id);
-                s_rgb[tid] = make_float4(c[0], c[1], c[2], 0.f);
-            } else {
-                s_rgb[tid] = rc;
+                rc.x = c[0]; rc.y = c[1]; rc.z = c[2];
             }
+            s_id[tid] = id; s_xy[tid] = xy; s_co[tid] = co; s_rgbc[tid] = rc;
         }
+        unsigned long long keeps[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const unsigned long long bal = __ballot((m4 >> g) & 1u);
-            if (lane == 0) s_set[g][wave] = bal;
+        for (int c = 0; c < 16; ++c) {
+            keeps[c] = __ballot((m16 >> c) & 1u);
+            if (lane == 0) reinterpret_cast<uint32_t*>(&s_cnt[c])[wave] = (uint32_t)__popcll(keeps[c]);
         }
         __syncthreads();
-        for (int sw = 0; sw < 4; ++sw) {
-            unsigned long long m = s_set[wave][sw];
-            m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
-            unsigned long long hit = 0ull;
-            while (m) {
-                const int bit = __ffsll((long long)m) - 1;
-                const int j = sw * 64 + bit;
-                m &= m - 1;
-                const uint32_t contributor = todo - (uint32_t)(i * 256 + j);     // 1-based index of this entry
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if ((m16 >> c) & 1u) {
+                const uint4 cn = s_cnt[c];
+                const uint32_t ahead = (wave > 0 ? cn.x : 0u) + (wave > 1 ? cn.y : 0u) + (wave > 2 ? cn.z : 0u);
+                s_list[c][ahead + (uint32_t)__popcll(keeps[c] & lanes_before)] = (uint8_t)tid;
+            }
+        }
+        __syncthreads();
+        {
+            const uint4 cn = s_cnt[cell];
+            const uint32_t tot = cn.x + cn.y + cn.z + cn.w;
+            const uint32_t first = todo - (uint32_t)(i * 256);          // contributor (1-based list index) of batch entry 0
+            // software pipeline as in the forward: indices four at a time, one group ahead; the entry one iteration ahead
+            const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
+            uint32_t word = lst[0], word_next = lst[1];
+            uint32_t j = word & 255u;
+            float2 xy = s_xy[j];
+            float4 co = s_co[j];
+            float4 rc = s_rgbc[j];
+            for (uint32_t k = 0; __ballot(k < tot) != 0ull; ++k) {
+                const uint32_t kn = k + 1u;
+                if ((kn & 3u) == 0u) { word = word_next; word_next = lst[(kn >> 2) + 1u]; }
+                const uint32_t jn = (word >> (8u * (kn & 3u))) & 255u;
+                const float2 xyn = s_xy[jn];
+                const float4 con = s_co[jn];
+                const float4 rcn = s_rgbc[jn];
                 // pixel took part iff index <= last_contributor (backward.cu:463-468); cheap rejects first (outside the ellipse,
                 // or below the Gaussian's alpha cut-off: alpha < 1/255 guaranteed, see preprocess_one -- the test the forward
-                // used to drop the pair), ONE wave-uniform branch out
-                const float2 xy = s_xy[j];
-                const float4 co = s_co[j];
+                // used to drop the pair)
                 const float dx = xy.x - pfx, dy = xy.y - pfy;
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                bool take = inside && contributor <= last_contributor && !(power > 0.0f) && !(power < s_cut[j]);
-                if (!__any(take)) continue;
-                float G = 0.f, alpha = 0.f;
-                if (take) {
-                    G = det_expf(power);
-                    alpha = fminf(0.99f, co.w * G);
-                    take = !(alpha < 1.0f / 255.0f);
-                }
-                if (!__any(take)) continue;      // wave-uniform: nobody in this 16x4 strip touches the Gaussian
-                float c9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (take) {
-                    T = T / (1.f - alpha);
-                    const float dchannel_dcolor = alpha * T;
-                    const float4 rgb = s_rgb[j];
-                    const float col[3] = {rgb.x, rgb.y, rgb.z};
-                    float dL_dalpha = 0.0f;
+                const bool near = k < tot && inside && first - j <= last_contributor && !(power > 0.0f) && !(power < rc.w);
+                if (__ballot(near) != 0ull) {
+                    const float G = det_expf_core(near ? power : 0.0f);
+                    const float alpha = fminf(0.99f, co.w * G);
+                    const bool take = near && !(alpha < 1.0f / 255.0f);
+                    const unsigned long long takers = __ballot(take);
+                    if (takers != 0ull) {                               // wave-uniform: somebody in this strip touches its Gaussian
+                        const float Tn = T / (1.f - alpha);
+                        const float dchannel_dcolor = alpha * Tn;
+                        const float col[3] = {rc.x, rc.y, rc.z};
+                        float c9[9];
+                        float dL_dalpha = 0.0f;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                        last_color[ch] = col[ch];
-                        dL_dalpha += (col[ch] - accum_rec[ch]) * dpix[ch];
-                        c9[ch] = dchannel_dcolor * dpix[ch];
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const float rec = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                            dL_dalpha += (col[ch] - rec) * dpix[ch];
+                            c9[ch] = dchannel_dcolor * dpix[ch];
+                            accum_rec[ch] = take ? rec : accum_rec[ch];
+                            last_color[ch] = take ? col[ch] : last_color[ch];
+                        }
+                        dL_dalpha *= Tn;
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        T = take ? Tn : T;
+                        last_alpha = take ? alpha : last_alpha;
+                        const float dL_dG = co.w * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                        const float dG_ddely = -gdy * co.z - gdx * co.y;
+                        c9[3] = dL_dG * dG_ddelx * ddelx_dx;
+                        c9[4] = dL_dG * dG_ddely * ddely_dy;
+                        c9[5] = -0.5f * gdx * dx * dL_dG;
+                        c9[6] = -0.5f * gdx * dy * dL_dG;
+                        c9[7] = -0.5f * gdy * dy * dL_dG;
+                        c9[8] = G * dL_dalpha;
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) c9[q] = row_sum_to_lane15(take ? c9[q] : 0.f);
+                        if ((lane & 15) == 15 && ((takers >> (16 * row)) & 0xFFFFull) != 0ull) {
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) lds_add(&s_acc[q][j], c9[q]);
+                        }
                     }
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                    const float dL_dG = co.w * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                    const float dG_ddely = -gdy * co.z - gdx * co.y;
-                    c9[3] = dL_dG * dG_ddelx * ddelx_dx;
-                    c9[4] = dL_dG * dG_ddely * ddely_dy;
-                    c9[5] = -0.5f * gdx * dx * dL_dG;
-                    c9[6] = -0.5f * gdx * dy * dL_dG;
-                    c9[7] = -0.5f * gdy * dy * dL_dG;
-                    c9[8] = G * dL_dalpha;
                 }
-#pragma unroll
-                for (int k = 0; k < 9; ++k) c9[k] = wave_sum_to_lane63(c9[k]);
-                if (lane == 63) {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) s_part[wave][k][j] = c9[k];
-                }
-                hit |= 1ull << bit;
+                j = jn; xy = xyn; co = con; rc = rcn;
             }
-            if (lane == 0) s_hit[wave][sw] = hit;
         }
         __syncthreads();
-        // entry `tid`: sum of the strips that touched it, one atomic per value
+        // entry `tid`: the tile's sums, one atomic per value
         {
-            const int sw = tid >> 6;
-            const unsigned long long bitm = 1ull << (tid & 63);
-            float c9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float c9[9];
             bool any = false;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (s_hit[g][sw] & bitm) {
-                    any = true;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) c9[k] += s_part[g][k][tid];
-                }
+            for (int q = 0; q < 9; ++q) { c9[q] = s_acc[q][tid]; any = any || c9[q] != 0.f; }
             if (any) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) s_acc[q][tid] = 0.f;
                 const uint32_t id = s_id[tid];
                 const size_t gv = vo + id, gs = (size_t)s * p.P + id;
                 float* dc = p.dL_dcolors + 3 * (colors_per_set ? gs : gv);
@@ -267,7 +280,6 @@ __device__ __forceinline__ void sh_backward(int deg, const float* sh, float ox, 
     dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * inv;
 }
 
-// grid ceil(S*P / 256).  One thread per (set, Gaussian); loops over the views of the set.
 // The backward of a tile replays exactly the entries its forward walked (tile_work): its launch order is dealt by that.
 __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* work, int n, uint32_t* order) {
     __shared__ uint32_t scratch[20];
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* work,
     deal_tiles(work, n, smax, order, s_class, scratch);
 }
 
+// grid ceil(S*P / 256).  One thread per (set, Gaussian); loops over the views of the set.
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, int S) {
     const size_t si = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (si >= (size_t)S * p.P) return;
@@ -487,7 +500,7 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
     hipMemsetAsync(p.dL_dcov3D, 0, nv * 6 * sizeof(float), st);
     hipMemsetAsync(p.dL_dopacity, 0, ns * sizeof(float), st);
     if (a->num_rendered != 0) hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_work, V * p.T, p.im.tile_order);
-    if (a->num_rendered != 0) hipLaunchKernelGGL(blend_backward_kernel, dim3((unsigned)(V * p.T)), dim3(kTile, kTile), 0, st, p);
+    if (a->num_rendered != 0) hipLaunchKernelGGL(blend_backward_kernel, dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;

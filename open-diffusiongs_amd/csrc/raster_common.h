@@ -60,6 +60,29 @@ __device__ __forceinline__ unsigned strip_mask(float2 xy, float4 co, float cut, 
     return m;
 }
 
+// The same box against the tile's sixteen 4 x 4 CELLS: bit 4 g + c = cell column c (pixels 4c..4c+3) of strip g.
+__device__ __forceinline__ unsigned cell_mask(float2 xy, float4 co, float cut, float tx0, float ty0) {
+    const float A = co.x, B = co.y, C = co.z;
+    if (cut > 0.0f) return 0u;
+    const float det = A * C - B * B, tr = A + C;
+    const float q = -2.0f * cut * 1.01f + 0.01f;
+    if (!(det > 0.0f) || !(A > 0.0f) || !(C > 0.0f) || !(tr * tr < 1.0e4f * det) || !(q < 1.0e30f)) return 0xFFFFu;
+    const float hx = sqrtf(q * C / det) * 1.001f + 0.01f, hy = sqrtf(q * A / det) * 1.001f + 0.01f;
+    if (!(hx < 1.0e30f) || !(hy < 1.0e30f) || !(xy.x == xy.x) || !(xy.y == xy.y)) return 0xFFFFu;
+    unsigned xm = 0u, m = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float xs = tx0 + 4.0f * (float)c;
+        if (!(xy.x + hx < xs) && !(xy.x - hx > xs + 3.0f)) xm |= 1u << c;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float ys = ty0 + 4.0f * (float)g;
+        if (!(xy.y + hy < ys) && !(xy.y - hy > ys + 3.0f)) m |= xm << (4 * g);
+    }
+    return m;
+}
+
 // Sum over the 64 lanes of a wave; the total is valid in lane 63 only.  Six v_add_f32_dpp (row shifts inside the 16-lane
 // rows, then row broadcasts) instead of six ds_bpermute round trips.
 #ifdef HIPEMU
@@ -83,6 +106,30 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 #endif
+
+// Sum over each 16-lane row of a wave; the total of a row is valid in its lane 15 only.
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+#ifdef HIPEMU
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+#else
+    v += dpp_mov<0x111>(v);   // row_shr:1
+    v += dpp_mov<0x112>(v);   // row_shr:2
+    v += dpp_mov<0x114>(v);   // row_shr:4
+    v += dpp_mov<0x118>(v);   // row_shr:8
+    return v;
+#endif
+}
+
+// fp32 add into LDS, no return value (ds_add_f32).
+__device__ __forceinline__ void lds_add(float* addr, float v) {
+#ifdef HIPEMU
+    atomicAdd(addr, v);
+#else
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+#endif
+}
 
 // Launch order of the per-tile kernels, by one workgroup of 1,024 threads: order[b] = the (view, tile) workgroup b takes.
 // The blend / sort kernels of a call are all resident at once at 4 views of 256^2 (1,024 workgroups, 4 per CU) and workgroup

@@ -722,26 +722,36 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups
     }
 }
 
-// grid V*T (tile_order picks the tile), block 16x16 = 4 wave64, each wave a 16x4 pixel strip.  forward.cu:261-374.
-// A batch of 256 list entries is staged in LDS; while staging, every thread also works out which strips ITS Gaussian can
-// reach (strip_mask) and four ballots per staging wave turn that into one 256-bit set per strip.  A wave then walks the
-// set bits of its strip only: in the trained-like regime the lists hold ~3,000 Gaussians per tile of
-// which a strip meets a fraction -- the list is the reference's rectangle-overlap list, the ellipse is much smaller.
+// grid V*T (tile_order picks the tile), 256 threads = 4 wave64.  forward.cu:261-374.
+//
+// Lanes and pixels.  Wave g owns the 16 x 4 strip g of the tile; its four 16-lane rows own the strip's four 4 x 4 CELLS (lane
+// l: cell column l >> 4, pixel (l & 3, (l >> 2) & 3) inside it).  The tile's list is the reference's -- every Gaussian whose
+// ceil(3 sigma_max) square overlaps the tile -- but a pair contributes only inside the ellipse power >= ln(1 / (255 opacity)),
+// and in the trained-like regime (~3,000 entries per tile, ellipses of a few pixels) a cell meets a fifth of its
+// tile's list.  So a batch of 256 entries is staged in LDS; while staging, every thread works out which of the sixteen cells
+// ITS entry can reach (cell_mask: the ellipse's bounding box, inflated -- conservative, so skipping changes no bit); ballots
+// compact the batch into sixteen index lists, front to back; and the four rows of a wave walk their four lists in lockstep,
+// each lane row reading its own entry.  Per (pixel, entry) the arithmetic is the reference's, in the reference's order
+// (forward.cu:332-358); the body has no per-lane branches: one wave-uniform branch leaves when no lane passes the alpha
+// cut-off, everything behind it is selects.
 __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
     __shared__ float4 s_rgbc[256];
-    __shared__ unsigned long long s_set[4][4];            // [strip][staging wave]
+    __shared__ uint4 s_cnt[16];                           // [cell] entries of the batch the cell keeps, per staging wave
+    __shared__ uint8_t s_list[17][256];                   // [cell] their batch indices, front to back (+ one row: the walk reads a group ahead)
     __shared__ uint32_t s_walk[4];
     const uint32_t vt = p.im.tile_order[blockIdx.x];           // (view, tile) this workgroup works on: scan_tiles_kernel
     const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T);
     const int bx = tile % p.gx, by = tile / p.gx;
-    const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, row = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pxi = bx * kTile + threadIdx.x, pyi = by * kTile + threadIdx.y;
+    const int cell = wave * 4 + row;
+    const int pxi = bx * kTile + 4 * row + (lane & 3), pyi = by * kTile + 4 * wave + ((lane >> 2) & 3);
     const bool inside = pxi < p.W && pyi < p.H;
     const float pfx = (float)pxi, pfy = (float)pyi;
     const float tx0 = (float)(bx * kTile), ty0 = (float)(by * kTile);
+    const unsigned long long lanes_before = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool ok = p.im.totals[1] == 0;
     uint2 rg = p.im.ranges[vt];
     if (!ok) rg.y = rg.x;
@@ -753,56 +763,72 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     for (int i = 0; i < rounds; ++i) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t pos = rg.x + (uint32_t)i * 256u + (uint32_t)tid;
-        unsigned m4 = 0u;
+        unsigned m16 = 0u;
         if (pos < rg.y) {
             const uint32_t id = p.bn.point_list[pos];
             const float2 xy = p.g.means2D[vo + id];
             const float4 co = p.g.conic_opacity[vo + id];
             const float4 rc = p.g.rgb_cut[vo + id];
             s_xy[tid] = xy; s_co[tid] = co; s_rgbc[tid] = rc;
-            m4 = strip_mask(xy, co, rc.w, tx0, ty0);
+            m16 = cell_mask(xy, co, rc.w, tx0, ty0);
         }
+        unsigned long long keeps[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const unsigned long long bal = __ballot((m4 >> g) & 1u);
-            if (lane == 0) s_set[g][wave] = bal;
+        for (int c = 0; c < 16; ++c) {
+            keeps[c] = __ballot((m16 >> c) & 1u);
+            if (lane == 0) reinterpret_cast<uint32_t*>(&s_cnt[c])[wave] = (uint32_t)__popcll(keeps[c]);
         }
         __syncthreads();
-        // Per (pixel, Gaussian) the common case is still a reject (power > 0, or below the Gaussian's alpha cut-off): the body is
-        // free of per-lane branches up to that test and leaves with ONE wave-uniform branch when no lane of the wave passes;
-        // the arithmetic of every lane is the reference's, in the reference's order (forward.cu:332-358).
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if ((m16 >> c) & 1u) {
+                const uint4 cn = s_cnt[c];
+                const uint32_t ahead = (wave > 0 ? cn.x : 0u) + (wave > 1 ? cn.y : 0u) + (wave > 2 ? cn.z : 0u);
+                s_list[c][ahead + (uint32_t)__popcll(keeps[c] & lanes_before)] = (uint8_t)tid;
+            }
+        }
+        __syncthreads();
         const uint32_t base = (uint32_t)i * 256u;
-        if (__ballot(!done) != 0ull) {                         // a wave whose 64 pixels are all finished only keeps the barriers
-            for (int sw = 0; sw < 4; ++sw) {
-                unsigned long long m = s_set[wave][sw];
-                m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
-                while (m) {
-                    const int j = sw * 64 + (__ffsll((long long)m) - 1);
-                    m &= m - 1;
-                    const float2 xy = s_xy[j];
-                    const float4 co = s_co[j];
-                    const float cut = s_rgbc[j].w;
-                    const float dx = xy.x - pfx, dy = xy.y - pfy;
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    const bool pass = !done && !(power > 0.0f) && !(power < cut);      // alpha < 1/255 guaranteed below `cut` (preprocess_one)
-                    if (__ballot(pass) == 0ull) continue;
-                    if (pass) {
-                        const float alpha = fminf(0.99f, co.w * det_expf(power));
-                        if (!(alpha < 1.0f / 255.0f)) {
-                            const float test_T = T * (1 - alpha);
-                            if (test_T < 0.0001f) {
-                                done = true;
-                            } else {
-                                const float4 rc = s_rgbc[j];
-                                C0 += rc.x * alpha * T;
-                                C1 += rc.y * alpha * T;
-                                C2 += rc.z * alpha * T;
-                                T = test_T;
-                                last_contributor = base + (uint32_t)j + 1u;
-                            }
-                        }
-                    }
+        const unsigned long long alive = __ballot(!done);
+        if (alive != 0ull) {                                    // a wave whose 64 pixels are all finished only keeps the barriers
+            const uint4 cn = s_cnt[cell];
+            const uint32_t tot = (((alive >> (16 * row)) & 0xFFFFull) != 0ull) ? cn.x + cn.y + cn.z + cn.w : 0u;
+            // software pipeline: the indices arrive four at a time, one group ahead; the entry itself one iteration ahead
+            // (bytes behind `tot` are stale indices of earlier batches: any of them addresses a staged record, none is used)
+            const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
+            uint32_t word = lst[0], word_next = lst[1];
+            uint32_t j = word & 255u;
+            float2 xy = s_xy[j];
+            float4 co = s_co[j];
+            float4 rc = s_rgbc[j];
+            for (uint32_t k = 0; __ballot(k < tot) != 0ull; ++k) {
+                const uint32_t kn = k + 1u;
+                const bool refill = (kn & 3u) == 0u;
+                uint32_t fetched = 0u;
+                if (refill) { word = word_next; fetched = lst[(kn >> 2) + 1u]; }
+                const uint32_t jn = (word >> (8u * (kn & 3u))) & 255u;
+                const float2 xyn = s_xy[jn];
+                const float4 con = s_co[jn];
+                const float4 rcn = s_rgbc[jn];
+                const float dx = xy.x - pfx, dy = xy.y - pfy;
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                const bool pass = k < tot && !done && !(power > 0.0f) && !(power < rc.w);  // alpha < 1/255 guaranteed below the cut (preprocess_one)
+                if (__ballot(pass) != 0ull) {
+                    const float alpha = fminf(0.99f, co.w * det_expf_core(pass ? power : 0.0f));
+                    const float test_T = T * (1 - alpha);
+                    const bool contributes = pass && !(alpha < 1.0f / 255.0f);
+                    const bool finishes = contributes && test_T < 0.0001f;
+                    const bool blends = contributes && !finishes;
+                    done = done || finishes;
+                    const float c0 = C0 + rc.x * alpha * T, c1 = C1 + rc.y * alpha * T, c2 = C2 + rc.z * alpha * T;
+                    C0 = blends ? c0 : C0;
+                    C1 = blends ? c1 : C1;
+                    C2 = blends ? c2 : C2;
+                    T = blends ? test_T : T;
+                    last_contributor = blends ? base + j + 1u : last_contributor;
                 }
+                j = jn; xy = xyn; co = con; rc = rcn;
+                if (refill) word_next = fetched;
             }
         }
     }
@@ -1003,7 +1029,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(VT), dim3(1024), lds, st, p);
         else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(VT), dim3(256), lds, st, p);
     }
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(VT), dim3(kTile, kTile), 0, st, p);
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(VT), dim3(256), 0, st, p);
     return check(st, a->debug);
 }
 
