@@ -250,10 +250,15 @@ __global__ __launch_bounds__(256) void radix_colscan_kernel(uint32_t* hist, uint
     const int v = blockIdx.y, d = threadIdx.x;
     uint32_t* h = hist + (size_t)v * NB * 256;
     uint32_t run = 0;
-    for (int b = 0; b < NB; ++b) {
-        const uint32_t c = h[(size_t)b * 256 + d];
-        h[(size_t)b * 256 + d] = run;
-        run += c;
+    for (int b0 = 0; b0 < NB; b0 += 16) {                      // sixteen loads per round trip: the walk is a latency chain
+        uint32_t c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = (b0 + u < NB) ? h[(size_t)(b0 + u) * 256 + d] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (b0 + u < NB) h[(size_t)(b0 + u) * 256 + d] = run;
+            run += c[u];
+        }
     }
     uint32_t total;
     const uint32_t ex = block_exclusive_scan<256>(run, scratch, &total);
@@ -615,11 +620,11 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
 
 // ---- binning, dense form ("scan") -------------------------------------------------------------------------------------
 // When Gaussians are large (random-init weights: ~50 tiles each, a tile is touched by a fifth of all Gaussians) listing the
-// instances first (emit) and sorting every tile's list (bitmap) moves each instance three times and expands 8 k bitmap words
-// per tile.  Here every tile filters the depth-ORDERED Gaussians directly: rank_rects_kernel leaves each Gaussian's tile
-// rectangle, packed in 32 bits, at its depth rank; tile_scan_kernel walks the ranks 64 at a time -- test, ballot, popcount --
-// and writes the hits in order: the same list the sort produces, with no atomics and no instance list.  Work is T x P tests
-// per view, so the host picks this form only where that product is small (256^2: 67 M).
+// instances first (emit) and sorting every tile's list moves each instance three times.  Here a tile filters the
+// depth-ORDERED Gaussians directly: rank_rects_kernel leaves each Gaussian's tile rectangle, packed in 32 bits, at its depth
+// rank; the blend kernel (scan_more below) walks the ranks 64 at a time -- test, ballot, popcount -- and takes the hits in
+// order: the list the sort produces, with no atomics and no instance list.  At most T x P tests per view, so the host picks
+// this form only where that product is small (256^2: 67 M).
 __global__ __launch_bounds__(256) void rank_rects_kernel(FwdParams p) {
     if (p.im.totals[1] != 0 || !binning_is_scan(p)) return;
     const int v = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
@@ -635,91 +640,95 @@ __global__ __launch_bounds__(256) void rank_rects_kernel(FwdParams p) {
     p.g.vals[1][(size_t)v * p.P + p.g.rank_of[gi]] = packed;   // the sort's spare value buffer
 }
 
-template <bool B> struct BoolC { static constexpr bool value = B; };
+// ------------------------------------------------------------------------------------------------
+// Scan form: the tile's list is produced ON DEMAND, inside the blend kernel.  A tile filters the depth-ORDERED Gaussians
+// (rank_rects_kernel left every Gaussian's tile rectangle at its depth rank) a window of ranks at a time -- 64 ranks per test:
+// two compares, two ballots, popcount -- and appends the hits to a ring in LDS (the blend's staging reads from there) and to
+// the tile's segment of point_list (what the backward replays).  It asks for more only when the ring runs dry, and a tile
+// whose 256 pixels are all saturated never asks again: in the regime this form is picked for (dense scenes: random-init
+// weights put 50,000 Gaussians on a tile and its pixels saturate after 800-2,200 of them) a tile tests a few percent of the
+// ranks, where a separate pass that builds complete lists tested all T x P pairs (0.38 ms of a 1.0 ms call at 256^2, 4
+// views).  The list in memory is therefore a PREFIX of the reference's list -- as long as the forward walked, which is all the
+// backward reads (tile_cursor holds its length).  Windows are sized from the tile's density for ~768 hits; a wave owns a
+// contiguous quarter of the window (count pass, prefix over the waves, emit pass that re-tests: no masks kept).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kRing = 2048;                          // entries; a window adds at most kRing - 255
 
-// grid (T, V), 256 threads, dynamic LDS = wgroups * 8 bytes (one 64-bit hit mask per group of 64 ranks of the window).
-__global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups) {
-    DGS_DYNAMIC_LDS(smem);
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem);
-    __shared__ uint32_t scratch[4];
-    if (p.im.totals[1] != 0 || !binning_is_scan(p)) return;
-    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint2 rg = p.im.ranges[(size_t)v * p.T + t];
-    if (rg.x == rg.y) return;
-    const uint32_t tx = (uint32_t)(t % p.gx), ty = (uint32_t)(t / p.gx);
-    const uint32_t* rects = p.g.vals[1] + (size_t)v * p.P;
-    const uint32_t* order = p.g.vals[0] + (size_t)v * p.P;   // rank -> Gaussian index
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t emitted = rg.x;
-    for (uint32_t w0 = 0; w0 < (uint32_t)p.P; w0 += (uint32_t)wgroups * 64u) {
-        const int ng = min(wgroups, (int)(((uint32_t)p.P - w0 + 63u) / 64u));
-        const int gpw = (ng + 3) / 4, g0 = wave * gpw, g1 = min(ng, g0 + gpw);        // a wave owns a contiguous quarter
-        // The loops are issue-bound (a wave tests 1 k groups per window): full batches of 8 groups take a path without bounds
-        // checks -- one base address + immediate offsets, the two compares AND-ed as wave masks, every lane writes the
-        // (uniform) mask, no exec juggling; the ragged end of a wave's range takes the checked path.
-        uint32_t cnt = 0;
-        auto test_batch = [&](int g, auto checked) {
-            constexpr bool CHECK = decltype(checked)::value;
-            const uint32_t rank0 = w0 + (uint32_t)g * 64u + (uint32_t)lane;
-            uint32_t r[8];
+struct TileScan {                                         // wave-uniform, every thread keeps a copy
+    uint32_t next_rank;                                   // first depth rank not tested yet
+    uint32_t found;                                       // entries produced so far (= written to point_list)
+    uint32_t head, waiting;                               // ring: next entry to consume, entries waiting
+};
+
+template <bool EMIT>
+__device__ __forceinline__ uint32_t scan_groups(const uint32_t* rects, const uint32_t* order, uint32_t rank_begin, int g0, int g1, uint32_t P,
+                                                uint32_t tx, uint32_t ty, int lane, unsigned long long lanes_before, uint32_t off, uint32_t* ring,
+                                                uint32_t ring_at, uint32_t* list, uint32_t list_at, uint32_t list_cap) {
+    uint32_t cnt = 0;
+    for (int g = g0; g < g1; g += 8) {
+        const uint32_t rank0 = rank_begin + (uint32_t)g * 64u + (uint32_t)lane;
+        uint32_t r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = (g + u < g1 && rank0 + 64u * u < P) ? rects[rank0 + 64u * u] : 0u;
+        uint32_t slot[8], val[8], setm = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t x0 = r[u] & 255u, y0 = (r[u] >> 8) & 255u, x1 = (r[u] >> 16) & 255u, y1 = r[u] >> 24;
+            const unsigned long long m = __ballot(tx - x0 < x1 - x0) & __ballot(ty - y0 < y1 - y0);   // unsigned: x0 <= tx < x1, y0 <= ty < y1
+            if (EMIT) {
+                const bool set = (m >> lane) & 1ull;
+                slot[u] = off + cnt + (uint32_t)__popcll(m & lanes_before);
+                val[u] = set ? order[rank0 + 64u * u] : 0u;
+                setm |= (uint32_t)set << u;
+            }
+            cnt += (uint32_t)__popcll(m);
+        }
+        if (EMIT) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                r[u] = (!CHECK || (g + u < g1 && rank0 + 64u * u < (uint32_t)p.P)) ? rects[rank0 + 64u * u] : 0u;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t x0 = r[u] & 255u, y0 = (r[u] >> 8) & 255u, x1 = (r[u] >> 16) & 255u, y1 = r[u] >> 24;
-                const unsigned long long m = __ballot(tx - x0 < x1 - x0) & __ballot(ty - y0 < y1 - y0);   // unsigned: x0 <= tx < x1, y0 <= ty < y1
-                if (!CHECK || g + u < g1) {
-                    masks[g + u] = m;
-                    cnt += (uint32_t)__popcll(m);
+                if (((setm >> u) & 1u) && list_at + slot[u] < list_cap) {
+                    ring[(ring_at + slot[u]) & (kRing - 1u)] = val[u];
+                    list[list_at + slot[u]] = val[u];
                 }
-            }
-        };
-        const int gfull = g0 + (g1 > g0 ? (g1 - g0) / 8 * 8 : 0);
-        const bool window_inside = w0 + (uint32_t)ng * 64u <= (uint32_t)p.P;      // no partial group in this window
-        for (int g = g0; g < gfull; g += 8) {
-            if (window_inside) test_batch(g, BoolC<false>{}); else test_batch(g, BoolC<true>{});
         }
-        if (gfull < g1) test_batch(gfull, BoolC<true>{});
+    }
+    return cnt;
+}
+
+// All 256 threads.  Tests at least one more window of ranks and appends its hits; returns with s advanced.
+__device__ __forceinline__ void scan_more(const FwdParams& p, TileScan& s, uint32_t* ring, uint32_t* scratch, const uint32_t* rects,
+                                          const uint32_t* order, uint32_t* list, uint32_t count, uint32_t tx, uint32_t ty, int lane, int wave,
+                                          unsigned long long lanes_before) {
+    const uint32_t P = (uint32_t)p.P;
+    unsigned long long want = 768ull * P / (count ? count : 1u);
+    uint32_t win = (uint32_t)(want > (1ull << 24) ? (1ull << 24) : want);
+    win = max(1024u, (win + 255u) & ~255u);
+    const uint32_t room = kRing - s.waiting;
+    uint32_t total = 0, off = 0;
+    int g0 = 0, g1 = 0;
+    for (;;) {
+        const int groups = (int)((min(win, P - s.next_rank) + 63u) / 64u);
+        const int gpw = (groups + 3) / 4;
+        g0 = wave * gpw; g1 = min(groups, g0 + gpw);
+        const uint32_t cnt = scan_groups<false>(rects, order, s.next_rank, g0, g1, P, tx, ty, lane, lanes_before, 0u, nullptr, 0u, nullptr, 0u, 0u);
         if (lane == 0) scratch[wave] = cnt;
         __syncthreads();
-        uint32_t off = emitted, total = 0;
+        total = 0; off = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint32_t c = scratch[w];
             if (w < wave) off += c;
             total += c;
         }
-        // the wave re-reads its own masks: 8 groups per step, the rank -> index loads of all of them in flight before the stores
-        auto emit_batch = [&](int g, auto checked) {
-            constexpr bool CHECK = decltype(checked)::value;
-            const uint32_t rank0 = w0 + (uint32_t)g * 64u + (uint32_t)lane;
-            uint32_t slot[8], val[8];
-            uint32_t setm = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned long long mv = (!CHECK || g + u < g1) ? masks[g + u] : 0ull;
-                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)mv), hi = __builtin_amdgcn_readfirstlane((uint32_t)(mv >> 32));
-                const unsigned long long m = ((unsigned long long)hi << 32) | lo;           // wave-uniform: scalar registers
-                const bool set = (m >> lane) & 1ull;
-#ifdef HIPEMU
-                slot[u] = off + (uint32_t)__popcll(m & lt_mask);
-#else
-                slot[u] = off + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));      // set bits below this lane
-#endif
-                off += (uint32_t)__popcll(m);
-                val[u] = set ? order[rank0 + 64u * u] : 0u;
-                setm |= (uint32_t)set << u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if ((setm >> u) & 1u) p.bn.point_list[slot[u]] = val[u];
-        };
-        for (int g = g0; g < gfull; g += 8) emit_batch(g, BoolC<false>{});
-        if (gfull < g1) emit_batch(gfull, BoolC<true>{});
-        emitted += total;
         __syncthreads();
+        if (total <= room || win <= 256u) break;           // 256 ranks cannot overflow the ring (waiting <= 255 when called)
+        win = max(256u, (win / 2u + 255u) & ~255u);
     }
+    scan_groups<true>(rects, order, s.next_rank, g0, g1, P, tx, ty, lane, lanes_before, off, ring, s.head + s.waiting, list, s.found, count);
+    __syncthreads();
+    s.next_rank += min(win, P - s.next_rank);
+    s.found += total;
+    s.waiting += total;
 }
 
 // grid V*T (tile_order picks the tile), 256 threads = 4 wave64.  forward.cu:261-374.
@@ -734,6 +743,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(FwdParams p, int wgroups
 // each lane row reading its own entry.  Per (pixel, entry) the arithmetic is the reference's, in the reference's order
 // (forward.cu:332-358); the body has no per-lane branches: one wave-uniform branch leaves when no lane passes the alpha
 // cut-off, everything behind it is selects.
+template <bool SCAN>
 __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
@@ -741,6 +751,9 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ uint4 s_cnt[16];                           // [cell] entries of the batch the cell keeps, per staging wave
     __shared__ uint8_t s_list[17][256];                   // [cell] their batch indices, front to back (+ one row: the walk reads a group ahead)
     __shared__ uint32_t s_walk[4];
+    __shared__ uint32_t s_ring[SCAN ? kRing : 1];         // scan form: list entries found, not yet staged
+    __shared__ uint32_t s_scan[4];
+    if (binning_is_scan(p) != SCAN) return;               // async mode launches both instantiations
     const uint32_t vt = p.im.tile_order[blockIdx.x];           // (view, tile) this workgroup works on: scan_tiles_kernel
     const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T);
     const int bx = tile % p.gx, by = tile / p.gx;
@@ -757,15 +770,23 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     if (!ok) rg.y = rg.x;
     const int rounds = (int)((rg.y - rg.x + 255u) / 256u);
     const size_t vo = (size_t)v * p.P;
+    const uint32_t* rects = p.g.vals[1] + vo;             // scan form: tile rectangle at depth rank (rank_rects_kernel)
+    const uint32_t* order = p.g.vals[0] + vo;             //            depth rank -> Gaussian index
+    TileScan ts{0u, 0u, 0u, 0u};
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
     for (int i = 0; i < rounds; ++i) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t pos = rg.x + (uint32_t)i * 256u + (uint32_t)tid;
+        const uint32_t need = min(256u, rg.y - rg.x - (uint32_t)i * 256u);
+        if (SCAN) {
+            while (ts.waiting < need && ts.next_rank < (uint32_t)p.P)
+                scan_more(p, ts, s_ring, s_scan, rects, order, p.bn.point_list + rg.x, rg.y - rg.x, (uint32_t)bx, (uint32_t)by, lane, wave, lanes_before);
+        }
         unsigned m16 = 0u;
-        if (pos < rg.y) {
-            const uint32_t id = p.bn.point_list[pos];
+        if (pos < rg.y && (!SCAN || (uint32_t)tid < ts.waiting)) {
+            const uint32_t id = SCAN ? s_ring[(ts.head + (uint32_t)tid) & (kRing - 1u)] : p.bn.point_list[pos];
             const float2 xy = p.g.means2D[vo + id];
             const float4 co = p.g.conic_opacity[vo + id];
             const float4 rc = p.g.rgb_cut[vo + id];
@@ -788,6 +809,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
             }
         }
         __syncthreads();
+        if (SCAN) { const uint32_t took = min(need, ts.waiting); ts.head += took; ts.waiting -= took; }
         const uint32_t base = (uint32_t)i * 256u;
         const unsigned long long alive = __ballot(!done);
         if (alive != 0ull) {                                    // a wave whose 64 pixels are all finished only keeps the barriers
@@ -848,7 +870,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     for (int o = 32; o > 0; o >>= 1) walked = max(walked, (uint32_t)__shfl_xor((int)walked, o));
     if (lane == 0) s_walk[wave] = walked;
     __syncthreads();
-    if (tid == 0) p.im.tile_work[vt] = max(max(s_walk[0], s_walk[1]), max(s_walk[2], s_walk[3]));
+    if (tid == 0) {
+        p.im.tile_work[vt] = max(max(s_walk[0], s_walk[1]), max(s_walk[2], s_walk[3]));
+        p.im.tile_cursor[vt] = SCAN ? ts.found : rg.y - rg.x;          // entries of the tile's list that exist in point_list
+    }
 }
 
 __global__ void mark_visible_kernel(int P, const float* means, const float* vm, uint8_t* present) {
@@ -1005,10 +1030,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
 
     if ((forms & ((1 << kFormRankSort) | (1 << kFormScan))) && !radix_done) radix_sort();
     if (forms & (1 << kFormScan)) {
-        int wgroups = ((P + 63) / 64 + 7) / 8 * 8;
-        if (wgroups > 7680) wgroups = 7680;                      // 60 KiB of masks per workgroup
         hipLaunchKernelGGL(rank_rects_kernel, gridP, dim3(256), 0, st, p);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(p.T, V), dim3(256), (size_t)wgroups * 8, st, p, wgroups);
+        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(VT), dim3(256), 0, st, p);
     }
     if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) {
         if (lds_tiles) hipLaunchKernelGGL((emit_instances_kernel<true>), gridP, dim3(256), (size_t)p.T * 8, st, p);
@@ -1029,7 +1052,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(VT), dim3(1024), lds, st, p);
         else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(VT), dim3(256), lds, st, p);
     }
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(VT), dim3(256), 0, st, p);
+    if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(VT), dim3(256), 0, st, p);
     return check(st, a->debug);
 }
 
@@ -1067,6 +1090,8 @@ int64_t dgs_raster_state_read(const char* name, int32_t P, int32_t W, int32_t H,
     else if (is("ranges")) { src = im.ranges; bytes = T * 8; }
     else if (is("n_contrib")) { src = im.n_contrib; bytes = HW * 4; }
     else if (is("final_T")) { src = im.final_T; bytes = HW * 4; }
+    else if (is("list_len")) { src = im.tile_cursor; bytes = T * 4; }       // entries of each tile's list present in point_list
+    else if (is("tile_work")) { src = im.tile_work; bytes = T * 4; }
     else if (is("point_list")) { src = bn.point_list; bytes = (size_t)(N < 0 ? 0 : N) * 4; }
     else return DGS_ERR_INVALID_ARGUMENT;
     if ((int64_t)bytes > dst_bytes) return DGS_ERR_INVALID_ARGUMENT;

@@ -51,6 +51,7 @@ def assert_forward_parity(backend, sc, cams, H, W, device, bg=(1.0, 1.0, 1.0), s
         ncon = rd("n_contrib", torch.int32, V * H * W).reshape(V, H, W)
         fT = rd("final_T", torch.float32, V * H * W).reshape(V, H, W)
         plist = rd("point_list", torch.int32, max(int(n_total), 1))[: int(n_total)]
+        have = rd("list_len", torch.int32, V * T).reshape(V, T)
     total = 0
     for v, cam in enumerate(cams):
         s = v // vps
@@ -77,7 +78,12 @@ def assert_forward_parity(backend, sc, cams, H, W, device, bg=(1.0, 1.0, 1.0), s
                 a, b = ranges[v, t]
                 oa, ob = org[t]
                 assert b - a == ob - oa, f"tile {t} of view {v}: length {b - a} vs oracle {ob - oa}"
-                np.testing.assert_array_equal(plist[a:b], opl[oa:ob].astype(np.int32), err_msg=f"sorted list tile {t} view {v}")
+                # the scan form produces a tile's list on demand: a prefix, at least as long as the blend walked
+                n_have = int(have[v, t])
+                gx = (W + 15) // 16
+                walked = int(ncon[v, 16 * (t // gx):16 * (t // gx) + 16, 16 * (t % gx):16 * (t % gx) + 16].max())
+                assert walked <= n_have <= b - a, f"tile {t} of view {v}: {n_have} list entries present, walked {walked}, length {b - a}"
+                np.testing.assert_array_equal(plist[a:a + n_have], opl[oa:oa + n_have].astype(np.int32), err_msg=f"sorted list tile {t} view {v}")
             np.testing.assert_array_equal(ncon[v], o.get("n_contrib").astype(np.int32).reshape(H, W), err_msg="n_contrib")
             np.testing.assert_array_equal(fT[v].view(np.uint32), o.get("final_T").view(np.uint32).reshape(H, W), err_msg="final_T bits")
         np.testing.assert_array_equal(color[v].cpu().numpy().view(np.uint32), o.get("out_color").view(np.uint32),

@@ -63,8 +63,13 @@ def dpix_for(res, seed=0):
 
 
 def per_tile_lists(get):
+    """Per-tile lists as far as they exist: the HIP path's scan form produces a tile's list on demand (a prefix, `list_len`)."""
     rng, pl = get("ranges").astype(np.int64), get("point_list")
-    return [pl[a:b] for a, b in rng]
+    try:
+        have = get("list_len").astype(np.int64)
+    except KeyError:
+        have = rng[:, 1] - rng[:, 0]
+    return [pl[a:a + h] for (a, b), h in zip(rng, have)]
 
 
 def compare(a, b, grads=False):
@@ -82,9 +87,10 @@ def compare(a, b, grads=False):
         st[f"{k}_bitdiff"] = int(np.count_nonzero(x.view(np.uint32) != y.view(np.uint32)))
         st[f"{k}_maxrel"] = float(np.max(np.abs(x - y) / np.maximum(np.abs(y), 1e-20), initial=0.0))
     la, lb = per_tile_lists(a), per_tile_lists(b)
-    st["num_rendered"] = (int(sum(len(t) for t in la)), int(sum(len(t) for t in lb)))
-    st["tiles_len_mismatch"] = sum(1 for x, y in zip(la, lb) if len(x) != len(y))
-    st["tiles_order_mismatch"] = sum(1 for x, y in zip(la, lb) if len(x) == len(y) and not np.array_equal(x, y))
+    ra, rb = a("ranges").astype(np.int64), b("ranges").astype(np.int64)
+    st["num_rendered"] = (int((ra[:, 1] - ra[:, 0]).sum()), int((rb[:, 1] - rb[:, 0]).sum()))
+    st["tiles_len_mismatch"] = int(np.count_nonzero((ra[:, 1] - ra[:, 0]) != (rb[:, 1] - rb[:, 0])))
+    st["tiles_order_mismatch"] = sum(1 for x, y in zip(la, lb) if not np.array_equal(x[:min(len(x), len(y))], y[:min(len(x), len(y))]))
     ca, cb = a("out_color").astype(np.float64), b("out_color").astype(np.float64)
     st["color_maxabs"] = float(np.abs(ca - cb).max())
     mse = float(np.mean((np.clip(ca, 0, 1) - np.clip(cb, 0, 1)) ** 2))
@@ -116,7 +122,7 @@ def hip_state(backend, sc, cam, res, device, sh_degree=0, dpix=None, bg=(1.0, 1.
             "tiles_touched": rd("tiles_touched", torch.int32, P), "ranges": rd("ranges", torch.int32, 2 * T).reshape(T, 2),
             "n_contrib": rd("n_contrib", torch.int32, res * res).reshape(res, res),
             "final_T": rd("final_T", torch.float32, res * res).reshape(res, res),
-            "point_list": rd("point_list", torch.int32, max(int(n), 1))[: int(n)]}
+            "point_list": rd("point_list", torch.int32, max(int(n), 1))[: int(n)], "list_len": rd("list_len", torch.int32, T)}
     if dpix is not None:
         t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
         use_sh, use_sr = "colors_precomp" not in kw, "cov3D_precomp" not in kw

@@ -42,6 +42,28 @@ def test_many_instances_per_tile_and_ties():
     assert_forward_parity(emu_backend(), sc, cams, H, W, CPU)
 
 
+def clustered_scene(P, n_front, res):
+    """n_front faint Gaussians stacked on the first tile, nearest to the camera, the rest tiny and elsewhere: the first tile's
+    list is a fraction of P but its entries are the first depth ranks (the scan form's window is sized from the average
+    density and has to shrink: scan_more), and no pixel saturates, so the whole list is walked."""
+    from dgs_amd import cameras
+    sc, cams = small_scene(P, res, res, seed=21, log_scale=-6.5, spread=0.5)
+    c2w = cameras.ring_cameras(1, phase_deg=25.0)[0]
+    ro, rd = cameras.pixel_rays(c2w, cameras.default_fxfycxcy(res, res), res, res)
+    o, d = np.asarray(ro).reshape(res, res, 3)[8, 8], np.asarray(rd).reshape(res, res, 3)[8, 8]
+    rng = np.random.default_rng(5)
+    sc["xyz"][:n_front] = (o + d * (1.6 + 0.2 * rng.uniform(size=(n_front, 1))) + rng.normal(0, 0.01, size=(n_front, 3))).astype(np.float32)
+    sc["scales"][:n_front] = np.exp(-2.6).astype(np.float32)
+    sc["opacities"][:n_front] = 0.02
+    return sc, cams
+
+
+def test_scan_window_shrinks_on_depth_clusters():
+    res = 48
+    sc, cams = clustered_scene(20000, 3000, res)
+    assert_forward_parity(emu_backend(), sc, cams, res, res, CPU)
+
+
 def test_precomputed_inputs_and_two_sets():
     H, W = 32, 48
     a, cams = small_scene(64, W, H, seed=2, n_views=4)
