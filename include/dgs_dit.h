@@ -315,6 +315,11 @@ typedef struct DgsDitRunBlocksArgs {
 } DgsDitRunBlocksArgs;
 int dgs_dit_run_blocks(const DgsDitModel* m, const DgsDitRunBlocksArgs* a, dgs_stream_t stream);
 
+/* Test hook: fills the LDS of every CU with NaN patterns (bf16 and f32).  The kernels above read operands that LDS-DMAs deliver
+ * asynchronously; a read that overtakes its DMA would otherwise see the previous launch's -- usually identical -- data and pass
+ * unnoticed.  tests/ call it in front of the kernels under test. */
+int dgs_debug_poison_lds(dgs_stream_t stream);
+
 int32_t dgs_dit_lpad(int32_t L);   /* padded rows per sample */
 size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W);
 int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream);

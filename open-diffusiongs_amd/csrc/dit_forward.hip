@@ -53,6 +53,15 @@ struct DitWorkspace {
     }
 };
 
+// dgs_debug_poison_lds: every 4-byte word of the workgroup's LDS = 0x7FC07FC0 (a NaN as f32 and as two bf16)
+__global__ __launch_bounds__(256) void poison_lds_kernel(int words) {
+    DGS_DYNAMIC_LDS(smem);
+    uint32_t* w = reinterpret_cast<uint32_t*>(smem);
+    for (int i = threadIdx.x; i < words; i += 256) w[i] = 0x7FC07FC0u;
+    __syncthreads();
+    if (w[(threadIdx.x * 97) % words] != 0x7FC07FC0u) __builtin_trap();      // keeps the stores
+}
+
 static int token_count(const DgsDitModel* m, int V, int H, int W) { return m->n_gaussians + V * (H / m->patch) * (W / m->patch); }
 
 }  // namespace dgs
@@ -121,6 +130,14 @@ int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last
     return DGS_OK;
 }
 }  // namespace
+
+extern "C" int dgs_debug_poison_lds(dgs_stream_t stream) {
+    constexpr int kBytes = 160 * 1024;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(dgs::poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess;
+    if (!ok) return DGS_ERR_DEVICE;
+    hipLaunchKernelGGL(dgs::poison_lds_kernel, dim3(2048), dim3(256), kBytes, static_cast<hipStream_t>(stream), kBytes / 4);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
 
 extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream) {
     if (!m || !a || a->B <= 0 || a->V <= 0 || a->H <= 0 || a->W <= 0) { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }

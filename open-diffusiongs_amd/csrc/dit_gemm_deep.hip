@@ -304,13 +304,44 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
             foff[ks][f] = f < WMB ? slab_off<BK>(wm * WROWS + 32 * f + frow, 2 * ks + fhalf) : A_BYTES + slab_off<BK>(wn * WN + 32 * (f - WMB) + frow, 2 * ks + fhalf);
     auto frag = [&](int slot, int ks, int f) { return *reinterpret_cast<const bf16x8*>(lds + slot * STAGE + foff[ks][f]); };
     const int nk = p.K / BK;                                      // a multiple of NS
+    constexpr int GA = A_BYTES / 1024 / NW;                       // DMA pieces per wave per slab: GA of A, G - GA of W
+#ifndef HIPEMU
+    // The DMA of a piece, all-scalar addressing: global address = SGPR pair (the operand's tile row 0 at the slab's k) + one
+    // 32-bit VGPR offset per piece (the lane's row and 16-byte chunk: loop-invariant), LDS address = M0 = SGPR + literal.
+    // tools/ubench/dma_piece_bench on MI355X, one piece per two MFMAs: this form costs 1 cycle of the MFMA stream per piece;
+    // a 64-bit VGPR address made by v_lshl_add_u64 with M0 restored from a spilled SGPR (v_readlane_b32) -- what hipcc made of
+    // the builtin with per-slab pointer arithmetic -- costs 29.
+    constexpr int RPI = 1024 / (2 * BK), CPR = BK / 8;
+    const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds + (uint32_t)wave * 1024u;
+    const char* sb_a = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);        // + 2 BK bytes per slab staged
+    const char* sb_w = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
+    uint32_t vo_a[GA], vo_w[G - GA];
+    {
+        const int r0 = lane / CPR, chunk = (lane % CPR) ^ (BK == 64 ? (r0 >> 1) & 7 : (r0 >> 2) & 3);     // piece rows are multiples of 16
+#pragma unroll
+        for (int q = 0; q < GA; ++q) vo_a[q] = (uint32_t)((((wave + NW * q) * RPI + r0) * p.lda + chunk * 8) * 2);
+#pragma unroll
+        for (int q = 0; q < G - GA; ++q) vo_w[q] = (uint32_t)((((wave + NW * q) * RPI + r0) * p.ldw + chunk * 8) * 2);
+    }
+    auto dma_piece = [&](auto slotc, auto qc) {                   // piece q (A pieces first) of the NEXT slab into ring slot `slot`
+        constexpr int slot = decltype(slotc)::value, q = decltype(qc)::value;
+        if constexpr (q < GA)
+            asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo_a[q]), "s"(sb_a), "s"(lds_wave), "n"(slot * STAGE + NW * q * 1024) : "memory", "m0", "scc");
+        else
+            asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo_w[q - GA]), "s"(sb_w), "s"(lds_wave), "n"(slot * STAGE + A_BYTES + NW * (q - GA) * 1024) : "memory", "m0", "scc");
+        if constexpr (q == G - 1) { sb_a += 2 * BK; sb_w += 2 * BK; }
+    };
+    auto stage_next = [&](auto slotc) { sliced_for<0, G>([&](auto qc) { dma_piece(slotc, qc); }); };
+    // ---- prologue: slabs 0 .. NS-2 in flight, then the fragments of slab 0, substep 0 ----
+    sliced_for<0, NS - 1>([&](auto sc) { stage_next(sc); });
+#else
     auto stage = [&](int t, int slot) {
         stage_slab<BM, BK, NW>(p.A, p.lda, m0, t * BK, lds + slot * STAGE, wave, lane);
         stage_slab<BN, BK, NW>(p.W, p.ldw, n0, t * BK, lds + slot * STAGE + A_BYTES, wave, lane);
     };
-    // ---- prologue: slabs 0 .. NS-2 in flight, then the fragments of slab 0, substep 0 ----
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) stage(s, s);
+#endif
     // ---- tiles with a single live 32-row block (the learned-token rows of every sample), folded into the first workgroups ----
     // An item is 32 rows x 32 columns (64 for BN = 128): the NW waves are ranges of K, every wave pulls its fragments straight from
     // L2 in one round trip per 128 / 256 columns of K (one trip for K = 1024), the ranges meet in the ring stage that iteration 0
@@ -338,22 +369,33 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     long long dbg_wait = 0, dbg_bar = 0;
     // NW = 4: the wave is alone on its SIMD, so a burst of G DMA issues at the top of the iteration is a bubble in the MFMA
     // stream; one DMA goes out behind each MFMA of the second half of substep 0 instead (those slices have no LDS read)
-    constexpr int GA = A_BYTES / 1024 / NW;
     constexpr bool SPREAD = NW == 4;
-    auto iteration = [&](int t, const int slot, auto refill_tag) {   // slot == t % NS, a literal at the call sites
-        constexpr bool refill = decltype(refill_tag)::value;           // slab t + NS - 1 exists
-        char* const dst = lds + ((slot + NS - 1) % NS) * STAGE;        // the stage of slab t - 1 (released by the last barrier)
+    auto iteration = [&](int t, auto slot_tag, auto refill_tag) {    // slot == t % NS, a literal at the call sites
+        constexpr int slot = decltype(slot_tag)::value;
+        constexpr bool refill = decltype(refill_tag)::value;           // slab t + NS - 1 exists; it goes into the stage of slab t - 1
+#ifndef HIPEMU
+        if constexpr (refill && !SPREAD && EXP != 1) stage_next(SIC<(slot + NS - 1) % NS>{});
+#else
+        char* const dst = lds + ((slot + NS - 1) % NS) * STAGE;
         if (refill && !SPREAD && EXP != 1) stage(t + NS - 1, (slot + NS - 1) % NS);
+#endif
         sliced_for<0, 2 * MF>([&](auto jc) {
             constexpr int J = decltype(jc)::value, ks = J / MF, i = (J % MF) / NI, j = J % NI;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks][i], fr[ks][WMB + j], acc[i][j], 0, 0, 0);
+#ifndef HIPEMU
+            __builtin_amdgcn_sched_barrier(0);                     // the MFMA leads its slice: what follows issues in its shadow
+#endif
             // the other register half: substep 1 of this slab, then substep 0 of the next one (stale data behind the last slab)
             constexpr int f = J % MF;
             if constexpr (f < NF && EXP != 2) fr[ks ^ 1][f] = frag(ks == 0 ? slot : (slot + 1) % NS, ks ^ 1, f);
             if constexpr (SPREAD && refill && ks == 0 && f >= MF - G && EXP != 1) {
                 constexpr int q = f - (MF - G);
+#ifndef HIPEMU
+                dma_piece(SIC<(slot + NS - 1) % NS>{}, SIC<q>{});
+#else
                 if constexpr (q < GA) stage_piece<BK, NW>(p.A, p.lda, m0, (t + NS - 1) * BK, dst, wave, lane, q);
                 else stage_piece<BK, NW>(p.W, p.ldw, n0, (t + NS - 1) * BK, dst + A_BYTES, wave, lane, q - GA);
+#endif
             }
 #ifndef HIPEMU
             __builtin_amdgcn_sched_barrier(0);
@@ -382,10 +424,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const long long dbg_t0 = p.dbg == 1 ? clock64() : 0;
 #endif
     for (int t = 0; t < nk - NS; t += NS)                          // unrolled by the ring depth: slots are literals
-        sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, decltype(sc)::value, std::true_type{}); });
+        sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, sc, std::true_type{}); });
     sliced_for<0, NS>([&](auto sc) {                               // the last slab goes out in the first of the last NS iterations
         constexpr int S = decltype(sc)::value;
-        iteration(nk - NS + S, S, std::integral_constant<bool, S == 0>{});
+        iteration(nk - NS + S, sc, std::integral_constant<bool, S == 0>{});
     });
 #ifndef HIPEMU
     const long long dbg_t1 = p.dbg == 1 ? clock64() : 0;

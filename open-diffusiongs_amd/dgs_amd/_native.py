@@ -255,7 +255,7 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
-               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks"]
+               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds"]
 
 
 def _declare_dit(L):
@@ -279,6 +279,8 @@ def _declare_dit(L):
         fn.restype = ctypes.c_size_t
         fn.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
     L.dgs_dit_saved_bytes.argtypes = L.dgs_dit_saved_bytes.argtypes + [ctypes.c_int32]
+    L.dgs_debug_poison_lds.restype = ctypes.c_int
+    L.dgs_debug_poison_lds.argtypes = [ctypes.c_void_p]
     L.dgs_dit_run_blocks.restype = ctypes.c_int
     L.dgs_dit_run_blocks.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitRunBlocksArgs), ctypes.c_void_p]
     L.dgs_dit_forward_train.restype = ctypes.c_int

@@ -34,6 +34,11 @@ class DitOps:
         if rc != 0:
             raise RuntimeError(f"dgs dit: {_native.status_string(self.lib, rc)} (status {rc})")
 
+    def poison_lds(self, device="cuda:0"):
+        """Test hook (dgs_debug_poison_lds): NaN patterns into every CU's LDS, so that a fragment read that overtakes its
+        LDS-DMA cannot pass on the previous launch's data."""
+        self._check(self.lib.dgs_debug_poison_lds(ctypes.c_void_p(torch.cuda.current_stream(torch.device(device)).cuda_stream)))
+
     def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None, valid_rows=0,
              resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None, algo=0,
              q_scale=0.0, splitk=False):

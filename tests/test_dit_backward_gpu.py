@@ -8,6 +8,15 @@ from dit_util import rel_l2, synth_inputs
 from oracle import dit_oracle as D
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def poisoned_lds():
+    """Every test starts from LDS full of NaN patterns: the GEMM / attention kernels read fragments that LDS-DMAs deliver
+    asynchronously, and a read that overtook its DMA would otherwise find the previous test's -- often identical -- data."""
+    from dgs_amd.dit import DitOps
+    DitOps().poison_lds()
+    yield
 DEV = "cuda:0"
 FIELDS = ("xyz", "features", "scaling", "rotation", "opacity")
 

@@ -12,13 +12,37 @@ from dit_util import golden_case, rel_l2, synth_inputs
 from oracle import dit_oracle as D
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def poisoned_lds():
+    """Every test starts from LDS full of NaN patterns: the GEMM / attention kernels read fragments that LDS-DMAs deliver
+    asynchronously, and a read that overtook its DMA would otherwise find the previous test's -- often identical -- data."""
+    from dgs_amd.dit import DitOps
+    DitOps().poison_lds()
+    yield
 FIELDS = ("xyz", "features", "scaling", "rotation", "opacity")
 DEV = "cuda:0"
 
 
+class _Poisoned:
+    """DitOps whose every kernel call starts from NaN-filled LDS (poisoned_lds above covers only a test's first launch)."""
+
+    def __init__(self, ops):
+        self._ops = ops
+
+    def __getattr__(self, name):
+        fn = getattr(self._ops, name)
+
+        def call(*a, **k):
+            self._ops.poison_lds()
+            return fn(*a, **k)
+        return call
+
+
 def _ops():
     from dgs_amd.dit import DitOps
-    return DitOps()
+    return _Poisoned(DitOps())
 
 
 def _bf(t):
