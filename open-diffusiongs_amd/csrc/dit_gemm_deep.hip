@@ -370,8 +370,17 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     // NW = 4: the wave is alone on its SIMD, so a burst of G DMA issues at the top of the iteration is a bubble in the MFMA
     // stream; one DMA goes out behind each MFMA of the second half of substep 0 instead (those slices have no LDS read)
     constexpr bool SPREAD = NW == 4;
-    auto iteration = [&](int t, auto slot_tag, auto refill_tag) {    // slot == t % NS, a literal at the call sites
+    // The gated-residual epilogue of the 128 x 128 tiles reads 64 KiB of the residual stream per workgroup; every workgroup of the
+    // one-round grid reaches its epilogue at the same time and a strip's loads cannot move above the previous strip's stores
+    // (out may alias resid), so the tile paid two exposed round trips (~16 k of a 90 k-cycle tile).  Here the whole tile's
+    // residual (64 registers) is requested behind the LAST DMA, eight slabs before the loop ends, and the counted waits of the
+    // remaining iterations let those loads stay in flight.
+    constexpr bool PREFETCH_RESID = EPI == DGS_EPI_GATE_RESIDUAL && BM == 128 && NW == 4;
+    constexpr int PRE_LOADS = PREFETCH_RESID ? WMB * (NI / 2) * 8 : 0;       // float4 loads per lane
+    float4 pre[PREFETCH_RESID ? WMB * (NI / 2) : 1][8];
+    auto iteration = [&](int t, auto slot_tag, auto refill_tag, auto pre_tag, auto left_tag) {    // slot == t % NS, a literal at the call sites
         constexpr int slot = decltype(slot_tag)::value;
+        constexpr int PRE_N = decltype(pre_tag)::value;                // residual loads in flight at the end of this iteration
         constexpr bool refill = decltype(refill_tag)::value;           // slab t + NS - 1 exists; it goes into the stage of slab t - 1
 #ifndef HIPEMU
         if constexpr (refill && !SPREAD && EXP != 1) stage_next(SIC<(slot + NS - 1) % NS>{});
@@ -401,6 +410,12 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
             __builtin_amdgcn_sched_barrier(0);
 #endif
         });
+        if constexpr (PRE_N > 0 && refill) {                       // the tail's first iteration: its DMAs were the last ones
+#pragma unroll
+            for (int i = 0; i < WMB; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; j += 2) residual_prefetch<2>(p, m0 + wm * WROWS + 32 * i, n0 + wn * WN + 32 * j, lane, pre[i * (NI / 2) + j / 2]);
+        }
         // slab t+1 (and older) has landed once at most this iteration's own DMAs are outstanding; then everybody is also
         // done reading slab t
 #ifndef HIPEMU
@@ -410,7 +425,11 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         // iteration t: slabs t+3 .. t+NS-1 stay in flight across the barrier (DMAs complete in issue order).  NS = 4: only the slab
         // issued in this iteration; NS = 8 (128 x 128 tiles, whose A operand streams from beyond L2): five slabs, ~3 k cycles of
         // latency tolerance.
-        if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
+        if constexpr (PRE_N > 0) {
+            // the residual loads went out behind the last DMA (below) and stay in flight to the epilogue: slabs t+3 .. nk-1 plus them
+            constexpr int left = decltype(left_tag)::value;       // slabs behind t+2 that exist
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(left * G + PRE_N) : "memory");
+        } else if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long w1 = 0;
         if (p.dbg == 1) w1 = clock64();
@@ -424,10 +443,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const long long dbg_t0 = p.dbg == 1 ? clock64() : 0;
 #endif
     for (int t = 0; t < nk - NS; t += NS)                          // unrolled by the ring depth: slots are literals
-        sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, sc, std::true_type{}); });
+        sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, sc, std::true_type{}, SIC<0>{}, SIC<0>{}); });
     sliced_for<0, NS>([&](auto sc) {                               // the last slab goes out in the first of the last NS iterations
         constexpr int S = decltype(sc)::value;
-        iteration(nk - NS + S, sc, std::integral_constant<bool, S == 0>{});
+        iteration(nk - NS + S, sc, std::integral_constant<bool, S == 0>{}, SIC<PRE_LOADS>{}, SIC<(NS - S - 3 > 0 ? NS - S - 3 : 0)>{});
     });
 #ifndef HIPEMU
     const long long dbg_t1 = p.dbg == 1 ? clock64() : 0;
@@ -437,7 +456,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #pragma unroll
         for (int i = 0; i < WMB; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; j += 2) store_strip<EPI, 2>(p, &acc[i][j], m0 + wm * WROWS + 32 * i, n0 + wn * WN + 32 * j, lane, patch);
+            for (int j = 0; j < NI; j += 2) {
+                if constexpr (PREFETCH_RESID) store_strip<EPI, 2>(p, &acc[i][j], m0 + wm * WROWS + 32 * i, n0 + wn * WN + 32 * j, lane, patch, pre[i * (NI / 2) + j / 2]);
+                else store_strip<EPI, 2>(p, &acc[i][j], m0 + wm * WROWS + 32 * i, n0 + wn * WN + 32 * j, lane, patch);
+            }
     } else {
 #pragma unroll
         for (int i = 0; i < WMB; ++i) store_block<EPI, NI>(p, acc[i], m0 + wm * WROWS + 32 * i + 4 * fhalf, n0 + wn * WN, lane);

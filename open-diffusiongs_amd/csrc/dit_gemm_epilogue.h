@@ -84,8 +84,18 @@ __device__ __forceinline__ bool epi_staged(const P&) { return true; }
 // acc[0 .. NB): NB side-by-side 32 x 32 accumulator blocks: rows m0 .. m0+31 (m0 = first row of the block), columns
 // n0 .. n0 + 32 NB - 1.  `patch` = this wave's private LDS patch (epi_strip_bytes(NB) bytes); nobody else touches it, so no
 // barrier is needed -- LDS operations of one wave execute in order.
-template <int EPI, int NB, class P>
-__device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch) {
+// `pre`: the strip's residual values (GATE_RESIDUAL), loaded by the caller ahead of time in the layout of the row-major pass
+// below (pre[it] = row it * RPI + rr, columns cc .. cc + 3): residual_prefetch.  nullptr = load them here.
+template <int NB, class P>
+__device__ __forceinline__ void residual_prefetch(const P& p, int m0, int n0, int lane, float4 (&pre)[8]) {
+    constexpr int C = 32 * NB, LPR = C / 4, RPI = 64 / LPR;
+    const int rr = lane / LPR, cc = (lane % LPR) * 4;
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) pre[it] = *reinterpret_cast<const float4*>(p.resid + (size_t)(m0 + it * RPI + rr) * p.ldo + n0 + cc);
+}
+
+template <int EPI, int NB, bool HAVE_PRE, class P>
+__device__ __forceinline__ void store_strip_impl(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch, const float4 (&pre)[8]) {
     constexpr int C = 32 * NB, S = C + 4;
     const int c = lane & 31, half = lane >> 5;
     const int b = m0 / p.rows_per_batch;                       // a 32-row block never straddles samples
@@ -129,7 +139,8 @@ __device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m
             const float4 v = *reinterpret_cast<const float4*>(st + row * S + cc);
             const size_t o = (size_t)(m0 + row) * p.ldo + n0 + cc;
             if (EPI == DGS_EPI_GATE_RESIDUAL) {
-                const float4 x = *reinterpret_cast<const float4*>(p.resid + o);
+                float4 x;
+                if constexpr (HAVE_PRE && 32 / RPI == 8) x = pre[it]; else x = *reinterpret_cast<const float4*>(p.resid + o);
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) =
                     make_float4(x.x + gate.x * v.x, x.y + gate.y * v.y, x.z + gate.z * v.z, x.w + gate.w * v.w);
                 if (p.aux) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.aux) + o) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
@@ -181,6 +192,16 @@ __device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m
         }
     }
     __builtin_amdgcn_wave_barrier();       // the patch is rewritten by the next strip
+}
+
+template <int EPI, int NB, class P>
+__device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch) {
+    const float4 none[8] = {};
+    store_strip_impl<EPI, NB, false>(p, acc, m0, n0, lane, patch, none);
+}
+template <int EPI, int NB, class P>
+__device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch, const float4 (&pre)[8]) {
+    store_strip_impl<EPI, NB, true>(p, acc, m0, n0, lane, patch, pre);
 }
 
 // One output element (row m, column n) through epilogue EPI: the scalar twin of store_strip, same arithmetic and roundings.
