@@ -240,6 +240,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     //      idle (main_loop ends with a barrier), every wave takes a private patch ----
     if (epi_staged<EPI>(p)) {
         char* patch = lds + wave * epi_strip_bytes(NI);
+        if constexpr (EPI == DGS_EPI_GATE_RESIDUAL) {
+            // both strips' residual values in ONE round trip: out may alias resid, so the second strip's loads cannot move above
+            // the first strip's stores by themselves
+            float4 pre[2][4 * NI];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                if (mi == 0 ? live0 : live1) residual_prefetch<NI>(p, m0 + wm * 64 + mi * 32, n0 + wn * (BN / 2), lane, pre[mi]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                if (mi == 0 ? live0 : live1) store_strip<EPI, NI>(p, acc[mi], m0 + wm * 64 + mi * 32, n0 + wn * (BN / 2), lane, patch, pre[mi]);
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
             if (mi == 0 ? live0 : live1) store_strip<EPI, NI>(p, acc[mi], m0 + wm * 64 + mi * 32, n0 + wn * (BN / 2), lane, patch);

@@ -85,9 +85,9 @@ __device__ __forceinline__ bool epi_staged(const P&) { return true; }
 // n0 .. n0 + 32 NB - 1.  `patch` = this wave's private LDS patch (epi_strip_bytes(NB) bytes); nobody else touches it, so no
 // barrier is needed -- LDS operations of one wave execute in order.
 // `pre`: the strip's residual values (GATE_RESIDUAL), loaded by the caller ahead of time in the layout of the row-major pass
-// below (pre[it] = row it * RPI + rr, columns cc .. cc + 3): residual_prefetch.  nullptr = load them here.
+// below (pre[it] = row it * RPI + rr, columns cc .. cc + 3; 4 NB of them): residual_prefetch.
 template <int NB, class P>
-__device__ __forceinline__ void residual_prefetch(const P& p, int m0, int n0, int lane, float4 (&pre)[8]) {
+__device__ __forceinline__ void residual_prefetch(const P& p, int m0, int n0, int lane, float4 (&pre)[4 * NB]) {
     constexpr int C = 32 * NB, LPR = C / 4, RPI = 64 / LPR;
     const int rr = lane / LPR, cc = (lane % LPR) * 4;
 #pragma unroll
@@ -95,7 +95,7 @@ __device__ __forceinline__ void residual_prefetch(const P& p, int m0, int n0, in
 }
 
 template <int EPI, int NB, bool HAVE_PRE, class P>
-__device__ __forceinline__ void store_strip_impl(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch, const float4 (&pre)[8]) {
+__device__ __forceinline__ void store_strip_impl(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch, const float4 (&pre)[4 * NB]) {
     constexpr int C = 32 * NB, S = C + 4;
     const int c = lane & 31, half = lane >> 5;
     const int b = m0 / p.rows_per_batch;                       // a 32-row block never straddles samples
@@ -140,7 +140,7 @@ __device__ __forceinline__ void store_strip_impl(const P& p, const f32x16* acc, 
             const size_t o = (size_t)(m0 + row) * p.ldo + n0 + cc;
             if (EPI == DGS_EPI_GATE_RESIDUAL) {
                 float4 x;
-                if constexpr (HAVE_PRE && 32 / RPI == 8) x = pre[it]; else x = *reinterpret_cast<const float4*>(p.resid + o);
+                if constexpr (HAVE_PRE) x = pre[it]; else x = *reinterpret_cast<const float4*>(p.resid + o);
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) =
                     make_float4(x.x + gate.x * v.x, x.y + gate.y * v.y, x.z + gate.z * v.z, x.w + gate.w * v.w);
                 if (p.aux) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.aux) + o) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
@@ -196,11 +196,11 @@ __device__ __forceinline__ void store_strip_impl(const P& p, const f32x16* acc, 
 
 template <int EPI, int NB, class P>
 __device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch) {
-    const float4 none[8] = {};
+    const float4 none[4 * NB] = {};
     store_strip_impl<EPI, NB, false>(p, acc, m0, n0, lane, patch, none);
 }
 template <int EPI, int NB, class P>
-__device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch, const float4 (&pre)[8]) {
+__device__ __forceinline__ void store_strip(const P& p, const f32x16* acc, int m0, int n0, int lane, char* patch, const float4 (&pre)[4 * NB]) {
     store_strip_impl<EPI, NB, true>(p, acc, m0, n0, lane, patch, pre);
 }
 
