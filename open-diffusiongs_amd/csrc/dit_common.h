@@ -74,10 +74,16 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 #endif
 }
 
+// Sum over the 64 lanes, in every lane: the DPP sum of lane 63 read back as a scalar (six ds_bpermute round trips -- ~400 cycles of
+// latency per sum -- before: LayerNorm does two per row, the adaLN GEMV one per output feature).
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef HIPEMU
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+#else
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_lane63(v)), 63));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

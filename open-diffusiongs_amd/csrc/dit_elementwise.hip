@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
+constexpr int kRowLinFeatures = 32;
+
 template <int MR>   // rows handled per pass (compile-time for register accumulators)
 __global__ __launch_bounds__(256) void rowlinear_kernel(RowLinParams p) {
     DGS_DYNAMIC_LDS(smem);
@@ -76,30 +78,46 @@ __global__ __launch_bounds__(256) void rowlinear_kernel(RowLinParams p) {
         xs[i] = v;
     }
     __syncthreads();
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= p.N) return;
-    float acc[MR];
+    // kRowLinFeatures output features per workgroup, a wave takes every fourth: the staging of x (and its SiLU) above is paid once
+    // per 32 features instead of once per 4, and two features' weight rows are in flight per wave (the adaLN GEMV of all 24 blocks
+    // streams 310 MB of weights once per forward: 3.0 TB/s with 4 features per workgroup)
+    const int n_end = min(p.N, ((int)blockIdx.x + 1) * kRowLinFeatures);
+    for (int n = blockIdx.x * kRowLinFeatures + wave; n < n_end; n += 8) {
+        const int n2 = n + 4;                                  // the wave's second feature of this pass (if it exists)
+        const bool two = n2 < n_end;
+        float acc[2][MR];
 #pragma unroll
-    for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-    const bf16_t* wr = p.W + (size_t)n * p.K;
-    for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
-        const uint4 w = *reinterpret_cast<const uint4*>(wr + k0);
-        const float wf[8] = {bf2f(w.x & 0xffffu), bf2f(w.x >> 16), bf2f(w.y & 0xffffu), bf2f(w.y >> 16),
-                             bf2f(w.z & 0xffffu), bf2f(w.z >> 16), bf2f(w.w & 0xffffu), bf2f(w.w >> 16)};
+        for (int m = 0; m < MR; ++m) { acc[0][m] = 0.f; acc[1][m] = 0.f; }
+        const bf16_t* wr0 = p.W + (size_t)n * p.K;
+        const bf16_t* wr1 = p.W + (size_t)(two ? n2 : n) * p.K;
+        for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
+            const uint4 w0 = *reinterpret_cast<const uint4*>(wr0 + k0);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(wr1 + k0);
+            const float wf[2][8] = {{bf2f(w0.x & 0xffffu), bf2f(w0.x >> 16), bf2f(w0.y & 0xffffu), bf2f(w0.y >> 16),
+                                     bf2f(w0.z & 0xffffu), bf2f(w0.z >> 16), bf2f(w0.w & 0xffffu), bf2f(w0.w >> 16)},
+                                    {bf2f(w1.x & 0xffffu), bf2f(w1.x >> 16), bf2f(w1.y & 0xffffu), bf2f(w1.y >> 16),
+                                     bf2f(w1.z & 0xffffu), bf2f(w1.z >> 16), bf2f(w1.w & 0xffffu), bf2f(w1.w >> 16)}};
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const float4 xa = *reinterpret_cast<const float4*>(xs + m * p.K + k0);
-            const float4 xb = *reinterpret_cast<const float4*>(xs + m * p.K + k0 + 4);
-            acc[m] += wf[0] * xa.x + wf[1] * xa.y + wf[2] * xa.z + wf[3] * xa.w + wf[4] * xb.x + wf[5] * xb.y + wf[6] * xb.z + wf[7] * xb.w;
+            for (int m = 0; m < MR; ++m) {
+                const float4 xa = *reinterpret_cast<const float4*>(xs + m * p.K + k0);
+                const float4 xb = *reinterpret_cast<const float4*>(xs + m * p.K + k0 + 4);
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+                    acc[f][m] += wf[f][0] * xa.x + wf[f][1] * xa.y + wf[f][2] * xa.z + wf[f][3] * xa.w + wf[f][4] * xb.x + wf[f][5] * xb.y + wf[f][6] * xb.z + wf[f][7] * xb.w;
+            }
         }
-    }
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-        float v = wave_sum(acc[m]);
-        if (lane == 0 && m < p.M) {
-            if (p.bias) v += p.bias[n];
-            if (p.silu_out) v = silu(v);
-            p.out[(size_t)m * p.N + n] = v;
+        for (int f = 0; f < 2; ++f) {
+            const int nf = f ? n2 : n;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                float v = wave_sum(acc[f][m]);
+                if (lane == 0 && m < p.M && (f == 0 || two)) {
+                    if (p.bias) v += p.bias[nf];
+                    if (p.silu_out) v = silu(v);
+                    p.out[(size_t)m * p.N + nf] = v;
+                }
+            }
         }
     }
 }
@@ -250,7 +268,7 @@ int launch_rowlinear(const DgsDitRowLinearArgs* a, hipStream_t st) {
     RowLinParams p;
     p.M = a->M; p.N = a->N; p.K = a->K; p.silu_in = a->silu_input; p.silu_out = a->silu_output;
     p.x = a->x; p.W = a->W; p.bias = a->bias; p.out = a->out;
-    const dim3 grid((a->N + 3) / 4), block(256);
+    const dim3 grid((a->N + kRowLinFeatures - 1) / kRowLinFeatures), block(256);
     if (a->M <= 1) hipLaunchKernelGGL((rowlinear_kernel<1>), grid, block, (size_t)1 * a->K * 4, st, p);
     else if (a->M <= 2) hipLaunchKernelGGL((rowlinear_kernel<2>), grid, block, (size_t)2 * a->K * 4, st, p);
     else if (a->M <= 4) hipLaunchKernelGGL((rowlinear_kernel<4>), grid, block, (size_t)4 * a->K * 4, st, p);
