@@ -30,6 +30,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -295,6 +296,7 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
+    ap.add_argument("--extras-timeout", type=float, default=900.0, help="seconds the informational objects may take before the line is printed without them")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -413,12 +415,27 @@ def main():
         if loop_ms is not None:
             out["sampling_loop_30_steps"] = {"ms_per_loop": round(loop_ms, 2), "renders_per_s": round(B * V * 30 / (loop_ms * 1e-3), 1),
                                              "note": "per GPU; informational, not part of value"}
+    # Everything below is informational.  The line that counts is complete at this point; if an informational object fails or
+    # stalls (the training step is the only place a collective runs), the line still goes out, with the reason, and the job ends.
+    def emit_and_leave(reason):
+        if rank == 0:
+            out["extras_error"] = reason
+            out.setdefault("cpu_baseline", None)
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(a.extras_timeout, emit_and_leave, args=(f"informational objects did not finish within {a.extras_timeout:.0f} s",))
+    watchdog.daemon = True
+    watchdog.start()
     if not a.no_extras:
-        rr = raster_roofline(dev, res, V) if rank == 0 else None
-        s512 = scene_512(dev) if rank == 0 else None
-        del model, eng
-        torch.cuda.empty_cache()
-        tb = train_bench(a, dev, rank, world, a.train_steps, 2)      # every rank: the step has a collective
+        try:
+            rr = raster_roofline(dev, res, V) if rank == 0 else None
+            s512 = scene_512(dev) if rank == 0 else None
+            del model, eng
+            torch.cuda.empty_cache()
+            tb = train_bench(a, dev, rank, world, a.train_steps, 2)      # every rank: the step has a collective
+        except Exception as e:                                          # noqa: BLE001 -- whatever it was, the line goes out
+            emit_and_leave(f"{type(e).__name__}: {e}")
         if rank == 0:
             out["raster"] = rr
             out["scene_512"] = s512
@@ -434,7 +451,9 @@ def main():
             out["psnr_vs_oracle_db"] = round(psnr, 2)
         else:
             out["cpu_baseline"] = None
+        watchdog.cancel()
         print(json.dumps(out), flush=True)
+    watchdog.cancel()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -75,10 +75,11 @@ def main():
     # whole model
     from dgs_amd import denoiser as dn
     sys.path.insert(0, ROOT)
-    from bench import synth_batch, dit_flops
+    from bench import dit_flops
+    from dgs_amd import synth
     m = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24), device=DEV)
     m.reset_parameters(seed=0)
-    batch, tt = synth_batch(a.batch, 4, a.res, torch.device(DEV), 0)
+    batch, tt = synth.make_batch(a.batch, a.res, V=4, device=torch.device(DEV), seed=0, with_t=True)
     eng = m.engine()
     t = timeit(lambda: eng.image_to_gaussians(batch["image"], batch["ray_o"], batch["ray_d"], tt), iters=10)
     print(f"  image_to_gaussians (whole DiT): {t * 1e3:.3f} ms = {dit_flops(L) * a.batch / t / 1e12:.1f} TFLOP/s ({dit_flops(L) * a.batch / t / 2.5e15 * 100:.1f}% of bf16 MFMA peak)")
