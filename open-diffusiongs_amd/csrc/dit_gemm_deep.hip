@@ -23,6 +23,7 @@ struct DeepParams {
     int M, N, K, lda, ldw, ldo, gate_stride, rows_per_batch, valid_rows, tiles_n, ntiles, dbg;
     int rows_ps, full_rows, tail_rows, nfull_items;             // sliced kernel: 256-row tile rows per sample (all / ring path / one live block), full items
     int ntail, tail_mode;                                       // sliced kernel: side jobs of the single-live-block tile rows (1: MFMA items, 2: two-row GEMV items)
+    int tail_wgs;                                               // > 0: that many workgroups BEHIND the tiles do nothing but the side jobs (idle CUs)
     int nsplit, splits_per_batch;                               // sliced kernel, split-K: items = nsplit x tiles, K = k_per_batch
     long long a_batch_stride, w_batch_stride, out_split_stride;
     const bf16_t* A;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const bf16_t* const A_all = p.A;                            // the split-K modes narrow p.A / p.W / p.K to this workgroup's range
     const bf16_t* const W_all = p.W;
     const int K_all = p.K;
-    auto side_jobs = [&]() {
+    auto side_jobs = [&](const int first, const int stride) {
         if (p.tail_mode == 2) {
             // At most two live rows behind the last full tile row (the DiT's learned tokens): a 2-row GEMV on the vector pipe.  An
             // item is 8 output columns of one sample and ONE memory round trip: the NW waves split K, every wave issues all of its
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
             const bool two = kw > 512;
             float* const part = reinterpret_cast<float*>(lds + (NS - 1) * STAGE);     // [k range][row][column of the item]
             const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-            for (int j = bid; j < p.ntail; j += (int)gridDim.x) {
+            for (int j = first; j < p.ntail; j += stride) {
                 const int blk = j % nblk, trr = j / nblk;
                 const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = blk * CPI + cq * 8;
                 const bf16_t* a_row0 = A_all + (size_t)tm0 * p.lda + k_lo + lane * 8;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
             }
             return;
         }
-        for (int j = p.nsplit > 1 ? p.ntail : bid; j < p.ntail; j += (int)gridDim.x) {
+        for (int j = p.nsplit > 1 ? p.ntail : first; j < p.ntail; j += stride) {
             constexpr int CBW = BN == 256 ? 1 : 2, KQ = NW / CBW, TPC = BN / (32 * CBW);   // column blocks, K ranges per item; items per tile column
             const int sub = j % TPC, ttn = (j / TPC) % p.tiles_n, trr = j / (TPC * p.tiles_n);
             const int tm0 = ((trr / p.tail_rows) * p.rows_ps + p.full_rows + trr % p.tail_rows) * BM, tn0 = ttn * BN + sub * 32 * CBW;
@@ -270,7 +271,11 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
             __syncthreads();                                            // `red` is rewritten by the next item / the ring
         }
     };
-    if (p.nfull_items == 0) { side_jobs(); return; }           // no full tile at all (<= 32 valid rows per sample)
+    if (p.nfull_items == 0) { side_jobs(bid, (int)gridDim.x); return; }           // no full tile at all (<= 32 valid rows per sample)
+    // One-round grids that leave CUs idle (QKV at one sample: 204 tiles of 256 x 256 on 256 CUs): the side jobs go to workgroups of
+    // their own behind the tiles -- the dispatcher puts them on the idle CUs at once, and no tile waits for a GEMV (as side jobs
+    // of the first 96 tile workgroups they held the whole launch back by ~9 us: 37 -> 46)
+    if (p.tail_wgs > 0 && bid >= p.nfull_items) { side_jobs(bid - p.nfull_items, p.tail_wgs); return; }
     int tile;
     if (p.nsplit > 1) {
         // split-K (weight gradients): item = (split, tile), split-major so that an XCD's tiles share operand panels; a split is
@@ -350,13 +355,13 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     // 2-4 us when the chip is streaming GEMM tiles and nothing else can hide it: as workgroups of their own (256 full tiles on
     // 256 CUs, so they start when the first full tiles retire) these items added 36 us when a wave walked all of K for one
     // column block, and still 14 us in this one-trip form.
-    side_jobs();
+    if (p.tail_wgs == 0) side_jobs(bid, (int)gridDim.x);
 #ifndef HIPEMU
     // Slabs 0 and 1 have to be there before iteration 0 (its second half prefetches fragments of slab 1); slabs 2 .. NS-2 may stay
     // in flight -- with the 8-stage ring of the 128 x 128 tiles, waiting for all seven (112 KiB per CU, every CU at once) cost
     // ~10 k cycles of every tile.  A workgroup that ran a side job has stores in flight too, and the counted waits of the loop
     // must see DMAs only: it drains completely.
-    if (bid < p.ntail && p.nsplit == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.tail_wgs == 0 && bid < p.ntail && p.nsplit == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
     __builtin_amdgcn_s_barrier();
 #else
@@ -504,6 +509,17 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
     const int gemv_ks = NW < p.K / 512 ? NW : p.K / 512, gemv_cpi = 8 * (NW / (gemv_ks > 0 ? gemv_ks : 1));
     p.ntail = samples * p.tail_rows * (gemv_ok ? p.N / gemv_cpi : p.tiles_n * (BN == 256 ? 8 : 2));
     p.ntiles = p.nfull_items ? p.nfull_items : p.ntail;
+    p.tail_wgs = 0;
+    if (p.nsplit <= 1 && p.ntail > 0 && p.nfull_items > 0) {
+#ifdef HIPEMU
+        static const int ncu = getenv("DGS_EMU_CUS") ? atoi(getenv("DGS_EMU_CUS")) : 0;       // tests exercise the tail-only workgroups with it
+#else
+        static const int ncu = [] { int n = 0, d = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess ? n : 0; }();
+#endif
+        const int idle = ncu - p.nfull_items;                      // a tile workgroup owns its CU's LDS
+        if (idle > 0) p.tail_wgs = idle < p.ntail ? idle : p.ntail;
+        p.ntiles += p.tail_wgs;
+    }
     if (p.nsplit > 1) {
         if (p.tail_rows || samples != 1) return DGS_ERR_INVALID_ARGUMENT;
         p.ntiles = p.nfull_items * p.nsplit;

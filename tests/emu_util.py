@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.join(_HERE, "hipemu"))
 
 _backend = None
 _lib = None
+# the emulated "chip" has 6 CUs: GEMM launches with fewer than 6 full tiles put their single-live-block side jobs on workgroups of
+# their own (dit_gemm_deep.hip, tail_wgs), launches with 6 or more keep them inside the first tile workgroups -- both get tested
+os.environ.setdefault("DGS_EMU_CUS", "6")
 
 
 def emu_lib():

@@ -352,6 +352,30 @@ def test_gemm_sliced(ops, N):
 
 
 
+@pytest.mark.parametrize("N,K", [(256, 1024), (1536, 1024), (512, 2048)])
+def test_gemm_sliced_learned_token_rows(ops, N, K):
+    """A full tile row plus two live rows behind it (L = 256 + 2): the two rows are GEMV side jobs -- on workgroups of their own
+    when the launch leaves CUs idle (1 or 2 tiles on the emulator's 6 CUs), inside the first tile workgroups otherwise (6 tiles)."""
+    g = torch.Generator().manual_seed(N + K)
+    M, L = 1024, 258
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    for algo in (_native.GEMM_SLICED, _native.GEMM_QUAD):
+        out = torch.full((M, N), 7.0)
+        ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=512, valid_rows=L, algo=algo)
+        for b in range(2):
+            assert torch.allclose(out[b * 512:b * 512 + L], ref[b * 512:b * 512 + L], atol=4e-3, rtol=1e-4), (algo, b)
+    x0 = torch.randn(M, N, generator=g)
+    gate = torch.randn(2, N, generator=g)
+    x = x0.clone()
+    ops.gemm(A, W, bias, _native.EPI_GATE_RESIDUAL, out=x, gate=gate, rows_per_batch=512, valid_rows=L, algo=_native.GEMM_SLICED)
+    want = x0 + gate.repeat_interleave(512, 0) * ref
+    for b in range(2):
+        assert torch.allclose(x[b * 512:b * 512 + L], want[b * 512:b * 512 + L], atol=6e-3, rtol=1e-4)
+
+
 def test_gemm_128_wide_gemv_tail_rows(ops):
     """The 128-wide kernel with one or two live rows behind a sample's last full tile (the DiT's learned tokens): those rows are
     GEMV items of the first workgroups, not a tile row.  Every epilogue the N = 1024 GEMMs use, two samples, K = 512 and a K
