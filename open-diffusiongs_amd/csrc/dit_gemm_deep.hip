@@ -337,8 +337,14 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         if constexpr (q == G - 1) { sb_a += 2 * BK; sb_w += 2 * BK; }
     };
     auto stage_next = [&](auto slotc) { sliced_for<0, G>([&](auto qc) { dma_piece(slotc, qc); }); };
-    // ---- prologue: slabs 0 .. NS-2 in flight, then the fragments of slab 0, substep 0 ----
-    sliced_for<0, NS - 1>([&](auto sc) { stage_next(sc); });
+    // ---- prologue: slabs 0 .. NS-2 in flight, then the fragments of slab 0, substep 0.  A workgroup with a side job issues only
+    //      slabs 0 and 1 first: vector memory returns in order, and behind all NS-1 slabs (112 KiB with the 8-stage ring) the side
+    //      job's one round trip became ~10 k cycles; the other slabs go out when the side job is done ----
+    //      (8-stage ring only: fc2 +2.4 -> +1.0 us for the two learned-token rows; with the 4-stage ring there is one slab to hold
+    //      back, and holding it back costs more than it saves: fc1 +4.1 -> +5.4)
+    const bool has_side_job = NS > 4 && p.tail_wgs == 0 && bid < p.ntail && p.nsplit == 1;
+    sliced_for<0, 2>([&](auto sc) { stage_next(sc); });
+    if (!has_side_job) sliced_for<2, NS - 1>([&](auto sc) { stage_next(sc); });
 #else
     auto stage = [&](int t, int slot) {
         stage_slab<BM, BK, NW>(p.A, p.lda, m0, t * BK, lds + slot * STAGE, wave, lane);
@@ -357,12 +363,12 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     // column block, and still 14 us in this one-trip form.
     if (p.tail_wgs == 0) side_jobs(bid, (int)gridDim.x);
 #ifndef HIPEMU
+    if (has_side_job) sliced_for<2, NS - 1>([&](auto sc) { stage_next(sc); });
     // Slabs 0 and 1 have to be there before iteration 0 (its second half prefetches fragments of slab 1); slabs 2 .. NS-2 may stay
     // in flight -- with the 8-stage ring of the 128 x 128 tiles, waiting for all seven (112 KiB per CU, every CU at once) cost
-    // ~10 k cycles of every tile.  A workgroup that ran a side job has stores in flight too, and the counted waits of the loop
-    // must see DMAs only: it drains completely.
-    if (p.tail_wgs == 0 && bid < p.ntail && p.nsplit == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
+    // ~10 k cycles of every tile.  Stores a side job left in flight are older than those slabs: "at most (NS-3) G operations
+    // outstanding" then still means slabs 0 and 1 have landed (loads return in order; a lingering store only makes the wait longer).
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
     __builtin_amdgcn_s_barrier();
 #else
     __syncthreads();

@@ -623,8 +623,8 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
 // instances first (emit) and sorting every tile's list moves each instance three times.  Here a tile filters the
 // depth-ORDERED Gaussians directly: rank_rects_kernel leaves each Gaussian's tile rectangle, packed in 32 bits, at its depth
 // rank; the blend kernel (scan_more below) walks the ranks 64 at a time -- test, ballot, popcount -- and takes the hits in
-// order: the list the sort produces, with no atomics and no instance list.  At most T x P tests per view, so the host picks
-// this form only where that product is small (256^2: 67 M).
+// order: the list the sort produces, with no atomics and no instance list.  At most T x P tests per view (a tile that never
+// saturates tests every rank), so the host rules the form out beyond T x P = 2^31 (512^2: 2^30).
 __global__ __launch_bounds__(256) void rank_rects_kernel(FwdParams p) {
     if (p.im.totals[1] != 0 || !binning_is_scan(p)) return;
     const int v = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
@@ -983,7 +983,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
 
     // binning form (binning_form_of): the host only rules forms out; the choice itself is made from the instance statistics --
     // on the host in the sync mode (it has just read them back), on the device in the async mode
-    const bool can_scan = p.gx <= 255 && p.gy <= 255 && (long long)p.T * P <= (1ll << 27);
+    const bool can_scan = p.gx <= 255 && p.gy <= 255 && (long long)p.T * P <= (1ll << 31);   // the scan is on demand: T x P is its worst case, not its cost
     p.bin_mode = a->binning_form;
     if (p.bin_mode < 0 || p.bin_mode > 3 || (p.bin_mode == 0 && !can_scan) || (p.bin_mode == kFormScan && !can_scan)) p.bin_mode = can_scan ? 0 : kFormBitonic;
     constexpr int kBitonicMax = 16384;                             // 128 KiB of LDS
