@@ -26,3 +26,4 @@ python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 tail -c 600 $out/${tag}_pytest_gpu.txt; cat $out/${tag}_smoke.txt | tail -2; cut -c1-300 $out/${tag}_bench.json
 (cd tools/ubench && ./place_bench 1024 400000 | tail -16) > $out/${tag}_placement_microbench.txt 2>&1
 (cd tools/ubench && ./dma_piece_bench) > $out/${tag}_dma_piece_microbench.txt 2>&1
+python tools/gemm_tail_cost.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_gemm_learned_token_rows.txt
