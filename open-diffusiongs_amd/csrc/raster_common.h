@@ -34,33 +34,15 @@ __device__ __forceinline__ M3 m3_t(const M3& A) {
 }
 
 
-// Which of a tile's four 16 x 4 pixel strips (rows 4g .. 4g+3 of the tile at pixel (tx0, ty0)) can a Gaussian touch at all?
+// Which of a tile's sixteen 4 x 4 pixel cells can a Gaussian touch at all?
 // A (pixel, Gaussian) pair contributes only if cut <= power <= 0 with power = -0.5 (A dx^2 + C dy^2) - B dx dy, i.e. inside
 // the ellipse A dx^2 + 2 B dx dy + C dy^2 <= -2 cut, whose bounding box has half extents sqrt(q C / det), sqrt(q A / det).
 // The box is inflated (1 % of q, 0.1 % + 0.01 px of the extents) against the rounding of the fp32 `power`; conics that are
-// not comfortably positive definite (condition number above 1e4, non-finite values) get all four bits.  CONSERVATIVE by
-// construction: a strip without its bit holds no pixel that passes the exact per-pixel test, so skipping it changes no
+// not comfortably positive definite (condition number above 1e4, non-finite values) get all sixteen bits.  CONSERVATIVE by
+// construction: a cell without its bit holds no pixel that passes the exact per-pixel test, so skipping it changes no
 // result bit.  (The per-tile LIST still is the reference's -- radius = ceil(3 sigma_max) rectangles; a small Gaussian is in
 // the lists of tiles its ellipse never reaches.)
-__device__ __forceinline__ unsigned strip_mask(float2 xy, float4 co, float cut, float tx0, float ty0) {
-    const float A = co.x, B = co.y, C = co.z;
-    if (cut > 0.0f) return 0u;                                   // alpha < 1/255 everywhere
-    const float det = A * C - B * B, tr = A + C;
-    const float q = -2.0f * cut * 1.01f + 0.01f;
-    if (!(det > 0.0f) || !(A > 0.0f) || !(C > 0.0f) || !(tr * tr < 1.0e4f * det) || !(q < 1.0e30f)) return 0xFu;   // NaN-safe
-    const float hx = sqrtf(q * C / det) * 1.001f + 0.01f, hy = sqrtf(q * A / det) * 1.001f + 0.01f;
-    if (!(hx < 1.0e30f) || !(hy < 1.0e30f) || !(xy.x == xy.x) || !(xy.y == xy.y)) return 0xFu;
-    if (xy.x + hx < tx0 || xy.x - hx > tx0 + 15.0f) return 0u;
-    unsigned m = 0u;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float ys = ty0 + 4.0f * (float)g;
-        if (!(xy.y + hy < ys) && !(xy.y - hy > ys + 3.0f)) m |= 1u << g;
-    }
-    return m;
-}
-
-// The same box against the tile's sixteen 4 x 4 CELLS: bit 4 g + c = cell column c (pixels 4c..4c+3) of strip g.
+// Bit 4 g + c = cell column c (pixels 4c .. 4c+3) of strip g (rows 4g .. 4g+3) of the tile at (tx0, ty0).
 __device__ __forceinline__ unsigned cell_mask(float2 xy, float4 co, float cut, float tx0, float ty0) {
     const float A = co.x, B = co.y, C = co.z;
     if (cut > 0.0f) return 0u;
@@ -83,27 +65,10 @@ __device__ __forceinline__ unsigned cell_mask(float2 xy, float4 co, float cut, f
     return m;
 }
 
-// Sum over the 64 lanes of a wave; the total is valid in lane 63 only.  Six v_add_f32_dpp (row shifts inside the 16-lane
-// rows, then row broadcasts) instead of six ds_bpermute round trips.
-#ifdef HIPEMU
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-#else
+#ifndef HIPEMU
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v += dpp_mov<0x111>(v);   // row_shr:1
-    v += dpp_mov<0x112>(v);   // row_shr:2
-    v += dpp_mov<0x114>(v);   // row_shr:4
-    v += dpp_mov<0x118>(v);   // row_shr:8    -> lane 15 of every 16-lane row holds the row sum
-    v += dpp_mov<0x142>(v);   // row_bcast:15 -> lanes 31 / 63 hold the sum of their row pair
-    v += dpp_mov<0x143>(v);   // row_bcast:31 -> lane 63 holds the wave sum
-    return v;
 }
 #endif
 

@@ -76,6 +76,39 @@ def test_gemm_production_shapes(M, N, K):
         assert rel_l2(vt.float()[0], ref[:, 2 * Wd:].t()) < 4e-3
 
 
+@pytest.mark.parametrize("name,N,K,epi", [("qkv", 3072, 1024, "QKV"), ("proj", 1024, 1024, "GATE_RESIDUAL"),
+                                          ("fc1", 4096, 1024, "GELU_BF16"), ("fc2", 1024, 4096, "GATE_RESIDUAL")])
+def test_block_gemms_at_the_shipped_shape_incl_learned_token_rows(name, N, K, epi):
+    """One sample at 256^2: 4,352 padded rows, 4,098 valid -- 32 full 128-row tiles plus the two learned-token rows, which every
+    kernel family treats specially (GEMV items behind the tile grid / side jobs of the first workgroups / workgroups of their own on
+    idle CUs).  Checked on the full tiles AND on those two rows separately: two wrong rows of 4,098 would hide in a tensor-wide norm."""
+    M, L = 4352, 4098
+    g = torch.Generator(device=DEV).manual_seed(len(name) + N + K)
+    A = _bf(torch.randn(M, K, generator=g, device=DEV))
+    W = _bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+    bias = torch.randn(N, generator=g, device=DEV)
+    ref = A.float() @ W.float().t() + bias
+    ops = _ops()
+    e = getattr(_native, "EPI_" + epi)
+    for algo in (_native.GEMM_AUTO, _native.GEMM_SIMPLE128, _native.GEMM_SLICED, _native.GEMM_SLICED128):
+        kw = dict(rows_per_batch=M, valid_rows=L, algo=algo)
+        if epi == "GATE_RESIDUAL":
+            x0 = torch.randn(M, N, generator=g, device=DEV)
+            gate = torch.randn(1, N, generator=g, device=DEV)
+            x = x0.clone()
+            ops.gemm(A, W, bias, e, out=x, gate=gate, **kw)
+            got, want, tol = x, x0 + gate * ref, 1e-5
+        elif epi == "GELU_BF16":
+            got, want, tol = ops.gemm(A, W, bias, e, **kw).float(), F.gelu(ref, approximate="tanh"), 4e-3
+        else:
+            qk, vt = ops.gemm(A, W, bias, e, **kw)
+            Wd = N // 3
+            got = torch.cat([qk.float()[:, :2 * Wd], vt.float()[0].t()], dim=1)
+            want, tol = ref, 4e-3
+        assert rel_l2(got[:L - 2], want[:L - 2]) < tol, (name, algo, "full tiles")
+        assert rel_l2(got[L - 2:L], want[L - 2:L]) < tol, (name, algo, "learned-token rows")
+
+
 @pytest.mark.parametrize("algo", [0, _native.GEMM_SLICED, _native.GEMM_QUAD])
 def test_gemm_training_epilogues_production_shapes(algo):
     """fc1 forward (GELU + saved pre-activation + transposed copy) and the fc2 input gradient (dGELU + transposed copy) at the
