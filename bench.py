@@ -33,6 +33,10 @@ import sys
 import threading
 import time
 
+# dmabuf IPC is the only mode this pool's host driver supports: without it RCCL's cross-process buffer exchange fails with
+# `hipIpcGetMemHandle: invalid argument`.  Set before the HIP runtime loads, whoever launched this process.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "open-diffusiongs_amd")):
     if _p not in sys.path:
@@ -296,7 +300,7 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
-    ap.add_argument("--extras-timeout", type=float, default=900.0, help="seconds the informational objects may take before the line is printed without them")
+    ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the informational objects may take before the line is printed without them")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -427,6 +431,7 @@ def main():
     watchdog = threading.Timer(a.extras_timeout, emit_and_leave, args=(f"informational objects did not finish within {a.extras_timeout:.0f} s",))
     watchdog.daemon = True
     watchdog.start()
+    x0 = time.perf_counter()
     if not a.no_extras:
         try:
             rr = raster_roofline(dev, res, V) if rank == 0 else None
@@ -440,6 +445,7 @@ def main():
             out["raster"] = rr
             out["scene_512"] = s512
             out["train_step"] = tb
+            out["extras_s"] = round(time.perf_counter() - x0, 1)       # wall time of the informational objects above
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not a.no_extras:
             model = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="relative_plk"), device=dev)
