@@ -399,3 +399,7 @@ class DGSDenoiser(nn.Module):
 @register("diffusion-gs-model-scene")
 class DGSDenoiserScene(DGSDenoiser):
     SCENE = True
+
+    @dataclass
+    class Config(DGSDenoiser.Config):   # denoiser_scene.py:179-204: the same fields; the depth-range triple is declared only here
+        range_setting_type: str = "linear_depth"   # never read by the reference: range_func is sigmoid(t) * (far - near) + near (:263)
