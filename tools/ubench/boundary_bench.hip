@@ -4,7 +4,8 @@
 //     gap    = first start of launch i+1 - last end of launch i      (no workgroup of either launch is running)
 //     ramp   = last start - first start of launch i+1                (the dispatcher filling the chip)
 //     spread = last end - first end of launch i                      (the tail, here only what the ramp leaves behind)
-// and, from HIP events around the whole sequence, the time per launch beyond the spin itself.  Grids / workgroup shapes are
+// and, from HIP events around the whole sequence, the time per launch beyond the spin itself; last, the same sequence captured
+// into one hipGraph.  Grids / workgroup shapes are
 // those of the DiT step's kernels: 256 x 512 threads (attention, one round), 1088 x 256 (LayerNorm), 512 x 256 (128-wide GEMM).
 //   hipcc --offload-arch=gfx950 -O2 -o boundary_bench boundary_bench.hip && ./boundary_bench
 #include <hip/hip_runtime.h>
@@ -26,17 +27,28 @@ __global__ void spin_kernel(unsigned long long* stamps, long long spin_ticks, in
     }
 }
 
-static void run(int G, int threads, int lds_bytes, double spin_us, int N) {
+static void run(int G, int threads, int lds_bytes, double spin_us, int N, bool graph = false) {
     unsigned long long* d;
     hipMalloc(&d, (size_t)N * G * 16);
     const long long ticks = (long long)(spin_us * 100.0);      // 100 MHz
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
+    hipStream_t st;
+    hipStreamCreate(&st);
+    hipGraphExec_t exec = nullptr;
+    if (graph) {                                               // the same N launches captured once, replayed as one hipGraph
+        hipGraph_t g;
+        hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+        for (int i = 0; i < N; ++i) hipLaunchKernelGGL(spin_kernel, dim3(G), dim3(threads), lds_bytes, st, d, ticks, i, lds_bytes / 4);
+        hipStreamEndCapture(st, &g);
+        hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    }
     for (int rep = 0; rep < 2; ++rep) {                        // the second pass is the measured one
-        hipEventRecord(e0, 0);
-        for (int i = 0; i < N; ++i) hipLaunchKernelGGL(spin_kernel, dim3(G), dim3(threads), lds_bytes, 0, d, ticks, i, lds_bytes / 4);
-        hipEventRecord(e1, 0);
+        hipEventRecord(e0, st);
+        if (graph) hipGraphLaunch(exec, st);
+        else for (int i = 0; i < N; ++i) hipLaunchKernelGGL(spin_kernel, dim3(G), dim3(threads), lds_bytes, st, d, ticks, i, lds_bytes / 4);
+        hipEventRecord(e1, st);
         hipDeviceSynchronize();
     }
     float ms = 0;
@@ -63,9 +75,9 @@ static void run(int G, int threads, int lds_bytes, double spin_us, int N) {
         }
     }
     std::sort(gaps.begin(), gaps.end());
-    printf("grid %4d x %3d thr, LDS %6d B, spin %6.1f us: per launch %7.2f us (events) = spin + %5.2f | first start -> last end %7.2f, "
+    printf("%s grid %4d x %3d thr, LDS %6d B, spin %6.1f us: per launch %7.2f us (events) = spin + %5.2f | first start -> last end %7.2f, "
            "ramp %5.2f, end spread %5.2f, gap to next launch mean %5.2f median %5.2f us\n",
-           G, threads, lds_bytes, spin_us, ms * 1e3 / N, ms * 1e3 / N - spin_us, busy / N, ramp / N, spread / N, gap / (N - 1),
+           graph ? "graph " : "stream", G, threads, lds_bytes, spin_us, ms * 1e3 / N, ms * 1e3 / N - spin_us, busy / N, ramp / N, spread / N, gap / (N - 1),
            gaps[gaps.size() / 2]);
     hipFree(d);
 }
@@ -76,6 +88,10 @@ int main() {
         run(256, 512, 65536, us, N);       // attention: one workgroup per CU
         run(512, 256, 49152, us, N);       // 128-wide GEMM: two per CU
         run(1088, 256, 0, us, N);          // LayerNorm: four rows per workgroup
+    }
+    for (double us : {5.0, 20.0}) {        // the same sequences as ONE hipGraph launch
+        run(256, 512, 65536, us, N, true);
+        run(1088, 256, 0, us, N, true);
     }
     return 0;
 }
