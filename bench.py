@@ -64,23 +64,35 @@ def kernel_flops(kind, L, B, width=1024):
     return 2.0 * L * n * B
 
 
-def kernel_source_sha():
-    """Identity of the kernels a PMC measurement belongs to: SHA-256 over every csrc/ source and header."""
+# A PMC measurement belongs to the sources of the kernels it counted: the whole csrc/ tree, or -- when only another family's
+# files changed since -- the family's own files (the attention kernel does not compile from raster_*.hip, nor the reverse).
+FAMILIES = {
+    "dit": lambda f: f.startswith("dit_") or f in ("dgs_device.h", "raster_state.h"),
+    "raster": lambda f: f.startswith("raster_") or f in ("camera.hip", "dgs_device.h"),
+}
+
+
+def kernel_source_sha(family=None, read=None, names=None):
+    """SHA-256 over the csrc/ sources and headers (of one family, or all).  `read` / `names` let tools/pmc_traffic.py hash the
+    files of a git revision instead of the working tree."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "open-diffusiongs_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+    read = read or (lambda f: open(os.path.join(d, f), "rb").read())
+    for f in sorted(names if names is not None else os.listdir(d)):
+        if f.endswith((".hip", ".h")) and (family is None or FAMILIES[family](f)):
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(read(f))
     return h.hexdigest()
 
 
-def pmc_traffic():
+def pmc_traffic(family):
     """profiles/pmc_traffic.json (tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this
-    very script, FETCH doubled per MI355X_MICROARCH.md).  Only returned when it was measured on the current kernel sources."""
+    very script, FETCH doubled per MI355X_MICROARCH.md).  Only returned when it was measured on the current sources of `family`."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return d if d.get("kernel_source_sha") == kernel_source_sha() else None
+        if d.get("kernel_source_sha") == kernel_source_sha() or d.get("family_sha", {}).get(family) == kernel_source_sha(family):
+            return d
+        return None
     except Exception:
         return None
 
@@ -156,7 +168,7 @@ def raster_roofline(dev, res, V, iters=10):
     be = default_backend()
     out = {"bound": "hbm", "peak": PEAK_HBM / 1e9, "unit": "GB/s", "views": V, "resolution": res}
     tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
-    traffic = pmc_traffic()
+    traffic = pmc_traffic("raster")
     for regime in ("init", "trained"):
         sc = synth.gaussian_scene(res, regime=regime, seed=0, activated=False)
         leaves = [tt(sc[k])[None].requires_grad_(True) for k in ("xyz", "shs", "scales", "rotations", "opacities")]
@@ -403,7 +415,7 @@ def main():
         kern_ms = [events[i][2 * j].elapsed_time(events[i][2 * j + 1]) for i in prof_steps for j in range(per_step)]
         avg_s = float(np.mean(kern_ms)) * 1e-3
         achieved = kernel_flops(a.roofline_kernel, L, B) / avg_s / 1e12
-        traffic = pmc_traffic()
+        traffic = pmc_traffic("dit")
         tr_bytes = None
         if traffic and B == 1 and res == 256 and V == 4:
             tr_bytes = traffic.get("dit", {}).get(a.roofline_kernel, {}).get("traffic_bytes_per_launch")

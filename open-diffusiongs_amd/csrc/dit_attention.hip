@@ -374,14 +374,25 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     // One iteration = one 64-key tile t.  MODE 0: steady state, 1: S(t+1) is the last tile (ragged: masked), 2: last tile
     // (no S(t+1)).  Straight-line copies instead of in-loop branches.  `cs*` hold P(t) (in: S'(t) - m), `ns*` receive
     // S'(t+1) - m: the caller alternates two register sets, so nothing is copied between iterations.
-    auto iteration = [&](int t, const int slot, auto mode_tag, f32x16& cs0, f32x16& cs1, f32x16& ns0, f32x16& ns1) {
+    // `fast_tag` = 1: the caller guarantees t + RING < ntiles and p.dbg == 0 -- both DMAs go out unconditionally, the wait is the
+    // literal vmcnt(2) and the barrier is unconditional; `live_tag` = 0 / 1 then replaces the run-time test of `wave_live` (2: test
+    // it).  The steady-state loop below runs on these copies: tools/ubench/issue_bench prices ONE scalar compare + branch in the
+    // MFMA + VALU stream at 16 (untaken) / 27 (taken) cycles of the wave and an s_add at 2.75, and the generic form spends ~10
+    // branches and ~30 other SALU per tile on conditions that never change inside the loop.
+    auto iteration = [&](int t, const int slot, auto mode_tag, f32x16& cs0, f32x16& cs1, f32x16& ns0, f32x16& ns1, auto fast_tag, auto live_tag) {
         constexpr int MODE = decltype(mode_tag)::value;     // slot == t % RING; a literal at the steady-state call sites
+        constexpr bool FAST = decltype(fast_tag)::value != 0;
+        constexpr int LIVE = decltype(live_tag)::value;
+        static_assert(!FAST || MODE == 0, "the fast form is the steady state");
         int issued = 0;
-        if (MODE == 0 && !(p.dbg & 1)) {
+        if constexpr (FAST) {
+            stage_k(t + RING, slot);
+            stage_v(t + RING - 1, (slot + RING - 1) & (RING - 1));
+        } else if (MODE == 0 && !(p.dbg & 1)) {
             if (t + RING < ntiles) { stage_k(t + RING, slot); ++issued; }
             if (t + RING - 1 < ntiles) { stage_v(t + RING - 1, (slot + RING - 1) & (RING - 1)); ++issued; }
         }
-        if (wave_live) {
+        if (LIVE == 1 || (LIVE == 2 && wave_live)) {
             bf16x8 vf[8];
             PFrag pf[4];
             float mx = 0.0f;
@@ -446,9 +457,14 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
             // everything issued BEFORE this iteration (K(t+3), V^T(t+2) and older) has landed once at most this
             // iteration's own DMAs are outstanding; then everybody is also done reading K(t+2)'s and V^T(t)'s slots
 #ifndef HIPEMU
-            if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+            if constexpr (FAST) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+            }
 #else
             (void)issued;
             __syncthreads();
@@ -463,26 +479,48 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
 #ifndef HIPEMU
     const long long dbg_t0 = (p.dbg & 4) ? clock64() : 0;
 #endif
-    // steady state, unrolled by the ring depth: ring slots are literals, every LDS address is register + immediate
+    // steady state, unrolled by the ring depth: ring slots are literals, every LDS address is register + immediate.  While all
+    // four iterations of a round still issue both of their DMAs (t + 3 + RING < ntiles) and no debug switch is set, the round runs
+    // on the branch-free copies -- one loop for the waves with queries, one for the waves that only stage and synchronise.
+    constexpr IC<0> GEN{};
+    constexpr IC<1> YES{};
+    constexpr IC<2> ASK{};
+    if (p.dbg == 0) {
+        if (wave_live) {
+            for (; t + 3 + RING < ntiles; t += 4) {
+                iteration(t, 0, Mode<0>{}, s0, s1, u0, u1, YES, YES);
+                iteration(t + 1, 1, Mode<0>{}, u0, u1, s0, s1, YES, YES);
+                iteration(t + 2, 2, Mode<0>{}, s0, s1, u0, u1, YES, YES);
+                iteration(t + 3, 3, Mode<0>{}, u0, u1, s0, s1, YES, YES);
+            }
+        } else {
+            for (; t + 3 + RING < ntiles; t += 4) {
+                iteration(t, 0, Mode<0>{}, s0, s1, u0, u1, YES, GEN);
+                iteration(t + 1, 1, Mode<0>{}, u0, u1, s0, s1, YES, GEN);
+                iteration(t + 2, 2, Mode<0>{}, s0, s1, u0, u1, YES, GEN);
+                iteration(t + 3, 3, Mode<0>{}, u0, u1, s0, s1, YES, GEN);
+            }
+        }
+    }
     for (; t + 3 < steady_end; t += 4) {
-        iteration(t, 0, Mode<0>{}, s0, s1, u0, u1);
-        iteration(t + 1, 1, Mode<0>{}, u0, u1, s0, s1);
-        iteration(t + 2, 2, Mode<0>{}, s0, s1, u0, u1);
-        iteration(t + 3, 3, Mode<0>{}, u0, u1, s0, s1);
+        iteration(t, 0, Mode<0>{}, s0, s1, u0, u1, GEN, ASK);
+        iteration(t + 1, 1, Mode<0>{}, u0, u1, s0, s1, GEN, ASK);
+        iteration(t + 2, 2, Mode<0>{}, s0, s1, u0, u1, GEN, ASK);
+        iteration(t + 3, 3, Mode<0>{}, u0, u1, s0, s1, GEN, ASK);
     }
     if (t + 1 < steady_end) {
-        iteration(t, t & 3, Mode<0>{}, s0, s1, u0, u1);
-        iteration(t + 1, (t + 1) & 3, Mode<0>{}, u0, u1, s0, s1);
+        iteration(t, t & 3, Mode<0>{}, s0, s1, u0, u1, GEN, ASK);
+        iteration(t + 1, (t + 1) & 3, Mode<0>{}, u0, u1, s0, s1, GEN, ASK);
         t += 2;
     }
     const int tl = ntiles - 1;
     if (t < steady_end) {                                       // odd count: the current scores end up in u
-        iteration(t, t & 3, Mode<0>{}, s0, s1, u0, u1);
-        if (ragged) { iteration(tl - 1, (tl - 1) & 3, Mode<1>{}, u0, u1, s0, s1); iteration(tl, tl & 3, Mode<2>{}, s0, s1, u0, u1); }
-        else iteration(tl, tl & 3, Mode<2>{}, u0, u1, s0, s1);
+        iteration(t, t & 3, Mode<0>{}, s0, s1, u0, u1, GEN, ASK);
+        if (ragged) { iteration(tl - 1, (tl - 1) & 3, Mode<1>{}, u0, u1, s0, s1, GEN, ASK); iteration(tl, tl & 3, Mode<2>{}, s0, s1, u0, u1, GEN, ASK); }
+        else iteration(tl, tl & 3, Mode<2>{}, u0, u1, s0, s1, GEN, ASK);
     } else {
-        if (ragged) { iteration(tl - 1, (tl - 1) & 3, Mode<1>{}, s0, s1, u0, u1); iteration(tl, tl & 3, Mode<2>{}, u0, u1, s0, s1); }
-        else iteration(tl, tl & 3, Mode<2>{}, s0, s1, u0, u1);
+        if (ragged) { iteration(tl - 1, (tl - 1) & 3, Mode<1>{}, s0, s1, u0, u1, GEN, ASK); iteration(tl, tl & 3, Mode<2>{}, u0, u1, s0, s1, GEN, ASK); }
+        else iteration(tl, tl & 3, Mode<2>{}, s0, s1, u0, u1, GEN, ASK);
     }
 
 #ifndef HIPEMU

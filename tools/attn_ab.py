@@ -1,0 +1,58 @@
+"""A/B of two builds of the library on the attention kernel: bit-compare of the outputs (the two builds are expected to execute
+the same arithmetic) at the production and the tail-shaped lengths, then alternating timed launches (HIP events).
+    python tools/attn_ab.py <base.so> [<new.so>]        (new defaults to the product library)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "open-diffusiongs_amd"))
+import torch
+
+from dgs_amd import _native
+from dgs_amd.dit import DitOps
+
+DEV = "cuda:0"
+base = DitOps(_native.open_library(os.path.abspath(sys.argv[1])))
+new = DitOps(_native.open_library(os.path.abspath(sys.argv[2])) if len(sys.argv) > 2 else None)
+heads, W = 16, 1024
+g = torch.Generator(device=DEV).manual_seed(0)
+bf = lambda *s: torch.randn(*s, generator=g, device=DEV).to(torch.bfloat16)
+
+
+def case(L, B):
+    lpad = (L + 255) // 256 * 256
+    qk, vt = bf(B * lpad, 2 * W), bf(B, W, lpad)
+    qk[3, :64] *= 6.0              # a spiky query row and key row: the rescale branch
+    qk[70 % L, W:W + 64] *= 6.0
+    return qk, vt, lpad
+
+
+for L, B in ((4098, 1), (4130, 1), (290, 2), (18, 2), (1026, 1), (600, 1), (16386, 1)):
+    qk, vt, lpad = case(L, B)
+    la, lb = torch.zeros(B, heads, lpad, device=DEV), torch.zeros(B, heads, lpad, device=DEV)
+    for ops in (base, new):
+        ops.poison_lds()
+    a = base.attention(qk, vt, L, heads, lse2=la, q_prescaled=True)
+    b = new.attention(qk, vt, L, heads, lse2=lb, q_prescaled=True)
+    torch.cuda.synchronize()
+    va, vb = a.view(B, lpad, W)[:, :L], b.view(B, lpad, W)[:, :L]
+    same = torch.equal(va.view(torch.int16), vb.view(torch.int16)) and torch.equal(la[:, :, :L], lb[:, :, :L])
+    print(f"L={L} B={B}: outputs bit-identical: {same}; finite: {bool(torch.isfinite(vb.float()).all())}; "
+          f"max |diff| {float((va.float() - vb.float()).abs().max()):.3g}", flush=True)
+
+for L, B, n in ((4098, 1, 60), (4098, 4, 20), (16386, 1, 8)):
+    qk, vt, lpad = case(L, B)
+    ev = {k: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)] for k in ("base", "new")}
+    for _ in range(5):
+        base.attention(qk, vt, L, heads, q_prescaled=True); new.attention(qk, vt, L, heads, q_prescaled=True)
+    for i in range(n):
+        for k, ops in (("base", base), ("new", new)):
+            e0, e1 = ev[k][i]
+            e0.record(); ops.attention(qk, vt, L, heads, q_prescaled=True); e1.record()
+    torch.cuda.synchronize()
+    t = {k: sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in v) for k, v in ev.items()}
+    med = {k: v[len(v) // 2] for k, v in t.items()}
+    flops = 4.0 * L * L * W * B
+    print(f"timing L={L} B={B}: base {med['base']:.1f} us ({flops / med['base'] / 1e6:.0f} TFLOP/s)  new {med['new']:.1f} us "
+          f"({flops / med['new'] / 1e6:.0f} TFLOP/s)  ratio {med['new'] / med['base']:.3f}  (median of {n}, incl. the output memset)", flush=True)

@@ -58,13 +58,14 @@ def collect(counter, out_dir, cmd):
 
 
 def main():
-    from bench import kernel_source_sha
+    from bench import FAMILIES, kernel_source_sha
     raw = os.path.join(ROOT, "gpurun_out", "pmc")
     os.makedirs(raw, exist_ok=True)
     head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
     out = {"_source": "tools/pmc_traffic.py: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes; FETCH_SIZE x 2 "
                       "(MI355X_MICROARCH.md, HBM); KiB -> bytes; averages per dispatch (dit) / per call of 4 views at 256^2 (raster)",
-           "kernel_source_sha": kernel_source_sha(), "git_head": head or None, "dit": {}, "raster": {}, "kernels": {}}
+           "kernel_source_sha": kernel_source_sha(), "family_sha": {f: kernel_source_sha(f) for f in FAMILIES},
+           "git_head": head or None, "dit": {}, "raster": {}, "kernels": {}}
     py = sys.executable
     bench = [py, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras"]
     f = collect("FETCH_SIZE", os.path.join(raw, "dit_fetch"), bench)
@@ -96,8 +97,27 @@ def main():
     print("wrote", path, "-> copy to profiles/pmc_traffic.json")
 
 
+def annotate(path):
+    """Adds `family_sha` to a JSON written before the per-family hashes existed: computed from the csrc/ files of the JSON's own
+    `git_head` (git show), after checking that the whole-tree hash of that revision IS the JSON's `kernel_source_sha`."""
+    from bench import FAMILIES, kernel_source_sha
+    d = json.load(open(path))
+    rev = d["git_head"]
+    ls = subprocess.run(["git", "ls-tree", "--name-only", f"{rev}:open-diffusiongs_amd/csrc"], capture_output=True, text=True, cwd=ROOT, check=True)
+    names = ls.stdout.split()
+    read = lambda f: subprocess.run(["git", "show", f"{rev}:open-diffusiongs_amd/csrc/{f}"], capture_output=True, cwd=ROOT, check=True).stdout
+    assert kernel_source_sha(read=read, names=names) == d["kernel_source_sha"], "the JSON was not measured on the sources of its git_head"
+    d["family_sha"] = {f: kernel_source_sha(f, read=read, names=names) for f in FAMILIES}
+    d["_family_sha_note"] = (f"family_sha added after the measurement by `tools/pmc_traffic.py --annotate`: hashes of the csrc/ files of git_head {rev} "
+                             "per kernel family (bench.FAMILIES); the whole-tree hash of that revision was checked against kernel_source_sha; no measured value was touched")
+    json.dump(d, open(path, "w"), indent=1)
+    print(json.dumps(d["family_sha"], indent=1))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--target":
+    if len(sys.argv) > 2 and sys.argv[1] == "--annotate":
+        annotate(sys.argv[2])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--target":
         target(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     else:
         main()
