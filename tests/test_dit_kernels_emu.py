@@ -438,3 +438,45 @@ def test_gemm_sliced_128_tiles(ops):
     o = ops.gemm(A, W, bias, _native.EPI_BF16, rows_per_batch=256, valid_rows=130, vt=vt, algo=sl)
     assert torch.allclose(o.float()[live], ref[live], atol=3e-2, rtol=1e-2)
     assert torch.equal(vt[:, :, :130], o.reshape(2, 256, N).transpose(1, 2)[:, :, :130])
+
+
+_GENERIC_ATTENTION = r"""
+import sys, torch
+sys.path[:0] = [{root!r}, {pkg!r}, {tests!r}]
+from dgs_amd.dit import DitOps
+from emu_util import emu_lib
+L, B, heads, out = int(sys.argv[1]), 2, 2, sys.argv[2]
+d = torch.load(out + ".in")
+lse2 = torch.zeros(B, heads, d["vt"].shape[2])
+o = DitOps(lib=emu_lib()).attention(d["qk"], d["vt"], L, heads, lse2=lse2, q_prescaled=True)
+torch.save(dict(o=o, lse2=lse2), out)
+"""
+
+
+@pytest.mark.parametrize("L", [520, 600, 1026])
+def test_attention_steady_state_copies_equal_the_generic_loop(ops, L, tmp_path):
+    """The branch-free steady-state rounds (dit_attention.hip: fast_tag / live_tag) against the generic loop the same library takes
+    when a debug bit is set (DGS_ATTN_DBG is read once per process, hence the second process): the two execute the same
+    arithmetic in the same order, so the outputs must be bit-identical -- queries, tail queries and log-sum-exp."""
+    import os
+    import subprocess
+    import sys
+    g = torch.Generator().manual_seed(L)
+    B, heads = 2, 2
+    lpad = (L + 127) // 128 * 128
+    qk = _bf(torch.randn(B * lpad, 2 * heads * 64, generator=g))
+    vt = _bf(torch.randn(B, heads * 64, lpad, generator=g))
+    qk[3, :64] *= 6.0                                   # spiky query / key rows: the rescale branch
+    qk[70, heads * 64:heads * 64 + 64] *= 6.0
+    lse2 = torch.zeros(B, heads, lpad)
+    fast = ops.attention(qk, vt, L, heads, lse2=lse2, q_prescaled=True)
+    out = str(tmp_path / "generic.pt")
+    torch.save(dict(qk=qk, vt=vt), out + ".in")
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    code = _GENERIC_ATTENTION.format(root=root, pkg=os.path.join(root, "open-diffusiongs_amd"), tests=here)
+    env = dict(os.environ, DGS_ATTN_DBG="16")          # an unused debug bit: p.dbg != 0 keeps every round on the generic form
+    subprocess.run([sys.executable, "-c", code, str(L), out], check=True, env=env, timeout=900)
+    gen = torch.load(out)
+    assert torch.equal(fast.view(torch.int16), gen["o"].view(torch.int16))
+    assert torch.equal(lse2, gen["lse2"])
