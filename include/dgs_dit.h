@@ -158,10 +158,15 @@ typedef struct DgsDitLayerNormBackwardArgs {
     float eps;
     const float* dx_in;        /* optional f32 [rows, width] added to the result (residual path)      */
     float* dx_out;             /* f32 [rows, width]                                                   */
-    float *dshift, *dscale, *dweight;   /* optional accumulators                                      */
+    float *dshift, *dscale, *dweight;   /* optional column sums, WRITTEN: [batch, mod_stride] x 2, [width]  */
+    void* scratch;             /* dgs_dit_layernorm_backward_scratch_bytes(rows, width, rows_per_batch) bytes of device memory when any
+                                  column sum is requested: per-workgroup partial rows, summed in a fixed order (no atomics:
+                                  the result is the same bits on every run)                              */
+    size_t scratch_bytes;
 } DgsDitLayerNormBackwardArgs;
 
-/* Backward of dgs_dit_rowlinear (M <= 8): dW [N,K] and db [N] are WRITTEN; dx [M,K] is ACCUMULATED. */
+/* Backward of dgs_dit_rowlinear (M <= 8): dW [N,K], db [N] and dx [M,K] are WRITTEN (dx through per-workgroup partial rows in
+ * `scratch`, summed in a fixed order). */
 typedef struct DgsDitRowLinearBackwardArgs {
     int32_t M, N, K;
     const float* x;            /* f32 [M, K] forward input (before the optional SiLU)                  */
@@ -169,9 +174,12 @@ typedef struct DgsDitRowLinearBackwardArgs {
     const uint16_t* W;         /* bf16 [N, K]                                                         */
     const float* dy;           /* f32 [M, N]                                                          */
     float *dW, *db, *dx;       /* each optional                                                       */
+    void* scratch;             /* dgs_dit_rowlinear_backward_scratch_bytes(M, N, K) bytes when dx is requested                         */
+    size_t scratch_bytes;
 } DgsDitRowLinearBackwardArgs;
 
-/* dy = gate * dx (bf16 [B*rows, W] and its token-contiguous copy [B, W, rows]); dgate[b, n] += sum_t dx[t, n] y[t, n]. */
+/* dy = gate * dx (bf16 [B*rows, W] and its token-contiguous copy [B, W, rows]); dgate[b, n] = sum_t dx[t, n] y[t, n];
+ * dbias[n] = sum_{b,t} dy[t, n] (the bias gradient of the Linear in front of the gate) -- both WRITTEN, order-deterministic. */
 typedef struct DgsDitGateMulArgs {
     int32_t B, rows, width;
     const float* dx;           /* f32 [B*rows, width]                                                 */
@@ -179,7 +187,10 @@ typedef struct DgsDitGateMulArgs {
     const float* gate;         /* [B, gate_stride]                                                    */
     int32_t gate_stride;
     uint16_t *dy, *dyT;
-    float* dgate;              /* [B, gate_stride] accumulated                                        */
+    float* dgate;              /* [B, gate_stride]                                                    */
+    float* dbias;              /* [width] or NULL                                                     */
+    void* scratch;             /* dgs_dit_gate_mul_scratch_bytes(B, rows, width) bytes                */
+    size_t scratch_bytes;
 } DgsDitGateMulArgs;
 
 typedef struct DgsDitRowLinearArgs {
@@ -299,6 +310,9 @@ int dgs_dit_layernorm(const DgsDitLayerNormArgs* a, dgs_stream_t stream);
 int dgs_dit_layernorm_backward(const DgsDitLayerNormBackwardArgs* a, dgs_stream_t stream);
 int dgs_dit_rowlinear_backward(const DgsDitRowLinearBackwardArgs* a, dgs_stream_t stream);
 int dgs_dit_gate_mul(const DgsDitGateMulArgs* a, dgs_stream_t stream);
+size_t dgs_dit_layernorm_backward_scratch_bytes(int32_t rows, int32_t width, int32_t rows_per_batch);
+size_t dgs_dit_rowlinear_backward_scratch_bytes(int32_t M, int32_t N, int32_t K);
+size_t dgs_dit_gate_mul_scratch_bytes(int32_t B, int32_t rows, int32_t width);
 int dgs_dit_rowlinear(const DgsDitRowLinearArgs* a, dgs_stream_t stream);
 
 /* DGSDenoiser.run_layers(first, last) (denoiser.py:441-447): DiT blocks [first, last) on a token tensor in the reference's

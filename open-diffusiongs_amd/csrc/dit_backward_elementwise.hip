@@ -9,8 +9,11 @@
 //   colsum_kernel               bias gradients  db[n] = sum_m dY[m, n]
 //   rowlinear_backward_kernel   Linear on <= 16 rows (adaLN, TimestepEmbedder, upsampler): dW (outer products), db, dx
 //   gaussians_backward_kernel   to_gs + hard pixel alignment (denoiser.py:103-120,370-413) -> d(decoder output), d(upsampler output)
-// Column sums over tokens are accumulated per workgroup in registers and flushed with one fp32 atomic per column per
-// workgroup (summation order across workgroups is not fixed, like the reference's atomics-based reductions in torch).
+// Column sums over tokens (bias / gate / shift / scale / LayerNorm-weight gradients, dx of the adaLN Linear) are ORDER-DETERMINISTIC:
+// every workgroup accumulates in registers, combines its waves in a fixed order through LDS and WRITES one partial row per column
+// block into a scratch slab; col_reduce_kernel then sums the slab rows in slot order (one launch per DiT block finishes all of the
+// block's column sums).  No fp32 atomics: two identical backward passes give identical bits (tools/train_determinism.py), and the
+// recompute mode reproduces the save-all gradients exactly.
 #include "dit_kernels.h"
 
 namespace dgs {
@@ -32,28 +35,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, int ld
 }
 
 // ------------------------------------------------------------------------------------------------
-// dy[m, n] = gate[b, n] * dx[m, n]  (bf16 row-major + transposed [B, W, rows]);  dgate[b, n] += sum_t dx[m, n] * y[m, n].
-// One workgroup = 64 tokens x 64 features of one sample.
+// dy[m, n] = gate[b, n] * dx[m, n]  (bf16 row-major + transposed [B, W, rows]).  One workgroup = 64 tokens x 64 features of one
+// sample; its two column sums go to part[(b * rows / 64 + token block)][0 .. 2W):
+//   [0, W)   sum_t dx[m, n] * y[m, n]      (the gate's gradient)
+//   [W, 2W)  sum_t dy[m, n] as rounded     (the bias gradient of the Linear whose output the gate multiplies)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gate_mul_kernel(const float* dx, const bf16_t* y, const float* gate, int gate_stride,
-                                                      bf16_t* dy, bf16_t* dyT, float* dgate, int rows, int W) {
+                                                      bf16_t* dy, bf16_t* dyT, float* part, int rows, int W) {
     __shared__ bf16_t tile[64][66];
+    __shared__ float red[2][4][64];
     const int b = blockIdx.z, t0 = blockIdx.y * 64, f0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const size_t base = ((size_t)b * rows + t0) * W + f0;
     const float gt = gate[(size_t)b * gate_stride + f0 + tx];
-    float acc = 0.f;
+    float acc = 0.f, accb = 0.f;
 #pragma unroll 4
     for (int r = ty; r < 64; r += 4) {
         const size_t o = base + (size_t)r * W + tx;
         const float d = dx[o];
-        const bf16_t v = (bf16_t)f2bf_fast(gt * d);
-        dy[o] = v;
-        tile[r][tx] = v;
+        const uint32_t v = f2bf_fast(gt * d);
+        dy[o] = (bf16_t)v;
+        tile[r][tx] = (bf16_t)v;
         acc += d * bf2f(y[o]);
+        accb += bf2f(v);
     }
-    atomicAdd(&dgate[(size_t)b * gate_stride + f0 + tx], acc);
+    red[0][ty][tx] = acc;
+    red[1][ty][tx] = accb;
     __syncthreads();
+    if (ty < 2) {
+        float* dst = part + ((size_t)b * (rows >> 6) + blockIdx.y) * (size_t)(2 * W) + (size_t)ty * W + f0 + tx;
+        *dst = (red[ty][0][tx] + red[ty][1][tx]) + (red[ty][2][tx] + red[ty][3][tx]);
+    }
     bf16_t* dst = dyT + ((size_t)b * W + f0) * rows + t0;
 #pragma unroll
     for (int r = ty; r < 64; r += 4) dst[(size_t)r * rows + tx] = tile[tx][r];
@@ -130,7 +142,9 @@ __global__ __launch_bounds__(512) void layernorm_backward_kernel(LnBwdParams p) 
             out[c4] = d;
         }
     }
-    // column sums: 8 waves -> LDS -> one fp32 atomic per column per workgroup, one quantity at a time (32 KiB of LDS)
+    // column sums: 8 waves -> LDS -> summed in wave order, one quantity at a time (32 KiB of LDS).  With a slab (`part`) the
+    // workgroup WRITES its row [shift | scale | weight]; without (single-workgroup launches: the learned-token rows of the
+    // upsampler head) it adds to the destinations -- plain adds, launches are stream-ordered.
     __shared__ float red[8][VPL * 256];
     float* const dst[3] = {p.dshift ? p.dshift + (size_t)b * p.mod_stride : nullptr, p.dscale ? p.dscale + (size_t)b * p.mod_stride : nullptr, p.dweight};
 #pragma unroll
@@ -145,27 +159,28 @@ __global__ __launch_bounds__(512) void layernorm_backward_kernel(LnBwdParams p) 
             float acc = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) acc += red[w][c];
-            atomicAdd(dst[qn] + c, acc);
+            if (p.part) p.part[(size_t)blockIdx.x * p.part_stride + qn * p.width + c] = acc;
+            else dst[qn][c] += acc;
         }
     }
 }
 
-// db[n] += sum_m dY[m, n]   (bf16 [M, ld]); workgroup = 256 rows x 64 columns (any N % 64 == 0)
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, int ld, int M, float* db) {
-    __shared__ float part[4][64];
+// part[row block][n] = sum over the block's rows of dY[m, n]   (bf16 [M, ld]); workgroup = 256 rows x 64 columns (any N % 64 == 0)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, int ld, int M, float* part, int N) {
+    __shared__ float sm[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + tx, m0 = blockIdx.y * 256;
     float acc = 0.f;
     for (int r = ty; r < 256 && m0 + r < M; r += 4) acc += bf2f(dy[(size_t)(m0 + r) * ld + n]);
-    part[ty][tx] = acc;
+    sm[ty][tx] = acc;
     __syncthreads();
-    if (ty == 0) atomicAdd(&db[n], (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
+    if (ty == 0) part[(size_t)blockIdx.y * N + n] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
 }
 
 // The same for N % 512 == 0 (every bias of the DiT blocks): workgroup = 128 rows x 512 columns, a wave reads 1 KiB of a row per
 // instruction (16 bytes per lane; the 2-byte loads above ran at 1.5 TB/s), 8 rows in flight per wave.
-__global__ __launch_bounds__(256) void colsum_wide_kernel(const bf16_t* dy, int ld, int M, float* db) {
-    __shared__ float part[4][512];
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const bf16_t* dy, int ld, int M, float* part, int N) {
+    __shared__ float sm[4][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 512 + lane * 8, m0 = blockIdx.y * 128;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -185,17 +200,39 @@ __global__ __launch_bounds__(256) void colsum_wide_kernel(const bf16_t* dy, int 
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) part[wave][lane * 8 + i] = acc[i];
+    for (int i = 0; i < 8; ++i) sm[wave][lane * 8 + i] = acc[i];
     __syncthreads();
     for (int c = threadIdx.x; c < 512; c += 256)
-        atomicAdd(&db[blockIdx.x * 512 + c], (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+        part[(size_t)blockIdx.y * N + blockIdx.x * 512 + c] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b * out_bstride + c] = sum_{s < slots} part[(b * slots + s) * part_stride + c]  for up to 8 independent jobs in one launch
+// (blockIdx.z = job, blockIdx.y = b, 64 columns per workgroup).  Thread (column, q) adds slots q, q + 4, ... in order, the four
+// sums are combined as (0 + 1) + (2 + 3): the same order on every run.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_reduce_kernel(ColReduceParams p) {
+    __shared__ float sm[4][64];
+    const ColReduceJob j = p.job[blockIdx.z];
+    const int tx = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + tx, b = blockIdx.y;
+    if (b >= j.batches || (int)blockIdx.x * 64 >= j.cols) return;      // uniform
+    float acc = 0.f;
+    if (c < j.cols) {
+        const float* src = j.part + (size_t)b * j.slots * j.part_stride + c;
+#pragma unroll 8
+        for (int s = q; s < j.slots; s += 4) acc += src[(size_t)s * j.part_stride];
+    }
+    sm[q][tx] = acc;
+    __syncthreads();
+    if (q == 0 && c < j.cols) j.out[(size_t)b * j.out_bstride + c] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Backward of  y[m, n] = sum_k act(x[m, k]) W[n, k] + b[n]  on M <= 16 rows (weight-streaming, one wave per output row n):
 //   dW[n, :] = sum_m dy[m, n] act(x[m, :])        (written, not accumulated)
 //   db[n]    = sum_m dy[m, n]
-//   dx[m, k] += act'(x[m, k]) sum_n dy[m, n] W[n, k]      (atomics; dx must be zeroed by the caller)
+//   dx[m, k]  = act'(x[m, k]) sum_n dy[m, n] W[n, k]      (per workgroup: a slab row part[blockIdx.x][M * K] that col_reduce sums,
+//                                                          or -- one workgroup only -- added to dx)
 // ------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
@@ -255,20 +292,26 @@ __global__ __launch_bounds__(256) void rowlinear_backward_kernel(RowLinBwdParams
         }
     }
     if (p.dx) {
+        // the four waves add their registers into the LDS copy one after the other (fixed order)
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+                for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int k0 = (lane + 64 * c) * 8;
-                if (k0 >= p.K) continue;
+                    for (int c = 0; c < MAXC; ++c) {
+                        const int k0 = (lane + 64 * c) * 8;
+                        if (k0 >= p.K) continue;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(&dxs[m * p.K + k0 + j], dxr[m][c][j]);   // 4 waves -> LDS
+                        for (int j = 0; j < 8; ++j) dxs[m * p.K + k0 + j] += dxr[m][c][j];
+                    }
             }
-        __syncthreads();
+            __syncthreads();
+        }
         for (int i = threadIdx.x; i < p.M * p.K; i += 256) {
             float g = dxs[i];
             if (p.silu_in) g *= dsilu_f(p.x[i]);
-            if (g != 0.f) atomicAdd(&p.dx[i], g);
+            if (p.part) p.part[(size_t)blockIdx.x * p.M * p.K + i] = g;
+            else p.dx[i] += g;
         }
     }
 }
@@ -335,10 +378,24 @@ int launch_transpose(const bf16_t* in, int ld, bf16_t* out, int B, int rows, int
     return ok();
 }
 
-int launch_gate_mul(const float* dx, const bf16_t* y, const float* gate, int gate_stride, bf16_t* dy, bf16_t* dyT, float* dgate, int B,
+int launch_gate_mul(const float* dx, const bf16_t* y, const float* gate, int gate_stride, bf16_t* dy, bf16_t* dyT, float* part, int B,
                     int rows, int W, hipStream_t st) {
-    if (rows % 64 || W % 64) return DGS_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(gate_mul_kernel, dim3(W / 64, rows / 64, B), dim3(256), 0, st, dx, y, gate, gate_stride, dy, dyT, dgate, rows, W);
+    if (rows % 64 || W % 64 || !part) return DGS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(gate_mul_kernel, dim3(W / 64, rows / 64, B), dim3(256), 0, st, dx, y, gate, gate_stride, dy, dyT, part, rows, W);
+    return ok();
+}
+
+int launch_col_reduce(const ColReduceJob* jobs, int njobs, hipStream_t st) {
+    if (njobs <= 0 || njobs > 8) return DGS_ERR_INVALID_ARGUMENT;
+    ColReduceParams p{};
+    int cols = 0, batches = 0;
+    for (int i = 0; i < njobs; ++i) {
+        p.job[i] = jobs[i];
+        if (!jobs[i].part || !jobs[i].out || jobs[i].slots <= 0 || jobs[i].cols <= 0 || jobs[i].batches <= 0) return DGS_ERR_INVALID_ARGUMENT;
+        cols = jobs[i].cols > cols ? jobs[i].cols : cols;
+        batches = jobs[i].batches > batches ? jobs[i].batches : batches;
+    }
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((cols + 63) / 64, batches, njobs), dim3(256), 0, st, p);
     return ok();
 }
 
@@ -346,9 +403,10 @@ int launch_layernorm_backward(const LnBwdParams& p0, hipStream_t st) {
     LnBwdParams p = p0;
     if (p.rows <= 0 || p.width % 256 || p.width > 2048) return DGS_ERR_INVALID_ARGUMENT;
     if (p.rows_per_batch <= 0) p.rows_per_batch = p.rows;
-    static const int rpb = [] { const char* e = getenv("DGS_LN_BWD_ROWS"); return e ? atoi(e) : 32; }();
-    p.rows_per_block = p.rows_per_batch % rpb == 0 ? rpb : p.rows_per_batch;   // never straddles samples
+    p.rows_per_block = ln_backward_rows_per_block(p.rows_per_batch);          // never straddles samples
     const dim3 grid((p.rows + p.rows_per_block - 1) / p.rows_per_block), block(512);
+    if (!p.part && grid.x != 1 && (p.dshift || p.dscale || p.dweight)) return DGS_ERR_INVALID_ARGUMENT;   // column sums need the slab
+    if (p.part && p.part_stride < 3 * p.width) return DGS_ERR_INVALID_ARGUMENT;
     switch (p.width / 256) {
         case 1: hipLaunchKernelGGL((layernorm_backward_kernel<1>), grid, block, 0, st, p); break;
         case 2: hipLaunchKernelGGL((layernorm_backward_kernel<2>), grid, block, 0, st, p); break;
@@ -358,17 +416,21 @@ int launch_layernorm_backward(const LnBwdParams& p0, hipStream_t st) {
     return ok();
 }
 
-int launch_colsum(const bf16_t* dy, int ld, int M, int N, float* db, hipStream_t st) {
-    if (N % 64) return DGS_ERR_INVALID_ARGUMENT;
-    if (N % 512 == 0 && ld % 8 == 0) hipLaunchKernelGGL(colsum_wide_kernel, dim3(N / 512, (M + 127) / 128), dim3(256), 0, st, dy, ld, M, db);
-    else hipLaunchKernelGGL(colsum_kernel, dim3(N / 64, (M + 255) / 256), dim3(256), 0, st, dy, ld, M, db);
+// part: [colsum_slots(M, N, ld)][N] slab rows, summed by launch_col_reduce
+int colsum_slots(int M, int N, int ld) { return (N % 512 == 0 && ld % 8 == 0) ? (M + 127) / 128 : (M + 255) / 256; }
+
+int launch_colsum(const bf16_t* dy, int ld, int M, int N, float* part, hipStream_t st) {
+    if (N % 64 || !part) return DGS_ERR_INVALID_ARGUMENT;
+    if (N % 512 == 0 && ld % 8 == 0) hipLaunchKernelGGL(colsum_wide_kernel, dim3(N / 512, (M + 127) / 128), dim3(256), 0, st, dy, ld, M, part, N);
+    else hipLaunchKernelGGL(colsum_kernel, dim3(N / 64, (M + 255) / 256), dim3(256), 0, st, dy, ld, M, part, N);
     return ok();
 }
 
 int launch_rowlinear_backward(const RowLinBwdParams& p, hipStream_t st) {
     if (p.M <= 0 || p.M > 8 || p.N <= 0 || p.K <= 0 || p.K % 8 || p.K > 1024) return DGS_ERR_INVALID_ARGUMENT;
-    const int rpb = 256;
+    const int rpb = ROWLINEAR_BWD_ROWS;
     const dim3 grid((p.N + rpb - 1) / rpb), block(256);
+    if (p.dx && !p.part && grid.x != 1) return DGS_ERR_INVALID_ARGUMENT;       // dx of several workgroups needs the slab
     const int mr = p.M <= 1 ? 1 : p.M <= 2 ? 2 : p.M <= 4 ? 4 : 8;
     const size_t lds = (size_t)2 * mr * p.K * sizeof(float);
     if (lds > 65536) return DGS_ERR_INVALID_ARGUMENT;
@@ -391,25 +453,75 @@ int launch_gaussians_backward(const GsBwdParams& p, hipStream_t st) {
 
 using namespace dgs;
 
+namespace {
+int ln_blocks(int rows, int rows_per_batch) {
+    const int rpb = ln_backward_rows_per_block(rows_per_batch > 0 ? rows_per_batch : rows);
+    return (rows + rpb - 1) / rpb;
+}
+}  // namespace
+
+extern "C" size_t dgs_dit_layernorm_backward_scratch_bytes(int32_t rows, int32_t width, int32_t rows_per_batch) {
+    if (rows <= 0 || width <= 0) return 0;
+    return (size_t)ln_blocks(rows, rows_per_batch) * 3 * width * sizeof(float);
+}
+extern "C" size_t dgs_dit_gate_mul_scratch_bytes(int32_t B, int32_t rows, int32_t width) {
+    if (B <= 0 || rows <= 0 || width <= 0) return 0;
+    return (size_t)B * (rows / 64) * 2 * width * sizeof(float);
+}
+extern "C" size_t dgs_dit_rowlinear_backward_scratch_bytes(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (size_t)((N + ROWLINEAR_BWD_ROWS - 1) / ROWLINEAR_BWD_ROWS) * M * K * sizeof(float);
+}
+
+// The three entry points below WRITE their column sums (dshift / dscale / dweight, dgate / dbias, dx): partial rows in the caller's
+// scratch, then one col_reduce launch -- the same two steps dgs_dit_backward runs, with the reduce of a whole block batched there.
 extern "C" int dgs_dit_layernorm_backward(const DgsDitLayerNormBackwardArgs* a, dgs_stream_t stream) {
     if (!a || !a->x || !a->dh || !a->dx_out) return DGS_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     LnBwdParams p{};
     p.rows = a->rows; p.width = a->width; p.mod_stride = a->mod_stride; p.rows_per_batch = a->rows_per_batch; p.dh_f32 = a->dh_f32;
     p.eps = a->eps; p.x = a->x; p.dh = a->dh; p.weight = a->weight; p.scale = a->scale; p.dx_in = a->dx_in; p.dx_out = a->dx_out;
     p.dshift = a->dshift; p.dscale = a->dscale; p.dweight = a->dweight;
-    return launch_layernorm_backward(p, static_cast<hipStream_t>(stream));
+    if (!(a->dshift || a->dscale || a->dweight)) return launch_layernorm_backward(p, st);
+    if (!a->scratch || a->scratch_bytes < dgs_dit_layernorm_backward_scratch_bytes(a->rows, a->width, a->rows_per_batch)) return DGS_ERR_ALLOC;
+    p.part = static_cast<float*>(a->scratch); p.part_stride = 3 * a->width;
+    const int rc = launch_layernorm_backward(p, st);
+    if (rc != DGS_OK) return rc;
+    const int rpbatch = a->rows_per_batch > 0 ? a->rows_per_batch : a->rows;
+    const int batches = a->rows / rpbatch, blocks = ln_blocks(a->rows, a->rows_per_batch);
+    ColReduceJob jobs[3];
+    int n = 0;
+    if (a->dshift) jobs[n++] = ColReduceJob{p.part, a->dshift, blocks / batches, p.part_stride, a->width, batches, a->mod_stride};
+    if (a->dscale) jobs[n++] = ColReduceJob{p.part + a->width, a->dscale, blocks / batches, p.part_stride, a->width, batches, a->mod_stride};
+    if (a->dweight) jobs[n++] = ColReduceJob{p.part + 2 * a->width, a->dweight, blocks, p.part_stride, a->width, 1, 0};
+    return launch_col_reduce(jobs, n, st);
 }
 
 extern "C" int dgs_dit_rowlinear_backward(const DgsDitRowLinearBackwardArgs* a, dgs_stream_t stream) {
     if (!a || !a->x || !a->W || !a->dy) return DGS_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     RowLinBwdParams p{};
     p.M = a->M; p.N = a->N; p.K = a->K; p.silu_in = a->silu_input; p.x = a->x; p.W = a->W; p.dy = a->dy;
     p.dW = a->dW; p.db = a->db; p.dx = a->dx;
-    return launch_rowlinear_backward(p, static_cast<hipStream_t>(stream));
+    if (!a->dx) return launch_rowlinear_backward(p, st);
+    if (!a->scratch || a->scratch_bytes < dgs_dit_rowlinear_backward_scratch_bytes(a->M, a->N, a->K)) return DGS_ERR_ALLOC;
+    p.part = static_cast<float*>(a->scratch);
+    const int rc = launch_rowlinear_backward(p, st);
+    if (rc != DGS_OK) return rc;
+    const ColReduceJob job{p.part, a->dx, (a->N + ROWLINEAR_BWD_ROWS - 1) / ROWLINEAR_BWD_ROWS, a->M * a->K, a->M * a->K, 1, 0};
+    return launch_col_reduce(&job, 1, st);
 }
 
 extern "C" int dgs_dit_gate_mul(const DgsDitGateMulArgs* a, dgs_stream_t stream) {
     if (!a || !a->dx || !a->y || !a->gate || !a->dy || !a->dyT || !a->dgate) return DGS_ERR_INVALID_ARGUMENT;
-    return launch_gate_mul(a->dx, a->y, a->gate, a->gate_stride, a->dy, a->dyT, a->dgate, a->B, a->rows, a->width,
-                           static_cast<hipStream_t>(stream));
+    if (!a->scratch || a->scratch_bytes < dgs_dit_gate_mul_scratch_bytes(a->B, a->rows, a->width)) return DGS_ERR_ALLOC;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(a->scratch);
+    const int rc = launch_gate_mul(a->dx, a->y, a->gate, a->gate_stride, a->dy, a->dyT, part, a->B, a->rows, a->width, st);
+    if (rc != DGS_OK) return rc;
+    ColReduceJob jobs[2];
+    int n = 0;
+    jobs[n++] = ColReduceJob{part, a->dgate, a->rows / 64, 2 * a->width, a->width, a->B, a->gate_stride};
+    if (a->dbias) jobs[n++] = ColReduceJob{part + a->width, a->dbias, a->B * (a->rows / 64), 2 * a->width, a->width, 1, 0};
+    return launch_col_reduce(jobs, n, st);
 }

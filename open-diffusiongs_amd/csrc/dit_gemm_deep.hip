@@ -389,7 +389,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     constexpr bool PREFETCH_RESID = EPI == DGS_EPI_GATE_RESIDUAL && BM == 128 && NW == 4;
     constexpr int PRE_LOADS = PREFETCH_RESID ? WMB * (NI / 2) * 8 : 0;       // float4 loads per lane
     float4 pre[PREFETCH_RESID ? WMB * (NI / 2) : 1][8];
-    auto iteration = [&](int t, auto slot_tag, auto refill_tag, auto pre_tag, auto left_tag) {    // slot == t % NS, a literal at the call sites
+    // `dbg_tag`: the cycle stamps of DGS_GEMM_DBG=1 exist only in the copy of the loop that a debug run takes -- as run-time tests of
+    // p.dbg they were three compare + branch pairs per slab in every run (tools/ubench/issue_bench: ~16 cycles each beside MFMAs)
+    auto iteration = [&](int t, auto slot_tag, auto refill_tag, auto pre_tag, auto left_tag, auto dbg_tag) {    // slot == t % NS, a literal at the call sites
+        constexpr bool DBG = decltype(dbg_tag)::value;
         constexpr int slot = decltype(slot_tag)::value;
         constexpr int PRE_N = decltype(pre_tag)::value;                // residual loads in flight at the end of this iteration
         constexpr bool refill = decltype(refill_tag)::value;           // slab t + NS - 1 exists; it goes into the stage of slab t - 1
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         // done reading slab t
 #ifndef HIPEMU
         long long w0 = 0;
-        if (p.dbg == 1) w0 = clock64();
+        if constexpr (DBG) w0 = clock64();
         // The second half of iteration t+1 already prefetches fragments of slab t+2, so slabs <= t+2 must have landed by the end of
         // iteration t: slabs t+3 .. t+NS-1 stay in flight across the barrier (DMAs complete in issue order).  NS = 4: only the slab
         // issued in this iteration; NS = 8 (128 x 128 tiles, whose A operand streams from beyond L2): five slabs, ~3 k cycles of
@@ -443,9 +446,9 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         } else if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long w1 = 0;
-        if (p.dbg == 1) w1 = clock64();
+        if constexpr (DBG) w1 = clock64();
         __builtin_amdgcn_s_barrier();
-        if (p.dbg == 1) { dbg_wait += w1 - w0; dbg_bar += clock64() - w1; }
+        if constexpr (DBG) { dbg_wait += w1 - w0; dbg_bar += clock64() - w1; }
 #else
         __syncthreads();
 #endif
@@ -453,12 +456,19 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #ifndef HIPEMU
     const long long dbg_t0 = p.dbg == 1 ? clock64() : 0;
 #endif
-    for (int t = 0; t < nk - NS; t += NS)                          // unrolled by the ring depth: slots are literals
-        sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, sc, std::true_type{}, SIC<0>{}, SIC<0>{}); });
-    sliced_for<0, NS>([&](auto sc) {                               // the last slab goes out in the first of the last NS iterations
-        constexpr int S = decltype(sc)::value;
-        iteration(nk - NS + S, sc, std::integral_constant<bool, S == 0>{}, SIC<PRE_LOADS>{}, SIC<(NS - S - 3 > 0 ? NS - S - 3 : 0)>{});
-    });
+    auto k_loop = [&](auto dbg_tag) {
+        for (int t = 0; t < nk - NS; t += NS)                      // unrolled by the ring depth: slots are literals
+            sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, sc, std::true_type{}, SIC<0>{}, SIC<0>{}, dbg_tag); });
+        sliced_for<0, NS>([&](auto sc) {                           // the last slab goes out in the first of the last NS iterations
+            constexpr int S = decltype(sc)::value;
+            iteration(nk - NS + S, sc, std::integral_constant<bool, S == 0>{}, SIC<PRE_LOADS>{}, SIC<(NS - S - 3 > 0 ? NS - S - 3 : 0)>{}, dbg_tag);
+        });
+    };
+#ifndef HIPEMU
+    if (p.dbg == 1) k_loop(std::true_type{});
+    else
+#endif
+        k_loop(std::false_type{});
 #ifndef HIPEMU
     const long long dbg_t1 = p.dbg == 1 ? clock64() : 0;
 #endif

@@ -51,8 +51,10 @@ struct LnBwdParams {
     const float *weight, *scale;
     const float* dx_in;      // optional residual-path gradient added to the result
     float* dx_out;
-    float *dshift, *dscale;  // [batch, mod_stride] accumulated (atomics), may be NULL
-    float* dweight;          // [width] accumulated, may be NULL
+    float *dshift, *dscale;  // [batch, mod_stride], may be NULL: which column sums are wanted (and, without `part`, where they are added)
+    float* dweight;          // [width], may be NULL
+    float* part;             // slab [workgroups][part_stride >= 3 width]: row = [shift | scale | weight] partial sums of one workgroup
+    int part_stride;         //   (col_reduce finishes them; NULL is only valid for single-workgroup launches, which ADD to the above)
 };
 
 struct RowLinBwdParams {
@@ -62,8 +64,20 @@ struct RowLinBwdParams {
     const float* dy;      // [M, N]
     float* dW;            // [N, K] or NULL
     float* db;            // [N] or NULL
-    float* dx;            // [M, K] or NULL
+    float* dx;            // [M, K] or NULL (with `part`: only says that dx is wanted)
+    float* part;          // slab [workgroups][M * K] partial dx rows, or NULL (single workgroup: ADDED to dx)
 };
+
+// One column-sum job of col_reduce_kernel: out[b * out_bstride + c] = sum_{s < slots} part[(b * slots + s) * part_stride + c]
+struct ColReduceJob {
+    const float* part;
+    float* out;
+    int slots, part_stride, cols, batches, out_bstride;
+};
+struct ColReduceParams { ColReduceJob job[8]; };
+
+constexpr int ROWLINEAR_BWD_ROWS = 256;     // output features per workgroup of rowlinear_backward_kernel
+inline int ln_backward_rows_per_block(int rows_per_batch) { return rows_per_batch % 32 == 0 ? 32 : rows_per_batch; }
 
 struct GsBwdParams {
     int B, V, H, W, ps, lpad, ng, C, scene, relative_plk;
@@ -75,10 +89,13 @@ struct GsBwdParams {
 };
 
 int launch_transpose(const bf16_t* in, int ld, bf16_t* out, int B, int rows, int F, hipStream_t st);
-int launch_gate_mul(const float* dx, const bf16_t* y, const float* gate, int gate_stride, bf16_t* dy, bf16_t* dyT, float* dgate, int B,
+// part: [B * rows / 64][2 W] (gate gradient | bias gradient partial sums)
+int launch_gate_mul(const float* dx, const bf16_t* y, const float* gate, int gate_stride, bf16_t* dy, bf16_t* dyT, float* part, int B,
                     int rows, int W, hipStream_t st);
+int launch_col_reduce(const ColReduceJob* jobs, int njobs, hipStream_t st);
+int colsum_slots(int M, int N, int ld);
 int launch_layernorm_backward(const LnBwdParams& p, hipStream_t st);
-int launch_colsum(const bf16_t* dy, int ld, int M, int N, float* db, hipStream_t st);
+int launch_colsum(const bf16_t* dy, int ld, int M, int N, float* part, hipStream_t st);
 int launch_rowlinear_backward(const RowLinBwdParams& p, hipStream_t st);
 int launch_gaussians_backward(const GsBwdParams& p, hipStream_t st);
 

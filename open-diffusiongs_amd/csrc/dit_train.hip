@@ -85,6 +85,11 @@ struct BwdScratch {
     size_t wpart_bytes;
     float* wpart;            // split-K partial planes of the weight-gradient GEMMs (largest: fc1 / fc2)
     float* xre;              // [M, W] recompute mode: where a re-run block writes its (already known) output
+    // slabs of per-workgroup partial column sums (dit_backward_elementwise.hip; summed by col_reduce in slot order)
+    float* ln_part[2];       // [M / 32][3W]   LayerNorm backward: shift | scale | weight     ([0]: LN2 / heads / input LN, [1]: LN1)
+    float* gate_part[2];     // [M / 64][2W]   gate_mul: gate gradient | bias gradient         ([0]: MLP branch, [1]: attention branch)
+    float *fc1b_part, *qkvb_part;   // [M / 128][4W], [M / 128][3W]   bias gradients of fc1 / qkv
+    float* rl_part;          // [nmod / 256][B * W]   dx of the adaLN Linear
     static BwdScratch carve(void* buf, const DgsDitModel* m, size_t B, size_t lpad, size_t* bytes) {
         Carver c(buf);
         BwdScratch s;
@@ -106,6 +111,11 @@ struct BwdScratch {
         s.wpart_bytes = dgs_dit_gemm_splitk_bytes((int)(4 * W), (int)W, (int)M, (int)lpad);
         s.wpart = c.take<float>(s.wpart_bytes / sizeof(float));
         s.xre = c.take<float>(M * W);
+        const size_t ln_blk = B * ((lpad + 31) / 32);
+        for (int i = 0; i < 2; ++i) { s.ln_part[i] = c.take<float>(ln_blk * 3 * W); s.gate_part[i] = c.take<float>(M / 64 * 2 * W); }
+        s.fc1b_part = c.take<float>((M + 127) / 128 * 4 * W); s.qkvb_part = c.take<float>((M + 127) / 128 * 3 * W);
+        const size_t nmod_rows = (6 * (size_t)m->layers + 4) * W;
+        s.rl_part = c.take<float>((nmod_rows + ROWLINEAR_BWD_ROWS - 1) / ROWLINEAR_BWD_ROWS * B * W);
         if (bytes) *bytes = c.bytes();
         return s;
     }
@@ -300,16 +310,16 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
     BwdScratch ws = BwdScratch::carve(a->workspace, m, (size_t)B, (size_t)lpad, &need);
     if (a->workspace_bytes < need) return DGS_ERR_ALLOC;
 
-    // accumulators that are filled with atomics start from zero
+    // No accumulator is filled with atomics: every column sum goes through a slab of per-workgroup partial rows and col_reduce
+    // (dit_backward_elementwise.hip), so two passes over the same inputs give the same bits.  What is zeroed here: the decoder
+    // head's gradient rows nobody writes (learned-token / padding rows), and the two tensors the single-workgroup launches of
+    // the upsampler head ADD to (stream-ordered plain adds).
     HIP_TRY(hipMemsetAsync(ws.dmod, 0, (size_t)B * nmod * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(ws.ddec, 0, (size_t)M * ND * sizeof(bf16_t), st));
     HIP_TRY(hipMemsetAsync(ws.dupn, 0, (size_t)B * ng * W * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(ws.dcvec, 0, (size_t)B * W * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(ws.dc1, 0, (size_t)B * W * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(gr->dec_ln_w, 0, W * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(gr->up_ln_w, 0, W * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(gr->in_ln_w, 0, W * sizeof(float), st));
     hipLaunchKernelGGL(fill_kernel, dim3((B * W + 255) / 256), dim3(256), 0, st, ws.ones, 1.0f, (size_t)B * W);
+    const int ln_slots = lpad / ln_backward_rows_per_block(lpad), gate_slots = lpad / 64;      // partial rows per sample
 
     // ---- to_gs + pixel alignment ----
     GsBwdParams gb;
@@ -331,8 +341,13 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
     LnBwdParams lb{};
     lb.rows = M; lb.width = W; lb.mod_stride = nmod; lb.rows_per_batch = lpad; lb.eps = 1e-5f; lb.x = sv.x_out; lb.dh = ws.dh;
     lb.weight = m->dec_ln_w; lb.scale = mod_dec + W; lb.dx_in = nullptr; lb.dx_out = ws.dxa; lb.dshift = dmod_dec; lb.dscale = dmod_dec + W;
-    lb.dweight = gr->dec_ln_w;
+    lb.dweight = gr->dec_ln_w; lb.part = ws.ln_part[0]; lb.part_stride = 3 * W;
     DGS_TRY(launch_layernorm_backward(lb, st));
+    {
+        const ColReduceJob jobs[2] = {{ws.ln_part[0], dmod_dec, ln_slots, 3 * W, 2 * W, B, nmod},
+                                      {ws.ln_part[0] + 2 * W, gr->dec_ln_w, B * ln_slots, 3 * W, W, 1, 0}};
+        DGS_TRY(launch_col_reduce(jobs, 2, st));
+    }
     // ---- upsampler head (the learned-token rows) ----
     RowLinBwdParams ub{};
     ub.M = B * ng; ub.N = C; ub.K = W; ub.x = sv.upn; ub.W = m->up_w; ub.dy = ws.dup; ub.dW = gr->up_w; ub.dx = ws.dupn;
@@ -364,24 +379,20 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         if (a->recompute && i + 1 < m->layers)
             DGS_TRY(block_forward_train(m, i, k, ws.xre, sv.mod, sv.attn_tail, sv.attn_tail_bytes, B, lpad, L, stream));
         // MLP branch
-        DGS_TRY(launch_gate_mul(dx, k.y2, mod + 5 * W, nmod, ws.dy, ws.dyT, dmod + 5 * W, B, lpad, W, st));
-        HIP_TRY(hipMemsetAsync(lg.fc2_b, 0, W * sizeof(float), st));
-        DGS_TRY(launch_colsum(ws.dy, W, M, W, lg.fc2_b, st));
+        DGS_TRY(launch_gate_mul(dx, k.y2, mod + 5 * W, nmod, ws.dy, ws.dyT, ws.gate_part[0], B, lpad, W, st));       // + fc2_b partials
         DGS_TRY(wgrad(ws.dyT, W, k.gT, 4 * W, lg.fc2_w, B, lpad, ws, stream));
         DGS_TRY(dgrad(ws.dy, W, lt.fc2_wT, 4 * W, ws.du, M, lpad, L, DGS_EPI_DGELU_BF16, k.u, ws.duT, stream));
-        HIP_TRY(hipMemsetAsync(lg.fc1_b, 0, 4 * W * sizeof(float), st));
-        DGS_TRY(launch_colsum(ws.du, 4 * W, M, 4 * W, lg.fc1_b, st));
+        DGS_TRY(launch_colsum(ws.du, 4 * W, M, 4 * W, ws.fc1b_part, st));
         DGS_TRY(launch_transpose(k.h2, W, ws.actT, B, lpad, W, st));
         DGS_TRY(wgrad(ws.duT, 4 * W, ws.actT, W, lg.fc1_w, B, lpad, ws, stream));
         DGS_TRY(dgrad(ws.du, 4 * W, lt.fc1_wT, W, ws.dh, M, lpad, L, DGS_EPI_BF16, nullptr, nullptr, stream));
         LnBwdParams l2{};
         l2.rows = M; l2.width = W; l2.mod_stride = nmod; l2.rows_per_batch = lpad; l2.eps = 1e-6f; l2.x = k.x_mid; l2.dh = ws.dh;
         l2.scale = mod + 4 * W; l2.dx_in = dx; l2.dx_out = dx_mid; l2.dshift = dmod + 3 * W; l2.dscale = dmod + 4 * W;
+        l2.part = ws.ln_part[0]; l2.part_stride = 3 * W;
         DGS_TRY(launch_layernorm_backward(l2, st));
         // attention branch
-        DGS_TRY(launch_gate_mul(dx_mid, k.y1, mod + 2 * W, nmod, ws.dy, ws.dyT, dmod + 2 * W, B, lpad, W, st));
-        HIP_TRY(hipMemsetAsync(lg.proj_b, 0, W * sizeof(float), st));
-        DGS_TRY(launch_colsum(ws.dy, W, M, W, lg.proj_b, st));
+        DGS_TRY(launch_gate_mul(dx_mid, k.y1, mod + 2 * W, nmod, ws.dy, ws.dyT, ws.gate_part[1], B, lpad, W, st));   // + proj_b partials
         DGS_TRY(launch_transpose(k.a, W, ws.actT, B, lpad, W, st));
         DGS_TRY(wgrad(ws.dyT, W, ws.actT, W, lg.proj_w, B, lpad, ws, stream));
         DGS_TRY(dgrad(ws.dy, W, lt.proj_wT, W, ws.da, M, lpad, L, DGS_EPI_BF16, nullptr, ws.daT, stream));
@@ -389,8 +400,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         ab.B = B; ab.heads = m->heads; ab.L = L; ab.lpad = lpad; ab.qkv = k.qkv; ab.qkvT = k.qkvT; ab.o = k.a; ab.dO = ws.da; ab.dOT = ws.daT;
         ab.lse2 = k.lse2; ab.D = ws.D; ab.dqkv = ws.dqkv; ab.scale = 0.125f;
         DGS_TRY(dgs_dit_attention_backward(&ab, stream));
-        HIP_TRY(hipMemsetAsync(lg.qkv_b, 0, 3 * W * sizeof(float), st));
-        DGS_TRY(launch_colsum(ws.dqkv, 3 * W, M, 3 * W, lg.qkv_b, st));
+        DGS_TRY(launch_colsum(ws.dqkv, 3 * W, M, 3 * W, ws.qkvb_part, st));
         DGS_TRY(launch_transpose(ws.dqkv, 3 * W, ws.dqkvT, B, lpad, 3 * W, st));
         DGS_TRY(launch_transpose(k.h1, W, ws.actT, B, lpad, W, st));
         DGS_TRY(wgrad(ws.dqkvT, 3 * W, ws.actT, W, lg.qkv_w, B, lpad, ws, stream));
@@ -398,30 +408,56 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         LnBwdParams l1{};
         l1.rows = M; l1.width = W; l1.mod_stride = nmod; l1.rows_per_batch = lpad; l1.eps = 1e-6f; l1.x = k.x_in; l1.dh = ws.dh;
         l1.scale = mod + W; l1.dx_in = dx_mid; l1.dx_out = dx; l1.dshift = dmod; l1.dscale = dmod + W;
+        l1.part = ws.ln_part[1]; l1.part_stride = 3 * W;
         DGS_TRY(launch_layernorm_backward(l1, st));
+        {   // every column sum of the block in one launch: six modulation gradients per sample, four bias gradients
+            const int bias_slots = colsum_slots(M, 4 * W, 4 * W);
+            const ColReduceJob jobs[8] = {
+                {ws.ln_part[1], dmod, ln_slots, 3 * W, 2 * W, B, nmod},                          // shift_msa | scale_msa
+                {ws.gate_part[1], dmod + 2 * W, gate_slots, 2 * W, W, B, nmod},                  // gate_msa
+                {ws.ln_part[0], dmod + 3 * W, ln_slots, 3 * W, 2 * W, B, nmod},                  // shift_mlp | scale_mlp
+                {ws.gate_part[0], dmod + 5 * W, gate_slots, 2 * W, W, B, nmod},                  // gate_mlp
+                {ws.gate_part[0] + W, lg.fc2_b, B * gate_slots, 2 * W, W, 1, 0},
+                {ws.gate_part[1] + W, lg.proj_b, B * gate_slots, 2 * W, W, 1, 0},
+                {ws.fc1b_part, lg.fc1_b, bias_slots, 4 * W, 4 * W, 1, 0},
+                {ws.qkvb_part, lg.qkv_b, colsum_slots(M, 3 * W, 3 * W), 3 * W, 3 * W, 1, 0}};
+            DGS_TRY(launch_col_reduce(jobs, 8, st));
+        }
         if (a->block_done) a->block_done(a->block_user, i);            // block i's eight gradients are final (enqueued)
     }
 
     // ---- input LayerNorm, learned tokens, tokenizer weight ----
     LnBwdParams li{};
     li.rows = M; li.width = W; li.rows_per_batch = lpad; li.eps = 1e-5f; li.x = sv.x0_pre; li.dh = dx; li.dh_f32 = 1; li.weight = m->in_ln_w;
-    li.dx_out = dx_mid; li.dweight = gr->in_ln_w;
+    li.dx_out = dx_mid; li.dweight = gr->in_ln_w; li.part = ws.ln_part[0]; li.part_stride = 3 * W;
     DGS_TRY(launch_layernorm_backward(li, st));
+    {
+        const ColReduceJob job{ws.ln_part[0] + 2 * W, gr->in_ln_w, B * ln_slots, 3 * W, W, 1, 0};
+        DGS_TRY(launch_col_reduce(&job, 1, st));
+    }
     hipLaunchKernelGGL(pos_embed_backward_kernel, dim3((ng * W + 255) / 256), dim3(256), 0, st, dx_mid, gr->pos_emb, B, lpad, L, ng, W);
-    // bf16 + token-contiguous copy of dx0 via gate_mul with a gate of ones (its dgate by-product goes to scratch)
-    DGS_TRY(launch_gate_mul(dx_mid, sv.xn_dec, ws.ones, W, ws.dy, ws.dyT, ws.dcvec, B, lpad, W, st));
-    HIP_TRY(hipMemsetAsync(ws.dcvec, 0, (size_t)B * W * sizeof(float), st));
+    // bf16 + token-contiguous copy of dx0 via gate_mul with a gate of ones (its column-sum by-products stay in the slab)
+    DGS_TRY(launch_gate_mul(dx_mid, sv.xn_dec, ws.ones, W, ws.dy, ws.dyT, ws.gate_part[0], B, lpad, W, st));
     DGS_TRY(launch_transpose(sv.emb, kin, ws.embT, B, lpad, kin, st));
     DGS_TRY(wgrad(ws.dyT, W, ws.embT, kin, gr->tok_w, B, lpad, ws, stream));   // kin = 576: 64-column tiles
 
     // ---- adaLN modulation Linear (all blocks + heads), TimestepEmbedder ----
     RowLinBwdParams ra{};
     ra.M = B; ra.N = nmod; ra.K = W; ra.silu_in = 1; ra.x = sv.cvec; ra.W = m->ada_w; ra.dy = ws.dmod; ra.dW = gr->ada_w; ra.db = gr->ada_b;
-    ra.dx = ws.dcvec;
+    ra.dx = ws.dcvec; ra.part = ws.rl_part;
     DGS_TRY(launch_rowlinear_backward(ra, st));
+    {
+        const ColReduceJob job{ws.rl_part, ws.dcvec, (nmod + ROWLINEAR_BWD_ROWS - 1) / ROWLINEAR_BWD_ROWS, B * W, B * W, 1, 0};
+        DGS_TRY(launch_col_reduce(&job, 1, st));
+    }
     RowLinBwdParams r1{};
     r1.M = B; r1.N = W; r1.K = W; r1.silu_in = 1; r1.x = sv.c1; r1.W = m->t_w1; r1.dy = ws.dcvec; r1.dW = gr->t_w1; r1.db = gr->t_b1; r1.dx = ws.dc1;
+    r1.part = ws.rl_part;
     DGS_TRY(launch_rowlinear_backward(r1, st));
+    {
+        const ColReduceJob job{ws.rl_part, ws.dc1, (W + ROWLINEAR_BWD_ROWS - 1) / ROWLINEAR_BWD_ROWS, B * W, B * W, 1, 0};
+        DGS_TRY(launch_col_reduce(&job, 1, st));
+    }
     RowLinBwdParams r0{};
     r0.M = B; r0.N = W; r0.K = 256; r0.silu_in = 0; r0.x = sv.temb; r0.W = m->t_w0; r0.dy = ws.dc1; r0.dW = gr->t_w0; r0.db = gr->t_b0;
     DGS_TRY(launch_rowlinear_backward(r0, st));

@@ -10,6 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
 
+ABI_VERSION = 3          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
 c_float_p = ctypes.POINTER(ctypes.c_float)
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
@@ -111,8 +112,9 @@ def lib():
         # that copy: loaded the other way round the process holds two runtimes and every launch fails with hipErrorNoDevice.
         import torch  # noqa: F401
         _lib = open_library(LIB_PATH)
-        if _lib.dgs_abi_version() != 1:
-            raise RuntimeError("dgs_amd: ABI version mismatch between Python binding and libdgs_hip.so")
+        if _lib.dgs_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"dgs_amd: ABI version mismatch: libdgs_hip.so reports {_lib.dgs_abi_version()}, this binding is written "
+                               f"for {ABI_VERSION} (include/dgs_raster.h DGS_ABI_VERSION) -- rebuild with `python -m dgs_amd.build`")
     return _lib
 
 
@@ -170,19 +172,20 @@ class DgsDitLayerNormBackwardArgs(ctypes.Structure):
                 ("dh_f32", ctypes.c_int32), ("weight", ctypes.c_void_p), ("scale", ctypes.c_void_p),
                 ("mod_stride", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32), ("eps", ctypes.c_float),
                 ("dx_in", ctypes.c_void_p), ("dx_out", ctypes.c_void_p), ("dshift", ctypes.c_void_p),
-                ("dscale", ctypes.c_void_p), ("dweight", ctypes.c_void_p)]
+                ("dscale", ctypes.c_void_p), ("dweight", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("scratch_bytes", ctypes.c_size_t)]
 
 
 class DgsDitRowLinearBackwardArgs(ctypes.Structure):
     _fields_ = [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("x", ctypes.c_void_p),
                 ("silu_input", ctypes.c_int32), ("W", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dW", ctypes.c_void_p),
-                ("db", ctypes.c_void_p), ("dx", ctypes.c_void_p)]
+                ("db", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("scratch_bytes", ctypes.c_size_t)]
 
 
 class DgsDitGateMulArgs(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("rows", ctypes.c_int32), ("width", ctypes.c_int32), ("dx", ctypes.c_void_p),
                 ("y", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("gate_stride", ctypes.c_int32), ("dy", ctypes.c_void_p),
-                ("dyT", ctypes.c_void_p), ("dgate", ctypes.c_void_p)]
+                ("dyT", ctypes.c_void_p), ("dgate", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("scratch", ctypes.c_void_p),
+                ("scratch_bytes", ctypes.c_size_t)]
 
 
 class DgsDitLayerWeights(ctypes.Structure):
@@ -255,7 +258,8 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
-               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds"]
+               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds",
+               "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes"]
 
 
 def _declare_dit(L):
@@ -267,6 +271,9 @@ def _declare_dit(L):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(argt), ctypes.c_void_p]
+    for fn in (L.dgs_dit_layernorm_backward_scratch_bytes, L.dgs_dit_rowlinear_backward_scratch_bytes, L.dgs_dit_gate_mul_scratch_bytes):
+        fn.restype = ctypes.c_size_t
+        fn.argtypes = [ctypes.c_int32] * 3
     L.dgs_dit_gemm_splitk_bytes.restype = ctypes.c_size_t
     L.dgs_dit_gemm_splitk_bytes.argtypes = [ctypes.c_int32] * 4
     L.dgs_dit_attention_tail_bytes.restype = ctypes.c_size_t

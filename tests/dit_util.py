@@ -43,3 +43,44 @@ def golden_case(kind, tag="hip256"):
     inp = dict(images=t("in_images"), ray_o=ray_o.contiguous(), ray_d=ray_d.contiguous(), t=t("in_t"))
     ref = {k: t("out_" + k) for k in ("xyz", "features", "scaling", "rotation", "opacity", "aligned")}
     return cfg, sd, inp, ref
+
+
+FIELDS = ("xyz", "features", "scaling", "rotation", "opacity")
+
+
+def oracle_gradients(sd, cfg, images, ray_o, ray_d, t, wts, dev):
+    """Parameter gradients of sum_k <out_k, wts_k> by torch autograd through the fp32 oracle evaluated on `dev`, ONE SAMPLE AT A
+    TIME (at L = 4098 the oracle's attention matrices are ~26 GB per sample) and summed over samples in fp64.
+    Returns (outputs per field [B, ...] fp32, {state-dict key: gradient fp64})."""
+    B = images.shape[0]
+    leaf = {k: v.to(dev).requires_grad_(True) for k, v in sd.items()}
+    total = {k: torch.zeros(v.shape, dtype=torch.float64, device=dev) for k, v in leaf.items()}
+    outs = {k: [] for k in FIELDS}
+    for b in range(B):
+        s = slice(b, b + 1)
+        ref, _ = D.image_to_gaussians(leaf, cfg, images[s].to(dev), ray_o[s].to(dev), ray_d[s].to(dev), t[s].to(dev))
+        sum((ref[k] * wts[k][s]).sum() for k in FIELDS).backward()
+        for k, v in leaf.items():
+            if v.grad is not None:
+                total[k] += v.grad.double()
+                v.grad = None
+        for k in FIELDS:
+            outs[k].append(ref[k].detach())
+        del ref
+    return {k: torch.cat(v, 0) for k, v in outs.items()}, total
+
+
+def gradient_errors(grads, ref):
+    """Per tensor: rel-L2, max |diff| / max |ref|, and for 2-D tensors the largest ROW error norm relative to the largest row norm
+    (a single wrong output feature / bias row cannot hide in the tensor norm; relative to the row's OWN norm the measure is noise
+    for rows of the adaLN weight gradients, which are one scalar dmod[n] times a common vector)."""
+    out = {}
+    for k, gv in grads.items():
+        r = ref[k].double()
+        g = gv.reshape(r.shape).double()
+        d = g - r
+        rec = {"rel_l2": float(d.norm() / r.norm().clamp_min(1e-30)), "max_abs": float(d.abs().max() / r.abs().max().clamp_min(1e-30))}
+        if r.dim() == 2 and r.shape[0] > 1:
+            rec["worst_row"] = float(d.norm(dim=1).max() / r.norm(dim=1).max().clamp_min(1e-30))
+        out[k] = rec
+    return out

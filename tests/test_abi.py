@@ -28,14 +28,16 @@ def test_every_declared_symbol_is_exported():
         for n in names:
             assert hasattr(lib, n), f"{n} declared in {header} but not exported"
         assert sorted(table) == names, (header, sorted(set(names) ^ set(table)))
-    assert lib.dgs_abi_version() == 1
+    assert lib.dgs_abi_version() == _native.ABI_VERSION == int(re.search(r"#define DGS_ABI_VERSION (\d+)", open(os.path.join(INC, "dgs_raster.h")).read()).group(1))
     assert lib.dgs_dit_lpad(4098) == 4352
     assert lib.dgs_status_string(-1).decode().startswith("invalid argument")
 
 
 def test_ctypes_structs_match_c_layout():
     structs = ["DgsRasterForwardArgs", "DgsRasterBackwardArgs", "DgsDitGemmArgs", "DgsDitAttentionArgs", "DgsDitLayerNormArgs",
-               "DgsDitRowLinearArgs", "DgsDitLayerWeights", "DgsDitModel", "DgsDitForwardArgs", "DgsSamplerStepArgs", "DgsMseArgs"]
+               "DgsDitRowLinearArgs", "DgsDitLayerWeights", "DgsDitModel", "DgsDitForwardArgs", "DgsSamplerStepArgs", "DgsMseArgs",
+               "DgsDitLayerNormBackwardArgs", "DgsDitRowLinearBackwardArgs", "DgsDitGateMulArgs", "DgsDitAttentionBackwardArgs",
+               "DgsDitBackwardArgs", "DgsDitRunBlocksArgs", "DgsResizeArgs"]
     src = '#include <stdio.h>\n#include "dgs_dit.h"\n#include "dgs_sampler.h"\n#include "dgs_loss.h"\nint main(){' + "".join(
         f'printf("%zu\\n", sizeof({s}));' for s in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:

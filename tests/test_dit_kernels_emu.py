@@ -250,11 +250,15 @@ def test_layernorm_backward(ops):
     h = F.layer_norm(x, (Wd,), w, None, 1e-6) * (1 + scale.repeat_interleave(rows, 0)) + shift.repeat_interleave(rows, 0)
     h.backward(dh.float())
     dmod = torch.zeros(B, 3 * Wd)
-    dw = torch.zeros(Wd)
+    dmod[:, :2 * Wd] = 7.0                         # the column sums are WRITTEN (per-workgroup partial rows + one ordered reduce)
+    dw = torch.full((Wd,), 7.0)
     dx = torch.zeros(B * rows, Wd)
+    nb = ops.lib.dgs_dit_layernorm_backward_scratch_bytes(B * rows, Wd, rows)
+    assert nb == B * (rows // 32) * 3 * Wd * 4
+    scratch = torch.full((nb // 4,), float("nan"))
     _call(ops, "dgs_dit_layernorm_backward", _native.DgsDitLayerNormBackwardArgs, rows=B * rows, width=Wd, x=x.detach(), dh=dh,
           dh_f32=0, weight=w.detach(), scale=mod[:, Wd:], mod_stride=3 * Wd, rows_per_batch=rows, eps=1e-6, dx_in=dx_in, dx_out=dx,
-          dshift=dmod, dscale=dmod[:, Wd:], dweight=dw)
+          dshift=dmod, dscale=dmod[:, Wd:], dweight=dw, scratch=scratch, scratch_bytes=nb)
     assert torch.allclose(dx, x.grad + dx_in, atol=2e-4, rtol=1e-3)
     assert torch.allclose(dmod[:, :Wd], shift.grad, atol=1e-3, rtol=1e-3)
     assert torch.allclose(dmod[:, Wd:2 * Wd], scale.grad, atol=2e-3, rtol=1e-3)
@@ -271,9 +275,11 @@ def test_rowlinear_backward_and_gate_mul(ops):
     b = torch.zeros(N, requires_grad=True)
     dy = torch.randn(M, N, generator=g)
     F.linear(F.silu(x), Wf, b).backward(dy)
-    dW, db, dx = torch.zeros(N, K), torch.zeros(N), torch.zeros(M, K)
+    dW, db, dx = torch.zeros(N, K), torch.zeros(N), torch.full((M, K), 7.0)
+    nb = ops.lib.dgs_dit_rowlinear_backward_scratch_bytes(M, N, K)
+    scratch = torch.full((nb // 4,), float("nan"))
     _call(ops, "dgs_dit_rowlinear_backward", _native.DgsDitRowLinearBackwardArgs, M=M, N=N, K=K, x=x.detach(), silu_input=1, W=Wb,
-          dy=dy, dW=dW, db=db, dx=dx)
+          dy=dy, dW=dW, db=db, dx=dx, scratch=scratch, scratch_bytes=nb)
     assert torch.allclose(dW, Wf.grad, atol=1e-4, rtol=1e-4) and torch.allclose(db, b.grad, atol=1e-5)
     assert torch.allclose(dx, x.grad, atol=1e-4, rtol=1e-4)
     # gate_mul
@@ -284,8 +290,14 @@ def test_rowlinear_backward_and_gate_mul(ops):
     dyo = torch.zeros(B * rows, Wd, dtype=torch.bfloat16)
     dyT = torch.zeros(B, Wd, rows, dtype=torch.bfloat16)
     dgate = torch.zeros(B, 2 * Wd)
+    dgate[:, Wd:] = 7.0
+    dbias = torch.full((Wd,), 7.0)
+    nb = ops.lib.dgs_dit_gate_mul_scratch_bytes(B, rows, Wd)
+    scratch = torch.full((nb // 4,), float("nan"))
     _call(ops, "dgs_dit_gate_mul", _native.DgsDitGateMulArgs, B=B, rows=rows, width=Wd, dx=dxr, y=y, gate=gate[:, Wd:], gate_stride=2 * Wd,
-          dy=dyo, dyT=dyT, dgate=dgate[:, Wd:])
+          dy=dyo, dyT=dyT, dgate=dgate[:, Wd:], dbias=dbias, scratch=scratch, scratch_bytes=nb)
+    assert torch.allclose(dbias, dyo.float().sum(0), atol=1e-3, rtol=1e-4)
+    assert float(dgate[:, :Wd].abs().max()) == 0.0
     want = gate[:, Wd:].repeat_interleave(rows, 0) * dxr
     assert torch.allclose(dyo.float(), want, atol=3e-2, rtol=1e-2)
     assert torch.equal(dyT, dyo.reshape(B, rows, Wd).transpose(1, 2))
