@@ -15,8 +15,9 @@ per GPU, RCCL); launched BY torch.distributed.run (the driver's way) it reads RA
 Prints ONE JSON line (rank 0).  Extra objects next to the contract keys:
   roofline      dominant DiT kernel, HIP events on the launch stream inside the timed region; `traffic` from the PMC passes of
                 tools/pmc_traffic.py IF they were taken on exactly these kernel sources (else null)
-  raster        the rasterizer on its HBM roofline, forward and forward+backward, in the regime the step renders (random-init
-                Gaussians) and the trained-like regime, algorithmic bytes 104 P + 84 N + 20 HW per view
+  raster        the rasterizer on its HBM and fp32-VALU rooflines, forward and forward+backward, in the regime the step renders
+                (random-init Gaussians) and the trained-like regime; bytes and pair evaluations are those the call
+                WALKS (from its own state: tile_work / list_len / tile_stats), not those of the N instances a full list would hold
   scene_512     BASELINE configs[4] at inference: the scene model's sampling step at 512^2 (L = 16,386, P = 1,048,578), informational
   train_step    BASELINE configs[3]: B = 4 samples / GPU, 10 rendered views, forward + backward + gradient all-reduce
                 (overlapped, RCCL) + AdamW step + weight refresh, `DataParallelTrainer.step` end to end
@@ -45,6 +46,16 @@ for _p in (ROOT, os.path.join(ROOT, "open-diffusiongs_amd")):
 PEAK_BF16_MFMA = 2.5e15      # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_HBM = 8.0e12            # spec, same guide "HBM3E peak BW"
 PROF_KINDS = {"attention": 1, "gemm_qkv": 2, "gemm_gate_residual": 3, "gemm_fc1_gelu": 4, "layernorm": 5}
+
+
+MODEL_CFG = dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="relative_plk")     # the shipped diffusion-gs-model
+DRY = {"on": False, "lib": None}    # --dry-run-cpu: CPU emulator build + gloo, a tiny model: exercises the N > 1 plumbing, measures nothing
+
+
+def _sync():
+    if not DRY["on"]:
+        import torch
+        torch.cuda.synchronize()
 
 
 def dit_flops(L, width=1024, layers=24, n_img_tokens=None, patch=8, gs_ch=14):
@@ -150,25 +161,36 @@ def cpu_baseline(model, batch, t, res, V, hip_gaussians, hip_render):
     mine = np.clip(hip_render[0, 0].cpu().numpy(), 0, 1)
     mse = float(np.mean((ref.astype(np.float64) - mine) ** 2))
     psnr = 200.0 if mse == 0 else -10.0 * np.log10(mse)
-    return dict(value=V / (t_dit + t_raster), unit="renders/s", cores=max(dit_threads, raster_threads), kind="port",
+    return dict(value=V / (t_dit + t_raster), unit="renders/s", cores=dit_threads, kind="port",
                 sample=f"1 sample of the same step: DiT forward at L=4098, all 24 blocks ({t_dit:.1f} s, torch-CPU fp32 oracle, "
                        f"{dit_threads} threads) + {V} oracle rasterizations at {res}^2 ({t_raster:.2f} s, C++ oracle, OpenMP over "
-                       f"Gaussians / tiles, {raster_threads} threads); host has {cores} cores"), float(psnr)
+                       f"Gaussians / tiles, {raster_threads} threads); `cores` = the threads of the DiT leg, which is 97 % of the time; host has {cores} cores"), float(psnr)
+
+
+PEAK_FP32_VALU = 157.3e12   # same guide, "Peak FP32 (vector)"
+FLOP_PER_PAIR_FWD, FLOP_PER_PAIR_BWD = 25.0, 65.0    # fp32 operations of one (pixel, Gaussian) evaluation, forward.cu:332-358 / backward.cu:463-532
 
 
 def raster_roofline(dev, res, V, iters=10):
-    """Rasterizer on its roofline (HBM, 8 TB/s): forward and forward+backward of V views of the DiffusionGS-shaped synthetic
-    scenes of SURVEY.md 8d, timed with HIP events on the launch stream (the rasterizer launches on torch's current stream).
-    Algorithmic bytes per view: forward 104 P + 84 N + 20 HW, backward 251 P + 40 N + 20 HW; blend work 256 N pair
-    evaluations (upper bound, before early-out)."""
+    """Rasterizer on its two rooflines: forward and forward+backward of V views of the DiffusionGS-shaped synthetic scenes of
+    SURVEY.md 8d, timed with HIP events on the launch stream (the rasterizer launches on torch's current stream).
+    `hbm`: algorithmic bytes of what the call WALKS -- per view 104 P + 20 HW (forward; + 251 P + 20 HW backward), per list
+      entry walked 4 (index) + 40 (record gather), per entry listed 4, per depth rank scanned 4 (scan form), per instance of a
+      materialised list 44 more (emit + sort: the list forms) -- the counts come from the call's own state (`tile_work`,
+      `list_len`, `tile_stats`), not from N: a saturated tile walks a few per cent of its list.
+    `valu`: the blend loops are fp32-VALU bound: pair evaluations actually executed (16 x the cell-list entries walked) x 25 (65 in
+      the backward) fp32 operations / call time against the 157.3 TFLOP/s vector peak; `lane_use` = executed pairs / lane slots the
+      waves issued (four 16-lane rows walk their cells' lists in lockstep)."""
     import numpy as np
     import torch
     from dgs_amd import cameras, synth
     from dgs_amd.raster import default_backend, render_views_autograd
     be = default_backend()
-    out = {"bound": "hbm", "peak": PEAK_HBM / 1e9, "unit": "GB/s", "views": V, "resolution": res}
+    out = {"views": V, "resolution": res, "exact_exp": bool(be.exact_exp),
+           "hbm": {"bound": "hbm", "peak": PEAK_HBM / 1e9, "unit": "GB/s"}, "valu": {"bound": "valu", "peak": PEAK_FP32_VALU / 1e12, "unit": "TFLOP/s"}}
     tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
     traffic = pmc_traffic("raster")
+    T = ((res + 15) // 16) ** 2
     for regime in ("init", "trained"):
         sc = synth.gaussian_scene(res, regime=regime, seed=0, activated=False)
         leaves = [tt(sc[k])[None].requires_grad_(True) for k in ("xyz", "shs", "scales", "rotations", "opacities")]
@@ -177,19 +199,32 @@ def raster_roofline(dev, res, V, iters=10):
         w = torch.randn(1, V, 3, res, res, device=dev) / (3 * res * res)
         P = int(leaves[0].shape[1])
         view, proj, campos, tanfov = be.cameras_from_c2w(c2w, k, res, res)
-        fwd = lambda: be.forward_views(torch.ones(3, device=dev), leaves[0].detach(), None, leaves[4].detach().reshape(1, -1),
-                                       leaves[2].detach(), leaves[3].detach(), 1.0, None, view, proj, campos, tanfov, 0.0, 0.0,
-                                       res, res, leaves[1].detach(), 0, False, False, views_per_set=V, raw_activations=True)
-        N = int(fwd()[0])
+        det = [x.detach() for x in leaves]
+        fwd = lambda: be.forward_views(torch.ones(3, device=dev), det[0], None, det[4].reshape(1, -1), det[2], det[3], 1.0, None, view, proj,
+                                       campos, tanfov, 0.0, 0.0, res, res, det[1], 0, False, False, views_per_set=V, raw_activations=True)
+        N, _color, radii, geom, binning, img = fwd()
+        N = int(N)
+        rd = lambda name, cnt: be.state_read(name, P, res, res, V, N, geom, binning, img, torch.int32, cnt).long()
+        be.backward_views(torch.ones(3, device=dev), det[0], radii, None, det[4].reshape(1, -1), det[2], det[3], 1.0, None, view, proj, campos,
+                          tanfov, 0.0, 0.0, w.reshape(V, 3, res, res), det[1], 0, geom, N, binning, img, False, views_per_set=V, raw_activations=True)
+        sf, sb = rd("tile_stats", V * T * 4).reshape(V * T, 4).sum(0).tolist(), rd("tile_stats_bwd", V * T * 4).reshape(V * T, 4).sum(0).tolist()
+        walked, listed = int(rd("tile_work", V * T).sum()), int(rd("list_len", V * T).sum())
+        scanned = sf[2]
+        inst = 0 if scanned else N                                       # the list forms materialise and sort all N instances
+        bytes_f = V * (104 * P + 20 * res * res) + 44 * walked + 4 * listed + 4 * scanned + 44 * inst
+        bytes_b = V * (251 * P + 20 * res * res) + 44 * walked
+        flop_f, flop_b = FLOP_PER_PAIR_FWD * 16 * sf[0], FLOP_PER_PAIR_BWD * 16 * sb[0]
 
         def fb():
             for x in leaves:
                 x.grad = None
             render_views_autograd(be, *leaves, res, res, c2w, k).backward(w)
 
-        rec = {"P": P, "N_per_view": N // V}
-        for name, fn, nbytes in (("forward", fwd, V * (104 * P + 20 * res * res) + 84 * N),
-                                 ("forward_backward", fb, V * (355 * P + 40 * res * res) + 124 * N)):
+        rec = {"P": P, "N_per_view": N // V, "binning": "scan" if scanned else "list", "entries_walked_per_view": walked // V,
+               "entries_listed_per_view": listed // V, "ranks_scanned_per_view": scanned // V,
+               "pair_evals_forward": 16 * sf[0], "pair_evals_backward": 16 * sb[0],
+               "lane_use_forward": round(16 * sf[0] / max(64 * sf[1], 1), 3), "lane_use_backward": round(16 * sb[0] / max(64 * sb[1], 1), 3)}
+        for name, fn, nbytes, flops in (("forward", fwd, bytes_f, flop_f), ("forward_backward", fb, bytes_f + bytes_b, flop_f + flop_b)):
             for _ in range(3):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -200,11 +235,14 @@ def raster_roofline(dev, res, V, iters=10):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
             rec[name] = {"ms": round(ms, 4), "views_per_s": round(V / ms * 1e3, 1), "algorithmic_bytes": int(nbytes),
-                         "achieved": round(nbytes / ms / 1e6, 1), "frac": round(nbytes / (ms * 1e-3) / PEAK_HBM, 4),
-                         "pair_evals_per_s": round(256.0 * N * (1 if name == "forward" else 2) / (ms * 1e-3), 0)}
+                         "hbm_achieved": round(nbytes / ms / 1e6, 1), "hbm_frac": round(nbytes / (ms * 1e-3) / PEAK_HBM, 4),
+                         "valu_achieved": round(flops / (ms * 1e-3) / 1e12, 2), "valu_frac": round(flops / (ms * 1e-3) / PEAK_FP32_VALU, 4),
+                         "pair_evals_per_s": round((16 * sf[0] + (16 * sb[0] if name != "forward" else 0)) / (ms * 1e-3), 0)}
             if traffic and traffic.get("raster", {}).get(regime, {}).get(name) is not None:
                 rec[name]["traffic"] = traffic["raster"][regime][name]
         out[regime] = rec
+    if traffic and traffic.get("fetch_calibration"):
+        out["fetch_calibration"] = traffic["fetch_calibration"]
     return out
 
 
@@ -254,12 +292,12 @@ def train_bench(a, dev, rank, world, steps, warmup):
     from dgs_amd import cameras, denoiser as dn, synth
     from dgs_amd.train import DataParallelTrainer
     B, V, res, RV = a.train_batch, a.views, a.res, a.train_views
-    model = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="relative_plk"), device=dev)
+    model = dn.DGSDenoiser(MODEL_CFG, device=dev, lib=DRY["lib"])
     model.reset_parameters(seed=0)          # identical replicas on every rank
     model = model.to(dev)                   # fp32 master parameters + optimizer state on the GPU
     model.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True)
-    tr = DataParallelTrainer(model, opt, bucket_bytes=a.bucket_mb << 20)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=not DRY["on"])
+    tr = DataParallelTrainer(model, opt, bucket_bytes=(a.bucket_mb << 20) if a.bucket_mb > 0 else None, compress=a.grad_exchange if a.grad_exchange != "fp32" else None)
     batch, t = synth.make_batch(B, res, V=V, device=dev, seed=100 + rank, with_t=True)
     rc2w = torch.tensor(np.stack([cameras.ring_cameras(RV, phase_deg=5.0 + 7 * b) for b in range(B)])).to(dev)
     rk = torch.tensor(cameras.default_fxfycxcy(res)).expand(B, RV, 4).contiguous().to(dev)
@@ -268,11 +306,11 @@ def train_bench(a, dev, rank, world, steps, warmup):
         loss = tr.step(batch, t, target, rc2w, rk)
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.step(batch, t, target, rc2w, rk)
-    torch.cuda.synchronize()
+    _sync()
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
@@ -284,14 +322,17 @@ def train_bench(a, dev, rank, world, steps, warmup):
     L = eng.num_tokens(V, res, res)
     ms = elapsed / steps * 1e3
     recompute = bool(eng._train.get("recompute"))
-    flops = (4 if recompute else 3) * dit_flops(L) * B
+    flops = (4 if recompute else 3) * dit_flops(L, MODEL_CFG["width"], MODEL_CFG["num_layers"]) * B
     log = tr.reducer.launch_log
+    tr.close()
     return {"ms_per_step": round(ms, 2), "samples_per_s": round(B * world / (ms * 1e-3), 2), "batch_per_gpu": B, "rendered_views": RV,
             "steps": steps, "warmup": warmup, "loss": round(float(loss), 6), "recompute": recompute,
             "dit_tflops_per_gpu": round(flops / (ms * 1e-3) / 1e12, 1), "frac_of_bf16_peak": round(flops / (ms * 1e-3) / PEAK_BF16_MFMA, 4),
             "saved_activation_gib": round(eng._train["saved"].numel() / 2 ** 30, 2),
-            "allreduce": {"world": world, "buckets": len(tr.reducer.bounds), "bucket_mib": a.bucket_mb,
+            "allreduce": {"world": world, "buckets": len(tr.reducer.bounds), "exchange": a.grad_exchange,
+                          "bucket_mib": [round((e - b) * 4 / 2 ** 20, 1) for b, e in tr.reducer.bounds],
                           "launched_during_backward": sum(1 for _, tag in log if isinstance(tag, int)),
+                          "last_bucket_mib": round((tr.reducer.bounds[-1][1] - tr.reducer.bounds[-1][0]) * 4 / 2 ** 20, 1),
                           "gradient_bytes": int(tr.fg.flat.numel() * 4)},
             "note": "DataParallelTrainer.step end to end: fwd + raster + MSE + bwd (+ overlapped all-reduce) + fused AdamW + weight refresh"}
 
@@ -309,7 +350,10 @@ def main():
     ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--train-views", type=int, default=10)
     ap.add_argument("--train-steps", type=int, default=5)
-    ap.add_argument("--bucket-mb", type=int, default=256)
+    ap.add_argument("--bucket-mb", type=int, default=0, help="all-reduce bucket size; 0 = 32 MiB per rank (dgs_amd/parallel.py)")
+    ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce (bf16: half the xGMI bytes)")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="NOT a measurement: the same script on the CPU emulator build of the kernels with "
+                    "gloo and a tiny model (width 256, 2 blocks, 64^2) -- what tests/test_bench_dry_run.py uses to exercise the N > 1 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
     ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the informational objects may take before the line is printed without them")
@@ -322,15 +366,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if a.dry_run_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu_util import emu_lib                 # test infrastructure: the csrc/*.hip sources compiled for the CPU emulator
+        DRY.update(on=True, lib=emu_lib())
+        MODEL_CFG.update(width=256, num_layers=2)
+        a.res, a.train_batch, a.train_views, a.no_extras = 64, min(a.train_batch, 2), min(a.train_views, 2), True
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL
+        if a.dry_run_cpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dry_note = {"dry_run": "CPU emulator + gloo + tiny model: exercises launch / timing / reduction plumbing, NOT a measurement"} if a.dry_run_cpu else {}
 
     if a.mode == "train":
         tb = train_bench(a, dev, rank, world, a.steps, a.warmup)
@@ -341,13 +397,13 @@ def main():
                 "ms_per_step": tb["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                 "data": "synthetic", "config": {"workload": f"obj-{a.res} training step (BASELINE.json configs[3]): B={a.train_batch} samples/GPU, "
                                                             f"4 input views, {a.train_views} rendered views, 460 M parameters, random init",
-                                                "parallelism": f"dp{world}"}, "train_step": tb}), flush=True)
+                                                "parallelism": f"dp{world}"}, "train_step": tb, **dry_note}), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
 
     from dgs_amd import denoiser as dn, synth
-    model = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="relative_plk"), device=dev)
+    model = dn.DGSDenoiser(MODEL_CFG, device=dev, lib=DRY["lib"])
     model.reset_parameters(seed=0)          # every rank the same random-init weights (pure data parallel inference)
     B, V, res = a.batch, a.views, a.res
     batch, t = synth.make_batch(B, res, V=V, device=dev, seed=rank, with_t=True)
@@ -379,29 +435,30 @@ def main():
         for timed in (False, True):
             loop_batch["image"] = batch["image"].clone()
             loop_batch["image_noisy"] = torch.randn_like(batch["image"][:, 1:])
-            torch.cuda.synchronize()
+            _sync()
             l0 = time.perf_counter()
             with torch.no_grad():
                 diffusion.p_sample_loop(model, loop_batch)
-            torch.cuda.synchronize()
+            _sync()
             if timed:
                 loop_ms = (time.perf_counter() - l0) * 1e3
 
     for _ in range(a.warmup):
         step()
-    per_step = {"attention": 24, "gemm_qkv": 24, "gemm_gate_residual": 48, "gemm_fc1_gelu": 24, "layernorm": 48}[a.roofline_kernel]
+    nl = MODEL_CFG["num_layers"]
+    per_step = {"attention": nl, "gemm_qkv": nl, "gemm_gate_residual": 2 * nl, "gemm_fc1_gelu": nl, "layernorm": 2 * nl}[a.roofline_kernel]
     # HIP events around every launch of the roofline kernel on every 4th step of the timed region: an event record is a packet
     # of its own between two kernels (~2 us), 48 of them per step were 1.5 % of the step they measure
-    prof_steps = [i for i in range(a.steps) if i % 4 == 0]
+    prof_steps = [] if a.dry_run_cpu else [i for i in range(a.steps) if i % 4 == 0]
     events = {i: [torch.cuda.Event(enable_timing=True) for _ in range(2 * per_step)] for i in prof_steps}
     for ev in events.values():  # materialise the HIP event handles before the timed region
         for e in ev:
             e.record()
-    barrier(); torch.cuda.synchronize()
+    barrier(); _sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         rendered, gaussians, _pc = step(prof=(PROF_KINDS[a.roofline_kernel], events[i]) if i in events else None)
-    torch.cuda.synchronize(); barrier()
+    _sync(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -413,7 +470,7 @@ def main():
         ms = elapsed / a.steps * 1e3
         value = B * V * world / (elapsed / a.steps)
         kern_ms = [events[i][2 * j].elapsed_time(events[i][2 * j + 1]) for i in prof_steps for j in range(per_step)]
-        avg_s = float(np.mean(kern_ms)) * 1e-3
+        avg_s = float(np.mean(kern_ms)) * 1e-3 if kern_ms else float("inf")
         achieved = kernel_flops(a.roofline_kernel, L, B) / avg_s / 1e12
         traffic = pmc_traffic("dit")
         tr_bytes = None
@@ -424,14 +481,15 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"obj-{res} sampling step (BASELINE.json configs[2]): DGSDenoiser.forward = DiT "
-                                   f"image_to_gaussians (width 1024, 24 blocks, L={L}, bf16 MFMA, fp32 accumulate) + {V} fp32 "
+                                   f"image_to_gaussians (width {MODEL_CFG['width']}, {nl} blocks, L={L}, bf16 MFMA, fp32 accumulate) + {V} fp32 "
                                    f"rasterizations of P={2 + V * res * res} Gaussians at {res}^2 per sample; random-init weights",
                        "batch_per_gpu": B, "views": V, "resolution": res, "tokens": L, "gaussians": 2 + V * res * res,
-                       "dit_tflop_per_sample": round(dit_flops(L) / 1e12, 3), "parallelism": f"dp{world}"},
+                       "dit_tflop_per_sample": round(dit_flops(L, MODEL_CFG["width"], nl) / 1e12, 3), "parallelism": f"dp{world}"},
             "roofline": {"kernel": a.roofline_kernel, "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_MFMA, 4), "traffic": tr_bytes,
                          "launches_timed": len(kern_ms), "avg_launch_us": round(avg_s * 1e6, 2),
-                         "step_frac_of_peak": round(dit_flops(L) * B / (ms * 1e-3) / PEAK_BF16_MFMA, 4)},
+                         "step_frac_of_peak": round(dit_flops(L, MODEL_CFG["width"], nl) * B / (ms * 1e-3) / PEAK_BF16_MFMA, 4)},
+            **dry_note,
         }
         if loop_ms is not None:
             out["sampling_loop_30_steps"] = {"ms_per_loop": round(loop_ms, 2), "renders_per_s": round(B * V * 30 / (loop_ms * 1e-3), 1),

@@ -269,12 +269,15 @@ typedef struct DgsDitModelT {
 
 typedef struct DgsDitLayerGrads {
     float *qkv_w, *proj_w, *fc1_w, *fc2_w, *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    float *ada_w, *ada_b;                      /* the block's adaLN_modulation.1: [6W, W], [6W] -- final together with the block's
+                                                  other gradients (its rows of the stacked DgsDitModel.ada_w)              */
 } DgsDitLayerGrads;
 
 typedef struct DgsDitGrads {                   /* f32 gradient of every parameter, same shapes as the state dict; WRITTEN   */
     float *t_w0, *t_b0, *t_w1, *t_b1, *tok_w, *pos_emb, *in_ln_w;
     const DgsDitLayerGrads* layer;             /* HOST array [layers]                                    */
-    float *ada_w, *ada_b;                      /* stacked like DgsDitModel.ada_w / ada_b                 */
+    float *head_ada_w, *head_ada_b;            /* the last 4W rows of the stacked DgsDitModel.ada_w / ada_b: upsampler (2W), then
+                                                  image_token_decoder (2W); final with the heads (stage = layers)          */
     float *up_ln_w, *up_w, *dec_ln_w, *dec_w;
 } DgsDitGrads;
 
@@ -287,8 +290,9 @@ typedef struct DgsDitBackwardArgs {
     int32_t recompute;                         /* must equal the forward's train_recompute              */
     /* Optional host callback, called from inside dgs_dit_backward as soon as the kernels that complete a GROUP of
      * gradients have been enqueued on `stream` (they have not run yet: order follow-up work behind the stream):
-     * stage = layers: the two heads (dec_w, dec_ln_w, up_w, up_ln_w); stage = layers-1 .. 0: that block's eight tensors;
-     * stage = -1: the rest (embeddings, adaLN stack, timestep MLP).  This is where a data-parallel caller enqueues the
+     * stage = layers: the two heads (dec_w, dec_ln_w, up_w, up_ln_w, head_ada_w / _b); stage = layers-1 .. 0: that block's ten
+     * tensors (incl. its adaLN Linear: a third of all parameters sits in those, none of it waits for the end of the backward);
+     * stage = -1: the rest (embeddings, timestep MLP: ~2 M parameters).  This is where a data-parallel caller enqueues the
      * all-reduce of a finished gradient bucket so that it overlaps the remaining backward (Lightning DDP's overlap,
      * configs/diffusionGS_rel.yaml:80).                                                                            */
     void (*block_done)(void* user, int32_t stage);

@@ -98,6 +98,11 @@ typedef struct DgsRasterForwardArgs {
                                     tests / measurement: 1 instance list + depth-rank bitmap sort, 2 per-tile scan of the
                                     depth-ordered Gaussians, 3 instance list + per-tile bitonic sort in LDS.  All forms
                                     produce the reference's lists bit for bit.                                       */
+    int32_t exact_exp;           /* exponential of a (pixel, Gaussian) pair in the blend loop.  0 (default): the hardware's
+                                    v_exp_f32 -- what the reference's `exp()` compiles to under its fast-math build; 1: a fixed
+                                    IEEE sequence the CPU oracle restates (oracle exp_mode 1), every float of the result
+                                    bit-identical with the oracle.  Integer artefacts that do not depend on alpha (radii, tile
+                                    lists, ranges, sort order) are identical in both; pass the same value to the backward.  */
 } DgsRasterForwardArgs;
 
 typedef struct DgsRasterBackwardArgs {
@@ -124,7 +129,9 @@ typedef struct DgsRasterBackwardArgs {
     const void* geom_buffer;
     const void* binning_buffer;
     const void* img_buffer;
-    /* gradient outputs; the callee zero-fills them (the reference's torch::zeros, rasterize_points.cu:148-156).
+    /* gradient outputs: the callee zero-fills what it accumulates into and WRITES every other element (the caller need not
+     * pre-fill anything; the reference's torch::zeros, rasterize_points.cu:148-156).  dL_dmeans2D, dL_dconic, dL_dcolors and
+     * dL_dopacity laid out back to back in that order are zeroed with one fill.
      * With V > 1 gradients of the views of one set are SUMMED into that set's slot.   */
     float* dL_dmeans2D;   /* [V,P,3]  (per view, like the reference's per-call tensor)   */
     float* dL_dconic;     /* [V,P,4]  scratch ([P,2,2] in the reference), never returned to Python */
@@ -136,6 +143,7 @@ typedef struct DgsRasterBackwardArgs {
     float* dL_dsh;        /* [S,P,M,3] or NULL */
     float* dL_dscales;    /* [S,P,3]  or NULL */
     float* dL_drotations; /* [S,P,4]  or NULL */
+    int32_t exact_exp;    /* as DgsRasterForwardArgs.exact_exp: must equal the forward's */
 } DgsRasterBackwardArgs;
 
 int dgs_abi_version(void);

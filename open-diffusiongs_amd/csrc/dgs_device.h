@@ -67,6 +67,26 @@ __device__ __forceinline__ float det_expf_core(float x) {
     return __builtin_ldexpf(y, (int)n);
 }
 
+// One v_exp_f32 (2^x, ~1 ulp, no denormal fix-up): the hardware exponential.  The CPU emulation build uses libm.
+__device__ __forceinline__ float hw_exp2(float x) {
+#ifdef HIPEMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+
+// exp(power) of a (pixel, Gaussian) pair inside the blend loops (-5.6 < power <= 0 for every pair that passes the cut-off).
+// FAST (the product default): v_mul + v_exp_f32 -- what the reference's CUDA `exp()` under fast math is on its hardware, two VALU
+//   instead of fourteen in the innermost loop of both blend kernels; integer artefacts that do not depend on alpha (radii, tile
+//   lists, ranges, sort order) are unaffected, colours move by a few fp32 ulp.
+// exact: det_expf_core, the fixed IEEE sequence the oracle restates (exp_mode 1): every float bit-identical with the oracle.
+template <bool FAST>
+__device__ __forceinline__ float blend_exp(float power) {
+    if constexpr (FAST) return hw_exp2(power * 1.44269504088896341f);
+    else return det_expf_core(power);
+}
+
 // Exclusive scan of one value per thread over a block of `NT` threads (NT multiple of 64, <= 1024).
 // `scratch` needs NT/64 + 1 uint32 of LDS.  Returns the exclusive prefix; *total receives the block sum.
 template <int NT>

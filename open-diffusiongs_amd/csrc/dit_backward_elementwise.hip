@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void rowlinear_backward_kernel(RowLinBwdParams
         float dyv[MR];
         float bsum = 0.f;
 #pragma unroll
-        for (int m = 0; m < MR; ++m) { dyv[m] = (m < p.M) ? p.dy[(size_t)m * p.N + n] : 0.f; bsum += dyv[m]; }
+        for (int m = 0; m < MR; ++m) { dyv[m] = (m < p.M) ? p.dy[(size_t)m * (p.ldy ? p.ldy : p.N) + n] : 0.f; bsum += dyv[m]; }
         if (p.db && lane == 0) p.db[n] = bsum;
         const bf16_t* wr = p.W + (size_t)n * p.K;
 #pragma unroll

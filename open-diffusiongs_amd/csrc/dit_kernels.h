@@ -61,7 +61,8 @@ struct RowLinBwdParams {
     int M, N, K, silu_in;
     const float* x;       // [M, K] pre-activation input
     const bf16_t* W;      // [N, K]
-    const float* dy;      // [M, N]
+    const float* dy;      // [M, N], row stride ldy (0: N)
+    int ldy;
     float* dW;            // [N, K] or NULL
     float* db;            // [N] or NULL
     float* dx;            // [M, K] or NULL (with `part`: only says that dx is wanted)
@@ -76,7 +77,8 @@ struct ColReduceJob {
 };
 struct ColReduceParams { ColReduceJob job[8]; };
 
-constexpr int ROWLINEAR_BWD_ROWS = 256;     // output features per workgroup of rowlinear_backward_kernel
+constexpr int ROWLINEAR_BWD_ROWS = 32;      // output features per workgroup of rowlinear_backward_kernel (a block's adaLN Linear, 6W rows, is a launch
+                                            // of its own: 192 workgroups at W = 1024; at 256 rows per workgroup it would stream on 24 CUs)
 inline int ln_backward_rows_per_block(int rows_per_batch) { return rows_per_batch % 32 == 0 ? 32 : rows_per_batch; }
 
 struct GsBwdParams {

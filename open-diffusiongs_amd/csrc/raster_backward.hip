@@ -22,7 +22,7 @@
 namespace dgs {
 
 struct BwdParams {
-    int P, D, M, W, H, V, vps, gx, gy, T, raw_act;
+    int P, D, M, W, H, V, vps, gx, gy, T, raw_act, exact_exp;
     const float *bg, *means3D, *shs, *colors_pre, *opac, *scales, *rots, *cov_pre, *viewm, *projm, *campos, *tanfov;
     float tanfovx, tanfovy, scale_mod;
     const int* radii;
@@ -47,8 +47,10 @@ struct BwdParams {
 // Measured per 4 views at 256^2, trained-like / random-init regime, forward + backward: one atomic per wave per value 4.14 /
 // 2.49 ms; 16 x 4 strip masks 3.45 / 2.11; + combining a tile's four strips in LDS 3.00 / 1.88; + launch order by work 2.33 /
 // 1.70; cells: see DESIGN.md.  (One wave per tile with four pixels per lane lost: a latency chain.)
+template <bool FAST_EXP>
 __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     __shared__ uint32_t s_id[256];
+    __shared__ uint2 s_stat[4];
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
     __shared__ float4 s_rgbc[256];                        // colour, alpha cut-off on `power`
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     const uint32_t todo = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));   // <= rg.y - rg.x
     const int rounds = (int)((todo + 255u) / 256u);
     const bool colors_per_set = p.colors_pre != nullptr;
+    uint32_t st_entries = 0, st_trips = 0;                      // tile_stats (measurement)
     for (int i = 0; i < rounds; ++i) {
         // batch entry e (0..255) = 1-based list index contributor = todo - (i * 256 + e), list position rg.x + contributor - 1
         const int idx = (int)todo - 1 - (i * 256 + tid);
@@ -139,7 +142,9 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             float2 xy = s_xy[j];
             float4 co = s_co[j];
             float4 rc = s_rgbc[j];
-            for (uint32_t k = 0; __ballot(k < tot) != 0ull; ++k) {
+            st_entries += tot;
+            uint32_t k = 0;
+            for (; __ballot(k < tot) != 0ull; ++k) {
                 const uint32_t kn = k + 1u;
                 if ((kn & 3u) == 0u) { word = word_next; word_next = lst[(kn >> 2) + 1u]; }
                 const uint32_t jn = (word >> (8u * (kn & 3u))) & 255u;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                 const bool near = k < tot && inside && first - j <= last_contributor && !(power > 0.0f) && !(power < rc.w);
                 if (__ballot(near) != 0ull) {
-                    const float G = det_expf_core(near ? power : 0.0f);
+                    const float G = blend_exp<FAST_EXP>(near ? power : 0.0f);
                     const float alpha = fminf(0.99f, co.w * G);
                     const bool take = near && !(alpha < 1.0f / 255.0f);
                     const unsigned long long takers = __ballot(take);
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                 }
                 j = jn; xy = xyn; co = con; rc = rcn;
             }
+            st_trips += k;
         }
         __syncthreads();
         // entry `tid`: the tile's sums, one atomic per value
@@ -216,6 +222,14 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             }
         }
     }
+    uint32_t ent = (lane & 15) == 0 ? st_entries : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ent += (uint32_t)__shfl_xor((int)ent, o);
+    if (lane == 0) s_stat[wave] = make_uint2(ent, st_trips);
+    __syncthreads();
+    if (tid == 0)
+        p.im.tile_stats[(size_t)p.V * p.T + vt] = make_uint4(s_stat[0].x + s_stat[1].x + s_stat[2].x + s_stat[3].x,
+                                                             s_stat[0].y + s_stat[1].y + s_stat[2].y + s_stat[3].y, 0u, (uint32_t)rounds);
 }
 
 // backward.cu:20-139 for one Gaussian of one view.  dRGB already has the clamp mask applied.  Adds into dsh[M][3] and dmean.
@@ -308,7 +322,11 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
     const int v0 = s * p.vps, v1 = min(p.V, v0 + p.vps);
     for (int v = v0; v < v1; ++v) {
         const size_t gi = (size_t)v * p.P + idx;
-        if (!(p.radii[gi] > 0)) continue;
+        if (!(p.radii[gi] > 0)) {                  // culled in this view: its dL_dcov3D row is zero (the buffer is not pre-filled)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.dL_dcov3D[6 * gi + k] = 0.f;
+            continue;
+        }
         const float* vm = p.viewm + 16 * v;
         const float* proj = p.projm + 16 * v;
         float tanx, tany;
@@ -481,7 +499,7 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
 
     BwdParams p{};
     p.P = P; p.D = a->D; p.M = a->M; p.W = W; p.H = H; p.V = V; p.vps = a->views_per_set;
-    p.gx = (W + kTile - 1) / kTile; p.gy = (H + kTile - 1) / kTile; p.T = p.gx * p.gy; p.raw_act = a->raw_activations;
+    p.gx = (W + kTile - 1) / kTile; p.gy = (H + kTile - 1) / kTile; p.T = p.gx * p.gy; p.raw_act = a->raw_activations; p.exact_exp = a->exact_exp ? 1 : 0;
     p.bg = a->background; p.means3D = a->means3D; p.shs = a->shs; p.colors_pre = a->colors_precomp; p.opac = a->opacities;
     p.scales = a->scales; p.rots = a->rotations; p.cov_pre = a->cov3D_precomp; p.viewm = a->viewmatrix; p.projm = a->projmatrix;
     p.campos = a->campos; p.tanfov = a->tanfov; p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.scale_mod = a->scale_modifier;
@@ -493,14 +511,23 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
     p.dL_dopacity = a->dL_dopacity; p.dL_dmeans3D = a->dL_dmeans3D; p.dL_dsh = a->dL_dsh; p.dL_dscales = a->dL_dscales;
     p.dL_drots = a->dL_drotations;
 
-    const size_t nv = (size_t)V * P, ns = (size_t)S * P;
-    hipMemsetAsync(p.dL_dmean2D, 0, nv * 3 * sizeof(float), st);
-    hipMemsetAsync(p.dL_dconic, 0, nv * 4 * sizeof(float), st);
-    hipMemsetAsync(p.dL_dcolors, 0, (a->colors_precomp ? ns : nv) * 3 * sizeof(float), st);
-    hipMemsetAsync(p.dL_dcov3D, 0, nv * 6 * sizeof(float), st);
-    hipMemsetAsync(p.dL_dopacity, 0, ns * sizeof(float), st);
+    // The four tensors the blend kernel accumulates into start from zero (the reference's torch::zeros, rasterize_points.cu:148-156);
+    // everything else is written in full by preprocess_backward_kernel.  A caller that lays the four out back to back
+    // (dgs_amd/raster.py does) gets ONE fill instead of four.
+    const size_t nv = (size_t)V * P, ns = (size_t)S * P, ncol = (a->colors_precomp ? ns : nv) * 3;
+    if (p.dL_dconic == p.dL_dmean2D + nv * 3 && p.dL_dcolors == p.dL_dconic + nv * 4 && p.dL_dopacity == p.dL_dcolors + ncol) {
+        hipMemsetAsync(p.dL_dmean2D, 0, (nv * 7 + ncol + ns) * sizeof(float), st);
+    } else {
+        hipMemsetAsync(p.dL_dmean2D, 0, nv * 3 * sizeof(float), st);
+        hipMemsetAsync(p.dL_dconic, 0, nv * 4 * sizeof(float), st);
+        hipMemsetAsync(p.dL_dcolors, 0, ncol * sizeof(float), st);
+        hipMemsetAsync(p.dL_dopacity, 0, ns * sizeof(float), st);
+    }
     if (a->num_rendered != 0) hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_work, V * p.T, p.im.tile_order);
-    if (a->num_rendered != 0) hipLaunchKernelGGL(blend_backward_kernel, dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
+    if (a->num_rendered != 0) {
+        if (p.exact_exp) hipLaunchKernelGGL(blend_backward_kernel<false>, dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(blend_backward_kernel<true>, dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
+    }
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;

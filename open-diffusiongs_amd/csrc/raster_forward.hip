@@ -32,6 +32,7 @@ struct FwdParams {
     int bin_mode;            // binning form: 0 chosen from the instance statistics (binning_form), else forced: 1 instance list + rank
                              // bitmap sort, 2 per-tile scan, 3 instance list + per-tile bitonic sort in LDS
     int bitonic_cap;         // longest tile list the bitonic form is launched for (LDS entries), 0: form not available
+    int exact_exp;           // blend exponential: 0 hardware v_exp_f32 (default), 1 det_expf (bit-identical floats with the oracle)
     int* radii;
     float* out_color;
     GeomState g;
@@ -743,7 +744,7 @@ __device__ __forceinline__ void scan_more(const FwdParams& p, TileScan& s, uint3
 // each lane row reading its own entry.  Per (pixel, entry) the arithmetic is the reference's, in the reference's order
 // (forward.cu:332-358); the body has no per-lane branches: one wave-uniform branch leaves when no lane passes the alpha
 // cut-off, everything behind it is selects.
-template <bool SCAN>
+template <bool SCAN, bool FAST_EXP>
 __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
@@ -751,9 +752,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ uint4 s_cnt[16];                           // [cell] entries of the batch the cell keeps, per staging wave
     __shared__ uint8_t s_list[17][256];                   // [cell] their batch indices, front to back (+ one row: the walk reads a group ahead)
     __shared__ uint32_t s_walk[4];
+    __shared__ uint2 s_stat[4];
     __shared__ uint32_t s_ring[SCAN ? kRing : 1];         // scan form: list entries found, not yet staged
     __shared__ uint32_t s_scan[4];
-    if (binning_is_scan(p) != SCAN) return;               // async mode launches both instantiations
+    if (binning_is_scan(p) != SCAN) return;               // async mode launches both forms
     const uint32_t vt = p.im.tile_order[blockIdx.x];           // (view, tile) this workgroup works on: scan_tiles_kernel
     const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T);
     const int bx = tile % p.gx, by = tile / p.gx;
@@ -776,8 +778,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
+    uint32_t st_entries = 0, st_trips = 0, st_batches = 0;      // tile_stats (measurement): per lane its cell's entries, per wave its loop trips
     for (int i = 0; i < rounds; ++i) {
         if (__syncthreads_count(done) == 256) break;
+        ++st_batches;
         const uint32_t pos = rg.x + (uint32_t)i * 256u + (uint32_t)tid;
         const uint32_t need = min(256u, rg.y - rg.x - (uint32_t)i * 256u);
         if (SCAN) {
@@ -823,7 +827,9 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
             float2 xy = s_xy[j];
             float4 co = s_co[j];
             float4 rc = s_rgbc[j];
-            for (uint32_t k = 0; __ballot(k < tot) != 0ull; ++k) {
+            st_entries += tot;
+            uint32_t k = 0;
+            for (; __ballot(k < tot) != 0ull; ++k) {
                 const uint32_t kn = k + 1u;
                 const bool refill = (kn & 3u) == 0u;
                 uint32_t fetched = 0u;
@@ -836,7 +842,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                 const bool pass = k < tot && !done && !(power > 0.0f) && !(power < rc.w);  // alpha < 1/255 guaranteed below the cut (preprocess_one)
                 if (__ballot(pass) != 0ull) {
-                    const float alpha = fminf(0.99f, co.w * det_expf_core(pass ? power : 0.0f));
+                    const float alpha = fminf(0.99f, co.w * blend_exp<FAST_EXP>(pass ? power : 0.0f));
                     const float test_T = T * (1 - alpha);
                     const bool contributes = pass && !(alpha < 1.0f / 255.0f);
                     const bool finishes = contributes && test_T < 0.0001f;
@@ -852,6 +858,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
                 j = jn; xy = xyn; co = con; rc = rcn;
                 if (refill) word_next = fetched;
             }
+            st_trips += k;
         }
     }
     if (inside) {
@@ -868,11 +875,16 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     uint32_t walked = last_contributor;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) walked = max(walked, (uint32_t)__shfl_xor((int)walked, o));
-    if (lane == 0) s_walk[wave] = walked;
+    uint32_t ent = (lane & 15) == 0 ? st_entries : 0u;                 // one lane per 16-lane row: the row's cell
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ent += (uint32_t)__shfl_xor((int)ent, o);
+    if (lane == 0) { s_walk[wave] = walked; s_stat[wave] = make_uint2(ent, st_trips); }
     __syncthreads();
     if (tid == 0) {
         p.im.tile_work[vt] = max(max(s_walk[0], s_walk[1]), max(s_walk[2], s_walk[3]));
         p.im.tile_cursor[vt] = SCAN ? ts.found : rg.y - rg.x;          // entries of the tile's list that exist in point_list
+        p.im.tile_stats[vt] = make_uint4(s_stat[0].x + s_stat[1].x + s_stat[2].x + s_stat[3].x, s_stat[0].y + s_stat[1].y + s_stat[2].y + s_stat[3].y,
+                                         SCAN ? ts.next_rank : 0u, st_batches);
     }
 }
 
@@ -949,6 +961,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     p.scales = a->scales; p.rots = a->rotations; p.cov_pre = a->cov3D_precomp; p.viewm = a->viewmatrix; p.projm = a->projmatrix;
     p.campos = a->campos; p.tanfov = a->tanfov; p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.scale_mod = a->scale_modifier;
     p.prefiltered = a->prefiltered; p.raw_act = a->raw_activations; p.radii = a->radii; p.out_color = a->out_color;
+    p.exact_exp = a->exact_exp ? 1 : 0;
 
     size_t gbytes, ibytes;
     GeomState::carve(nullptr, (size_t)P, (size_t)V, &gbytes);
@@ -967,8 +980,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     }
 
     const int VT = V * p.T;
-    hipMemsetAsync(p.im.tile_count, 0, (size_t)VT * sizeof(uint32_t), st);
-    hipMemsetAsync(p.im.totals, 0, 4 * sizeof(int32_t), st);
+    // tile_count and totals are neighbours in the image state (ImageState::carve): one fill
+    hipMemsetAsync(p.im.tile_count, 0, (size_t)(reinterpret_cast<char*>(p.im.totals + 4) - reinterpret_cast<char*>(p.im.tile_count)), st);
     const dim3 gridP((P + 255) / 256, V);
     const bool lds_tiles = p.T <= 4096;
     if (lds_tiles) hipLaunchKernelGGL((preprocess_kernel<true>), gridP, dim3(256), (size_t)p.T * 4, st, p);
@@ -1031,7 +1044,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     if ((forms & ((1 << kFormRankSort) | (1 << kFormScan))) && !radix_done) radix_sort();
     if (forms & (1 << kFormScan)) {
         hipLaunchKernelGGL(rank_rects_kernel, gridP, dim3(256), 0, st, p);
-        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(VT), dim3(256), 0, st, p);
+        if (p.exact_exp) hipLaunchKernelGGL((blend_forward_kernel<true, false>), dim3(VT), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((blend_forward_kernel<true, true>), dim3(VT), dim3(256), 0, st, p);
     }
     if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) {
         if (lds_tiles) hipLaunchKernelGGL((emit_instances_kernel<true>), gridP, dim3(256), (size_t)p.T * 8, st, p);
@@ -1052,7 +1066,10 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(VT), dim3(1024), lds, st, p);
         else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(VT), dim3(256), lds, st, p);
     }
-    if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(VT), dim3(256), 0, st, p);
+    if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) {
+        if (p.exact_exp) hipLaunchKernelGGL((blend_forward_kernel<false, false>), dim3(VT), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((blend_forward_kernel<false, true>), dim3(VT), dim3(256), 0, st, p);
+    }
     return check(st, a->debug);
 }
 
@@ -1092,6 +1109,8 @@ int64_t dgs_raster_state_read(const char* name, int32_t P, int32_t W, int32_t H,
     else if (is("final_T")) { src = im.final_T; bytes = HW * 4; }
     else if (is("list_len")) { src = im.tile_cursor; bytes = T * 4; }       // entries of each tile's list present in point_list
     else if (is("tile_work")) { src = im.tile_work; bytes = T * 4; }
+    else if (is("tile_stats")) { src = im.tile_stats; bytes = T * 16; }                // forward blend: see raster_state.h
+    else if (is("tile_stats_bwd")) { src = im.tile_stats + T; bytes = T * 16; }
     else if (is("point_list")) { src = bn.point_list; bytes = (size_t)(N < 0 ? 0 : N) * 4; }
     else return DGS_ERR_INVALID_ARGUMENT;
     if ((int64_t)bytes > dst_bytes) return DGS_ERR_INVALID_ARGUMENT;

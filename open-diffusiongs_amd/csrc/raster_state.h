@@ -81,6 +81,8 @@ struct ImageState {
     int32_t* totals;               // [4]     {num_rendered, status, longest tile list, -}
     uint32_t* tile_order;          // [V*T]   launch order of the per-tile kernels (workgroup b works on tile tile_order[b])
     uint32_t* tile_work;           // [V*T]   list entries the forward blend walked before the tile was finished
+    uint4* tile_stats;             // [2][V*T] measurement (forward, backward): {cell-list entries walked (x 16 pixels = pair evaluations),
+                                   //          wave loop trips (x 64 lanes = lane slots issued), depth ranks scanned (scan form), batches}
     static ImageState carve(void* buf, size_t W, size_t H, size_t V, size_t* bytes) {
         Carver c(buf);
         ImageState s;
@@ -88,11 +90,12 @@ struct ImageState {
         s.final_T = c.take<float>(V * W * H);
         s.n_contrib = c.take<uint32_t>(V * W * H);
         s.tile_count = c.take<uint32_t>(V * T);
+        s.totals = c.take<int32_t>(4);             // directly behind tile_count: the forward zeroes both with one fill
         s.tile_cursor = c.take<uint32_t>(V * T);
         s.ranges = c.take<uint2>(V * T);
-        s.totals = c.take<int32_t>(4);
         s.tile_order = c.take<uint32_t>(V * T);
         s.tile_work = c.take<uint32_t>(V * T);
+        s.tile_stats = c.take<uint4>(2 * V * T);
         if (bytes) *bytes = c.bytes();
         return s;
     }

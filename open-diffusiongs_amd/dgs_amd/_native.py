@@ -30,7 +30,7 @@ class DgsRasterForwardArgs(ctypes.Structure):
         ("img_alloc", ALLOC_FN), ("img_user", ctypes.c_void_p),
         ("binning_alloc", ALLOC_FN), ("binning_user", ctypes.c_void_p),
         ("binning_capacity", ctypes.c_int64), ("num_rendered_dev", ctypes.c_void_p),
-        ("num_rendered", ctypes.c_int64), ("binning_form", ctypes.c_int32),
+        ("num_rendered", ctypes.c_int64), ("binning_form", ctypes.c_int32), ("exact_exp", ctypes.c_int32),
     ]
 
 
@@ -50,6 +50,7 @@ class DgsRasterBackwardArgs(ctypes.Structure):
         ("dL_dmeans2D", ctypes.c_void_p), ("dL_dconic", ctypes.c_void_p), ("dL_dcolors", ctypes.c_void_p),
         ("dL_dcov3D", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p), ("dL_dmeans3D", ctypes.c_void_p),
         ("dL_dsh", ctypes.c_void_p), ("dL_dscales", ctypes.c_void_p), ("dL_drotations", ctypes.c_void_p),
+        ("exact_exp", ctypes.c_int32),
     ]
 
 
@@ -226,13 +227,13 @@ class DgsDitModelT(ctypes.Structure):
 
 
 class DgsDitLayerGrads(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_void_p) for k in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b")]
+    _fields_ = [(k, ctypes.c_void_p) for k in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ada_w", "ada_b")]
 
 
 class DgsDitGrads(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("t_w0", "t_b0", "t_w1", "t_b1", "tok_w", "pos_emb", "in_ln_w")] + \
                [("layer", ctypes.POINTER(DgsDitLayerGrads))] + \
-               [(k, ctypes.c_void_p) for k in ("ada_w", "ada_b", "up_ln_w", "up_w", "dec_ln_w", "dec_w")]
+               [(k, ctypes.c_void_p) for k in ("head_ada_w", "head_ada_b", "up_ln_w", "up_w", "dec_ln_w", "dec_w")]
 
 
 class DgsDitBackwardArgs(ctypes.Structure):

@@ -307,20 +307,24 @@ class DitEngine:
         mt.layer = ctypes.cast(layersT, ctypes.POINTER(DgsDitLayerWeightsT))
         mt.dec_wT = tkeep["dec"].data_ptr()
         # flat gradient buffer: one slot per engine tensor (ada_w / ada_b are the stacked adaLN tensors)
-        shapes = [("dec_w", k["dec_w"].shape), ("dec_ln_w", (W,)), ("up_w", k["up_w"].shape), ("up_ln_w", (W,))]
+        # (the adaLN Linear of a block -- 6W x W, a third of all parameters -- sits with its block: its gradient is final when the
+        # block's backward is, not at the end)
+        shapes = [("dec_w", k["dec_w"].shape), ("dec_ln_w", (W,)), ("up_w", k["up_w"].shape), ("up_ln_w", (W,)),
+                  ("head_ada_w", (4 * W, W)), ("head_ada_b", (4 * W,))]
         for i in reversed(range(L)):
             for short in ("fc2", "fc1", "proj", "qkv"):
                 shapes += [(f"{i}.{short}_w", k[f"{i}.{short}_w"].shape), (f"{i}.{short}_b", k[f"{i}.{short}_b"].shape)]
-        shapes += [("in_ln_w", (W,)), ("pos_emb", k["pos_emb"].shape), ("tok_w", k["tok_w"].shape), ("ada_w", k["ada_w"].shape),
-                   ("ada_b", k["ada_b"].shape), ("t_w1", k["t_w1"].shape), ("t_b1", (W,)), ("t_w0", k["t_w0"].shape), ("t_b0", (W,))]
+            shapes += [(f"{i}.ada_w", (6 * W, W)), (f"{i}.ada_b", (6 * W,))]
+        shapes += [("in_ln_w", (W,)), ("pos_emb", k["pos_emb"].shape), ("tok_w", k["tok_w"].shape),
+                   ("t_w1", k["t_w1"].shape), ("t_b1", (W,)), ("t_w0", k["t_w0"].shape), ("t_b0", (W,))]
         fg = FlatGrads(shapes, self.device)
         lgr = (DgsDitLayerGrads * L)()
         for i in range(L):
-            for short in ("qkv", "proj", "fc1", "fc2"):
+            for short in ("qkv", "proj", "fc1", "fc2", "ada"):
                 setattr(lgr[i], short + "_w", fg.view(f"{i}.{short}_w").data_ptr())
                 setattr(lgr[i], short + "_b", fg.view(f"{i}.{short}_b").data_ptr())
         gr = DgsDitGrads()
-        for name in ("t_w0", "t_b0", "t_w1", "t_b1", "tok_w", "pos_emb", "in_ln_w", "ada_w", "ada_b", "up_ln_w", "up_w", "dec_ln_w", "dec_w"):
+        for name in ("t_w0", "t_b0", "t_w1", "t_b1", "tok_w", "pos_emb", "in_ln_w", "head_ada_w", "head_ada_b", "up_ln_w", "up_w", "dec_ln_w", "dec_w"):
             setattr(gr, name, fg.view(name).data_ptr())
         gr.layer = ctypes.cast(lgr, ctypes.POINTER(DgsDitLayerGrads))
         self._train = dict(tkeep=tkeep, layersT=layersT, mt=mt, fg=fg, lgr=lgr, gr=gr, saved=None, bws=None, shape=None)
@@ -335,16 +339,14 @@ class DitEngine:
         out["image_tokenizer.1.weight"] = fg.view("tok_w")
         out["gaussians_pos_embedding"] = fg.view("pos_emb")
         out["transformer_input_layernorm.weight"] = fg.view("in_ln_w")
-        aw, ab = fg.view("ada_w"), fg.view("ada_b")
         for i in range(L):
             p = f"transformer.{i}."
-            for short, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+            for short, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2"), ("ada", "adaLN_modulation.1")):
                 out[p + key + ".weight"], out[p + key + ".bias"] = fg.view(f"{i}.{short}_w"), fg.view(f"{i}.{short}_b")
-            out[p + "adaLN_modulation.1.weight"], out[p + "adaLN_modulation.1.bias"] = aw[6 * W * i:6 * W * (i + 1)], ab[6 * W * i:6 * W * (i + 1)]
-        o = 6 * W * L
+        aw, ab = fg.view("head_ada_w"), fg.view("head_ada_b")
         for j, head in enumerate(("upsampler", "image_token_decoder")):
-            out[head + ".adaLN_modulation.1.weight"] = aw[o + 2 * W * j:o + 2 * W * (j + 1)]
-            out[head + ".adaLN_modulation.1.bias"] = ab[o + 2 * W * j:o + 2 * W * (j + 1)]
+            out[head + ".adaLN_modulation.1.weight"] = aw[2 * W * j:2 * W * (j + 1)]
+            out[head + ".adaLN_modulation.1.bias"] = ab[2 * W * j:2 * W * (j + 1)]
         out["upsampler.layernorm.weight"], out["upsampler.linear.weight"] = fg.view("up_ln_w"), fg.view("up_w")
         out["image_token_decoder.layernorm.weight"], out["image_token_decoder.linear.weight"] = fg.view("dec_ln_w"), fg.view("dec_w")
         return out
@@ -389,7 +391,7 @@ class DitEngine:
     def backward(self, dxyz, dfeatures, dscaling, drotation, dopacity, block_hook=None):
         """Gradients of every parameter into the flat buffer (overwritten).  Must follow `forward_train`.
         block_hook(stage) is called on the host as soon as a group of gradients has been ENQUEUED on the current stream
-        (stage = layers: heads, layers-1..0: that block, -1: the rest) -- the place to start a bucket's all-reduce."""
+        (stage = layers: heads, layers-1..0: that block incl. its adaLN Linear, -1: the rest) -- the place to start a bucket's all-reduce."""
         tr = self._train_state()
         B, V, H, W = tr["shape"]
         dev = self.device

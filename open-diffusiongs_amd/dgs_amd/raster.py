@@ -32,8 +32,11 @@ def _prep(t, device):
 
 
 class RasterBackend:
-    def __init__(self, lib=None):
+    def __init__(self, lib=None, exact_exp=None):
         self.lib = lib if lib is not None else _native.lib()
+        # exponential of the blend loops (dgs_raster.h `exact_exp`): False = the hardware's v_exp_f32 (product default), True = the
+        # fixed IEEE sequence the CPU oracle restates (floats bit-identical with the oracle: what the bit-exact parity tests select)
+        self.exact_exp = bool(int(os.environ.get("DGS_RASTER_EXACT_EXP", "0") or 0)) if exact_exp is None else bool(exact_exp)
 
     # -- helpers ---------------------------------------------------------------------------
     @staticmethod
@@ -84,8 +87,10 @@ class RasterBackend:
         M = 0
         if keep["sh"] is not None:
             M = int(keep["sh"].shape[-2])
-        out_color = torch.zeros((V, 3, H, W), dtype=torch.float32, device=device)    # rasterize_points.cu:64
-        radii = torch.zeros((V, P), dtype=torch.int32, device=device)                  # rasterize_points.cu:65
+        # rasterize_points.cu:64-65 allocate zeros; here the kernels write every pixel and every radius (P == 0: nothing runs)
+        alloc = torch.zeros if P == 0 else torch.empty
+        out_color = alloc((V, 3, H, W), dtype=torch.float32, device=device)
+        radii = alloc((V, P), dtype=torch.int32, device=device)
         holder = {"geom": torch.empty(0, dtype=torch.uint8, device=device),
                   "binning": torch.empty(0, dtype=torch.uint8, device=device),
                   "img": torch.empty(0, dtype=torch.uint8, device=device)}
@@ -105,6 +110,7 @@ class RasterBackend:
         a.geom_alloc, a.img_alloc, a.binning_alloc = cbs
         a.binning_capacity = int(binning_capacity)
         a.binning_form = int(os.environ.get("DGS_RASTER_BIN", "0") or 0)     # tests / measurement only (dgs_raster.h)
+        a.exact_exp = int(self.exact_exp)
         ndev = None
         if binning_capacity > 0:
             ndev = torch.zeros(2, dtype=torch.int32, device=device)
@@ -141,16 +147,24 @@ class RasterBackend:
         S, P = int(means3D.shape[0]), int(means3D.shape[1])
         V = int(viewmatrix.shape[0])
         H, W = int(dL_dpix.shape[-2]), int(dL_dpix.shape[-1])
-        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
         keep = dict(bg=_prep(background, device), means=_prep(means3D, device), colors=_prep(colors, device),
                     op=_prep(opacity, device), scales=_prep(scales, device), rots=_prep(rotations, device),
                     cov=_prep(cov3D_precomp, device), vm=_prep(viewmatrix, device), pm=_prep(projmatrix, device),
                     cam=_prep(campos, device), sh=_prep(sh, device), tanfov=_prep(tanfov, device), g=_prep(dL_dpix, device))
         M = int(keep["sh"].shape[-2]) if keep["sh"] is not None else 0
         use_sr = keep["cov"] is None
-        out = dict(means2D=z(V, P, 3), conic=z(V, P, 4), cov3D=z(V, P, 6), opacity=z(S, P), means3D=z(S, P, 3),
-                   colors=z(S, P, 3) if keep["colors"] is not None else z(V, P, 3), sh=z(S, P, max(M, 0), 3),
-                   scales=z(S, P, 3) if use_sr else None, rotations=z(S, P, 4) if use_sr else None)
+        # ONE allocation for every gradient, no fill from here: the library zeroes the four tensors it accumulates into (laid out
+        # back to back: one fill) and writes every element of the others
+        shapes = [("means2D", (V, P, 3)), ("conic", (V, P, 4)), ("colors", (S, P, 3) if keep["colors"] is not None else (V, P, 3)),
+                  ("opacity", (S, P)), ("cov3D", (V, P, 6)), ("means3D", (S, P, 3)), ("sh", (S, P, max(M, 0), 3))]
+        if use_sr:
+            shapes += [("scales", (S, P, 3)), ("rotations", (S, P, 4))]
+        sizes = [int(torch.Size(sh).numel()) for _, sh in shapes]
+        flat = (torch.zeros if P == 0 else torch.empty)(sum(sizes), dtype=torch.float32, device=device)
+        out, o = dict(scales=None, rotations=None), 0
+        for (name, sh), n in zip(shapes, sizes):
+            out[name] = flat[o:o + n].view(sh)
+            o += n
         if P == 0:
             return out
         a = _native.DgsRasterBackwardArgs()
@@ -169,6 +183,7 @@ class RasterBackend:
         a.dL_dopacity, a.dL_dmeans3D = _ptr(out["opacity"]), _ptr(out["means3D"])
         a.dL_dsh = _ptr(out["sh"]) if M else None
         a.dL_dscales, a.dL_drotations = (_ptr(out["scales"]), _ptr(out["rotations"])) if use_sr else (None, None)
+        a.exact_exp = int(self.exact_exp)
         rc = self.lib.dgs_raster_backward(ctypes.byref(a), self._stream(device))
         self._check(rc)
         return out

@@ -23,14 +23,18 @@ from .parallel import BucketedAllReduce
 
 
 class DataParallelTrainer:
-    def __init__(self, model, optimizer, bucket_bytes=256 << 20, accumulate_grad_batches=1, group=None):
+    """Owns the model's training hooks while it lives: `.grad` of every parameter is a view of the engine's flat gradient buffer,
+    the backward writes there in place and reports finished groups to the bucketed all-reduce.  `close()` (or leaving the `with`
+    block) hands the model back: a later plain `loss.backward()` then returns gradients through autograd again."""
+
+    def __init__(self, model, optimizer, bucket_bytes=None, accumulate_grad_batches=1, group=None, compress=None):
         self.model, self.opt = model, optimizer
         self.accumulate = int(accumulate_grad_batches)
         eng = model.engine()
         self.fg = eng._train_state()["fg"]
         if next(model.parameters()).device != self.fg.flat.device:
             raise RuntimeError("DataParallelTrainer: the module's parameters must live on the engine's device (model.to(device))")
-        self.reducer = BucketedAllReduce(self.fg.flat, bucket_bytes, group=group)
+        self.reducer = BucketedAllReduce(self.fg.flat, bucket_bytes, group=group, compress=compress)
         self.world = self.reducer.world
         self._accum = torch.zeros_like(self.fg.flat) if self.accumulate > 1 else None
         self._summed_to = 0
@@ -40,6 +44,23 @@ class DataParallelTrainer:
         model._block_hook = self._on_gradients_final
         self._attach_grads()
         self.last_psnr = None
+
+    def close(self):
+        """Give the model back: no in-place gradients, no per-block hook; the parameters keep COPIES of their last gradients."""
+        m = self.model
+        if getattr(m, "_block_hook", None) == self._on_gradients_final:
+            m._block_hook = None
+            m._grads_in_place = False
+            for p in m.parameters():
+                if p.grad is not None:
+                    p.grad = p.grad.clone()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _attach_grads(self):
         """.grad of every parameter = its slice of the flat buffer (adaLN slices included): written by the backward, reduced
@@ -54,8 +75,8 @@ class DataParallelTrainer:
         if stage < 0:
             return self.fg.flat.numel()
         if stage >= self._layers:
-            return self.fg.end_of("up_ln_w")
-        return self.fg.end_of(f"{stage}.qkv_b")
+            return self.fg.end_of("head_ada_b")
+        return self.fg.end_of(f"{stage}.ada_b")
 
     def _on_gradients_final(self, stage):
         """Host callback from inside dgs_dit_backward: flat[:end] is final once the kernels enqueued so far have run."""
@@ -71,6 +92,8 @@ class DataParallelTrainer:
         """batch: dict(image, ray_o, ray_d, c2w, fxfycxcy) like the reference's input_batch (leading dim = accumulate *
         per-micro-batch size when accumulate_grad_batches > 1); target [b, v, 3, H, W].  Returns the (local) mean loss."""
         m, K = self.model, self.accumulate
+        if m._block_hook != self._on_gradients_final:
+            raise RuntimeError("DataParallelTrainer.step after close() (or another trainer took the model over)")
         self._attach_grads()
         c2w = batch["c2w"] if render_c2w is None else render_c2w
         k = batch["fxfycxcy"] if render_fxfycxcy is None else render_fxfycxcy

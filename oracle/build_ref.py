@@ -18,6 +18,11 @@ What it does (only where /root/reference exists, i.e. in the build container -- 
                                                  default does in its own places: what a user's build looks like)
 
 rasterize_points.cu / ext.cpp (the torch binding) are not built: ref_shim.hip plays that role without torch.
+
+  3. copy the reference's render glue diffusionGS/models/gsrenderer/{gs_core.py, renderer.py} VERBATIM into oracle/_ref/py/ under
+     the reference's own package path (git-ignored like the rest of oracle/_ref/): oracle/ref_glue.py imports it on top of the
+     drop-in `diff_gaussian_rasterization` package -- the reference's Camera / render_opencv_cam / DeferredGaussianRender running
+     unchanged over the product (tests/test_ref_glue_gpu.py).
 """
 import os
 import re
@@ -56,8 +61,27 @@ def _translate():
             fh.write(text)
 
 
+GLUE_SRC = "/root/reference/diffusionGS/models/gsrenderer"
+GLUE_DST = os.path.join(OUT, "py", "diffusionGS", "models", "gsrenderer")
+
+
+def build_py():
+    """Step 3: the reference's Python render glue, byte for byte, as package diffusionGS.models.gsrenderer under oracle/_ref/py."""
+    if not os.path.isdir(GLUE_SRC):
+        return all(os.path.exists(os.path.join(GLUE_DST, f)) for f in ("gs_core.py", "renderer.py"))
+    os.makedirs(GLUE_DST, exist_ok=True)
+    d = os.path.join(OUT, "py")
+    for part in ("diffusionGS", "models", "gsrenderer"):
+        d = os.path.join(d, part)
+        open(os.path.join(d, "__init__.py"), "a").close()
+    for f in ("gs_core.py", "renderer.py"):
+        shutil.copyfile(os.path.join(GLUE_SRC, f), os.path.join(GLUE_DST, f))
+    return True
+
+
 def build(force=False, verbose=False):
     """Returns True when both libraries exist afterwards."""
+    build_py()
     if not os.path.isdir(REF):
         return available()           # GPU box: prebuilt or nothing
     shim = os.path.join(HERE, "ref_shim.hip")

@@ -1,4 +1,8 @@
-"""Shared parity checks: HIP path (or its CPU-emulated build) vs the CPU oracle, bit-exact."""
+"""Shared parity checks: HIP path (or its CPU-emulated build) vs the CPU oracle.  exact=True (dgs_raster.h `exact_exp` = 1): every
+integer AND float artefact bit-exact; exact=False (the product default: hardware v_exp_f32 in the blend loops): everything that does
+not depend on alpha bit-exact, colour / final_T within 1e-5, n_contrib equal on all but <= 1e-5 of the pixels."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -6,9 +10,26 @@ from oracle.raster_oracle import RasterOracle
 from util_scene import oracle_forward
 
 
+@contextlib.contextmanager
+def exp_mode(backend, exact):
+    """The blend exponential of `backend` for the duration of a forward (+ backward) pair; None leaves the backend as it is."""
+    old = backend.exact_exp
+    if exact is not None:
+        backend.exact_exp = bool(exact)
+    try:
+        yield backend
+    finally:
+        backend.exact_exp = old
+
+
 def run_backend_forward(backend, sc, cams, H, W, device, bg=(1.0, 1.0, 1.0), sh_degree=0, colors_precomp=None,
-                        cov3D_precomp=None, views_per_set=None, debug=True):
+                        cov3D_precomp=None, views_per_set=None, debug=True, exact=None):
     """Renders all `cams` in ONE batched call.  sc arrays are [P,...] (one set) or [S,P,...]."""
+    with exp_mode(backend, exact):
+        return _run_backend_forward(backend, sc, cams, H, W, device, bg, sh_degree, colors_precomp, cov3D_precomp, views_per_set, debug)
+
+
+def _run_backend_forward(backend, sc, cams, H, W, device, bg, sh_degree, colors_precomp, cov3D_precomp, views_per_set, debug):
     t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
     xyz = t(sc["xyz"])
     if xyz.dim() == 2:
@@ -30,9 +51,9 @@ def run_backend_forward(backend, sc, cams, H, W, device, bg=(1.0, 1.0, 1.0), sh_
 
 
 def assert_forward_parity(backend, sc, cams, H, W, device, bg=(1.0, 1.0, 1.0), sh_degree=0, views_per_set=None,
-                          check_state=True, colors_precomp=None, cov3D_precomp=None):
-    """Bit-exact comparison of every integer and float artefact of the forward pass, per view."""
-    out = run_backend_forward(backend, sc, cams, H, W, device, bg, sh_degree, colors_precomp, cov3D_precomp, views_per_set)
+                          check_state=True, colors_precomp=None, cov3D_precomp=None, exact=True):
+    """Comparison of every integer and float artefact of the forward pass, per view (see the module docstring for `exact`)."""
+    out = run_backend_forward(backend, sc, cams, H, W, device, bg, sh_degree, colors_precomp, cov3D_precomp, views_per_set, exact=exact)
     n_total, color, radii, geom, binning, img = out
     V = len(cams)
     xyz = np.asarray(sc["xyz"])
@@ -62,7 +83,7 @@ def assert_forward_parity(backend, sc, cams, H, W, device, bg=(1.0, 1.0, 1.0), s
             kw.update(colors_precomp=np.asarray(colors_precomp)[s] if multi else colors_precomp, shs=None)
         if cov3D_precomp is not None:
             kw.update(cov3D_precomp=np.asarray(cov3D_precomp)[s] if multi else cov3D_precomp, scales=None, rotations=None)
-        n = oracle_forward(o, scv, cam, H, W, bg=bg, sh_degree=sh_degree, exp_mode=1, **kw)
+        n = oracle_forward(o, scv, cam, H, W, bg=bg, sh_degree=sh_degree, exp_mode=1 if exact else 0, **kw)
         total += n
         np.testing.assert_array_equal(radii[v].cpu().numpy(), o.get("radii"), err_msg=f"radii view {v}")
         if check_state:
@@ -84,9 +105,23 @@ def assert_forward_parity(backend, sc, cams, H, W, device, bg=(1.0, 1.0, 1.0), s
                 walked = int(ncon[v, 16 * (t // gx):16 * (t // gx) + 16, 16 * (t % gx):16 * (t % gx) + 16].max())
                 assert walked <= n_have <= b - a, f"tile {t} of view {v}: {n_have} list entries present, walked {walked}, length {b - a}"
                 np.testing.assert_array_equal(plist[a:a + n_have], opl[oa:oa + n_have].astype(np.int32), err_msg=f"sorted list tile {t} view {v}")
-            np.testing.assert_array_equal(ncon[v], o.get("n_contrib").astype(np.int32).reshape(H, W), err_msg="n_contrib")
-            np.testing.assert_array_equal(fT[v].view(np.uint32), o.get("final_T").view(np.uint32).reshape(H, W), err_msg="final_T bits")
-        np.testing.assert_array_equal(color[v].cpu().numpy().view(np.uint32), o.get("out_color").view(np.uint32),
-                                      err_msg=f"colour bits view {v}")
+            if exact:
+                np.testing.assert_array_equal(ncon[v], o.get("n_contrib").astype(np.int32).reshape(H, W), err_msg="n_contrib")
+                np.testing.assert_array_equal(fT[v].view(np.uint32), o.get("final_T").view(np.uint32).reshape(H, W), err_msg="final_T bits")
+        if exact:
+            np.testing.assert_array_equal(color[v].cpu().numpy().view(np.uint32), o.get("out_color").view(np.uint32),
+                                          err_msg=f"colour bits view {v}")
+        else:
+            # a pair whose alpha sits within an ulp of the 1/255 cut-off (or whose T crosses 1e-4) may be counted by one side only:
+            # such a pixel differs in n_contrib and by up to alpha T c <= 4e-3 in colour; every other pixel agrees to 1e-5
+            same = np.ones((H, W), bool)
+            if check_state:
+                same = ncon[v] == o.get("n_contrib").astype(np.int32).reshape(H, W)
+                bad = int((~same).sum())
+                assert bad <= max(2, int(1e-5 * H * W)), f"n_contrib differs on {bad} of {H * W} pixels (view {v})"    # the bar of tests/test_raster_ref_gpu.py
+                np.testing.assert_allclose(fT[v][same], o.get("final_T").reshape(H, W)[same], atol=1e-5, err_msg="final_T")
+            diff = np.abs(color[v].cpu().numpy() - o.get("out_color"))
+            assert float(diff[:, same].max()) <= 1e-5 and float(diff.max()) <= 5e-3, \
+                f"view {v}: colour differs by {float(diff[:, same].max()):.3g} on pixels with equal n_contrib, {float(diff.max()):.3g} overall"
     assert int(n_total) == total, (n_total, total)
     return out

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from oracle.raster_oracle import RasterOracle
-from parity_util import run_backend_forward
+from parity_util import exp_mode, run_backend_forward
 from util_scene import oracle_forward
 
 NAMES = {"means2D": "dL_dmeans2D", "colors": "dL_dcolors", "opacity": "dL_dopacity", "means3D": "dL_dmeans3D",
@@ -20,8 +20,14 @@ def close(got, ref, rtol=2e-4, what=""):
 
 
 def assert_backward_parity(backend, sc, cams, H, W, device, sh_degree=0, bg=(1.0, 1.0, 1.0), seed=0, colors_precomp=None,
-                           cov3D_precomp=None):
-    """One Gaussian set rendered into len(cams) views in ONE batched call; oracle: per view, gradients summed over views."""
+                           cov3D_precomp=None, exact=None):
+    """One Gaussian set rendered into len(cams) views in ONE batched call; oracle: per view, gradients summed over views.
+    exact=None: the backend's own blend exponential (the product default, hardware v_exp_f32) -- the bars are relative."""
+    with exp_mode(backend, exact):
+        return _assert_backward_parity(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp)
+
+
+def _assert_backward_parity(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp):
     t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
     V = len(cams)
     out = run_backend_forward(backend, sc, cams, H, W, device, bg, sh_degree, colors_precomp, cov3D_precomp, V, debug=True)

@@ -26,6 +26,15 @@ def test_small_scenes_bit_exact(deg, seed, H, W):
     assert_forward_parity(emu_backend(), sc, cams, H, W, CPU, bg=(0.3, 0.6, 0.9), sh_degree=deg)
 
 
+def test_product_default_hardware_exp_on_the_emulator():
+    """`exact_exp` = 0 (what the product runs): integer artefacts and per-Gaussian state bit-exact, colours within 1e-5 (on the
+    emulator the `hardware` exponential is libm's exp2f: this checks the plumbing of the mode, the GPU test checks v_exp_f32)."""
+    res = 64
+    sc = synth.gaussian_scene(res, regime="trained", seed=0)
+    cams, _, _ = synth.render_cameras(res, 2, phase_deg=10)
+    assert_forward_parity(emu_backend(), sc, cams, res, res, CPU, exact=False)
+
+
 def test_diffusiongs_shaped_64_multi_view():
     res = 64
     sc = synth.gaussian_scene(res, regime="trained", seed=0)

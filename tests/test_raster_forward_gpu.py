@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from dgs_amd import synth
-from parity_util import assert_forward_parity, run_backend_forward
+from parity_util import assert_forward_parity, exp_mode, run_backend_forward
 from util_scene import small_scene
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +40,16 @@ def test_diffusiongs_shaped_bit_exact(res, regime, views):
     sc = synth.gaussian_scene(res, regime=regime, seed=0)
     cams, _, _ = synth.render_cameras(res, views, phase_deg=10)
     assert_forward_parity(_backend(), sc, cams, res, res, _dev())
+
+
+@pytest.mark.parametrize("res,regime,views,deg", [(64, "trained", 4, 0), (64, "init", 2, 0), (128, "trained", 2, 0), (256, "trained", 1, 0), (256, "init", 4, 0)])
+def test_product_default_hardware_exp(res, regime, views, deg):
+    """The product default (`exact_exp` = 0: v_exp_f32 in the blend loops): radii, tile counts, ranges, sorted lists, depth / mean /
+    conic / colour state bit-exact against the oracle as before; colour and final_T within 1e-5, n_contrib equal on all but
+    <= 1e-5 of the pixels (the bars tests/test_raster_ref_gpu.py applies between the oracle and the reference's own code)."""
+    sc = synth.gaussian_scene(res, regime=regime, seed=0)
+    cams, _, _ = synth.render_cameras(res, views, phase_deg=10)
+    assert_forward_parity(_backend(), sc, cams, res, res, _dev(), exact=False)
 
 
 def test_bench_regime_256_four_views_and_512_bit_exact(request, binning_form):
@@ -153,8 +163,12 @@ def test_dropin_binding_matches_oracle():
         sh_degree=1, campos=t(cam["campos"]), prefiltered=False, debug=False)
     rast = dgr.GaussianRasterizer(settings)
     means2D = torch.zeros(500, 3, device=dev)
-    color, radii = rast(means3D=t(sc["xyz"]), means2D=means2D, shs=t(sc["shs"]), colors_precomp=None, opacities=t(sc["opacities"]),
-                        scales=t(sc["scales"]), rotations=t(sc["rotations"]), cov3D_precomp=None)
+    with exp_mode(_backend(), True):             # bit-identical floats with the oracle: the deterministic blend exponential
+        color, radii = rast(means3D=t(sc["xyz"]), means2D=means2D, shs=t(sc["shs"]), colors_precomp=None, opacities=t(sc["opacities"]),
+                            scales=t(sc["scales"]), rotations=t(sc["rotations"]), cov3D_precomp=None)
+    fast, radii_fast = rast(means3D=t(sc["xyz"]), means2D=means2D, shs=t(sc["shs"]), colors_precomp=None, opacities=t(sc["opacities"]),
+                            scales=t(sc["scales"]), rotations=t(sc["rotations"]), cov3D_precomp=None)
+    assert torch.equal(radii, radii_fast) and float((fast - color).abs().max()) < 1e-5        # product default: hardware exp
     o = RasterOracle()
     oracle_forward(o, sc, cam, H, W, sh_degree=1, exp_mode=1)
     assert np.array_equal(color.cpu().numpy().view(np.uint32), o.get("out_color").view(np.uint32))

@@ -57,6 +57,32 @@ def collect(counter, out_dir, cmd):
     return rows
 
 
+def calibrate(raw):
+    """tools/ubench/fetch_calib_bench under --pmc FETCH_SIZE: what the counter reports for patterns of known byte counts (streaming,
+    one 16-byte piece per 128- / 64-byte line, the blend's record gather).  `reported_bytes` is the RAW counter (KiB x 1024, no
+    doubling): 64 B per TCC_EA0_RDREQ.  If a sparse request moved 128 B, `line128` would run at `gbps_if_128B_per_request`."""
+    exe = os.path.join(ROOT, "tools", "ubench", "fetch_calib_bench")
+    if not os.path.exists(exe):
+        src = exe + ".hip"
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-o", exe, src], check=True, stderr=subprocess.DEVNULL)
+    plain = subprocess.run([exe], capture_output=True, text=True).stdout.split("\n")
+    rows = {l.split()[0]: l.split()[1:] for l in plain[1:] if len(l.split()) == 5}
+    f = collect("FETCH_SIZE", os.path.join(raw, "calib_fetch"), [exe])
+    key = {"stream": "stream_kernel", "line128": "line_kernel<128>", "line64": "line_kernel<64>", "records": "records_kernel"}
+    out = {}
+    for pat, (lanes, useful, ms, _) in rows.items():
+        hit = [v for k, v in f.items() if key[pat] in k]
+        if not hit:
+            continue
+        reported = 1024.0 * hit[0][0] / max(hit[0][1], 1)
+        lanes, useful, ms = int(lanes), int(useful), float(ms)
+        req = reported / 64.0
+        out[pat] = {"lanes": lanes, "useful_bytes": useful, "ms": ms, "reported_bytes": int(reported),
+                    "reported_over_useful": round(reported / useful, 4), "requests_per_lane": round(req / lanes, 4),
+                    "gbps_if_64B_per_request": round(req * 64 / ms / 1e6, 1), "gbps_if_128B_per_request": round(req * 128 / ms / 1e6, 1)}
+    return out
+
+
 def main():
     from bench import FAMILIES, kernel_source_sha
     raw = os.path.join(ROOT, "gpurun_out", "pmc")
@@ -91,9 +117,13 @@ def main():
             out["raster"][regime][what] = int(fb + wb)
             out["raster"][regime][what + "_detail"] = {"fetch_bytes": int(fb), "write_bytes": int(wb), "calls": iters,
                                                        "per_kernel_fetch_bytes": {k[:60]: int(2048 * v[0] / iters) for k, v in f.items() if "dgs::" in k}}
+    try:
+        out["fetch_calibration"] = calibrate(raw)
+    except Exception as e:                      # noqa: BLE001 -- the calibration is an annex, the traffic figures stand without it
+        out["fetch_calibration"] = {"error": f"{type(e).__name__}: {e}"}
     path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
-    print(json.dumps({k: out[k] for k in ("dit", "raster")}, indent=1))
+    print(json.dumps({k: out[k] for k in ("dit", "raster", "fetch_calibration")}, indent=1))
     print("wrote", path, "-> copy to profiles/pmc_traffic.json")
 
 
