@@ -54,6 +54,32 @@ typedef struct DgsResizeArgs {
 int dgs_resize_bilinear(const DgsResizeArgs* args, dgs_stream_t stream);
 int dgs_resize_bilinear_backward(const DgsResizeArgs* args, dgs_stream_t stream);
 
+/* The two loss terms on the denoiser's pixel-aligned points `img_aligned_xyz` (losses.py:288-292, 325-364; `lambda_pointsdist: 1.0`
+ * is the only active term of the first training steps of configs/diffusionGS_rel.yaml), forward values and the gradient with
+ * respect to `aligned` in two passes over the tensors, every sum reduced in a fixed order:
+ *   points-distribution loss, per sample b:
+ *       dist = |aligned - ray_o|_2 per pixel; per (b, view): mean and UNBIASED std of dist over the view's pixels (detached);
+ *       target = (dist - mean) / (std + 1e-8) * 0.5 + |ray_o|_2;   pointsdist[b] = mean over (v, h, w) of (dist - target)^2
+ *   xyz loss, one scalar for the batch (optional: gt and masks given):
+ *       xyz = sum((aligned * m - gt * m)^2) / sum(m),  m = masks [B, V, 1, H, W] broadcast over the three coordinates
+ *   grad = w_pointsdist[b] * d pointsdist[b] / d aligned + w_xyz * d xyz / d aligned      (optional)                            */
+typedef struct DgsPointsLossArgs {
+    int32_t B, V, H, W;
+    const float* aligned;      /* f32 [B, V, 3, H, W]                                                       */
+    const float* ray_o;        /* f32 [B, V, 3, H, W]                                                       */
+    const float* gt;           /* optional f32 [B, V, 3, H, W]                                              */
+    const float* masks;        /* optional f32 [B, V, 1, H, W] (required with gt)                            */
+    float* pointsdist;         /* out f32 [B]                                                               */
+    float* xyz;                /* out f32 [1] (written when gt is given)                                    */
+    const float* w_pointsdist; /* optional f32 [B]: upstream gradient of pointsdist[b] (NULL: 0)             */
+    float w_xyz;               /* upstream gradient of xyz                                                  */
+    float* grad;               /* optional out f32 [B, V, 3, H, W]                                          */
+    float* workspace;          /* f32 [dgs_points_loss_workspace_floats(B, V)]                               */
+} DgsPointsLossArgs;
+
+int64_t dgs_points_loss_workspace_floats(int32_t B, int32_t V);
+int dgs_points_loss(const DgsPointsLossArgs* args, dgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -551,17 +551,23 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     if (wave_live) {                                    // lane owns query q, d = db*32 + 8 g + 4 half + (0..3)
         if (p.lse2 && half == 0) p.lse2[((size_t)b * p.heads + head) * p.lpad + q] = lse_out;
         bf16_t* orow = p.out + (row0 + q) * (size_t)(p.heads * 64) + head * 64;
+        // a lane pair (l31, l31 + 32) holds 8 consecutive d of two neighbouring 8-column groups: one exchange per dword makes
+        // that 16 contiguous bytes per lane -- four 16-byte stores instead of eight 8-byte ones (the store tail is issue-bound)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(orow + (i >> 2) * 32 + 8 * (i & 3) + 4 * half) = outv[i];
+        for (int i = 0; i < 8; i += 2) {
+            half_swap(outv[i].x, outv[i + 1].x);
+            half_swap(outv[i].y, outv[i + 1].y);
+            *reinterpret_cast<uint4*>(orow + (i >> 2) * 32 + 8 * ((i & 3) + half)) = make_uint4(outv[i].x, outv[i].y, outv[i + 1].x, outv[i + 1].y);
+        }
     }
     MAIN_STAMP(4);
     if (!tail_r) return;
     // the last workgroup of this (sample, head) to get here merges the per-tile records
 #ifndef HIPEMU
-    // stores retire in order: with at most the 8 output stores outstanding, every record store of this wave has been
+    // stores retire in order: with at most the 4 output stores outstanding, every record store of this wave has been
     // performed (sc1: at the memory side).  A wave without live queries issued no output stores behind its records,
     // so it has to drain completely.
-    if (wave_live) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (wave_live) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     int* flag = reinterpret_cast<int*>(lds);

@@ -107,6 +107,19 @@ __device__ __forceinline__ float xor32_sum(float v) {
 }
 #endif
 
+// Exchange between the two halves of a wave (v_permlane32_swap): afterwards lanes 0-31 hold {their own a, the upper half's a} in
+// (a, b) and lanes 32-63 hold {the lower half's b, their own b} -- two 8-byte row pieces of a lane pair become one 16-byte piece
+// per lane (cdna_hip_programming.md T21: row-per-lane epilogue stores as dwordx4 instead of 2 x dwordx2).
+__device__ __forceinline__ void half_swap(uint32_t& a, uint32_t& b) {
+#ifdef HIPEMU
+    const uint32_t oa = (uint32_t)__shfl_xor((int)a, 32), ob = (uint32_t)__shfl_xor((int)b, 32);
+    if (threadIdx.x & 32) a = ob; else b = oa;
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+#endif
+}
+
 // XCD-aware remap of a linear workgroup id (cdna_hip_programming.md T1, bijective form): hardware places block b on
 // XCD b % 8; give every XCD a contiguous range of logical ids so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -333,7 +333,14 @@ class DgsResizeArgs(ctypes.Structure):
                 ("add", ctypes.c_float), ("ddst", ctypes.c_void_p), ("dsrc", ctypes.c_void_p)]
 
 
-LOSS_SYMBOLS = ["dgs_mse_psnr", "dgs_resize_bilinear", "dgs_resize_bilinear_backward"]
+class DgsPointsLossArgs(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("V", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("aligned", ctypes.c_void_p),
+                ("ray_o", ctypes.c_void_p), ("gt", ctypes.c_void_p), ("masks", ctypes.c_void_p), ("pointsdist", ctypes.c_void_p),
+                ("xyz", ctypes.c_void_p), ("w_pointsdist", ctypes.c_void_p), ("w_xyz", ctypes.c_float), ("grad", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p)]
+
+
+LOSS_SYMBOLS = ["dgs_mse_psnr", "dgs_resize_bilinear", "dgs_resize_bilinear_backward", "dgs_points_loss", "dgs_points_loss_workspace_floats"]
 
 
 def _declare_loss(L):
@@ -342,6 +349,10 @@ def _declare_loss(L):
     for fn in (L.dgs_resize_bilinear, L.dgs_resize_bilinear_backward):
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(DgsResizeArgs), ctypes.c_void_p]
+    L.dgs_points_loss.restype = ctypes.c_int
+    L.dgs_points_loss.argtypes = [ctypes.POINTER(DgsPointsLossArgs), ctypes.c_void_p]
+    L.dgs_points_loss_workspace_floats.restype = ctypes.c_int64
+    L.dgs_points_loss_workspace_floats.argtypes = [ctypes.c_int32, ctypes.c_int32]
     return L
 
 

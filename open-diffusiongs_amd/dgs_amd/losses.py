@@ -1,7 +1,9 @@
-"""Image-space loss consumer on the device: per-sample MSE + PSNR and the MSE gradient in one pass.
+"""Loss consumers on the device: per-sample MSE + PSNR and the MSE gradient in one pass, the LPIPS
+input resize, and the two terms on the denoiser's pixel-aligned points (points-distribution and xyz loss) with their gradient.
 
-Mirrors diffusionGS/utils/losses.py: the `l2_loss` / `psnr` terms of LossComputer.forward (:281-285, :303) and `compute_psnr`
-(:399-402).  LPIPS / SSIM (network-based) are out of scope.  csrc/loss.hip through include/dgs_loss.h; no CPU fallback."""
+Mirrors diffusionGS/utils/losses.py: the `l2_loss` / `psnr` terms of LossComputer.forward (:281-285, :303), `compute_psnr`
+(:399-402), `l2_loss_xyz` (:288-292) and `pointsdist_loss` (:325-364).  LPIPS / SSIM (network-based) are out of scope.
+csrc/loss.hip through include/dgs_loss.h; no CPU fallback."""
 import ctypes
 
 import torch
@@ -101,3 +103,54 @@ def lpips_input(images, size=(256, 256), lib=None):
     LPIPS module for renderings and targets ([n, 3, h, w] in (0, 1) -> [n, 3, 256, 256] in (-1, 1)), one fused launch,
     differentiable.  The network behind it is out of scope."""
     return _LpipsInput.apply(images, tuple(size), 2.0, -1.0, lib)
+
+
+def _points_call(aligned, ray_o, gt, masks, w_pd, w_xyz, want_grad, lib):
+    B, V, C, H, W = aligned.shape
+    assert C == 3 and ray_o.shape == aligned.shape
+    dev = aligned.device
+    L = lib or _native.lib()
+    f = lambda x: None if x is None else x.contiguous().float()
+    al, ro, gt, masks = f(aligned), f(ray_o), f(gt), f(masks)
+    if gt is not None:
+        assert masks is not None and tuple(masks.shape) == (B, V, 1, H, W) and gt.shape == aligned.shape
+    pd = torch.empty(B, dtype=torch.float32, device=dev)
+    xyz = torch.zeros(1, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(al) if want_grad else None
+    ws = torch.empty(int(L.dgs_points_loss_workspace_floats(B, V)), dtype=torch.float32, device=dev)
+    wpd = f(w_pd)
+    a = _native.DgsPointsLossArgs()
+    ptr = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else None
+    a.B, a.V, a.H, a.W = B, V, H, W
+    a.aligned, a.ray_o, a.gt, a.masks, a.pointsdist, a.xyz = ptr(al), ptr(ro), ptr(gt), ptr(masks), ptr(pd), ptr(xyz)
+    a.w_pointsdist, a.w_xyz, a.grad, a.workspace = ptr(wpd), float(w_xyz), ptr(grad), ptr(ws)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if al.is_cuda else None
+    rc = L.dgs_points_loss(ctypes.byref(a), stream)
+    if rc != 0:
+        raise RuntimeError(f"dgs_points_loss failed: {rc}")
+    return pd, xyz[0], grad
+
+
+class _PointsLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aligned, ray_o, gt, masks, lib):
+        pd, xyz, _ = _points_call(aligned, ray_o, gt, masks, None, 0.0, False, lib)
+        ctx.save_for_backward(aligned, ray_o, *([gt, masks] if gt is not None else []))
+        ctx.lib = lib
+        return pd, xyz
+
+    @staticmethod
+    def backward(ctx, g_pd, g_xyz):
+        aligned, ray_o, *rest = ctx.saved_tensors
+        gt, masks = rest if rest else (None, None)
+        w_pd = g_pd if g_pd is not None else torch.zeros(aligned.shape[0], device=aligned.device)
+        w_xyz = float(g_xyz) if (g_xyz is not None and gt is not None) else 0.0      # one host read of a scalar; 0 without a gt
+        _, _, grad = _points_call(aligned, ray_o, gt, masks, w_pd, w_xyz, True, ctx.lib)
+        return grad.to(aligned.dtype), None, None, None, None
+
+
+def points_losses(img_aligned_xyz, ray_o, gt_img_aligned_xyz=None, masks=None, lib=None):
+    """losses.py:288-292,325-364 on the device: -> (pointsdist_loss [b], l2_loss_xyz scalar -- 0 without a gt), both differentiable
+    w.r.t. `img_aligned_xyz` [b, v, 3, h, w] (the statistics of the points-distribution target are detached, as in the reference).
+    `masks` [b, v, 1, h, w] is the reference's `masks_input`."""
+    return _PointsLoss.apply(img_aligned_xyz, ray_o, gt_img_aligned_xyz, masks, lib)

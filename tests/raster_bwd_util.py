@@ -20,14 +20,26 @@ def close(got, ref, rtol=2e-4, what=""):
 
 
 def assert_backward_parity(backend, sc, cams, H, W, device, sh_degree=0, bg=(1.0, 1.0, 1.0), seed=0, colors_precomp=None,
-                           cov3D_precomp=None, exact=None):
+                           cov3D_precomp=None, exact=True, rtol=2e-4):
     """One Gaussian set rendered into len(cams) views in ONE batched call; oracle: per view, gradients summed over views.
-    exact=None: the backend's own blend exponential (the product default, hardware v_exp_f32) -- the bars are relative."""
+    exact=True: the oracle's own exponential in the blend loops (the 2e-4 bar then measures summation order only);
+    exact=False / None: the product default (hardware v_exp_f32) -- a pair whose alpha sits within an ulp of the 1/255 cut-off
+    may then be counted by one side only, which moves that Gaussian's gradient by its whole contribution: pass rtol=2e-3."""
     with exp_mode(backend, exact):
-        return _assert_backward_parity(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp)
+        return _assert_backward_parity(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp, rtol)
 
 
-def _assert_backward_parity(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp):
+def _assert_backward_parity(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp, rtol):
+    global close
+    _close = close
+    close = lambda got, ref, what="": _close(got, ref, rtol=rtol, what=what)
+    try:
+        return _assert_backward_parity_body(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp)
+    finally:
+        close = _close
+
+
+def _assert_backward_parity_body(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp):
     t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
     V = len(cams)
     out = run_backend_forward(backend, sc, cams, H, W, device, bg, sh_degree, colors_precomp, cov3D_precomp, V, debug=True)

@@ -17,7 +17,7 @@ def _run(*flags):
     env = dict(os.environ, OMP_NUM_THREADS="4")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "1", *flags],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "1", *flags],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -28,10 +28,10 @@ def _run(*flags):
 @pytest.mark.parametrize("exchange", ["fp32", "bf16"])
 def test_two_rank_training_step_through_respawn(exchange):
     d = _run("--mode", "train", "--train-batch", "1", "--bucket-mb", "1", "--grad-exchange", exchange)
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert "dry_run" in d and d["unit"] == "samples/s" and d["value"] > 0
     ts = d["train_step"]
-    assert abs(d["value"] - 2 * ts["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]     # whole-job aggregate
+    assert abs(d["value"] - 2 * ts["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 0.006                # whole-job aggregate (2 decimals)
     ar = ts["allreduce"]
     assert ar["world"] == 2 and ar["exchange"] == exchange and ar["buckets"] == len(ar["bucket_mib"]) >= 3
     assert ar["launched_during_backward"] >= ar["buckets"] - 2     # all but the tail overlap the backward
@@ -41,5 +41,5 @@ def test_two_rank_training_step_through_respawn(exchange):
 def test_two_rank_inference_step_through_respawn():
     d = _run("--mode", "infer")
     assert d["n_gpus"] == 2 and d["unit"] == "renders/s" and "dry_run" in d and d["value"] > 0
-    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]                       # B = 1, 4 views, 2 ranks
+    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) <= 0.006                                  # B = 1, 4 views, 2 ranks
     assert d["config"]["parallelism"] == "dp2" and d["cpu_baseline"] is None

@@ -37,6 +37,53 @@ def _check(lib, device):
     assert torch.equal(losses.mse_psnr(render.detach(), target, lib=lib)[1], l2.detach())
 
 
+def _check_points(lib, device, b=2, v=3, h=20, w=28):
+    """losses.py:288-292,325-364 (l2_loss_xyz, pointsdist_loss) against the reference's torch expressions in fp64: values and the
+    gradient w.r.t. img_aligned_xyz under per-sample / scalar upstream weights; with and without a gt; deterministic."""
+    from dgs_amd import losses
+    g = torch.Generator().manual_seed(11)
+    ray_o = (torch.randn(b, v, 3, 1, 1, generator=g) * 0.3 + torch.tensor([0.0, 0.0, 2.0]).reshape(1, 1, 3, 1, 1)).expand(b, v, 3, h, w).contiguous()
+    ray_d = torch.nn.functional.normalize(torch.randn(b, v, 3, h, w, generator=g), dim=2)
+    aligned = (ray_o + ray_d * (1.5 + 0.5 * torch.rand(b, v, 1, h, w, generator=g))).to(device).requires_grad_(True)
+    gt = ray_o + ray_d * (1.4 + 0.6 * torch.rand(b, v, 1, h, w, generator=g))
+    masks = (torch.rand(b, v, 1, h, w, generator=g) > 0.3).float()
+    wts = torch.tensor([0.7, 1.9][:b])
+
+    def ref(al, with_gt):
+        ro, al = ray_o.double(), al.double()
+        dist = (al - ro).norm(dim=2, p=2, keepdim=True)
+        dd = dist.detach()
+        trgt = (dd - dd.mean(dim=(2, 3, 4), keepdim=True)) / (dd.std(dim=(2, 3, 4), keepdim=True) + 1e-8) * 0.5 + ro.norm(dim=2, p=2, keepdim=True)
+        pd = ((dist - trgt) ** 2).mean(dim=(1, 2, 3, 4))
+        xyz = F.mse_loss(al * masks.double(), gt.double() * masks.double(), reduction="sum") / masks.double().sum() if with_gt else torch.zeros((), dtype=torch.float64)
+        return pd, xyz
+
+    for with_gt in (True, False):
+        aligned.grad = None
+        pd, xyz = losses.points_losses(aligned, ray_o.to(device), gt.to(device) if with_gt else None, masks.to(device) if with_gt else None, lib=lib)
+        ((pd * wts.to(device)).sum() + 0.6 * xyz).backward()
+        ar = aligned.detach().cpu().double().requires_grad_(True)
+        rpd, rxyz = ref(ar, with_gt)
+        ((rpd * wts.double()).sum() + 0.6 * rxyz).backward()
+        assert torch.allclose(pd.detach().cpu().double(), rpd.detach(), rtol=2e-4), (pd, rpd)
+        assert torch.allclose(xyz.detach().cpu().double(), rxyz.detach(), rtol=1e-5, atol=1e-12), (xyz, rxyz)
+        gerr = float((aligned.grad.cpu().double() - ar.grad).abs().max() / ar.grad.abs().max())
+        assert gerr < 2e-4, (with_gt, gerr)
+        again = losses.points_losses(aligned.detach(), ray_o.to(device), gt.to(device) if with_gt else None, masks.to(device) if with_gt else None, lib=lib)
+        assert torch.equal(again[0], pd.detach()) and torch.equal(again[1], xyz.detach())        # fixed reduction order
+
+
+def test_points_losses_on_emulator():
+    from emu_util import emu_lib
+    _check_points(emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+def test_points_losses_on_gpu():
+    _check_points(None, "cuda:0")
+    _check_points(None, "cuda:0", b=2, v=4, h=256, w=256)
+
+
 def _check_resize(lib, device, planes=(3, 3), sizes=((256, 256), (512, 512), (64, 96), (300, 200))):
     """The LPIPS input path (losses.py:304-309) vs F.interpolate: the reference's two cases (256 -> 256, 512 -> 256) and odd
     up / down factors; values and the gradient w.r.t. the rendering."""

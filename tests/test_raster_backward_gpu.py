@@ -40,6 +40,14 @@ def test_full_size_256_vs_oracle(regime, views):
     assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV)
 
 
+@pytest.mark.parametrize("regime,views", [("trained", 2), ("init", 1)])
+def test_full_size_256_product_default_exp(regime, views):
+    """The same with the product's blend exponential (hardware v_exp_f32, `exact_exp` = 0): 2e-3 of each tensor's max."""
+    sc = synth.gaussian_scene(256, regime=regime, seed=0)
+    cams, _, _ = synth.render_cameras(256, 4, phase_deg=10)
+    assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV, exact=False, rtol=2e-3)
+
+
 def test_precomputed_colors_and_long_lists():
     H, W = 32, 48
     sc, cams = small_scene(120, W, H, seed=8, n_views=2)
