@@ -76,6 +76,15 @@ __device__ __forceinline__ float hw_exp2(float x) {
 #endif
 }
 
+// One v_rcp_f32 (1 ulp); the emulation build divides.
+__device__ __forceinline__ float hw_rcp(float x) {
+#ifdef HIPEMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+
 // exp(power) of a (pixel, Gaussian) pair inside the blend loops (-5.6 < power <= 0 for every pair that passes the cut-off).
 // FAST (the product default): v_mul + v_exp_f32 -- what the reference's CUDA `exp()` under fast math is on its hardware, two VALU
 //   instead of fourteen in the innermost loop of both blend kernels; integer artefacts that do not depend on alpha (radii, tile

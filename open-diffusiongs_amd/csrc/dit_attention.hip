@@ -74,22 +74,6 @@ union PFrag { bf16x8 v; uint32_t u[4]; };
 
 constexpr int TAIL_REC = 66;          // floats per (key tile, query) record: max, sum, O[64]
 
-__device__ __forceinline__ void st_agent(float* ptr, float v) {
-#ifdef HIPEMU
-    *ptr = v;
-#else
-    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ float2 ld_agent2(const float2* ptr) {
-#ifdef HIPEMU
-    return *ptr;
-#else
-    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-#endif
-}
-
 __device__ __forceinline__ int pi16(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // one key tile of the tail queries, by one wave; rec = this tile's records [r][TAIL_REC]
@@ -267,11 +251,8 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-#ifndef HIPEMU
-#define MAIN_STAMP(i) if ((p.dbg & 8) && blockIdx.x == 0 && tid == 0) dgs_attn_dbg[4096 + 16 + (i)] = clock64()
-#else
-#define MAIN_STAMP(i)
-#endif
+    const int dbg = kInstrumented ? p.dbg : 0;         // debug switches exist in the instrumented library only (dit_common.h)
+#define MAIN_STAMP(i) if ((dbg & 8) && blockIdx.x == 0 && tid == 0) dgs_attn_dbg[4096 + 16 + (i)] = cycle_stamp()
     MAIN_STAMP(0);
     // ---- block -> (sample, head, query block) ----
     int id = blockIdx.x;
@@ -345,9 +326,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < RING - 1; ++j)
         if (j < ntiles) stage_v(j, j);
-#ifndef HIPEMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    wait_vmcnt<0>();
     __syncthreads();
     MAIN_STAMP(1);
     // ---- first tile: S'(0), its row max = the initial running max; fragments of K(1) ----
@@ -374,7 +353,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     // One iteration = one 64-key tile t.  MODE 0: steady state, 1: S(t+1) is the last tile (ragged: masked), 2: last tile
     // (no S(t+1)).  Straight-line copies instead of in-loop branches.  `cs*` hold P(t) (in: S'(t) - m), `ns*` receive
     // S'(t+1) - m: the caller alternates two register sets, so nothing is copied between iterations.
-    // `fast_tag` = 1: the caller guarantees t + RING < ntiles and p.dbg == 0 -- both DMAs go out unconditionally, the wait is the
+    // `fast_tag` = 1: the caller guarantees t + RING < ntiles and dbg == 0 -- both DMAs go out unconditionally, the wait is the
     // literal vmcnt(2) and the barrier is unconditional; `live_tag` = 0 / 1 then replaces the run-time test of `wave_live` (2: test
     // it).  The steady-state loop below runs on these copies: tools/ubench/issue_bench prices ONE scalar compare + branch in the
     // MFMA + VALU stream at 16 (untaken) / 27 (taken) cycles of the wave and an s_add at 2.75, and the generic form spends ~10
@@ -388,7 +367,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
         if constexpr (FAST) {
             stage_k(t + RING, slot);
             stage_v(t + RING - 1, (slot + RING - 1) & (RING - 1));
-        } else if (MODE == 0 && !(p.dbg & 1)) {
+        } else if (MODE == 0 && !(dbg & 1)) {
             if (t + RING < ntiles) { stage_k(t + RING, slot); ++issued; }
             if (t + RING - 1 < ntiles) { stage_v(t + RING - 1, (slot + RING - 1) & (RING - 1)); ++issued; }
         }
@@ -432,9 +411,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
                         max_step<K - 48>(ns0, ns1, mx);
                     }
                 });
-#ifndef HIPEMU
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                sched_fence();
             });
             if constexpr (MODE != 2) {
                 mx = xor32_max(mx);                     // relative to the running max
@@ -456,19 +433,14 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
         if (MODE != 2) {
             // everything issued BEFORE this iteration (K(t+3), V^T(t+2) and older) has landed once at most this
             // iteration's own DMAs are outstanding; then everybody is also done reading K(t+2)'s and V^T(t)'s slots
-#ifndef HIPEMU
             if constexpr (FAST) {
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                wait_vmcnt<2>();
+                raw_barrier();
             } else {
-                if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+                if (issued == 2) wait_vmcnt<2>();
+                else wait_vmcnt<0>();
+                if (!(dbg & 2)) raw_barrier();
             }
-#else
-            (void)issued;
-            __syncthreads();
-#endif
         }
     };
     const bool ragged = mask_from < ntiles && ntiles > 1;       // the last tile holds keys >= L
@@ -476,16 +448,14 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     MAIN_STAMP(2);
     f32x16 u0, u1;                                              // second score register set
     int t = 0;
-#ifndef HIPEMU
-    const long long dbg_t0 = (p.dbg & 4) ? clock64() : 0;
-#endif
+    const long long dbg_t0 = (dbg & 4) ? cycle_stamp() : 0;
     // steady state, unrolled by the ring depth: ring slots are literals, every LDS address is register + immediate.  While all
     // four iterations of a round still issue both of their DMAs (t + 3 + RING < ntiles) and no debug switch is set, the round runs
     // on the branch-free copies -- one loop for the waves with queries, one for the waves that only stage and synchronise.
     constexpr IC<0> GEN{};
     constexpr IC<1> YES{};
     constexpr IC<2> ASK{};
-    if (p.dbg == 0) {
+    if (dbg == 0) {
         if (wave_live) {
             for (; t + 3 + RING < ntiles; t += 4) {
                 iteration(t, 0, Mode<0>{}, s0, s1, u0, u1, YES, YES);
@@ -523,9 +493,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
         else iteration(tl, tl & 3, Mode<2>{}, s0, s1, u0, u1, GEN, ASK);
     }
 
-#ifndef HIPEMU
-    if ((p.dbg & 4) && lane == 0 && blockIdx.x < 512) dgs_attn_dbg[blockIdx.x * 8 + wave] = clock64() - dbg_t0;
-#endif
+    if ((dbg & 4) && lane == 0 && blockIdx.x < 512) dgs_attn_dbg[blockIdx.x * 8 + wave] = cycle_stamp() - dbg_t0;
     MAIN_STAMP(3);
     // ---- finish: O[q, d] = O^T / l, packed to bf16 now (frees the accumulators), stored behind the tail tile ----
     uint2 outv[8];
@@ -563,30 +531,20 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     MAIN_STAMP(4);
     if (!tail_r) return;
     // the last workgroup of this (sample, head) to get here merges the per-tile records
-#ifndef HIPEMU
     // stores retire in order: with at most the 4 output stores outstanding, every record store of this wave has been
     // performed (sc1: at the memory side).  A wave without live queries issued no output stores behind its records,
     // so it has to drain completely.
-    if (wave_live) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    if (wave_live) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
     int* flag = reinterpret_cast<int*>(lds);
-#ifndef HIPEMU
-    __builtin_amdgcn_s_barrier();                      // raw barriers: __syncthreads() would also drain the output stores
-#else
-    __syncthreads();
-#endif
+    raw_barrier();                                     // raw barriers: __syncthreads() would also drain the output stores
     if (tid == 0) {
         const unsigned prev = atomicAdd(p.tail_cnt + bh, 1u);
         *flag = prev + 1 == (unsigned)p.nqb;
         if (*flag) p.tail_cnt[bh] = 0;                 // leave the counter ready for the next launch
     }
-#ifndef HIPEMU
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#else
-    __syncthreads();
-#endif
+    wait_lgkmcnt0();
+    raw_barrier();
     if (*flag) tail_merge(p, bh, ntiles, tail_r, lds);
 }
 
@@ -615,7 +573,7 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     p.nfull = a->L / 32;                       // full 32-query wave units; the L % 32 rest goes to the tail workgroups
     p.nqb = p.nfull ? (p.nfull + NW - 1) / NW : 1;        // L < 32: one workgroup per head, tail path only
     p.nmain = a->B * a->heads * p.nqb;
-    static const int dbg = getenv("DGS_ATTN_DBG") ? atoi(getenv("DGS_ATTN_DBG")) : 0;
+    static const int dbg = kInstrumented && getenv("DGS_ATTN_DBG") ? atoi(getenv("DGS_ATTN_DBG")) : 0;     // instrumented library only
     p.dbg = dbg;
     const int r = a->L % 32;
     p.tail_ws = nullptr; p.tail_cnt = nullptr;
@@ -639,7 +597,7 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
         lds_attr = lds_bytes;
     }
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(p.nmain), dim3(512), lds_bytes, st, p);
-#ifndef HIPEMU
+#ifdef DGS_INSTRUMENT
     if (dbg & 4) {
         static long long host[4096 + 64];
         (void)hipStreamSynchronize(st);

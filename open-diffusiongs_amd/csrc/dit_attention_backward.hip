@@ -60,11 +60,7 @@ __device__ __forceinline__ bf16x8 pack_rows(const f32x16& s, int r0) {
     return f.v;
 }
 template <bool V> struct BoolTag { static constexpr bool value = V; };
-#ifdef HIPEMU
-#define DGS_SCHED_FENCE() ((void)0)
-#else
-#define DGS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
+#define DGS_SCHED_FENCE() sched_fence()
 
 __device__ __forceinline__ f32x16 zero_acc() {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

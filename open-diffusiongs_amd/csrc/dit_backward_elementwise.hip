@@ -272,19 +272,25 @@ __global__ __launch_bounds__(256) void rowlinear_backward_kernel(RowLinBwdParams
         for (int c = 0; c < MAXC; ++c) {
             const int k0 = (lane + 64 * c) * 8;
             if (k0 >= p.K) continue;
-            const uint4 w = *reinterpret_cast<const uint4*>(wr + k0);
-            const float wf[8] = {bf2f(w.x & 0xffffu), bf2f(w.x >> 16), bf2f(w.y & 0xffffu), bf2f(w.y >> 16),
-                                 bf2f(w.z & 0xffffu), bf2f(w.z >> 16), bf2f(w.w & 0xffffu), bf2f(w.w >> 16)};
-            float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.dx) {                                          // uniform: the weight row is only needed for dx
+                const uint4 w = *reinterpret_cast<const uint4*>(wr + k0);
+                const float wf[8] = {bf2f(w.x & 0xffffu), bf2f(w.x >> 16), bf2f(w.y & 0xffffu), bf2f(w.y >> 16),
+                                     bf2f(w.z & 0xffffu), bf2f(w.z >> 16), bf2f(w.w & 0xffffu), bf2f(w.w >> 16)};
 #pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                const float4 xa = *reinterpret_cast<const float4*>(xs + m * p.K + k0);
-                const float4 xb = *reinterpret_cast<const float4*>(xs + m * p.K + k0 + 4);
-                const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                for (int m = 0; m < MR; ++m)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { g[j] += dyv[m] * xv[j]; dxr[m][c][j] += dyv[m] * wf[j]; }
+                    for (int j = 0; j < 8; ++j) dxr[m][c][j] += dyv[m] * wf[j];
             }
             if (p.dW) {
+                float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const float4 xa = *reinterpret_cast<const float4*>(xs + m * p.K + k0);
+                    const float4 xb = *reinterpret_cast<const float4*>(xs + m * p.K + k0 + 4);
+                    const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += dyv[m] * xv[j];
+                }
                 float4* dst = reinterpret_cast<float4*>(p.dW + (size_t)n * p.K + k0);
                 dst[0] = make_float4(g[0], g[1], g[2], g[3]);
                 dst[1] = make_float4(g[4], g[5], g[6], g[7]);
@@ -428,7 +434,7 @@ int launch_colsum(const bf16_t* dy, int ld, int M, int N, float* part, hipStream
 
 int launch_rowlinear_backward(const RowLinBwdParams& p, hipStream_t st) {
     if (p.M <= 0 || p.M > 8 || p.N <= 0 || p.K <= 0 || p.K % 8 || p.K > 1024) return DGS_ERR_INVALID_ARGUMENT;
-    const int rpb = ROWLINEAR_BWD_ROWS;
+    const int rpb = p.rows_per_block > 0 ? p.rows_per_block : ROWLINEAR_BWD_ROWS;
     const dim3 grid((p.N + rpb - 1) / rpb), block(256);
     if (p.dx && !p.part && grid.x != 1) return DGS_ERR_INVALID_ARGUMENT;       // dx of several workgroups needs the slab
     const int mr = p.M <= 1 ? 1 : p.M <= 2 ? 2 : p.M <= 4 ? 4 : 8;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dgs_device.h"
 
@@ -24,7 +25,6 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
 #ifdef HIPEMU
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
-__device__ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
 __device__ __forceinline__ uint32_t f2bf_fast(float v) { return f2bf(v); }
 #else
 // one v_cvt_pk_bf16_f32 (round-to-nearest-even, same result as f2bf) instead of ~10 integer VALU ops per value
@@ -35,9 +35,9 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ uint32_t f2bf_fast(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v); }
-// bare v_exp_f32 (no denormal-range fix-up): callers only pass x <= ~8, tiny results may flush to 0
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif
+// bare v_exp_f32 (no denormal-range fix-up): callers only pass x <= ~8, tiny results may flush to 0
+__device__ __forceinline__ float fast_exp2(float x) { return hw_exp2(x); }
 
 // two packed bf16 values times c, rounded back to bf16 (pre-scaled attention queries: c = +-scale * log2(e))
 __device__ __forceinline__ uint32_t scale_bf2(uint32_t two, float c) {
@@ -106,6 +106,109 @@ __device__ __forceinline__ float xor32_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 #endif
+
+// ---- execution primitives: the hardware form, and what tests/hipemu (cooperative fibers, synchronous memory) runs in its place.
+//      The kernels themselves carry no #ifdef: every fork between the gfx950 build and the CPU emulation build lives in this file,
+//      dgs_device.h and raster_common.h. ----
+// counted wait on the vector-memory queue (LDS-DMAs complete in issue order: "at most N still in flight")
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#ifndef HIPEMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void wait_lgkmcnt0() {
+#ifndef HIPEMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+// workgroup barrier WITHOUT the memory-queue drain __syncthreads() carries (LDS-DMAs stay in flight across it)
+__device__ __forceinline__ void raw_barrier() {
+#ifndef HIPEMU
+    __builtin_amdgcn_s_barrier();
+#else
+    __syncthreads();
+#endif
+}
+// fence for hipcc's instruction scheduler: what is written before it issues before it
+__device__ __forceinline__ void sched_fence() {
+#ifndef HIPEMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// Instrumentation (cycle stamps, measurement variants: DGS_GEMM_DBG / DGS_ATTN_DBG / DGS_GEMM_EXP) exists only in a library built
+// with -DDGS_INSTRUMENT (`DGS_INSTRUMENT=1 python -m dgs_amd.build` -> lib/libdgs_hip_instr.so, for tools/): in the product library
+// every `if constexpr (kInstrumented)` branch is discarded, the run-time debug word is the literal 0.
+#if defined(DGS_INSTRUMENT) && !defined(HIPEMU)
+constexpr bool kInstrumented = true;
+#else
+constexpr bool kInstrumented = false;
+#endif
+// shader-clock / constant 100 MHz stamps of the debug modes (0 on the emulator)
+__device__ __forceinline__ long long cycle_stamp() {
+#ifndef HIPEMU
+    return clock64();
+#else
+    return 0;
+#endif
+}
+__device__ __forceinline__ long long wall_stamp() {
+#ifndef HIPEMU
+    return wall_clock64();
+#else
+    return 0;
+#endif
+}
+// 32-bit LDS address of a pointer into the workgroup's LDS (what M0 takes); the emulator addresses LDS through the pointer itself
+__device__ __forceinline__ uint32_t lds_address(const char* p) {
+#ifndef HIPEMU
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)p;
+#else
+    (void)p;
+    return 0u;
+#endif
+}
+// One LDS-DMA wave-instruction (1 KiB) with all-scalar addressing: lane's 16 bytes at sbase + voff -> LDS lds_wave + LIT + 16 lane.
+// Global address = SGPR pair + one loop-invariant 32-bit VGPR offset, LDS address = M0 = SGPR + literal: tools/ubench/dma_piece_bench
+// prices this form at 1 cycle of the MFMA stream per piece, against 29 for what hipcc makes of the builtin with per-slab pointer
+// arithmetic (64-bit VGPR address by v_lshl_add_u64, M0 restored from a spilled SGPR).  `lds_wave_ptr` = the same LDS place as a
+// pointer (used by the emulator only).
+template <int LIT>
+__device__ __forceinline__ void lds_dma_scalar(const char* sbase, uint32_t voff, uint32_t lds_wave, char* lds_wave_ptr) {
+#ifndef HIPEMU
+    (void)lds_wave_ptr;
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave), "n"(LIT) : "memory", "m0", "scc");
+#else
+    (void)lds_wave;
+    glds16(sbase + voff, lds_wave_ptr + LIT);
+#endif
+}
+// agent-scope (sc1) relaxed store / 8-byte load: performed at the memory side, coherent across XCDs without a fence
+__device__ __forceinline__ void st_agent(float* ptr, float v) {
+#ifdef HIPEMU
+    *ptr = v;
+#else
+    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ float2 ld_agent2(const float2* ptr) {
+#ifdef HIPEMU
+    return *ptr;
+#else
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+#endif
+}
+
+// compute units of the current device (host side; the emulator's "chip" has DGS_EMU_CUS of them)
+inline int compute_unit_count() {
+#ifdef HIPEMU
+    return getenv("DGS_EMU_CUS") ? atoi(getenv("DGS_EMU_CUS")) : 0;
+#else
+    int n = 0, d = 0;
+    return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess ? n : 0;
+#endif
+}
 
 // Exchange between the two halves of a wave (v_permlane32_swap): afterwards lanes 0-31 hold {their own a, the upper half's a} in
 // (a, b) and lanes 32-63 hold {the lower half's b, their own b} -- two 8-byte row pieces of a lane pair become one 16-byte piece

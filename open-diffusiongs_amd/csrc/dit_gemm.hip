@@ -93,9 +93,7 @@ __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int fha
             for (int j = 0; j < NI; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
                 if (i == 0 && j == 0 && ks < 3) read(ks + 1, h ^ 1);
-#ifndef HIPEMU
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                sched_fence();
             }
     }
 }

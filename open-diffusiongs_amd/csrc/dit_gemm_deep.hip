@@ -55,34 +55,6 @@ __device__ __forceinline__ int slab_off(int r, int c) {
     return BK == 64 ? r * 128 + ((c ^ ((r >> 1) & 7)) << 4) : r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
 }
 
-// DMA one [ROWS][BK] slab: wave-instructions of 1 KiB (1024 / (2 BK) rows each), spread over the NW waves.
-template <int ROWS, int BK, int NW = 8>
-__device__ __forceinline__ void stage_slab(const bf16_t* g, int ld, int row0, int k0, char* dst, int wave, int lane) {
-    constexpr int RPI = 1024 / (2 * BK);          // rows per instruction: 8 (BK 64) or 16 (BK 32)
-    constexpr int CPR = BK / 8;                   // 16-byte chunks per row
-    constexpr int NINST = ROWS / RPI;
-#pragma unroll
-    for (int q = 0; q < (NINST + NW - 1) / NW; ++q) {
-        const int piece = wave + NW * q;
-        if (NINST % NW != 0 && piece >= NINST) break;
-        const int row = piece * RPI + lane / CPR;
-        const int slot = lane % CPR;
-        const int chunk = BK == 64 ? (slot ^ ((row >> 1) & 7)) : (slot ^ ((row >> 2) & 3));
-        glds16(g + (size_t)(row0 + row) * ld + k0 + chunk * 8, dst + piece * 1024);
-    }
-}
-
-// One wave-instruction of stage_slab (piece = wave + NW * q), for kernels that spread the DMA issue over their MFMA slices.
-template <int BK, int NW>
-__device__ __forceinline__ void stage_piece(const bf16_t* g, int ld, int row0, int k0, char* dst, int wave, int lane, int q) {
-    constexpr int RPI = 1024 / (2 * BK), CPR = BK / 8;
-    const int piece = wave + NW * q;
-    const int row = piece * RPI + lane / CPR;
-    const int slot = lane % CPR;
-    const int chunk = BK == 64 ? (slot ^ ((row >> 1) & 7)) : (slot ^ ((row >> 2) & 3));
-    glds16(g + (size_t)(row0 + row) * ld + k0 + chunk * 8, dst + piece * 1024);
-}
-
 template <int EPI, int NI>
 __device__ __forceinline__ void store_block(const DeepParams& p, const f32x16 (&acc)[NI], int mbase, int nbase, int lane) {
     // D fragment: col (n) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); mbase already includes 4 * (lane >> 5)
@@ -175,10 +147,9 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     static_assert(NW == 8 || BN == 256 || (BM == 128 && BN == 128), "4 waves: 256 x 256 tiles (128 x 128 per wave) or 128 x 128 tiles (64 x 64)");
     static_assert(WMB * NI >= G, "one DMA piece behind each MFMA of the spread half");
     DGS_DYNAMIC_LDS(lds);
-#ifndef HIPEMU
-    const long long dbg_k0 = p.dbg == 1 ? clock64() : 0;
-    const long long dbg_w0 = p.dbg == 1 ? wall_clock64() : 0;         // constant 100 MHz: gives the shader clock the cycle stamps ran at
-#endif
+    const int dbg = kInstrumented ? p.dbg : 0;                        // the product library carries no instrumentation
+    const long long dbg_k0 = dbg == 1 ? cycle_stamp() : 0;
+    const long long dbg_w0 = dbg == 1 ? wall_stamp() : 0;             // constant 100 MHz: gives the shader clock the cycle stamps ran at
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -310,14 +281,11 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     auto frag = [&](int slot, int ks, int f) { return *reinterpret_cast<const bf16x8*>(lds + slot * STAGE + foff[ks][f]); };
     const int nk = p.K / BK;                                      // a multiple of NS
     constexpr int GA = A_BYTES / 1024 / NW;                       // DMA pieces per wave per slab: GA of A, G - GA of W
-#ifndef HIPEMU
-    // The DMA of a piece, all-scalar addressing: global address = SGPR pair (the operand's tile row 0 at the slab's k) + one
-    // 32-bit VGPR offset per piece (the lane's row and 16-byte chunk: loop-invariant), LDS address = M0 = SGPR + literal.
-    // tools/ubench/dma_piece_bench on MI355X, one piece per two MFMAs: this form costs 1 cycle of the MFMA stream per piece;
-    // a 64-bit VGPR address made by v_lshl_add_u64 with M0 restored from a spilled SGPR (v_readlane_b32) -- what hipcc made of
-    // the builtin with per-slab pointer arithmetic -- costs 29.
+    // The DMA of a piece, all-scalar addressing (lds_dma_scalar): global address = SGPR pair (the operand's tile row 0 at the slab's
+    // k) + one 32-bit VGPR offset per piece (the lane's row and 16-byte chunk: loop-invariant), LDS address = M0 = SGPR + literal.
     constexpr int RPI = 1024 / (2 * BK), CPR = BK / 8;
-    const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds + (uint32_t)wave * 1024u;
+    char* const lds_mine = lds + wave * 1024;
+    const uint32_t lds_wave = lds_address(lds) + (uint32_t)wave * 1024u;
     const char* sb_a = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);        // + 2 BK bytes per slab staged
     const char* sb_w = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
     uint32_t vo_a[GA], vo_w[G - GA];
@@ -330,10 +298,8 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     }
     auto dma_piece = [&](auto slotc, auto qc) {                   // piece q (A pieces first) of the NEXT slab into ring slot `slot`
         constexpr int slot = decltype(slotc)::value, q = decltype(qc)::value;
-        if constexpr (q < GA)
-            asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo_a[q]), "s"(sb_a), "s"(lds_wave), "n"(slot * STAGE + NW * q * 1024) : "memory", "m0", "scc");
-        else
-            asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo_w[q - GA]), "s"(sb_w), "s"(lds_wave), "n"(slot * STAGE + A_BYTES + NW * (q - GA) * 1024) : "memory", "m0", "scc");
+        if constexpr (q < GA) lds_dma_scalar<slot * STAGE + NW * q * 1024>(sb_a, vo_a[q], lds_wave, lds_mine);
+        else lds_dma_scalar<slot * STAGE + A_BYTES + NW * (q - GA) * 1024>(sb_w, vo_w[q - GA], lds_wave, lds_mine);
         if constexpr (q == G - 1) { sb_a += 2 * BK; sb_w += 2 * BK; }
     };
     auto stage_next = [&](auto slotc) { sliced_for<0, G>([&](auto qc) { dma_piece(slotc, qc); }); };
@@ -345,14 +311,6 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const bool has_side_job = NS > 4 && p.tail_wgs == 0 && bid < p.ntail && p.nsplit == 1;
     sliced_for<0, 2>([&](auto sc) { stage_next(sc); });
     if (!has_side_job) sliced_for<2, NS - 1>([&](auto sc) { stage_next(sc); });
-#else
-    auto stage = [&](int t, int slot) {
-        stage_slab<BM, BK, NW>(p.A, p.lda, m0, t * BK, lds + slot * STAGE, wave, lane);
-        stage_slab<BN, BK, NW>(p.W, p.ldw, n0, t * BK, lds + slot * STAGE + A_BYTES, wave, lane);
-    };
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) stage(s, s);
-#endif
     // ---- tiles with a single live 32-row block (the learned-token rows of every sample), folded into the first workgroups ----
     // An item is 32 rows x 32 columns (64 for BN = 128): the NW waves are ranges of K, every wave pulls its fragments straight from
     // L2 in one round trip per 128 / 256 columns of K (one trip for K = 1024), the ranges meet in the ring stage that iteration 0
@@ -362,17 +320,13 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     // 256 CUs, so they start when the first full tiles retire) these items added 36 us when a wave walked all of K for one
     // column block, and still 14 us in this one-trip form.
     if (p.tail_wgs == 0) side_jobs(bid, (int)gridDim.x);
-#ifndef HIPEMU
     if (has_side_job) sliced_for<2, NS - 1>([&](auto sc) { stage_next(sc); });
     // Slabs 0 and 1 have to be there before iteration 0 (its second half prefetches fragments of slab 1); slabs 2 .. NS-2 may stay
     // in flight -- with the 8-stage ring of the 128 x 128 tiles, waiting for all seven (112 KiB per CU, every CU at once) cost
     // ~10 k cycles of every tile.  Stores a side job left in flight are older than those slabs: "at most (NS-3) G operations
     // outstanding" then still means slabs 0 and 1 have landed (loads return in order; a lingering store only makes the wait longer).
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
-    __builtin_amdgcn_s_barrier();
-#else
-    __syncthreads();
-#endif
+    wait_vmcnt<(NS - 3) * G>();
+    raw_barrier();
     bf16x8 fr[2][NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) fr[0][f] = frag(0, 0, f);
@@ -396,33 +350,19 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         constexpr int slot = decltype(slot_tag)::value;
         constexpr int PRE_N = decltype(pre_tag)::value;                // residual loads in flight at the end of this iteration
         constexpr bool refill = decltype(refill_tag)::value;           // slab t + NS - 1 exists; it goes into the stage of slab t - 1
-#ifndef HIPEMU
         if constexpr (refill && !SPREAD && EXP != 1) stage_next(SIC<(slot + NS - 1) % NS>{});
-#else
-        char* const dst = lds + ((slot + NS - 1) % NS) * STAGE;
-        if (refill && !SPREAD && EXP != 1) stage(t + NS - 1, (slot + NS - 1) % NS);
-#endif
         sliced_for<0, 2 * MF>([&](auto jc) {
             constexpr int J = decltype(jc)::value, ks = J / MF, i = (J % MF) / NI, j = J % NI;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks][i], fr[ks][WMB + j], acc[i][j], 0, 0, 0);
-#ifndef HIPEMU
-            __builtin_amdgcn_sched_barrier(0);                     // the MFMA leads its slice: what follows issues in its shadow
-#endif
+            sched_fence();                                         // the MFMA leads its slice: what follows issues in its shadow
             // the other register half: substep 1 of this slab, then substep 0 of the next one (stale data behind the last slab)
             constexpr int f = J % MF;
             if constexpr (f < NF && EXP != 2) fr[ks ^ 1][f] = frag(ks == 0 ? slot : (slot + 1) % NS, ks ^ 1, f);
             if constexpr (SPREAD && refill && ks == 0 && f >= MF - G && EXP != 1) {
                 constexpr int q = f - (MF - G);
-#ifndef HIPEMU
                 dma_piece(SIC<(slot + NS - 1) % NS>{}, SIC<q>{});
-#else
-                if constexpr (q < GA) stage_piece<BK, NW>(p.A, p.lda, m0, (t + NS - 1) * BK, dst, wave, lane, q);
-                else stage_piece<BK, NW>(p.W, p.ldw, n0, (t + NS - 1) * BK, dst + A_BYTES, wave, lane, q - GA);
-#endif
             }
-#ifndef HIPEMU
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            sched_fence();
         });
         if constexpr (PRE_N > 0 && refill) {                       // the tail's first iteration: its DMAs were the last ones
 #pragma unroll
@@ -432,9 +372,8 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         }
         // slab t+1 (and older) has landed once at most this iteration's own DMAs are outstanding; then everybody is also
         // done reading slab t
-#ifndef HIPEMU
         long long w0 = 0;
-        if constexpr (DBG) w0 = clock64();
+        if constexpr (DBG) w0 = cycle_stamp();
         // The second half of iteration t+1 already prefetches fragments of slab t+2, so slabs <= t+2 must have landed by the end of
         // iteration t: slabs t+3 .. t+NS-1 stay in flight across the barrier (DMAs complete in issue order).  NS = 4: only the slab
         // issued in this iteration; NS = 8 (128 x 128 tiles, whose A operand streams from beyond L2): five slabs, ~3 k cycles of
@@ -442,20 +381,16 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         if constexpr (PRE_N > 0) {
             // the residual loads went out behind the last DMA (below) and stay in flight to the epilogue: slabs t+3 .. nk-1 plus them
             constexpr int left = decltype(left_tag)::value;       // slabs behind t+2 that exist
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(left * G + PRE_N) : "memory");
-        } else if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_vmcnt<left * G + PRE_N>();
+        } else if constexpr (refill) wait_vmcnt<(NS - 3) * G>();
+        else wait_vmcnt<0>();
         long long w1 = 0;
-        if constexpr (DBG) w1 = clock64();
-        __builtin_amdgcn_s_barrier();
-        if constexpr (DBG) { dbg_wait += w1 - w0; dbg_bar += clock64() - w1; }
-#else
-        __syncthreads();
-#endif
+        if constexpr (DBG) w1 = cycle_stamp();
+        raw_barrier();
+        if constexpr (DBG) { dbg_wait += w1 - w0; dbg_bar += cycle_stamp() - w1; }
+        (void)t;
     };
-#ifndef HIPEMU
-    const long long dbg_t0 = p.dbg == 1 ? clock64() : 0;
-#endif
+    const long long dbg_t0 = dbg == 1 ? cycle_stamp() : 0;
     auto k_loop = [&](auto dbg_tag) {
         for (int t = 0; t < nk - NS; t += NS)                      // unrolled by the ring depth: slots are literals
             sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, sc, std::true_type{}, SIC<0>{}, SIC<0>{}, dbg_tag); });
@@ -464,14 +399,13 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
             iteration(nk - NS + S, sc, std::integral_constant<bool, S == 0>{}, SIC<PRE_LOADS>{}, SIC<(NS - S - 3 > 0 ? NS - S - 3 : 0)>{}, dbg_tag);
         });
     };
-#ifndef HIPEMU
-    if (p.dbg == 1) k_loop(std::true_type{});
-    else
-#endif
+    if constexpr (kInstrumented) {
+        if (dbg == 1) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
+    } else {
         k_loop(std::false_type{});
-#ifndef HIPEMU
-    const long long dbg_t1 = p.dbg == 1 ? clock64() : 0;
-#endif
+    }
+    const long long dbg_t1 = dbg == 1 ? cycle_stamp() : 0;
     if (epi_staged<EPI>(p)) {          // the ring is idle now (everybody passed the last barrier): a private LDS patch per wave
         char* patch = lds + wave * epi_strip_bytes(2);
 #pragma unroll
@@ -485,22 +419,20 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 #pragma unroll
         for (int i = 0; i < WMB; ++i) store_block<EPI, NI>(p, acc[i], m0 + wm * WROWS + 32 * i + 4 * fhalf, n0 + wn * WN, lane);
     }
-#ifndef HIPEMU
-    if (p.dbg == 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (kInstrumented) if (dbg == 1) {
+        wait_vmcnt<0>();
         if (tid == 0) {
-            atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[6]), (unsigned long long)(clock64() - dbg_k0));
+            atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[6]), (unsigned long long)(cycle_stamp() - dbg_k0));
             atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[7]), (unsigned long long)dbg_wait);
             atomicMin(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[8]), (unsigned long long)dbg_k0);
-            atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[9]), (unsigned long long)clock64());
+            atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[9]), (unsigned long long)cycle_stamp());
         }
         if (blockIdx.x == 0 && tid == 0) {
             dgs_gemm_dbg[0] = dbg_t1 - dbg_t0; dgs_gemm_dbg[1] = dbg_wait; dgs_gemm_dbg[2] = dbg_bar; dgs_gemm_dbg[3] = nk;
-            dgs_gemm_dbg[4] = dbg_t0 - dbg_k0; dgs_gemm_dbg[5] = clock64() - dbg_t1;
-            dgs_gemm_dbg[10] = clock64() - dbg_k0; dgs_gemm_dbg[11] = wall_clock64() - dbg_w0;
+            dgs_gemm_dbg[4] = dbg_t0 - dbg_k0; dgs_gemm_dbg[5] = cycle_stamp() - dbg_t1;
+            dgs_gemm_dbg[10] = cycle_stamp() - dbg_k0; dgs_gemm_dbg[11] = wall_stamp() - dbg_w0;
         }
     }
-#endif
 }
 
 template <int EPI, int BN, int NW = 8, int BM = 256>
@@ -527,11 +459,7 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
     p.ntiles = p.nfull_items ? p.nfull_items : p.ntail;
     p.tail_wgs = 0;
     if (p.nsplit <= 1 && p.ntail > 0 && p.nfull_items > 0) {
-#ifdef HIPEMU
-        static const int ncu = getenv("DGS_EMU_CUS") ? atoi(getenv("DGS_EMU_CUS")) : 0;       // tests exercise the tail-only workgroups with it
-#else
-        static const int ncu = [] { int n = 0, d = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess ? n : 0; }();
-#endif
+        static const int ncu = compute_unit_count();               // (the emulator reads DGS_EMU_CUS: tests exercise the tail-only workgroups with it)
         const int idle = ncu - p.nfull_items;                      // a tile workgroup owns its CU's LDS
         if (idle > 0) p.tail_wgs = idle < p.ntail ? idle : p.ntail;
         p.ntiles += p.tail_wgs;
@@ -541,7 +469,7 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
         p.ntiles = p.nfull_items * p.nsplit;
     }
     auto kern = gemm_sliced_kernel<EPI, BN, NW, 0, BM>;
-    if constexpr (EPI == DGS_EPI_F32 && BN == 256 && BM == 256) {              // DGS_GEMM_EXP=1|2: the measurement variants
+    if constexpr (kInstrumented && EPI == DGS_EPI_F32 && BN == 256 && BM == 256) {   // DGS_GEMM_EXP=1|2: the measurement variants (instrumented library only)
         static const int exp = getenv("DGS_GEMM_EXP") ? atoi(getenv("DGS_GEMM_EXP")) : 0;
         if (exp == 1) kern = gemm_sliced_kernel<EPI, BN, NW, 1>;
         if (exp == 2) kern = gemm_sliced_kernel<EPI, BN, NW, 2>;
@@ -552,9 +480,9 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DGS_ERR_DEVICE;
         attr_set = true;
     }
-    static const int dbg = getenv("DGS_GEMM_DBG") ? atoi(getenv("DGS_GEMM_DBG")) : 0;   // 1: cycle stamps
+    static const int dbg = kInstrumented && getenv("DGS_GEMM_DBG") ? atoi(getenv("DGS_GEMM_DBG")) : 0;   // 1: cycle stamps (instrumented library only)
     p.dbg = dbg;
-#ifndef HIPEMU
+#ifdef DGS_INSTRUMENT
     if (dbg == 1) {
         const long long z[4] = {0, 0, 0x7fffffffffffffffLL, 0};
         (void)hipStreamSynchronize(st);
@@ -562,7 +490,7 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
     }
 #endif
     hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(64 * NW), LDS, st, p);
-#ifndef HIPEMU
+#ifdef DGS_INSTRUMENT
     if (dbg == 1) {
         long long h[12];
         (void)hipStreamSynchronize(st);

@@ -17,24 +17,14 @@ __device__ __forceinline__ float epi_gelu_tanh(float x) {
     // nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)
     //   = x / (1 + 2^(-2 log2(e) u)) : two multiplies, one fma, v_exp_f32, one add, v_rcp_f32 (1 ulp), one multiply --
     // an IEEE division and __expf's range handling cost ~25 VALU per element, which made this epilogue a third of fc1.
-#ifdef HIPEMU
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x / (1.0f + __expf(-2.0f * u));
-#else
     const float t = x * __builtin_fmaf(x * x, -2.0f * 1.4426950408889634f * 0.7978845608028654f * 0.044715f, -2.0f * 1.4426950408889634f * 0.7978845608028654f);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-#endif
+    return x * hw_rcp(1.0f + hw_exp2(t));
 }
 
 // d/dx of the above: s + x s (1 - s) 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2),  s = sigmoid(2u)
 __device__ __forceinline__ float epi_dgelu_tanh(float x) {
-#ifdef HIPEMU
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float sg = 1.0f / (1.0f + __expf(-2.0f * u));
-#else
     const float t = x * __builtin_fmaf(x * x, -2.0f * 1.4426950408889634f * 0.7978845608028654f * 0.044715f, -2.0f * 1.4426950408889634f * 0.7978845608028654f);
-    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-#endif
+    const float sg = hw_rcp(1.0f + hw_exp2(t));
     return sg + x * sg * (1.0f - sg) * (2.0f * 0.7978845608028654f) * __builtin_fmaf(x * x, 3.0f * 0.044715f, 1.0f);
 }
 

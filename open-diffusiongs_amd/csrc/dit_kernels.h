@@ -67,6 +67,7 @@ struct RowLinBwdParams {
     float* db;            // [N] or NULL
     float* dx;            // [M, K] or NULL (with `part`: only says that dx is wanted)
     float* part;          // slab [workgroups][M * K] partial dx rows, or NULL (single workgroup: ADDED to dx)
+    int rows_per_block;   // output features per workgroup (0: ROWLINEAR_BWD_ROWS)
 };
 
 // One column-sum job of col_reduce_kernel: out[b * out_bstride + c] = sum_{s < slots} part[(b * slots + s) * part_stride + c]
@@ -77,8 +78,8 @@ struct ColReduceJob {
 };
 struct ColReduceParams { ColReduceJob job[8]; };
 
-constexpr int ROWLINEAR_BWD_ROWS = 32;      // output features per workgroup of rowlinear_backward_kernel (a block's adaLN Linear, 6W rows, is a launch
-                                            // of its own: 192 workgroups at W = 1024; at 256 rows per workgroup it would stream on 24 CUs)
+constexpr int ROWLINEAR_BWD_ROWS = 256;     // output features per workgroup of rowlinear_backward_kernel (default; the slab of dx partial rows is sized by it)
+constexpr int ROWLINEAR_DW_ROWS = 32;       // ... of a launch that only writes dW / db (a block's adaLN Linear, 6W rows: 192 workgroups at W = 1024)
 inline int ln_backward_rows_per_block(int rows_per_batch) { return rows_per_batch % 32 == 0 ? 32 : rows_per_batch; }
 
 struct GsBwdParams {

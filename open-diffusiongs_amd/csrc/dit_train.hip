@@ -362,15 +362,15 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         lu.dshift = dmod_up + (size_t)b * nmod; lu.dscale = dmod_up + W + (size_t)b * nmod; lu.dweight = gr->up_ln_w;
         DGS_TRY(launch_layernorm_backward(lu, st));
     }
-    // adaLN Linear of a group of modulation rows [row0, row0 + rows) of the stacked weight: dW / db are written, the group's
-    // partial dx rows go to its own slots of the slab (summed over ALL groups at the end: d cvec)
+    // adaLN Linear of a group of modulation rows [row0, row0 + rows) of the stacked weight: dW = dmod (x) silu(cvec) and db are
+    // WRITTEN here, with the group (pure streaming stores, no weight read); d cvec -- the one quantity that needs every group -- is
+    // one pass over the stacked weight at the end
     auto ada_backward = [&](int row0, int rows, float* dW, float* db) -> int {
         RowLinBwdParams ra{};
         ra.M = B; ra.N = rows; ra.K = W; ra.silu_in = 1; ra.x = sv.cvec; ra.W = m->ada_w + (size_t)row0 * W; ra.dy = ws.dmod + row0; ra.ldy = nmod;
-        ra.dW = dW; ra.db = db; ra.dx = ws.dcvec; ra.part = ws.rl_part + (size_t)(row0 / ROWLINEAR_BWD_ROWS) * B * W;
+        ra.dW = dW; ra.db = db; ra.rows_per_block = ROWLINEAR_DW_ROWS;
         return launch_rowlinear_backward(ra, st);
     };
-    if ((6 * W) % ROWLINEAR_BWD_ROWS) return DGS_ERR_INVALID_ARGUMENT;
     DGS_TRY(ada_backward(6 * W * m->layers, 4 * W, gr->head_ada_w, gr->head_ada_b));
     if (a->block_done) a->block_done(a->block_user, m->layers);     // dec_w, dec_ln_w, up_w, up_ln_w, head_ada_* are final (enqueued)
 
@@ -452,8 +452,11 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
     DGS_TRY(launch_transpose(sv.emb, kin, ws.embT, B, lpad, kin, st));
     DGS_TRY(wgrad(ws.dyT, W, ws.embT, kin, gr->tok_w, B, lpad, ws, stream));   // kin = 576: 64-column tiles
 
-    // ---- d cvec = sum over every adaLN group's partial rows (heads, blocks), TimestepEmbedder ----
+    // ---- d cvec: all modulation rows (blocks + heads) against the stacked adaLN weight; then the TimestepEmbedder ----
     {
+        RowLinBwdParams ra{};
+        ra.M = B; ra.N = nmod; ra.K = W; ra.silu_in = 1; ra.x = sv.cvec; ra.W = m->ada_w; ra.dy = ws.dmod; ra.dx = ws.dcvec; ra.part = ws.rl_part;
+        DGS_TRY(launch_rowlinear_backward(ra, st));
         const ColReduceJob job{ws.rl_part, ws.dcvec, (nmod + ROWLINEAR_BWD_ROWS - 1) / ROWLINEAR_BWD_ROWS, B * W, B * W, 1, 0};
         DGS_TRY(launch_col_reduce(&job, 1, st));
     }

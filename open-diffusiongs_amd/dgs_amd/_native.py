@@ -8,7 +8,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
+# DGS_AMD_LIBRARY: another build of the SAME sources -- the instrumented library of tools/ (`DGS_INSTRUMENT=1 python -m dgs_amd.build`)
+# or an A/B side (tools/ab_build.sh).  Never a fallback: whatever is named must exist and pass the ABI check.
+LIB_PATH = os.environ.get("DGS_AMD_LIBRARY") or os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
 
 ABI_VERSION = 3          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
 c_float_p = ctypes.POINTER(ctypes.c_float)

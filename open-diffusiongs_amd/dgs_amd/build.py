@@ -35,25 +35,36 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=False):
-    os.makedirs(LIB_DIR, exist_ok=True)
+def build_hip(force=False, verbose=False, instrument=None):
+    """instrument (default: env DGS_INSTRUMENT=1): the tools' build with -DDGS_INSTRUMENT -- cycle stamps and measurement variants of
+    the GEMM / attention kernels (DGS_GEMM_DBG, DGS_ATTN_DBG, DGS_GEMM_EXP) -- as lib/libdgs_hip_instr.so (objects under lib/instr/);
+    load it with DGS_AMD_LIBRARY=<path>.  The product library has none of it compiled in."""
+    if instrument is None:
+        instrument = os.environ.get("DGS_INSTRUMENT", "0") not in ("", "0")
+    if instrument:
+        return _build(force, verbose, os.path.join(LIB_DIR, "instr"), os.path.join(LIB_DIR, "libdgs_hip_instr.so"), ["-DDGS_INSTRUMENT"])
+    return _build(force, verbose, LIB_DIR, LIB_PATH, [])
+
+
+def _build(force, verbose, obj_dir, lib_path, extra):
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
     objs, rebuilt = [], False
     for src in sources():
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + extra + FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             rebuilt = True
         objs.append(o)
-    if rebuilt or not os.path.exists(LIB_PATH):
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
-    return LIB_PATH
+    if rebuilt or not os.path.exists(lib_path):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -112,16 +112,17 @@ def assert_forward_parity(backend, sc, cams, H, W, device, bg=(1.0, 1.0, 1.0), s
             np.testing.assert_array_equal(color[v].cpu().numpy().view(np.uint32), o.get("out_color").view(np.uint32),
                                           err_msg=f"colour bits view {v}")
         else:
-            # a pair whose alpha sits within an ulp of the 1/255 cut-off (or whose T crosses 1e-4) may be counted by one side only:
-            # such a pixel differs in n_contrib and by up to alpha T c <= 4e-3 in colour; every other pixel agrees to 1e-5
-            same = np.ones((H, W), bool)
+            # a pair whose alpha sits within an ulp of the 1/255 cut-off (or whose T crosses 1e-4) may be counted by one side only --
+            # anywhere in a pixel's list, so n_contrib need not differ: such a pixel is off by up to alpha T c <= 4e-3; every other
+            # pixel agrees to 1e-5.  Expected: a fraction of a pixel per view (~3e7 pairs x the width of an ulp window)
+            allowed = max(2, int(1e-5 * H * W))
             if check_state:
-                same = ncon[v] == o.get("n_contrib").astype(np.int32).reshape(H, W)
-                bad = int((~same).sum())
-                assert bad <= max(2, int(1e-5 * H * W)), f"n_contrib differs on {bad} of {H * W} pixels (view {v})"    # the bar of tests/test_raster_ref_gpu.py
-                np.testing.assert_allclose(fT[v][same], o.get("final_T").reshape(H, W)[same], atol=1e-5, err_msg="final_T")
-            diff = np.abs(color[v].cpu().numpy() - o.get("out_color"))
-            assert float(diff[:, same].max()) <= 1e-5 and float(diff.max()) <= 5e-3, \
-                f"view {v}: colour differs by {float(diff[:, same].max()):.3g} on pixels with equal n_contrib, {float(diff.max()):.3g} overall"
+                bad = int((ncon[v] != o.get("n_contrib").astype(np.int32).reshape(H, W)).sum())
+                assert bad <= allowed, f"n_contrib differs on {bad} of {H * W} pixels (view {v})"    # the bar of tests/test_raster_ref_gpu.py
+                dT = np.abs(fT[v] - o.get("final_T").reshape(H, W))
+                assert int((dT > 1e-5).sum()) <= allowed and float(dT.max()) <= 5e-3, (v, int((dT > 1e-5).sum()), float(dT.max()))
+            diff = np.abs(color[v].cpu().numpy() - o.get("out_color")).max(axis=0)
+            off = int((diff > 1e-5).sum())
+            assert off <= allowed and float(diff.max()) <= 5e-3, f"view {v}: {off} pixels differ by more than 1e-5 (max {float(diff.max()):.3g})"
     assert int(n_total) == total, (n_total, total)
     return out
