@@ -307,6 +307,10 @@ int dgs_dit_forward_train(const DgsDitModel* m, const DgsDitForwardArgs* a, void
 int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, const DgsDitGrads* grads, const DgsDitBackwardArgs* a,
                      dgs_stream_t stream);
 
+/* Padding contract of the token-row tensors (rows_per_batch > valid_rows): rows at and behind valid_rows are never computed; of the
+ * 32-row block that holds the last valid rows only the valid rows are written.  Consumers (the attention kernel multiplies masked
+ * probabilities 0 by the V^T padding columns) need FINITE values there: allocate `out`, `aux` and `vt` zero-filled (or any finite
+ * fill) once; the library never writes a non-finite value into padding.                                                       */
 int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream);
 int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream);
 int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, dgs_stream_t stream);
@@ -323,14 +327,16 @@ int dgs_dit_rowlinear(const DgsDitRowLinearArgs* a, dgs_stream_t stream);
  * order.  The workspace is the one of dgs_dit_forward for a shape with the same token count (V views of H x W with
  * n_gaussians + V (H/patch) (W/patch) == L). */
 typedef struct DgsDitRunBlocksArgs {
-    int32_t B, L, V;           /* samples, tokens per sample (n_gaussians + image tokens), views (only used to validate L)    */
+    int32_t B, L, V;           /* samples, tokens per sample (n_gaussians + image tokens), views (0: not given; else only used to
+                                  check that L - n_gaussians is a multiple of it)                                              */
     int32_t first, last;       /* block range [first, last)                                                                  */
     const float* tokens_in;    /* f32 [B, L, W]: [gaussian tokens, image tokens]                                             */
     const float* cvec;         /* f32 [B, W]: the timestep embedding c = t_embedder(t)                                       */
     float* tokens_out;         /* f32 [B, L, W]                                                                              */
-    void* workspace;           /* dgs_dit_workspace_bytes of a shape with L tokens, zero-filled once                         */
+    void* workspace;           /* dgs_dit_workspace_bytes_for_tokens(m, B, L) bytes, zero-filled once                        */
     size_t workspace_bytes;
 } DgsDitRunBlocksArgs;
+size_t dgs_dit_workspace_bytes_for_tokens(const DgsDitModel* m, int32_t B, int32_t L);   /* the workspace depends on (B, L) only */
 int dgs_dit_run_blocks(const DgsDitModel* m, const DgsDitRunBlocksArgs* a, dgs_stream_t stream);
 
 /* Test hook: fills the LDS of every CU with NaN patterns (bf16 and f32).  The kernels above read operands that LDS-DMAs deliver

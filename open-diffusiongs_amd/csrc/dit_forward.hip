@@ -71,6 +71,13 @@ using namespace dgs;
 // 256-row granularity: the 256 x 256 GEMM tiles must not straddle samples (the 128-wide kernels skip the extra dead tile)
 extern "C" int32_t dgs_dit_lpad(int32_t L) { return (L + 255) / 256 * 256; }
 
+extern "C" size_t dgs_dit_workspace_bytes_for_tokens(const DgsDitModel* m, int32_t B, int32_t L) {
+    if (!m || B <= 0 || L <= 0) return 0;
+    size_t bytes = 0;
+    DitWorkspace::carve(nullptr, m, (size_t)B, (size_t)dgs_dit_lpad(L), L, &bytes);
+    return bytes;
+}
+
 extern "C" size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W) {
     if (!m || B <= 0 || V <= 0 || H <= 0 || W <= 0 || m->patch <= 0) return 0;
     size_t bytes = 0;
@@ -231,7 +238,7 @@ extern "C" int dgs_dit_run_blocks(const DgsDitModel* m, const DgsDitRunBlocksArg
     if (!m || !a || a->B <= 0 || a->B > 16 || a->L <= m->n_gaussians || a->first < 0 || a->last > m->layers || a->first > a->last ||
         !a->tokens_in || !a->tokens_out || !a->cvec || !a->workspace)
         return DGS_ERR_INVALID_ARGUMENT;
-    if ((a->L - m->n_gaussians) % a->V) return DGS_ERR_INVALID_ARGUMENT;
+    if (a->V > 0 && (a->L - m->n_gaussians) % a->V) return DGS_ERR_INVALID_ARGUMENT;     // V is a consistency check only (0: not given)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int B = a->B, W = m->width, ng = m->n_gaussians, L = a->L, lpad = dgs_dit_lpad(L);
     const int nmod = (6 * m->layers + 4) * W;

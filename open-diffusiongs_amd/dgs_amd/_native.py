@@ -262,7 +262,8 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
                "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds",
-               "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes"]
+               "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes",
+               "dgs_dit_workspace_bytes_for_tokens"]
 
 
 def _declare_dit(L):
@@ -285,6 +286,8 @@ def _declare_dit(L):
     L.dgs_dit_lpad.argtypes = [ctypes.c_int32]
     L.dgs_dit_workspace_bytes.restype = ctypes.c_size_t
     L.dgs_dit_workspace_bytes.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.dgs_dit_workspace_bytes_for_tokens.restype = ctypes.c_size_t
+    L.dgs_dit_workspace_bytes_for_tokens.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32]
     for fn in (L.dgs_dit_saved_bytes, L.dgs_dit_backward_workspace_bytes):
         fn.restype = ctypes.c_size_t
         fn.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]

@@ -11,6 +11,7 @@ load_state_dict); compute is ONE C call into libdgs_hip.so for the DiT (dgs_amd.
 for all (sample, view) rasterizations (dgs_amd.raster).  There is no PyTorch fallback.
 """
 import copy
+import warnings
 import math
 from dataclasses import dataclass, fields
 
@@ -363,7 +364,21 @@ class DGSDenoiser(nn.Module):
 
     def image_to_gaussians(self, images, ray_o, ray_d, t, training=False):   # denoiser.py:306-416
         ng = self.cfg.n_gaussians
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):   # differentiable in train AND eval mode
+        differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())   # in train AND eval mode
+        if differentiable and not self.training and (images.shape[0] > 4 or (self._engine is not None and self._engine.pending_backward)):
+            # an eval-mode caller that did not wrap inference in no_grad(): the differentiable path takes at most 4 samples per call
+            # and owns ONE activation arena -- serve it from the inference engine (the reference's inference entry points all run
+            # under no_grad, so nobody differentiates this result)
+            if not getattr(self, "_warned_eval_grad", False):
+                warnings.warn("DGSDenoiser (eval mode, grad enabled): batch > 4 or a pending backward -- running the inference engine, "
+                              "the outputs of this call are not differentiable; wrap inference in torch.no_grad()")
+                self._warned_eval_grad = True
+            differentiable = False
+        if differentiable:
+            if images.shape[0] > 4:
+                raise RuntimeError("DGSDenoiser: the differentiable path (forward that saves activations + backward) handles at most 4 "
+                                   "samples per call; use gradient accumulation (DataParallelTrainer accumulate_grad_batches) or a "
+                                   "smaller per-GPU batch")
             names = [n for n, _ in self.named_parameters()]
             outs = _DitFunction.apply(self, names, images, ray_o, ray_d, t, *[p for _, p in self.named_parameters()])
             xyz, aligned = outs[0], outs[5]
@@ -386,7 +401,7 @@ class DGSDenoiser(nn.Module):
     def dtype(self):
         return next(self.parameters()).dtype
 
-    def run_layers(self, start, end, views=4):   # denoiser.py:441-447
+    def run_layers(self, start, end, views=None):   # denoiser.py:441-447 (same signature; `views` only adds a consistency check)
         """-> custom_forward(concat_nerf_img_tokens [b, L, d], t = t_embedder(timesteps) [b, d]) running blocks [start, end).
         The reference hands this closure to torch.utils.checkpoint; here checkpointing lives inside the training path
         (`recompute_policy`), and the closure is an inference-mode utility on the same kernels."""

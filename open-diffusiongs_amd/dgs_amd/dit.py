@@ -52,18 +52,18 @@ class DitOps:
         dev = A.device
         if epilogue == _native.EPI_QKV:
             ldo = 2 * N // 3
-            if out is None:
-                out = torch.empty((M, ldo), dtype=torch.bfloat16, device=dev)
+            if out is None:      # zero-filled: padding rows are never written and must be finite (dgs_dit.h "padding contract")
+                out = torch.zeros((M, ldo), dtype=torch.bfloat16, device=dev)
             if vt is None:
-                vt = torch.empty((M // rows_per_batch, N // 3, rows_per_batch), dtype=torch.bfloat16, device=dev)
+                vt = torch.zeros((M // rows_per_batch, N // 3, rows_per_batch), dtype=torch.bfloat16, device=dev)
         elif epilogue in (_native.EPI_BF16, _native.EPI_GELU_BF16, _native.EPI_DGELU_BF16):
             ldo = N
             if out is None:
-                out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+                out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
         else:
             ldo = N
             if out is None:
-                out = torch.empty((M, N), dtype=torch.float32, device=dev)
+                out = torch.zeros((M, N), dtype=torch.float32, device=dev)
         a = DgsDitGemmArgs()
         a.M, a.N, a.K = M, N, K
         a.A, a.lda, a.W, a.ldw = _p(A), (lda if lda is not None else A.stride(0)), _p(W), (ldw if ldw is not None else W.stride(0))
@@ -265,20 +265,26 @@ class DitEngine:
         return out, aligned
 
 
-    def run_blocks(self, tokens, cvec, first, last, views=4):
+    def run_blocks(self, tokens, cvec, first, last, views=None):
         """DiT blocks [first, last) on tokens [B, L, W] (reference order: gaussian tokens first) under cvec [B, W] = t_embedder(t):
-        DGSDenoiser.run_layers (denoiser.py:441-447).  Inference-mode utility."""
+        DGSDenoiser.run_layers (denoiser.py:441-447).  Inference-mode utility; any token count (the workspace depends on (B, L)
+        only; `views`, when given, is just checked against L)."""
         dev = self.device
         B, L, W = tokens.shape
-        n_img = (L - self.ng) // views
-        side = int(round(n_img ** 0.5))
-        assert self.ng + views * side * side == L, "token count is not n_gaussians + views * (side / patch)^2"
-        ws = self._workspace(B, views, side * self.patch, side * self.patch)
+        need = int(self.lib.dgs_dit_workspace_bytes_for_tokens(ctypes.byref(self.model), B, L))
+        if need == 0:
+            raise RuntimeError("dgs dit: invalid shape for workspace")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        elif self._ws_shape != ("tokens", B, L):       # different carving: padding rows must be finite again
+            self._ws.zero_()
+        self._ws_shape = ("tokens", B, L)
+        ws = self._ws
         tin = tokens.to(dev, torch.float32).contiguous()
         c = cvec.to(dev, torch.float32).contiguous()
         out = torch.empty_like(tin)
         a = _native.DgsDitRunBlocksArgs()
-        a.B, a.L, a.V, a.first, a.last = B, L, views, int(first), int(last)
+        a.B, a.L, a.V, a.first, a.last = B, L, int(views or 0), int(first), int(last)
         a.tokens_in, a.cvec, a.tokens_out, a.workspace, a.workspace_bytes = _p(tin), _p(c), _p(out), _p(ws), ws.numel()
         rc = self.lib.dgs_dit_run_blocks(ctypes.byref(self.model), ctypes.byref(a), _stream(dev))
         if rc != 0:

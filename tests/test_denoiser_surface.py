@@ -1,6 +1,7 @@
 """Operator surface: registry names, Config fields, state-dict keys (checkpoint compatibility) and an end-to-end
 DGSDenoiser.forward (DiT -> Gaussians -> batched rasterization) on the CPU emulator vs oracle DiT + oracle rasterizer."""
 import numpy as np
+import pytest
 import torch
 
 from dgs_amd import denoiser as dn
@@ -216,8 +217,14 @@ def test_run_layers_matches_oracle_blocks():
     ref = tokens
     for i in range(1, 3):
         ref = D.dit_block(ref, c, sd, f"transformer.{i}.", 4)
-    out = m.run_layers(1, 3, views=V)(tokens, c)
+    out = m.run_layers(1, 3)(tokens, c)                    # the reference's signature: run_layers(start, end)
     assert out.shape == tokens.shape and rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
     two = m.run_layers(2, 3, views=V)(m.run_layers(1, 2, views=V)(tokens, c), c)
     assert torch.equal(two, out)
-    assert torch.equal(m.run_layers(1, 1, views=V)(tokens, c), tokens)          # empty range: identity
+    assert torch.equal(m.run_layers(1, 1)(tokens, c), tokens)                   # empty range: identity
+    # a token count that is no square grid of views (5 image tokens + 2): the workspace depends on (B, L) only
+    odd = torch.randn(1, 7, 256, generator=g)
+    ref7 = D.dit_block(odd, c[:1], sd, "transformer.0.", 4)
+    assert rel_l2(m.run_layers(0, 1)(odd, c[:1]), ref7) < 2e-2
+    with pytest.raises(RuntimeError):
+        m.run_layers(0, 1, views=3)(odd, c[:1])            # 5 image tokens are not 3 views of anything

@@ -19,7 +19,7 @@ def wrap(owner, name):
     def f(*a, **k):
         out = orig(*a, **k)
         t = out if isinstance(out, torch.Tensor) else None
-        if t is not None and t.is_cuda and t.numel() * t.element_size() >= (32 << 20):
+        if t is not None and t.is_cuda and t.numel() * t.element_size() >= (int(os.environ.get("FILL_MIN_MIB", "32")) << 20):
             st = [s for s in traceback.extract_stack()[:-1] if "find_fills" not in s.filename][-3:]
             LOG.append((name, t.numel() * t.element_size() / 2 ** 20, " <- ".join(f"{os.path.basename(s.filename)}:{s.lineno}" for s in reversed(st))))
         return out
@@ -50,6 +50,12 @@ for i in range(3):
     LOG.clear()
     tr.step(batch, t, target, rc2w, rk)
     torch.cuda.synchronize()
+import collections
+print("fills in the third step (>= FILL_MIN_MIB MiB), grouped by call site:")
+cnt = collections.Counter((n, w) for n, _, w in LOG)
+for (n, w), c in cnt.most_common(25):
+    print(f"  {c:4d} x {n:12s} {w}")
+LOG = [x for x in LOG if x[1] >= 32]
 print("large fills in the third step:")
 for name, mib, where in LOG:
     print(f"  {name:12s} {mib:9.1f} MiB  {where}")
