@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                 rc.x = c[0]; rc.y = c[1]; rc.z = c[2];
             }
             s_id[tid] = id; s_xy[tid] = xy; s_co[tid] = co; s_rgbc[tid] = rc;
+        } else {
+            // finite records in the slots without an entry (the walk reads ahead of its lists), as in the forward
+            s_id[tid] = 0u; s_xy[tid] = make_float2(0.f, 0.f); s_co[tid] = make_float4(0.f, 0.f, 0.f, 0.f); s_rgbc[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         unsigned long long keeps[16];
 #pragma unroll
@@ -135,37 +138,29 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             const uint4 cn = s_cnt[cell];
             const uint32_t tot = cn.x + cn.y + cn.z + cn.w;
             const uint32_t first = todo - (uint32_t)(i * 256);          // contributor (1-based list index) of batch entry 0
-            // software pipeline as in the forward: indices four at a time, one group ahead; the entry one iteration ahead
-            const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
-            uint32_t word = lst[0], word_next = lst[1];
-            uint32_t j = word & 255u;
-            float2 xy = s_xy[j];
-            float4 co = s_co[j];
-            float4 rc = s_rgbc[j];
-            st_entries += tot;
-            uint32_t k = 0;
-            for (; __ballot(k < tot) != 0ull; ++k) {
-                const uint32_t kn = k + 1u;
-                if ((kn & 3u) == 0u) { word = word_next; word_next = lst[(kn >> 2) + 1u]; }
-                const uint32_t jn = (word >> (8u * (kn & 3u))) & 255u;
-                const float2 xyn = s_xy[jn];
-                const float4 con = s_co[jn];
-                const float4 rcn = s_rgbc[jn];
+            // software pipeline as in the forward: a cell's indices four at a time (one word, the next word a group ahead), the
+            // entry one step ahead in two register sets that take turns; unrolled by the word: no copies, literal shifts
+            struct Entry { float2 xy; float4 co; float4 rc; };
+            auto load = [&](uint32_t j) { return Entry{s_xy[j], s_co[j], s_rgbc[j]}; };
+            auto step = [&](uint32_t k, uint32_t j, const Entry& e) {
                 // pixel took part iff index <= last_contributor (backward.cu:463-468); cheap rejects first (outside the ellipse,
                 // or below the Gaussian's alpha cut-off: alpha < 1/255 guaranteed, see preprocess_one -- the test the forward
                 // used to drop the pair)
-                const float dx = xy.x - pfx, dy = xy.y - pfy;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                const bool near = k < tot && inside && first - j <= last_contributor && !(power > 0.0f) && !(power < rc.w);
+                const float dx = e.xy.x - pfx, dy = e.xy.y - pfy;
+                const float power = -0.5f * (e.co.x * dx * dx + e.co.z * dy * dy) - e.co.y * dx * dy;
+                const bool near = k < tot && inside && first - j <= last_contributor && !(power > 0.0f) && !(power < e.rc.w);
                 if (__ballot(near) != 0ull) {
                     const float G = blend_exp<FAST_EXP>(near ? power : 0.0f);
-                    const float alpha = fminf(0.99f, co.w * G);
+                    const float alpha = fminf(0.99f, e.co.w * G);
                     const bool take = near && !(alpha < 1.0f / 255.0f);
                     const unsigned long long takers = __ballot(take);
                     if (takers != 0ull) {                               // wave-uniform: somebody in this strip touches its Gaussian
-                        const float Tn = T / (1.f - alpha);
+                        // product default: one v_rcp_f32 serves both divisions by (1 - alpha) (the exact mode keeps the reference's two
+                        // correctly rounded divisions, backward.cu:478,506: ~10 VALU each)
+                        const float inv1ma = FAST_EXP ? hw_rcp(1.f - alpha) : 0.f;
+                        const float Tn = FAST_EXP ? T * inv1ma : T / (1.f - alpha);
                         const float dchannel_dcolor = alpha * Tn;
-                        const float col[3] = {rc.x, rc.y, rc.z};
+                        const float col[3] = {e.rc.x, e.rc.y, e.rc.z};
                         float c9[9];
                         float dL_dalpha = 0.0f;
 #pragma unroll
@@ -177,13 +172,13 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                             last_color[ch] = take ? col[ch] : last_color[ch];
                         }
                         dL_dalpha *= Tn;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        dL_dalpha += (FAST_EXP ? -T_final * inv1ma : -T_final / (1.f - alpha)) * bg_dot;
                         T = take ? Tn : T;
                         last_alpha = take ? alpha : last_alpha;
-                        const float dL_dG = co.w * dL_dalpha;
+                        const float dL_dG = e.co.w * dL_dalpha;
                         const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                        const float dG_ddely = -gdy * co.z - gdx * co.y;
+                        const float dG_ddelx = -gdx * e.co.x - gdy * e.co.y;
+                        const float dG_ddely = -gdy * e.co.z - gdx * e.co.y;
                         c9[3] = dL_dG * dG_ddelx * ddelx_dx;
                         c9[4] = dL_dG * dG_ddely * ddely_dy;
                         c9[5] = -0.5f * gdx * dx * dL_dG;
@@ -198,7 +193,19 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                         }
                     }
                 }
-                j = jn; xy = xyn; co = con; rc = rcn;
+            };
+            const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
+            uint32_t word = lst[0];
+            Entry ea = load(word & 255u), eb;
+            st_entries += tot;
+            uint32_t k = 0;
+            for (; __ballot(k < tot) != 0ull; k += 4) {
+                const uint32_t word_next = lst[(k >> 2) + 1u];
+                eb = load((word >> 8) & 255u);  step(k, word & 255u, ea);
+                ea = load((word >> 16) & 255u); step(k + 1u, (word >> 8) & 255u, eb);
+                eb = load(word >> 24);          step(k + 2u, (word >> 16) & 255u, ea);
+                ea = load(word_next & 255u);    step(k + 3u, word >> 24, eb);
+                word = word_next;
             }
             st_trips += k;
         }

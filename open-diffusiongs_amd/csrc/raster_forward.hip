@@ -796,6 +796,11 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
             const float4 rc = p.g.rgb_cut[vo + id];
             s_xy[tid] = xy; s_co[tid] = co; s_rgbc[tid] = rc;
             m16 = cell_mask(xy, co, rc.w, tx0, ty0);
+        } else {
+            // a slot without an entry holds a finite record: the walk reads ahead of its lists (stale indices), and the product-default
+            // arithmetic multiplies a masked-out lane's colour by a zero weight instead of selecting -- 0 * NaN from LDS left by an
+            // earlier kernel would poison the pixel
+            s_xy[tid] = make_float2(0.f, 0.f); s_co[tid] = make_float4(0.f, 0.f, 0.f, 0.f); s_rgbc[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         unsigned long long keeps[16];
 #pragma unroll
@@ -819,44 +824,50 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
         if (alive != 0ull) {                                    // a wave whose 64 pixels are all finished only keeps the barriers
             const uint4 cn = s_cnt[cell];
             const uint32_t tot = (((alive >> (16 * row)) & 0xFFFFull) != 0ull) ? cn.x + cn.y + cn.z + cn.w : 0u;
-            // software pipeline: the indices arrive four at a time, one group ahead; the entry itself one iteration ahead
+            // software pipeline: the cell's indices arrive four at a time (one 32-bit word, the next word a group ahead), the
+            // entry itself one step ahead, in two register sets that take turns -- the loop is unrolled by the word, so there is
+            // no copy between steps and every shift is a literal (the rotating form spent 13 of its ~45 VALU per step on moves)
             // (bytes behind `tot` are stale indices of earlier batches: any of them addresses a staged record, none is used)
-            const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
-            uint32_t word = lst[0], word_next = lst[1];
-            uint32_t j = word & 255u;
-            float2 xy = s_xy[j];
-            float4 co = s_co[j];
-            float4 rc = s_rgbc[j];
-            st_entries += tot;
-            uint32_t k = 0;
-            for (; __ballot(k < tot) != 0ull; ++k) {
-                const uint32_t kn = k + 1u;
-                const bool refill = (kn & 3u) == 0u;
-                uint32_t fetched = 0u;
-                if (refill) { word = word_next; fetched = lst[(kn >> 2) + 1u]; }
-                const uint32_t jn = (word >> (8u * (kn & 3u))) & 255u;
-                const float2 xyn = s_xy[jn];
-                const float4 con = s_co[jn];
-                const float4 rcn = s_rgbc[jn];
-                const float dx = xy.x - pfx, dy = xy.y - pfy;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                const bool pass = k < tot && !done && !(power > 0.0f) && !(power < rc.w);  // alpha < 1/255 guaranteed below the cut (preprocess_one)
+            struct Entry { float2 xy; float4 co; float4 rc; };
+            auto load = [&](uint32_t j) { return Entry{s_xy[j], s_co[j], s_rgbc[j]}; };
+            auto step = [&](uint32_t k, uint32_t j, const Entry& e) {
+                const float dx = e.xy.x - pfx, dy = e.xy.y - pfy;
+                const float power = -0.5f * (e.co.x * dx * dx + e.co.z * dy * dy) - e.co.y * dx * dy;
+                const bool pass = k < tot && !done && !(power > 0.0f) && !(power < e.rc.w);  // alpha < 1/255 guaranteed below the cut (preprocess_one)
                 if (__ballot(pass) != 0ull) {
-                    const float alpha = fminf(0.99f, co.w * blend_exp<FAST_EXP>(pass ? power : 0.0f));
+                    const float alpha = fminf(0.99f, e.co.w * blend_exp<FAST_EXP>(pass ? power : 0.0f));
                     const float test_T = T * (1 - alpha);
                     const bool contributes = pass && !(alpha < 1.0f / 255.0f);
                     const bool finishes = contributes && test_T < 0.0001f;
                     const bool blends = contributes && !finishes;
                     done = done || finishes;
-                    const float c0 = C0 + rc.x * alpha * T, c1 = C1 + rc.y * alpha * T, c2 = C2 + rc.z * alpha * T;
-                    C0 = blends ? c0 : C0;
-                    C1 = blends ? c1 : C1;
-                    C2 = blends ? c2 : C2;
+                    if constexpr (FAST_EXP) {
+                        // product default: one weight, three fused multiply-adds (5 VALU for 12; the exact mode keeps the
+                        // reference's (c alpha) T products and separate adds, forward.cu:352-353, for bit-identity with the oracle)
+                        const float w = blends ? alpha * T : 0.0f;
+                        C0 = __builtin_fmaf(e.rc.x, w, C0); C1 = __builtin_fmaf(e.rc.y, w, C1); C2 = __builtin_fmaf(e.rc.z, w, C2);
+                    } else {
+                        const float c0 = C0 + e.rc.x * alpha * T, c1 = C1 + e.rc.y * alpha * T, c2 = C2 + e.rc.z * alpha * T;
+                        C0 = blends ? c0 : C0;
+                        C1 = blends ? c1 : C1;
+                        C2 = blends ? c2 : C2;
+                    }
                     T = blends ? test_T : T;
                     last_contributor = blends ? base + j + 1u : last_contributor;
                 }
-                j = jn; xy = xyn; co = con; rc = rcn;
-                if (refill) word_next = fetched;
+            };
+            const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
+            uint32_t word = lst[0];
+            Entry ea = load(word & 255u), eb;
+            st_entries += tot;
+            uint32_t k = 0;
+            for (; __ballot(k < tot) != 0ull; k += 4) {
+                const uint32_t word_next = lst[(k >> 2) + 1u];
+                eb = load((word >> 8) & 255u);  step(k, word & 255u, ea);
+                ea = load((word >> 16) & 255u); step(k + 1u, (word >> 8) & 255u, eb);
+                eb = load(word >> 24);          step(k + 2u, (word >> 16) & 255u, ea);
+                ea = load(word_next & 255u);    step(k + 3u, word >> 24, eb);
+                word = word_next;
             }
             st_trips += k;
         }

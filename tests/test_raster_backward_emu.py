@@ -17,6 +17,13 @@ def test_backward_matches_oracle(deg, seed, H, W, views):
     assert_backward_parity(emu_backend(), sc, cams, H, W, DEV, sh_degree=deg, bg=(0.3, 0.6, 0.9), seed=seed)
 
 
+def test_backward_product_default_arithmetic():
+    """`exact_exp` = 0 (what the product runs): hardware exponential, one reciprocal for both divisions by (1 - alpha) -- the same
+    gradients to 2e-3 of each tensor's max (on the emulator the `hardware` forms are libm's: this checks the mode's plumbing)."""
+    sc, cams = small_scene(200, 48, 48, seed=5, sh_degree=1, n_views=2)
+    assert_backward_parity(emu_backend(), sc, cams, 48, 48, DEV, sh_degree=1, exact=False, rtol=2e-3)
+
+
 def test_backward_precomputed_inputs():
     H, W = 32, 48
     sc, cams = small_scene(120, W, H, seed=8, n_views=2)

@@ -12,6 +12,16 @@ from util_scene import small_scene
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def poisoned_lds():
+    """Every test starts from LDS full of NaN patterns (dgs_debug_poison_lds): the blend kernels read ahead of their per-cell lists
+    into record slots no entry was staged into, and the product-default arithmetic multiplies masked-out lanes by a zero weight --
+    whatever an earlier kernel left in LDS must not be able to reach a pixel."""
+    from dgs_amd.dit import DitOps
+    DitOps().poison_lds()
+    yield
+
+
 @pytest.fixture(params=["scan", "sort", "bitonic", "auto"], autouse=True)
 def binning_form(request, monkeypatch):
     """Both binning forms of raster_forward.hip (per-tile scan of the depth-ordered Gaussians / instance list + per-tile bitmap

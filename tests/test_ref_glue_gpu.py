@@ -10,6 +10,16 @@ import torch
 from dgs_amd import cameras, synth
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def poisoned_lds():
+    """Every test starts from LDS full of NaN patterns (dgs_debug_poison_lds): the blend kernels read ahead of their per-cell lists
+    into record slots no entry was staged into, and the product-default arithmetic multiplies masked-out lanes by a zero weight --
+    whatever an earlier kernel left in LDS must not be able to reach a pixel."""
+    from dgs_amd.dit import DitOps
+    DitOps().poison_lds()
+    yield
 DEV = torch.device("cuda:0")
 NAMES = ("xyz", "features", "scaling", "rotation", "opacity")
 
