@@ -227,17 +227,23 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
     if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
 }
 
-// flat VALU op list of the softmax of one tile: group g = K / 12 produces pf[g] from 8 scores as (exp2, exp2, pack) x 4
-// (the row sums are NOT formed on the VALU: a ones fragment rides through the matrix pipe beside V^T, see `lacc`)
-template <int K> __device__ __forceinline__ void softmax_step(f32x16& s0, f32x16& s1, PFrag (&pf)[4]) {
+// flat VALU op list of the softmax of one tile: group g = K / 12 produces pf[g] from 8 scores as (exp2 + row-sum add, exp2 +
+// add, pack) x 4.  The row sums l = sum_k P[q][k] are two running fp32 adds per lane (one per key block; the lane pair (l, l ^ 32)
+// holds the two halves of a query's keys and is combined ONCE, in the epilogue): a ones fragment beside V^T used to form them on the
+// matrix pipe (4 of a tile's 20 MFMAs and 20 registers); the loop is matrix-pipe-bound since the VALU diet, so they went back.
+template <int K> __device__ __forceinline__ void softmax_step(f32x16& s0, f32x16& s1, PFrag (&pf)[4], float& l0, float& l1) {
     constexpr int g = K / 12, o = K % 12, j = o / 3, base = 8 * (g & 1);
     f32x16& s = g < 2 ? s0 : s1;
-    if constexpr (o % 3 < 2) s[base + 2 * j + o % 3] = fast_exp2(s[base + 2 * j + o % 3]);
-    else pf[g].u[j] = pack_bf2(s[base + 2 * j], s[base + 2 * j + 1]);
+    float& l = g < 2 ? l0 : l1;
+    if constexpr (o % 3 < 2) {
+        s[base + 2 * j + o % 3] = fast_exp2(s[base + 2 * j + o % 3]);
+        l += s[base + 2 * j + o % 3];
+    } else pf[g].u[j] = pack_bf2(s[base + 2 * j], s[base + 2 * j + 1]);
 }
-// VALU steps per slice, balanced by issue cycles (tools/ubench/issue_bench: v_exp_f32 8, v_cvt_pk / v_max3 5, LDS read
-// ~5; at most 30 per slice incl. its LDS reads, next to the MFMA's 8): softmax steps in slices 0-15, row max in 15-18.
-__device__ constexpr int SLICE_END[20] = {2, 4, 8, 12, 14, 16, 20, 24, 28, 29, 30, 34, 38, 42, 46, 51, 56, 61, 64, 64};
+// VALU steps per slice (cumulative), balanced by issue cycles (tools/ubench/issue_bench: v_exp_f32 8, v_add 4, v_cvt_pk / v_max3 5,
+// LDS read ~5, next to the MFMA's 32): softmax steps 0-47 in slices 0-12 (fewer in the slices that also issue LDS reads: 0-1, 4-5,
+// 9-10; pf[ks] is complete 2+ slices before P V slice 8 + 2 ks), the row max of the next tile (steps 48-63) in slices 12-15.
+__device__ constexpr int SLICE_END[16] = {3, 6, 11, 16, 19, 22, 27, 32, 37, 39, 41, 46, 51, 56, 60, 64};
 // row max of the next tile's scores, two per step (one v_max3_f32 each; hipcc fuses only every other pair on its own)
 template <int K> __device__ __forceinline__ void max_step(const f32x16& n0, const f32x16& n1, float& mx) {
     const f32x16& n = K < 8 ? n0 : n1;
@@ -284,12 +290,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[j][r] = 0.0f;
-    // Row sums l = sum_k P[q][k] come out of the matrix pipe: lacc^T = ones . P^T accumulates beside O^T (every row of the
-    // 32 x 32 block is the same sum, of the bf16-rounded P the numerator uses) -- 4 more MFMAs per tile instead of 32 adds.
-    f32x16 lacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lacc[r] = 0.0f;
-    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    float lsum0 = 0.0f, lsum1 = 0.0f;                   // row sums of this lane's half of the keys, per key block (softmax_step)
     float m_run = 0.0f;                                   // log2 units (scores are pre-scaled)
 
     const int ntiles = (p.L + KB - 1) / KB;
@@ -378,9 +379,9 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
             const char* const vtile = vring + slot * KV_TILE_BYTES;
             const char* const ktile1 = kring + ((slot + 1) & (RING - 1)) * KV_TILE_BYTES;      // K(t+1)
             const char* const ktile2 = kring + ((slot + 2) & (RING - 1)) * KV_TILE_BYTES;      // K(t+2)
-            static_for<0, 20>([&](auto jc) {
+            static_for<0, 16>([&](auto jc) {
                 constexpr int J = decltype(jc)::value;
-                // ---- matrix pipe: slices 0-7 S'(t+1); slices 8-19 per k-step { O^T block 0, O^T block 1, row sums } ----
+                // ---- matrix pipe: slices 0-7 S'(t+1); slices 8-15 per k-step { O^T block 0, O^T block 1 } ----
                 if constexpr (J < 8) {
                     if constexpr (MODE != 2) {
                         constexpr int ks = J >> 1;
@@ -388,9 +389,8 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
                         else ns1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[J], qf[ks], ks == 0 ? negm : ns1, 0, 0, 0);
                     }
                 } else {
-                    constexpr int ks = (J - 8) / 3, w = (J - 8) % 3;
-                    if constexpr (w < 2) oacc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2 * ks + w], pf[ks].v, oacc[w], 0, 0, 0);
-                    else lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[ks].v, lacc, 0, 0, 0);
+                    constexpr int ks = (J - 8) / 2, w = (J - 8) % 2;
+                    oacc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2 * ks + w], pf[ks].v, oacc[w], 0, 0, 0);
                 }
                 // ---- LDS: three bursts -- slices 0-1: K(t+1) fragments 4-7 (used from slice 4); 4-5: V^T(t) fragments 0-3 (from
                 //      slice 8); 9-10: V^T(t) fragments 4-7 (from slice 14) and K(t+2) fragments 0-3 (next iteration).  hipcc waits
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
                 constexpr int K0 = J == 0 ? 0 : SLICE_END[J == 0 ? 0 : J - 1], K1 = SLICE_END[J];
                 static_for<K0, K1>([&](auto kc) {
                     constexpr int K = decltype(kc)::value;
-                    if constexpr (K < 48) softmax_step<K>(cs0, cs1, pf);
+                    if constexpr (K < 48) softmax_step<K>(cs0, cs1, pf, lsum0, lsum1);
                     else if constexpr (MODE != 2) {
                         if constexpr (MODE == 1 && K == 48) mask_tile(ns0, ns1, (t + 1) * KB);
                         max_step<K - 48>(ns0, ns1, mx);
@@ -424,9 +424,10 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
                     m_run += d;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        oacc[0][r] *= alpha; oacc[1][r] *= alpha; lacc[r] *= alpha;
+                        oacc[0][r] *= alpha; oacc[1][r] *= alpha;
                         ns0[r] -= d; ns1[r] -= d; negm[r] -= d;
                     }
+                    lsum0 *= alpha; lsum1 *= alpha;
                 }
             }
         }
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     uint2 outv[8];
     float lse_out = 0.0f;
     if (wave_live) {
-        const float l_tot = lacc[0];                        // every row of the ones block holds the full row sum
+        const float l_tot = xor32_sum(lsum0 + lsum1);       // the lane pair (l, l ^ 32) holds the two halves of the query's keys
         const float inv = 1.0f / l_tot;
         lse_out = m_run + log2f(l_tot);
 #pragma unroll
