@@ -222,10 +222,6 @@ constexpr int RING = 4;
 __device__ long long dgs_attn_dbg[4096 + 64];   // DGS_ATTN_DBG & 4: loop cycles (s_memtime) per wave of the first 512 workgroups; & 8: phases of wg 0
 
 
-template <int I> struct IC { static constexpr int value = I; };
-template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
-}
 
 // flat VALU op list of the softmax of one tile: group g = K / 12 produces pf[g] from 8 scores as (exp2 + row-sum add, exp2 +
 // add, pack) x 4.  The row sums l = sum_k P[q][k] are two running fp32 adds per lane (one per key block; the lane pair (l, l ^ 32)

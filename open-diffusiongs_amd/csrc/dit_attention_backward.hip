@@ -18,12 +18,15 @@
 // the previous one (P / dS accumulator registers become B fragments after bf16 packing), and the operands that have to be
 // read "transposed" come from token-contiguous copies ([B, features, lpad]) written by the producing GEMM epilogues.
 #include "dit_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include "dgs_dit.h"
 
 namespace dgs {
 
 constexpr int BQ = 256, BNW = 8, BT = 64;      // rows per workgroup, waves, rows per tile of the walked dimension
 constexpr int TILE_B = BT * 64 * 2;            // 8 KiB: one [64][64] bf16 tile
+constexpr int DQ_STAGE = 3 * TILE_B, DKV_STAGE = 4 * TILE_B + 512, BWD_RING = 3;   // LDS bytes per staged tile set, stages
 
 struct AttnBwdParams {
     int B, heads, L, lpad, ld;                 // ld: row stride of the row-major q / k / v / o / do / dqkv tensors
@@ -37,7 +40,10 @@ struct AttnBwdParams {
     bf16_t *dq, *dk, *dv;                      // row-major [B*lpad, ld_d] (offset to the dq / dk / dv feature blocks)
     int ld_d;
     float scale, scale_log2e;
+    int nmain, ntail;                          // 256-row blocks walked by the MFMA workgroups; tokens behind them (tail roles) or 0
+    int dbg;                                   // instrumented library only (DGS_ATTN_DBG & 16: phase stamps of the dK/dV loop)
 };
+__device__ long long dgs_attn_bwd_dbg[2 * 8 * 8];       // [wave 0 | wave 5][tiles 20..27][tile top, scores done, products done, published, barrier]
 
 // row-major [64][64] tile, 16-byte chunk swizzle c ^ ((row >> 1) & 7)
 __device__ __forceinline__ void put_rows(char* tile, int r, int c, uint4 v) {
@@ -59,12 +65,190 @@ __device__ __forceinline__ bf16x8 pack_rows(const f32x16& s, int r0) {
     for (int j = 0; j < 4; ++j) f.u[j] = pack_bf2(s[r0 + 2 * j], s[r0 + 2 * j + 1]);
     return f.v;
 }
+// 1-D grids, XCD-aware.  Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2, and the workgroups of one
+// (sample, head) all walk the SAME tiles of that head.  With a (block, head, sample) grid a head's 16 workgroups sat on all 8 XCDs
+// and every L2 fetched every head's tiles.  Here group g = sample * heads + head runs entirely on XCD g % 8: measured at L = 4098,
+// FETCH_SIZE of the dK / dV kernel 5.4 x lower, the pair of kernels -11 % at 4 samples and -32 % at 1 (one round of workgroups: the
+// slowest XCD no longer sets the time).
+__device__ __forceinline__ void block_coords(const AttnBwdParams& p, int& blk, int& head, int& b) {
+    const int id = blockIdx.x, nblk = p.nmain + p.ntail, groups = p.heads * p.B;
+    int g;
+    if (groups % 8 == 0) { const int slot = id >> 3; g = (id & 7) + 8 * (slot / nblk); blk = slot % nblk; }
+    else { g = id / nblk; blk = id % nblk; }
+    head = g % p.heads; b = g / p.heads;
+}
 template <bool V> struct BoolTag { static constexpr bool value = V; };
+// Knock-out builds (tools/knockout_build.sh: -DDGS_INSTRUMENT -DDGS_KNOCK=n, timing only, wrong results): what one ingredient of the
+// dK / dV loop costs.  1 no exponentials, 2 no dS (multiply + pack), 3 no statistics reads, 4 no query pre-scaling in the publish,
+// 5 no product MFMAs (and their fragment reads), 6 no score fragment reads, 7 score fragment reads into registers no MFMA uses.  The product library compiles none of it.
+#if defined(DGS_INSTRUMENT) && defined(DGS_KNOCK)
+constexpr int kKnock = DGS_KNOCK;
+#else
+constexpr int kKnock = 0;
+#endif
 #define DGS_SCHED_FENCE() sched_fence()
+__device__ __forceinline__ bf16x8 words4(const uint32_t* w) {
+    union { bf16x8 v; uint32_t u[4]; } f;
+    f.u[0] = w[0]; f.u[1] = w[1]; f.u[2] = w[2]; f.u[3] = w[3];
+    return f.v;
+}
+// The VALU work of accumulator registers (2U, 2U + 1) of one 32-row block: P = exp2(-(lse - S')), dS / scale = P (dP - D), packed
+// to bf16 pairs (word U of the block: the B fragment of k-step U / 4 of the block's second-stage MFMAs is words 4 (U / 4) .. + 3).
+// One such unit rides in the shadow of ONE MFMA of the other block (see the tile bodies).
+template <bool RAGGED, bool WITH_P, int U>
+__device__ __forceinline__ void softmax_grad_unit(const f32x16& s, const f32x16& e, uint32_t* pw, uint32_t* dw, int row0, int L) {
+    constexpr int r = 2 * U;
+    float p0 = kKnock == 1 ? -s[r] : fast_exp2(-s[r]), p1 = kKnock == 1 ? -s[r + 1] : fast_exp2(-s[r + 1]);
+    float d0 = e[r], d1 = e[r + 1];
+    if (RAGGED) {                                // rows >= L of the walked dimension: no valid statistics, contribute nothing
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        if (row >= L) { p0 = 0.f; d0 = 0.f; }
+        if (row + 1 >= L) { p1 = 0.f; d1 = 0.f; }
+    }
+    if (WITH_P) pw[U] = pack_bf2(p0, p1);
+    if constexpr (kKnock == 2 && WITH_P) { dw[U] = pw[U]; return; }
+    dw[U] = pack_bf2(p0 * d0, p1 * d1);
+}
 
 __device__ __forceinline__ f32x16 zero_acc() {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     return z;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The tokens behind the last full 256-block (the model's sequences are V x patches + 2: L % 256 = 2).  As one more block of the
+// two grids they cost a whole workgroup walk each for two live lanes: with B x heads = 64 that was a fifth round of workgroups
+// on the 256 CUs behind four full ones (and a second round behind one at B = 1).  Instead one extra workgroup per tail token
+// (block >= nmain) does that token's row of dQ (and D), or of dK / dV, on the VALU: eight lanes per walked row (one 16-byte
+// chunk of its 64 features each), dot products by v_dot2c_f32_bf16 and a sum over the eight lanes, with the operand roundings of
+// the MFMA path (bf16(-scale log2(e) q), bf16 k / v / dO; P and dS stay fp32 here); the 64 row slots of the workgroup are summed
+// in a fixed order (lanes, then waves through LDS): as deterministic as the MFMA path.  A few % of one MFMA workgroup's time.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BWD_TAIL_MAX = 8;
+
+__device__ __forceinline__ uint4 prescaled(uint4 q, float c) {
+    q.x = scale_bf2(q.x, c); q.y = scale_bf2(q.y, c); q.z = scale_bf2(q.z, c); q.w = scale_bf2(q.w, c);
+    return q;
+}
+__device__ __forceinline__ void axpy8(float (&acc)[8], float a, uint4 x) {
+    acc[0] += a * bf2f(x.x & 0xffffu); acc[1] += a * bf2f(x.x >> 16); acc[2] += a * bf2f(x.y & 0xffffu); acc[3] += a * bf2f(x.y >> 16);
+    acc[4] += a * bf2f(x.z & 0xffffu); acc[5] += a * bf2f(x.z >> 16); acc[6] += a * bf2f(x.w & 0xffffu); acc[7] += a * bf2f(x.w >> 16);
+}
+// sum of acc over the workgroup's 64 row slots (lanes of equal chunk, then the waves in order) -> out[64] (bf16, times c), tid < 64
+__device__ __forceinline__ void tail_reduce_store(float (&acc)[8], float* red, float c, bf16_t* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = acc[i];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v = xor32_sum(v);
+        if (lane < 8) red[wave * 64 + lane * 8 + i] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < BNW; ++w) v += red[w * 64 + tid];
+        out[tid] = (bf16_t)f2bf(c * v);
+    }
+    __syncthreads();
+}
+// rows [L, end of the 32-row unit L falls into) of one head's 64 columns: the exact zeros the MFMA path's last block used to store
+__device__ __forceinline__ void tail_zero_rows(const AttnBwdParams& p, bf16_t* base /* row 0 of the sample, head's column 0 */) {
+    const int first = p.L, last = min(p.lpad, (p.L + 31) / 32 * 32);
+    const int tid = threadIdx.x;
+    if (tid < (last - first) * 8) *reinterpret_cast<uint4*>(base + (size_t)(first + (tid >> 3)) * p.ld_d + (tid & 7) * 8) = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// The walk of a tail workgroup: 64 row slots x TAIL_UNR rows per batch, the next batch's loads in flight while this one is used
+// (one row per slot and trip was 65 dependent L2 / HBM round trips: the tail workgroup took as long as an MFMA one).
+constexpr int TAIL_UNR = 8, TAIL_BATCH = 64 * TAIL_UNR;
+struct TailRows { uint4 a[TAIL_UNR], b[TAIL_UNR]; float s0[TAIL_UNR], s1[TAIL_UNR]; };
+template <class Fetch, class Use>
+__device__ __forceinline__ void tail_walk(int L, Fetch&& fetch, Use&& use) {
+    TailRows A, B;
+    fetch(A, 0);
+    for (int r0 = 0; r0 < L; r0 += 2 * TAIL_BATCH) {         // (uniform trip count: the lane sums run with the whole wave)
+        fetch(B, r0 + TAIL_BATCH);
+        use(A, r0);
+        fetch(A, r0 + 2 * TAIL_BATCH);
+        use(B, r0 + TAIL_BATCH);
+    }
+}
+
+__device__ __forceinline__ void tail_query_role(const AttnBwdParams& p, int blk, int head, int b, float* red) {
+    const int tid = threadIdx.x, c = tid & 7, slot = tid >> 3;
+    const int tq = p.nmain * BQ + (blk - p.nmain);
+    const size_t row0 = (size_t)b * p.lpad;
+    const bf16_t* Kg = p.k + row0 * p.ld + head * 64 + c * 8;
+    const bf16_t* Vg = p.v + row0 * p.ld + head * 64 + c * 8;
+    const uint4 qs = prescaled(*reinterpret_cast<const uint4*>(p.q + (row0 + tq) * p.ld + head * 64 + c * 8), -p.scale_log2e);
+    const uint4 dov = *reinterpret_cast<const uint4*>(p.dO + (row0 + tq) * p.ld_o + head * 64 + c * 8);
+    const uint4 ov = *reinterpret_cast<const uint4*>(p.o + (row0 + tq) * p.ld_o + head * 64 + c * 8);
+    const float Dq = oct_sum(dot8_bf16(ov, dov));
+    const size_t stat = ((size_t)b * p.heads + head) * p.lpad + tq;
+    const float lse = p.lse2[stat];
+    if (tid == 0) p.D[stat] = -Dq;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    tail_walk(p.L,
+        [&](TailRows& r, int k0) {
+#pragma unroll
+            for (int u = 0; u < TAIL_UNR; ++u) {
+                const int k = min(k0 + slot + 64 * u, p.L - 1);            // rows past L: loaded from the last one, not used
+                r.a[u] = *reinterpret_cast<const uint4*>(Kg + (size_t)k * p.ld);
+                r.b[u] = *reinterpret_cast<const uint4*>(Vg + (size_t)k * p.ld);
+            }
+        },
+        [&](const TailRows& r, int k0) {
+#pragma unroll
+            for (int u = 0; u < TAIL_UNR; ++u) {
+                const float s = oct_sum(dot8_bf16(qs, r.a[u])), dp = oct_sum(dot8_bf16(dov, r.b[u]));      // s = -scale log2(e) q . k
+                axpy8(acc, k0 + slot + 64 * u < p.L ? fast_exp2(-(lse + s)) * (dp - Dq) : 0.f, r.a[u]);
+            }
+        });
+    bf16_t* dq_head = p.dq + row0 * p.ld_d + head * 64;
+    tail_reduce_store(acc, red, p.scale, dq_head + (size_t)tq * p.ld_d);
+    if (blk == p.nmain) tail_zero_rows(p, dq_head);
+}
+
+__device__ __forceinline__ void tail_key_role(const AttnBwdParams& p, int blk, int head, int b, float* red) {
+    const int tid = threadIdx.x, c = tid & 7, slot = tid >> 3;
+    const int tk = p.nmain * BQ + (blk - p.nmain);
+    const size_t row0 = (size_t)b * p.lpad;
+    const bf16_t* Qg = p.q + row0 * p.ld + head * 64 + c * 8;
+    const bf16_t* dOg = p.dO + row0 * p.ld_o + head * 64 + c * 8;
+    const float* lseg = p.lse2 + ((size_t)b * p.heads + head) * p.lpad;
+    const float* Dg = p.D + ((size_t)b * p.heads + head) * p.lpad;
+    const uint4 kk = *reinterpret_cast<const uint4*>(p.k + (row0 + tk) * p.ld + head * 64 + c * 8);
+    const uint4 vk = *reinterpret_cast<const uint4*>(p.v + (row0 + tk) * p.ld + head * 64 + c * 8);
+    float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    tail_walk(p.L,
+        [&](TailRows& r, int q0) {
+#pragma unroll
+            for (int u = 0; u < TAIL_UNR; ++u) {
+                const int q = min(q0 + slot + 64 * u, p.L - 1);
+                r.a[u] = *reinterpret_cast<const uint4*>(Qg + (size_t)q * p.ld);
+                r.b[u] = *reinterpret_cast<const uint4*>(dOg + (size_t)q * p.ld_o);
+                r.s0[u] = lseg[q];
+                r.s1[u] = Dg[q];
+            }
+        },
+        [&](const TailRows& r, int q0) {
+#pragma unroll
+            for (int u = 0; u < TAIL_UNR; ++u) {
+                const float s = oct_sum(dot8_bf16(prescaled(r.a[u], -p.scale_log2e), kk)), dp = oct_sum(dot8_bf16(r.b[u], vk));
+                const float pr = q0 + slot + 64 * u < p.L ? fast_exp2(-(r.s0[u] + s)) : 0.f;
+                axpy8(av, pr, r.b[u]);
+                axpy8(ak, pr * (dp + r.s1[u]), r.a[u]);        // the scratch holds -D
+            }
+        });
+    bf16_t* dk_head = p.dk + row0 * p.ld_d + head * 64;
+    bf16_t* dv_head = p.dv + row0 * p.ld_d + head * 64;
+    tail_reduce_store(ak, red, p.scale, dk_head + (size_t)tk * p.ld_d);
+    tail_reduce_store(av, red, 1.f, dv_head + (size_t)tk * p.ld_d);
+    if (blk == p.nmain) { tail_zero_rows(p, dk_head); tail_zero_rows(p, dv_head); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -74,11 +258,14 @@ __device__ __forceinline__ f32x16 zero_acc() {
 //   dQ^T += K^T . dS^T     (A: K^T permuted tile, B: packed dS^T accumulator registers)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 3 * TILE_B];     // [stage][K | V | K^T]
+    DGS_DYNAMIC_LDS(lds);                                                // [3 stages][K | V | K^T] : 72 KiB
+    constexpr int STAGE = DQ_STAGE;
+    int qblk, head, b;
+    block_coords(p, qblk, head, b);
+    if (qblk >= p.nmain) { tail_query_role(p, qblk, head, b, reinterpret_cast<float*>(lds)); return; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int qblk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const size_t row0 = (size_t)b * p.lpad;
     const int q_raw = qblk * BQ + wave * 32 + l31;
     const int q = q_raw < p.lpad ? q_raw : p.lpad - 1;          // the last block may reach past lpad: clamp loads, never store
@@ -122,71 +309,83 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
         vreg = *reinterpret_cast<const uint4*>(Vg + (size_t)(t * BT + sr) * p.ld + sc * 8);
         ktreg = *reinterpret_cast<const uint4*>(KTg + (size_t)sr * p.lpad + t * BT + sc * 8);
     };
-    auto publish = [&](int stage) {
-        char* base = lds + stage * 3 * TILE_B;
-        put_rows(base, sr, sc, kreg);
-        put_rows(base + TILE_B, sr, sc, vreg);
-        put_perm(base + 2 * TILE_B, sr, sc, ktreg);
+    auto publish_piece = [&](int stage, int piece) {
+        char* base = lds + stage * STAGE;
+        if (piece == 0) put_rows(base, sr, sc, kreg);
+        if (piece == 1) put_rows(base + TILE_B, sr, sc, vreg);
+        if (piece == 2) put_perm(base + 2 * TILE_B, sr, sc, ktreg);
     };
+    auto publish = [&](int stage) { publish_piece(stage, 0); publish_piece(stage, 1); publish_piece(stage, 2); };
+    // Three stages, ONE barrier per tile: tile t + 2 is fetched (registers) at the top of tile t and published behind its last
+    // MFMAs, into the stage tile t - 1 was read from (every wave left that tile through the barrier before this one); the barrier
+    // at the bottom of tile t makes it visible one whole tile before its first read.  So a wave may read tile t + 1's first
+    // fragments BEFORE the barrier that ends tile t (published during tile t - 1): the LDS latency after each barrier -- 8 waves
+    // issuing their first reads at once, both waves of every SIMD waiting on them -- is off the tile's critical path.  The
+    // publish (wait for the fetch, swizzled LDS writes: 440 cycles as a phase of its own between the last MFMA and the barrier,
+    // stamped) rides in the gaps of the last k-steps, which carry no exponentials.  (Past the last fetched tile it re-writes stale
+    // registers into a stage nobody reads again.)
     issue(0);
     publish(0);
+    if (ntiles > 1) { issue(1); publish(1); }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): retire the fragment loads before the loop (see forward kernel)
     __syncthreads();
+    bf16x8 fa[4][2];                                  // K rows | V rows of score step i in slot i & 3: a ring ACROSS tiles
+    auto read_a = [&](const char* base, int i) {                    // step i = (block, k-step)
+        fa[i & 3][0] = get_rows(base, 32 * (i >> 2) + l31, i & 3, half);
+        fa[i & 3][1] = get_rows(base + TILE_B, 32 * (i >> 2) + l31, i & 3, half);
+    };
+    int cur = 0, nxt = 1, nn = 2;                     // stages of tiles t, t + 1, t + 2
+    if (wave_live) { read_a(lds, 0); read_a(lds, 1); read_a(lds, 2); }
     auto tile = [&](int t, auto ragged_tag) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
-        const bool more = t + 1 < ntiles;
-        if (more) issue(t + 1);
+        const bool more2 = t + 2 < ntiles;
+        if (more2) issue(t + 2);
         if (wave_live) {
-            const char* base = lds + (t & 1) * 3 * TILE_B;
-            f32x16 s0, s1, e0, e1;                       // s = lse - S', e = dP - D
-            // Every LDS fragment is read into the other half of a register double buffer behind the first MFMA of the step
-            // before the one that consumes it (hipcc waits lgkmcnt(0) at first use: a read issued right before its MFMA
-            // exposes the whole LDS latency, 24 times per tile); sched_barrier fences keep this order.
+            const char* base = lds + cur * STAGE;
+            const char* nbase = lds + nxt * STAGE;
+            f32x16 s[2], e[2];                           // per 32-key block: s = lse - S', e = dP - D
+            // Every LDS fragment is read THREE steps (six MFMAs) before the MFMAs that consume it, into a register ring (hipcc waits
+            // for a fragment at its first use); sched_barrier fences keep the order.  Key block 0's scores first, block 1's next
+            // with block 0's exponentials in their shadow, then the dQ MFMAs of block 0's k-steps with block 1's exponentials in
+            // theirs.  (Measured, profiles/r03_attn_bwd_*.txt: this in-wave interleave and the ring depth are each worth < 1 % --
+            // the two waves of a SIMD overlap each other's phases anyway; what the loop's time went to was found elsewhere: the
+            // grid's XCD placement, the tail tokens' workgroups, the publish phase.)
             const char* kt = base + 2 * TILE_B;
-            bf16x8 fa[2][4], fk[2][2];
-            auto read4 = [&](int ks, int h) {
-                fa[h][0] = get_rows(base, l31, ks, half); fa[h][1] = get_rows(base, 32 + l31, ks, half);
-                fa[h][2] = get_rows(base + TILE_B, l31, ks, half); fa[h][3] = get_rows(base + TILE_B, 32 + l31, ks, half);
-            };
-            auto read2 = [&](int ks, int h) { fk[h][0] = get_rows(kt, l31, ks, half); fk[h][1] = get_rows(kt, 32 + l31, ks, half); };
-            read4(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int h = ks & 1;
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0], qf[ks], ks == 0 ? lse16 : s0, 0, 0, 0);
-                if (ks < 3) read4(ks + 1, h ^ 1); else read2(0, 0);
+            bf16x8 fk[4][2];
+            uint32_t dw[2][8];
+            const int key0 = t * BT + 4 * half;
+            auto read2 = [&](int ks) { fk[ks][0] = get_rows(kt, l31, ks, half); fk[ks][1] = get_rows(kt, 32 + l31, ks, half); };
+            static_for<0, 8>([&](auto ic) {
+                constexpr int I = decltype(ic)::value, blk = I >> 2, ks = I & 3, h = I & 3;
+                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0], qf[ks], ks == 0 ? lse16 : s[blk], 0, 0, 0);
+                if constexpr (I < 5) read_a(base, I + 3); else read2(I - 5);
+                if constexpr (blk == 1) softmax_grad_unit<RAGGED, false, 2 * ks>(s[0], e[0], nullptr, dw[0], key0, p.L);
                 DGS_SCHED_FENCE();
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1], qf[ks], ks == 0 ? lse16 : s1, 0, 0, 0);
+                e[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1], dof[ks], ks == 0 ? negd16 : e[blk], 0, 0, 0);
+                if constexpr (blk == 1) softmax_grad_unit<RAGGED, false, 2 * ks + 1>(s[0], e[0], nullptr, dw[0], key0, p.L);
                 DGS_SCHED_FENCE();
-                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][2], dof[ks], ks == 0 ? negd16 : e0, 0, 0, 0);
-                DGS_SCHED_FENCE();
-                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][3], dof[ks], ks == 0 ? negd16 : e1, 0, 0, 0);
-                DGS_SCHED_FENCE();
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p0 = fast_exp2(-s0[r]), p1 = fast_exp2(-s1[r]);
-                if (RAGGED) {
-                    const int key = t * BT + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (key >= p.L) { p0 = 0.f; e0[r] = 0.f; }
-                    if (key + 32 >= p.L) { p1 = 0.f; e1[r] = 0.f; }
-                }
-                s0[r] = p0 * e0[r];                      // dS / scale
-                s1[r] = p1 * e1[r];
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int h = ks & 1;
-                const bf16x8 dsf = pack_rows(ks < 2 ? s0 : s1, 8 * (ks & 1));
+            });
+            static_for<0, 4>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value, h = ks;
+                const bf16x8 dsf = words4(dw[ks >> 1] + 4 * (ks & 1));
                 dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[h][0], dsf, dq0, 0, 0, 0);
-                if (ks < 3) read2(ks + 1, h ^ 1);
+                if constexpr (ks == 0) read2(3); else read_a(nbase, ks - 1);                // (past the last tile: unused reads)
+                if constexpr (ks < 2) {
+                    softmax_grad_unit<RAGGED, false, 4 * ks>(s[1], e[1], nullptr, dw[1], key0 + 32, p.L);
+                    softmax_grad_unit<RAGGED, false, 4 * ks + 1>(s[1], e[1], nullptr, dw[1], key0 + 32, p.L);
+                } else if constexpr (ks == 2) publish_piece(nn, 0);
+                else publish_piece(nn, 2);
                 DGS_SCHED_FENCE();
                 dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[h][1], dsf, dq1, 0, 0, 0);
+                if constexpr (ks < 2) {
+                    softmax_grad_unit<RAGGED, false, 4 * ks + 2>(s[1], e[1], nullptr, dw[1], key0 + 32, p.L);
+                    softmax_grad_unit<RAGGED, false, 4 * ks + 3>(s[1], e[1], nullptr, dw[1], key0 + 32, p.L);
+                } else if constexpr (ks == 2) publish_piece(nn, 1);
                 DGS_SCHED_FENCE();
-            }
-        }
-        if (more) publish((t + 1) & 1);
+            });
+        } else publish(nn);
         __syncthreads();
+        const int c = cur; cur = nxt; nxt = nn; nn = c;
     };
     const int nplain = p.L / BT;                          // tiles without keys >= L
     for (int t = 0; t < nplain; ++t) tile(t, BoolTag<false>{});
@@ -209,12 +408,14 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
 //   dK^T += Q^T . dS       (A: Q^T permuted tile,  B: packed dS accumulator registers)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams p) {
-    DGS_DYNAMIC_LDS(lds);                                                // [stage][Q | dO | Q^T | dO^T | lse[64] | -D[64]] : 65 KiB
-    constexpr int STAGE = 4 * TILE_B + 512;
+    DGS_DYNAMIC_LDS(lds);                                                // [3 stages][Q | dO | Q^T | dO^T | lse[64] | -D[64]] : 97.5 KiB
+    constexpr int STAGE = DKV_STAGE;
+    int kblk, head, b;
+    block_coords(p, kblk, head, b);
+    if (kblk >= p.nmain) { tail_key_role(p, kblk, head, b, reinterpret_cast<float*>(lds)); return; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int kblk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const size_t row0 = (size_t)b * p.lpad;
     const int key_raw = kblk * BQ + wave * 32 + l31;
     const int key = key_raw < p.lpad ? key_raw : p.lpad - 1;
@@ -249,95 +450,125 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
         qtreg = *reinterpret_cast<const uint4*>(QTg + (size_t)sr * p.lpad + t * BT + sc * 8);
         dotreg = *reinterpret_cast<const uint4*>(dOTg + (size_t)sr * p.lpad + t * BT + sc * 8);
     };
-    auto publish = [&](int stage) {
+    auto publish_piece = [&](int stage, int piece) {
         char* base = lds + stage * STAGE;
-        uint4 qs = qreg;                                  // the S operand: bf16(-scale log2(e) q); Q^T below stays raw (it feeds dK)
-        qs.x = scale_bf2(qs.x, -p.scale_log2e); qs.y = scale_bf2(qs.y, -p.scale_log2e);
-        qs.z = scale_bf2(qs.z, -p.scale_log2e); qs.w = scale_bf2(qs.w, -p.scale_log2e);
-        put_rows(base, sr, sc, qs);
-        put_rows(base + TILE_B, sr, sc, doreg);
-        put_perm(base + 2 * TILE_B, sr, sc, qtreg);
-        put_perm(base + 3 * TILE_B, sr, sc, dotreg);
-        if (tid < 128) reinterpret_cast<float*>(base + 4 * TILE_B)[tid] = statreg;
+        if (piece == 0) put_rows(base, sr, sc, kKnock == 4 ? qreg : prescaled(qreg, -p.scale_log2e));     // the S operand: bf16(-scale log2(e) q); Q^T stays raw (it feeds dK)
+        if (piece == 1) put_rows(base + TILE_B, sr, sc, doreg);
+        if (piece == 2) put_perm(base + 2 * TILE_B, sr, sc, qtreg);
+        if (piece == 3) {
+            put_perm(base + 3 * TILE_B, sr, sc, dotreg);
+            if (tid < 128) reinterpret_cast<float*>(base + 4 * TILE_B)[tid] = statreg;
+        }
     };
+    auto publish = [&](int stage) { publish_piece(stage, 0); publish_piece(stage, 1); publish_piece(stage, 2); publish_piece(stage, 3); };
+    // three stages, one barrier per tile, the next tile's first reads issued before it, the publish in the gaps of the last
+    // k-steps (see the dQ kernel)
     issue(0);
     publish(0);
+    if (ntiles > 1) { issue(1); publish(1); }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    f32x16 s[2], e[2];                                // per 32-query block: s = lse - S', e = dP - D
+    bf16x8 fa[4][2];                                  // Q rows | dO rows of score step i in slot i & 3: a ring ACROSS tiles
+    bf16x8 fsink[4][2];                               // (knock-out 7: the reads happen, the MFMAs do not depend on them)
+    auto read_a = [&](const char* base, int i) {                    // step i = (block, k-step)
+        if constexpr (kKnock == 6) return;
+        if constexpr (kKnock == 7) {
+            fsink[i & 3][0] = get_rows(base, 32 * (i >> 2) + l31, i & 3, half);
+            fsink[i & 3][1] = get_rows(base + TILE_B, 32 * (i >> 2) + l31, i & 3, half);
+            return;
+        }
+        fa[i & 3][0] = get_rows(base, 32 * (i >> 2) + l31, i & 3, half);
+        fa[i & 3][1] = get_rows(base + TILE_B, 32 * (i >> 2) + l31, i & 3, half);
+    };
+    // per-query statistics, loaded INTO the accumulators' initial values: register r of block 0 / 1 is query 8 (r >> 2) + 4 half +
+    // (r & 3) (+ 32) of the tile (staged with the tiles: an L2 round trip per tile otherwise)
+    auto load_stats = [&](const char* base, int blk) {
+        if constexpr (kKnock == 3) return;
+        const float* lt = reinterpret_cast<const float*>(base + 4 * TILE_B) + 4 * half + 32 * blk;
+        const float* dt = lt + 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 l = *reinterpret_cast<const float4*>(lt + 8 * g), d = *reinterpret_cast<const float4*>(dt + 8 * g);
+            s[blk][4 * g] = l.x; s[blk][4 * g + 1] = l.y; s[blk][4 * g + 2] = l.z; s[blk][4 * g + 3] = l.w;
+            e[blk][4 * g] = d.x; e[blk][4 * g + 1] = d.y; e[blk][4 * g + 2] = d.z; e[blk][4 * g + 3] = d.w;
+        }
+    };
+    int cur = 0, nxt = 1, nn = 2;                     // stages of tiles t, t + 1, t + 2
+    if (wave_live) { read_a(lds, 0); load_stats(lds, 0); read_a(lds, 1); read_a(lds, 2); }
+    const bool stamped = kInstrumented && (p.dbg & 16) && blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 5);
+    auto stamp = [&](int t, int i) {
+        if constexpr (kInstrumented)
+            if (stamped && t >= 20 && t < 28) dgs_attn_bwd_dbg[((wave ? 1 : 0) * 8 + (t - 20)) * 8 + i] = cycle_stamp();
+    };
     auto tile = [&](int t, auto ragged_tag) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
-        const bool more = t + 1 < ntiles;
-        if (more) issue(t + 1);
+        const bool more2 = t + 2 < ntiles;
+        stamp(t, 0);
+        if (more2) issue(t + 2);
         if (wave_live) {
-            const char* base = lds + (t & 1) * STAGE;
-            // per-query statistics, loaded INTO the accumulators' initial values: register r of block 0 / 1 is query 8 (r >> 2) + 4 half + (r & 3) (+ 32) of the tile
-            const float* lt = reinterpret_cast<const float*>(base + 4 * TILE_B) + 4 * half;     // staged with the tiles: an L2
-            const float* dt = lt + 64;                                                          // round trip per tile otherwise
-            f32x16 s0, s1, e0, e1;                       // s = lse - S', e = dP - D
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 l0 = *reinterpret_cast<const float4*>(lt + 8 * g), l1 = *reinterpret_cast<const float4*>(lt + 32 + 8 * g);
-                const float4 d0 = *reinterpret_cast<const float4*>(dt + 8 * g), d1 = *reinterpret_cast<const float4*>(dt + 32 + 8 * g);
-                s0[4 * g] = l0.x; s0[4 * g + 1] = l0.y; s0[4 * g + 2] = l0.z; s0[4 * g + 3] = l0.w;
-                s1[4 * g] = l1.x; s1[4 * g + 1] = l1.y; s1[4 * g + 2] = l1.z; s1[4 * g + 3] = l1.w;
-                e0[4 * g] = d0.x; e0[4 * g + 1] = d0.y; e0[4 * g + 2] = d0.z; e0[4 * g + 3] = d0.w;
-                e1[4 * g] = d1.x; e1[4 * g + 1] = d1.y; e1[4 * g + 2] = d1.z; e1[4 * g + 3] = d1.w;
-            }
-            // fragments one step ahead in a register double buffer (see the dQ kernel)
+            const char* base = lds + cur * STAGE;
+            const char* nbase = lds + nxt * STAGE;
+            // score fragments three steps ahead in a register ring, product fragments one k-step (four MFMAs) ahead, the
+            // exponentials of one query block in the shadow of the other block's MFMAs (see the dQ kernel and softmax_grad_unit);
+            // block 1's statistics behind the first MFMA, the next tile's block 0 statistics and first fragments behind the last
+            // k-step of this one
             const char* qt = base + 2 * TILE_B;
             const char* dot = base + 3 * TILE_B;
-            bf16x8 fa[2][4];
-            auto read_s = [&](int ks, int h) {
-                fa[h][0] = get_rows(base, l31, ks, half); fa[h][1] = get_rows(base, 32 + l31, ks, half);
-                fa[h][2] = get_rows(base + TILE_B, l31, ks, half); fa[h][3] = get_rows(base + TILE_B, 32 + l31, ks, half);
+            bf16x8 fg[2][4];
+            uint32_t pw[2][8], dw[2][8];
+            const int q0 = t * BT + 4 * half;
+            auto read_g_half = [&](int ks, int h, int part) {
+                if (part == 0) { fg[h][0] = get_rows(dot, l31, ks, half); fg[h][1] = get_rows(dot, 32 + l31, ks, half); }
+                else { fg[h][2] = get_rows(qt, l31, ks, half); fg[h][3] = get_rows(qt, 32 + l31, ks, half); }
             };
-            auto read_g = [&](int ks, int h) {
-                fa[h][0] = get_rows(dot, l31, ks, half); fa[h][1] = get_rows(dot, 32 + l31, ks, half);
-                fa[h][2] = get_rows(qt, l31, ks, half); fa[h][3] = get_rows(qt, 32 + l31, ks, half);
-            };
-            read_s(0, 0);
+            auto read_g = [&](int ks, int h) { read_g_half(ks, h, 0); read_g_half(ks, h, 1); };
+            static_for<0, 8>([&](auto ic) {
+                constexpr int I = decltype(ic)::value, blk = I >> 2, ks = I & 3, h = I & 3;
+                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0], kf[ks], s[blk], 0, 0, 0);
+                if constexpr (I < 5) read_a(base, I + 3); else if constexpr (I < 7) read_g_half(0, 0, I - 5);
+                if constexpr (I == 0) load_stats(base, 1);
+                if constexpr (blk == 1) softmax_grad_unit<RAGGED, true, 2 * ks>(s[0], e[0], pw[0], dw[0], q0, p.L);
+                DGS_SCHED_FENCE();
+                e[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1], vf[ks], e[blk], 0, 0, 0);
+                if constexpr (blk == 1) softmax_grad_unit<RAGGED, true, 2 * ks + 1>(s[0], e[0], pw[0], dw[0], q0, p.L);
+                DGS_SCHED_FENCE();
+            });
+            stamp(t, 1);
+            static_for<0, 4>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value, h = ks & 1;
+                const bf16x8 pf = words4(pw[ks >> 1] + 4 * (ks & 1)), dsf = words4(dw[ks >> 1] + 4 * (ks & 1));
+                if constexpr (kKnock != 5) dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[h][0], pf, dv0, 0, 0, 0);
+                else { dv0[ks] += __builtin_bit_cast(float, pw[ks >> 1][4 * (ks & 1)]); dk0[ks] += __builtin_bit_cast(float, dw[ks >> 1][4 * (ks & 1)]); }
+                if constexpr (ks < 3) read_g(ks + 1, h ^ 1); else read_a(nbase, 0);        // (past the last tile: unused reads)
+                if constexpr (ks < 2) softmax_grad_unit<RAGGED, true, 4 * ks>(s[1], e[1], pw[1], dw[1], q0 + 32, p.L);
+                DGS_SCHED_FENCE();
+                if constexpr (kKnock != 5) dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[h][1], pf, dv1, 0, 0, 0);
+                if constexpr (ks < 2) softmax_grad_unit<RAGGED, true, 4 * ks + 1>(s[1], e[1], pw[1], dw[1], q0 + 32, p.L);
+                if constexpr (ks == 2) publish_piece(nn, 0);
+                if constexpr (ks == 3) load_stats(nbase, 0);
+                DGS_SCHED_FENCE();
+                if constexpr (kKnock != 5) dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[h][2], dsf, dk0, 0, 0, 0);
+                if constexpr (ks < 2) softmax_grad_unit<RAGGED, true, 4 * ks + 2>(s[1], e[1], pw[1], dw[1], q0 + 32, p.L);
+                if constexpr (ks == 2) publish_piece(nn, 1);
+                if constexpr (ks == 3) { read_a(nbase, 1); publish_piece(nn, 3); }
+                DGS_SCHED_FENCE();
+                if constexpr (kKnock != 5) dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[h][3], dsf, dk1, 0, 0, 0);
+                if constexpr (ks < 2) softmax_grad_unit<RAGGED, true, 4 * ks + 3>(s[1], e[1], pw[1], dw[1], q0 + 32, p.L);
+                if constexpr (ks == 2) publish_piece(nn, 2);
+                if constexpr (ks == 3) read_a(nbase, 2);
+                DGS_SCHED_FENCE();
+            });
+            if constexpr (kKnock == 7) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int h = ks & 1;
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0], kf[ks], s0, 0, 0, 0);
-                if (ks < 3) read_s(ks + 1, h ^ 1); else read_g(0, 0);
-                DGS_SCHED_FENCE();
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1], kf[ks], s1, 0, 0, 0);
-                DGS_SCHED_FENCE();
-                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][2], vf[ks], e0, 0, 0, 0);
-                DGS_SCHED_FENCE();
-                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][3], vf[ks], e1, 0, 0, 0);
-                DGS_SCHED_FENCE();
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fsink[i][0]), "v"(fsink[i][1]));
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p0 = fast_exp2(-s0[r]), p1 = fast_exp2(-s1[r]);
-                if (RAGGED) {                            // queries >= L: lse / D of padding rows are not meaningful
-                    const int qq = t * BT + 8 * (r >> 2) + 4 * half + (r & 3);
-                    if (qq >= p.L) { p0 = 0.f; e0[r] = 0.f; }
-                    if (qq + 32 >= p.L) { p1 = 0.f; e1[r] = 0.f; }
-                }
-                e0[r] = p0 * e0[r]; e1[r] = p1 * e1[r];   // dS / scale
-                s0[r] = p0; s1[r] = p1;                    // P
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int h = ks & 1;
-                const bf16x8 pf = pack_rows(ks < 2 ? s0 : s1, 8 * (ks & 1));
-                const bf16x8 dsf = pack_rows(ks < 2 ? e0 : e1, 8 * (ks & 1));
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0], pf, dv0, 0, 0, 0);
-                if (ks < 3) read_g(ks + 1, h ^ 1);
-                DGS_SCHED_FENCE();
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1], pf, dv1, 0, 0, 0);
-                DGS_SCHED_FENCE();
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][2], dsf, dk0, 0, 0, 0);
-                DGS_SCHED_FENCE();
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][3], dsf, dk1, 0, 0, 0);
-                DGS_SCHED_FENCE();
-            }
-        }
-        if (more) publish((t + 1) & 1);
+            stamp(t, 2);
+        } else publish(nn);
+        stamp(t, 3);
         __syncthreads();
+        stamp(t, 4);
+        const int c = cur; cur = nxt; nxt = nn; nn = c;
     };
     const int nplain = p.L / BT;                          // tiles without queries >= L
     for (int t = 0; t < nplain; ++t) tile(t, BoolTag<false>{});
@@ -379,15 +610,38 @@ extern "C" int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, 
     p.dq = a->dqkv; p.dk = a->dqkv + W; p.dv = a->dqkv + 2 * W;
     p.scale = a->scale; p.scale_log2e = a->scale * 1.44269504088896341f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((a->L + BQ - 1) / BQ, a->heads, a->B);
-    hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(512), 0, st, p);
-    constexpr int DKV_LDS = 2 * (4 * TILE_B + 512);
+    const int full = a->L / BQ, rest = a->L % BQ;
+    const bool tail = full >= 1 && rest >= 1 && rest <= BWD_TAIL_MAX;
+    p.nmain = tail ? full : (a->L + BQ - 1) / BQ;
+    p.ntail = tail ? rest : 0;
+    const dim3 grid((p.nmain + p.ntail) * a->heads * a->B);
+    constexpr int DQ_LDS = BWD_RING * DQ_STAGE, DKV_LDS = BWD_RING * DKV_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS) != hipSuccess)
             return DGS_ERR_DEVICE;
         attr_set = true;
     }
+    p.dbg = 0;
+#ifdef DGS_INSTRUMENT
+    static const int dbg = getenv("DGS_ATTN_DBG") ? atoi(getenv("DGS_ATTN_DBG")) : 0;
+    p.dbg = dbg;
+#endif
+    hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(512), DQ_LDS, st, p);
     hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(512), DKV_LDS, st, p);
+#ifdef DGS_INSTRUMENT
+    if (dbg & 16) {
+        static long long host[2 * 8 * 8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(dgs_attn_bwd_dbg), sizeof(host));
+        for (int w = 0; w < 2; ++w)
+            for (int t = 0; t < 8; ++t) {
+                const long long* h = host + (w * 8 + t) * 8;
+                fprintf(stderr, "[attn bwd dbg] dkv wg 100 wave %d tile %d: scores %lld  products %lld  publish %lld  barrier %lld  | tile %lld cycles\n", w ? 5 : 0, 20 + t,
+                        h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[4] - h[0]);
+            }
+    }
+#endif
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }

@@ -107,6 +107,38 @@ __device__ __forceinline__ float xor32_sum(float v) {
 }
 #endif
 
+// sum over each aligned group of 8 lanes, in all 8 (three DPP adds: the quad's two pair swaps, then the mirrored other quad)
+__device__ __forceinline__ float oct_sum(float v) {
+#ifdef HIPEMU
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+#else
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm:[1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm:[2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    return v;
+#endif
+}
+// c + a.lo b.lo + a.hi b.hi of two packed bf16 pairs, fp32 accumulation (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+#ifdef HIPEMU
+    return c + bf2f(a & 0xffffu) * bf2f(b & 0xffffu) + bf2f(a >> 16) * bf2f(b >> 16);
+#else
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, b), c, false);
+#endif
+}
+__device__ __forceinline__ float dot8_bf16(uint4 a, uint4 b) {
+    return dot2_bf16(a.w, b.w, dot2_bf16(a.z, b.z, dot2_bf16(a.y, b.y, dot2_bf16(a.x, b.x, 0.f))));
+}
+
+// compile-time loops: static_for<0, N>([&](auto ic) { constexpr int I = decltype(ic)::value; ... })
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
+}
+
+
 // ---- execution primitives: the hardware form, and what tests/hipemu (cooperative fibers, synchronous memory) runs in its place.
 //      The kernels themselves carry no #ifdef: every fork between the gfx950 build and the CPU emulation build lives in this file,
 //      dgs_device.h and raster_common.h. ----
