@@ -88,14 +88,36 @@ __global__ __launch_bounds__(512) void layernorm_backward_kernel(LnBwdParams p) 
 #pragma unroll
     for (int i = 0; i < VPL; ++i) a_shift[i] = a_scale[i] = a_w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_w = 1.0f / (float)p.width;
-    for (int r = wave; r < p.rows_per_block; r += 8) {
-        const int row = row0 + r;
-        if (row >= p.rows) break;       // (no barrier inside the loop)
-        const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)row * p.width);
-        float4 n[VPL], dn[VPL];
+    // One workgroup per CU (160+ VGPRs), 8-9 rows per wave one after the other: every load of a row is in flight before its first
+    // wave sum (x, dh, the incoming dx), and the NEXT row's x -- the head of its chain of dependent sums -- behind them.
+    const int last = min(row0 + p.rows_per_block, p.rows);
+    float4 nx[VPL];
+    if (row0 + wave < last) {
+        const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)(row0 + wave) * p.width);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) nx[i] = xr[i * 64 + lane];
+    }
+    for (int row = row0 + wave; row < last; row += 8) {       // (no barrier inside the loop)
+        float4 n[VPL], dn[VPL], g[VPL], rin[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c4 = i * 64 + lane;
+            n[i] = nx[i];
+            if (p.dh_f32) g[i] = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dh) + (size_t)row * p.width)[c4];
+            else {
+                const uint2 u = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.dh) + (size_t)row * p.width)[c4];
+                g[i] = make_float4(bf2f(u.x & 0xffffu), bf2f(u.x >> 16), bf2f(u.y & 0xffffu), bf2f(u.y >> 16));
+            }
+            if (p.dx_in) rin[i] = reinterpret_cast<const float4*>(p.dx_in + (size_t)row * p.width)[c4];
+        }
+        if (row + 8 < last) {
+            const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)(row + 8) * p.width);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) nx[i] = xr[i * 64 + lane];
+        }
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) { n[i] = xr[i * 64 + lane]; sum += (n[i].x + n[i].y) + (n[i].z + n[i].w); }
+        for (int i = 0; i < VPL; ++i) sum += (n[i].x + n[i].y) + (n[i].z + n[i].w);
         const float mean = wave_sum(sum) * inv_w;
         float sq = 0.f;
 #pragma unroll
@@ -109,22 +131,16 @@ __global__ __launch_bounds__(512) void layernorm_backward_kernel(LnBwdParams p) 
         for (int i = 0; i < VPL; ++i) {
             const int c4 = i * 64 + lane;
             n[i].x *= rstd; n[i].y *= rstd; n[i].z *= rstd; n[i].w *= rstd;
-            float4 g;
-            if (p.dh_f32) g = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dh) + (size_t)row * p.width)[c4];
-            else {
-                const uint2 u = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.dh) + (size_t)row * p.width)[c4];
-                g = make_float4(bf2f(u.x & 0xffffu), bf2f(u.x >> 16), bf2f(u.y & 0xffffu), bf2f(u.y >> 16));
-            }
             float4 w = make_float4(1.f, 1.f, 1.f, 1.f), m1 = make_float4(1.f, 1.f, 1.f, 1.f);
             if (p.weight) w = reinterpret_cast<const float4*>(p.weight)[c4];
             if (p.scale) {
                 const float4 sc = reinterpret_cast<const float4*>(p.scale + (size_t)b * p.mod_stride)[c4];
                 m1 = make_float4(1.f + sc.x, 1.f + sc.y, 1.f + sc.z, 1.f + sc.w);
             }
-            a_shift[i].x += g.x; a_shift[i].y += g.y; a_shift[i].z += g.z; a_shift[i].w += g.w;
-            a_scale[i].x += g.x * n[i].x * w.x; a_scale[i].y += g.y * n[i].y * w.y; a_scale[i].z += g.z * n[i].z * w.z; a_scale[i].w += g.w * n[i].w * w.w;
-            a_w[i].x += g.x * m1.x * n[i].x; a_w[i].y += g.y * m1.y * n[i].y; a_w[i].z += g.z * m1.z * n[i].z; a_w[i].w += g.w * m1.w * n[i].w;
-            dn[i] = make_float4(g.x * m1.x * w.x, g.y * m1.y * w.y, g.z * m1.z * w.z, g.w * m1.w * w.w);
+            a_shift[i].x += g[i].x; a_shift[i].y += g[i].y; a_shift[i].z += g[i].z; a_shift[i].w += g[i].w;
+            a_scale[i].x += g[i].x * n[i].x * w.x; a_scale[i].y += g[i].y * n[i].y * w.y; a_scale[i].z += g[i].z * n[i].z * w.z; a_scale[i].w += g[i].w * n[i].w * w.w;
+            a_w[i].x += g[i].x * m1.x * n[i].x; a_w[i].y += g[i].y * m1.y * n[i].y; a_w[i].z += g[i].z * m1.z * n[i].z; a_w[i].w += g[i].w * m1.w * n[i].w;
+            dn[i] = make_float4(g[i].x * m1.x * w.x, g[i].y * m1.y * w.y, g[i].z * m1.z * w.z, g[i].w * m1.w * w.w);
             s1 += (dn[i].x + dn[i].y) + (dn[i].z + dn[i].w);
             s2 += (dn[i].x * n[i].x + dn[i].y * n[i].y) + (dn[i].z * n[i].z + dn[i].w * n[i].w);
         }
@@ -135,10 +151,7 @@ __global__ __launch_bounds__(512) void layernorm_backward_kernel(LnBwdParams p) 
             const int c4 = i * 64 + lane;
             float4 d = make_float4(rstd * (dn[i].x - m1s - n[i].x * m2s), rstd * (dn[i].y - m1s - n[i].y * m2s),
                                    rstd * (dn[i].z - m1s - n[i].z * m2s), rstd * (dn[i].w - m1s - n[i].w * m2s));
-            if (p.dx_in) {
-                const float4 r0 = reinterpret_cast<const float4*>(p.dx_in + (size_t)row * p.width)[c4];
-                d.x += r0.x; d.y += r0.y; d.z += r0.z; d.w += r0.w;
-            }
+            if (p.dx_in) { d.x += rin[i].x; d.y += rin[i].y; d.z += rin[i].z; d.w += rin[i].w; }
             out[c4] = d;
         }
     }
@@ -405,11 +418,13 @@ int launch_col_reduce(const ColReduceJob* jobs, int njobs, hipStream_t st) {
     return ok();
 }
 
+int ln_backward_compute_units() { return compute_unit_count_cached(); }
+
 int launch_layernorm_backward(const LnBwdParams& p0, hipStream_t st) {
     LnBwdParams p = p0;
     if (p.rows <= 0 || p.width % 256 || p.width > 2048) return DGS_ERR_INVALID_ARGUMENT;
     if (p.rows_per_batch <= 0) p.rows_per_batch = p.rows;
-    p.rows_per_block = ln_backward_rows_per_block(p.rows_per_batch);          // never straddles samples
+    p.rows_per_block = ln_backward_rows_per_block(p.rows_per_batch, p.rows, ln_backward_compute_units());
     const dim3 grid((p.rows + p.rows_per_block - 1) / p.rows_per_block), block(512);
     if (!p.part && grid.x != 1 && (p.dshift || p.dscale || p.dweight)) return DGS_ERR_INVALID_ARGUMENT;   // column sums need the slab
     if (p.part && p.part_stride < 3 * p.width) return DGS_ERR_INVALID_ARGUMENT;
@@ -461,7 +476,7 @@ using namespace dgs;
 
 namespace {
 int ln_blocks(int rows, int rows_per_batch) {
-    const int rpb = ln_backward_rows_per_block(rows_per_batch > 0 ? rows_per_batch : rows);
+    const int rpb = ln_backward_rows_per_block(rows_per_batch > 0 ? rows_per_batch : rows, rows, ln_backward_compute_units());
     return (rows + rpb - 1) / rpb;
 }
 }  // namespace

@@ -241,6 +241,15 @@ inline int compute_unit_count() {
     return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess ? n : 0;
 #endif
 }
+// the same, asked once per process on the device (the emulator re-reads its environment variable: tests change it)
+inline int compute_unit_count_cached() {
+#ifdef HIPEMU
+    return compute_unit_count();
+#else
+    static const int n = compute_unit_count();
+    return n;
+#endif
+}
 
 // Exchange between the two halves of a wave (v_permlane32_swap): afterwards lanes 0-31 hold {their own a, the upper half's a} in
 // (a, b) and lanes 32-63 hold {the lower half's b, their own b} -- two 8-byte row pieces of a lane pair become one 16-byte piece

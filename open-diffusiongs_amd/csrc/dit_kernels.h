@@ -80,7 +80,19 @@ struct ColReduceParams { ColReduceJob job[8]; };
 
 constexpr int ROWLINEAR_BWD_ROWS = 256;     // output features per workgroup of rowlinear_backward_kernel (default; the slab of dx partial rows is sized by it)
 constexpr int ROWLINEAR_DW_ROWS = 32;       // ... of a launch that only writes dW / db (a block's adaLN Linear, 6W rows: 192 workgroups at W = 1024)
-inline int ln_backward_rows_per_block(int rows_per_batch) { return rows_per_batch % 32 == 0 ? 32 : rows_per_batch; }
+// Rows per workgroup of layernorm_backward_kernel (never straddles samples; the column-sum slab has one row per workgroup).  The
+// kernel runs one 512-thread workgroup per CU (160 VGPRs): with 32 rows each, the training shape (4 x 4224 rows) was 528 workgroups
+// on 256 CUs -- two full rounds and a third for 16 of them, 83 us at 2.9 TB/s.  The smallest divisor of the sample's rows that
+// gets every row into ONE round (66 there: 256 workgroups) takes a third off.  `ncu` 0 (unknown): 32 rows as before.
+inline int ln_backward_rows_per_block(int rows_per_batch, int rows, int ncu) {
+    if (ncu > 0 && rows > 0) {
+        const int want = (rows + ncu - 1) / ncu < 16 ? 16 : (rows + ncu - 1) / ncu;
+        for (int d = want; d <= rows_per_batch && d <= 8 * want; ++d)
+            if (rows_per_batch % d == 0) return d;
+    }
+    return rows_per_batch % 32 == 0 ? 32 : rows_per_batch;
+}
+int ln_backward_compute_units();           // cached device query (dit_backward_elementwise.hip)
 
 struct GsBwdParams {
     int B, V, H, W, ps, lpad, ng, C, scene, relative_plk;

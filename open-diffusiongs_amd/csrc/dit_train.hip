@@ -111,7 +111,7 @@ struct BwdScratch {
         s.wpart_bytes = dgs_dit_gemm_splitk_bytes((int)(4 * W), (int)W, (int)M, (int)lpad);
         s.wpart = c.take<float>(s.wpart_bytes / sizeof(float));
         s.xre = c.take<float>(M * W);
-        const size_t ln_blk = B * ((lpad + 31) / 32);
+        const size_t ln_blk = M / ln_backward_rows_per_block((int)lpad, (int)M, ln_backward_compute_units());
         for (int i = 0; i < 2; ++i) { s.ln_part[i] = c.take<float>(ln_blk * 3 * W); s.gate_part[i] = c.take<float>(M / 64 * 2 * W); }
         s.fc1b_part = c.take<float>((M + 127) / 128 * 4 * W); s.qkvb_part = c.take<float>((M + 127) / 128 * 3 * W);
         const size_t nmod_rows = (6 * (size_t)m->layers + 4) * W;
@@ -319,7 +319,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
     HIP_TRY(hipMemsetAsync(ws.dupn, 0, (size_t)B * ng * W * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(gr->up_ln_w, 0, W * sizeof(float), st));
     hipLaunchKernelGGL(fill_kernel, dim3((B * W + 255) / 256), dim3(256), 0, st, ws.ones, 1.0f, (size_t)B * W);
-    const int ln_slots = lpad / ln_backward_rows_per_block(lpad), gate_slots = lpad / 64;      // partial rows per sample
+    const int ln_slots = lpad / ln_backward_rows_per_block(lpad, M, ln_backward_compute_units()), gate_slots = lpad / 64;      // partial rows per sample
 
     // ---- to_gs + pixel alignment ----
     GsBwdParams gb;

@@ -240,9 +240,13 @@ def _call(ops, fn, struct, **kw):
     assert rc == 0, rc
 
 
-def test_layernorm_backward(ops):
+@pytest.mark.parametrize("cus,rows,rpb", [(0, 64, 32), (3, 66, 66), (8, 96, 24)])
+def test_layernorm_backward(ops, monkeypatch, cus, rows, rpb):
+    """rows per workgroup: 32 when the CU count is unknown, else the smallest divisor of the sample's rows (>= 16) that puts all rows
+    into one round of workgroups (DGS_EMU_CUS plays the device query on the emulator): 2 x 66 rows on 3 CUs -> 66, 2 x 96 on 8 -> 24."""
+    monkeypatch.setenv("DGS_EMU_CUS", str(cus))
     g = torch.Generator().manual_seed(21)
-    B, rows, Wd = 2, 64, 1024
+    B, Wd = 2, 1024
     x = (torch.randn(B * rows, Wd, generator=g) * 2 + 0.5).requires_grad_(True)
     w = (1 + 0.2 * torch.randn(Wd, generator=g)).requires_grad_(True)
     mod = torch.randn(B, 3 * Wd, generator=g)
@@ -257,7 +261,7 @@ def test_layernorm_backward(ops):
     dw = torch.full((Wd,), 7.0)
     dx = torch.zeros(B * rows, Wd)
     nb = ops.lib.dgs_dit_layernorm_backward_scratch_bytes(B * rows, Wd, rows)
-    assert nb == B * (rows // 32) * 3 * Wd * 4
+    assert nb == B * (rows // rpb) * 3 * Wd * 4
     scratch = torch.full((nb // 4,), float("nan"))
     _call(ops, "dgs_dit_layernorm_backward", _native.DgsDitLayerNormBackwardArgs, rows=B * rows, width=Wd, x=x.detach(), dh=dh,
           dh_f32=0, weight=w.detach(), scale=mod[:, Wd:], mod_stride=3 * Wd, rows_per_batch=rows, eps=1e-6, dx_in=dx_in, dx_out=dx,
