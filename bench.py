@@ -50,6 +50,7 @@ PROF_KINDS = {"attention": 1, "gemm_qkv": 2, "gemm_gate_residual": 3, "gemm_fc1_
 
 MODEL_CFG = dict(width=1024, in_channels=9, patch_size=8, num_layers=24, ray_pe_type="relative_plk")     # the shipped diffusion-gs-model
 DRY = {"on": False, "lib": None}    # --dry-run-cpu: CPU emulator build + gloo, a tiny model: exercises the N > 1 plumbing, measures nothing
+DIST = {"on": False}                 # a process group exists (world > 1, or --force-dist on one GPU): barriers + max-over-ranks reductions are issued
 
 
 def _sync():
@@ -297,24 +298,25 @@ def train_bench(a, dev, rank, world, steps, warmup):
     model = model.to(dev)                   # fp32 master parameters + optimizer state on the GPU
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=not DRY["on"])
-    tr = DataParallelTrainer(model, opt, bucket_bytes=(a.bucket_mb << 20) if a.bucket_mb > 0 else None, compress=a.grad_exchange if a.grad_exchange != "fp32" else None)
+    tr = DataParallelTrainer(model, opt, bucket_bytes=(a.bucket_mb << 20) if a.bucket_mb > 0 else None, compress=a.grad_exchange if a.grad_exchange != "fp32" else None,
+                             force_collectives=a.force_dist)
     batch, t = synth.make_batch(B, res, V=V, device=dev, seed=100 + rank, with_t=True)
     rc2w = torch.tensor(np.stack([cameras.ring_cameras(RV, phase_deg=5.0 + 7 * b) for b in range(B)])).to(dev)
     rk = torch.tensor(cameras.default_fxfycxcy(res)).expand(B, RV, 4).contiguous().to(dev)
     target = torch.rand(B, RV, 3, res, res, device=dev)
     for _ in range(warmup):
         loss = tr.step(batch, t, target, rc2w, rk)
-    if world > 1:
+    if DIST["on"]:
         torch.distributed.barrier()
     _sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.step(batch, t, target, rc2w, rk)
     _sync()
-    if world > 1:
+    if DIST["on"]:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if DIST["on"]:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -329,7 +331,7 @@ def train_bench(a, dev, rank, world, steps, warmup):
             "steps": steps, "warmup": warmup, "loss": round(float(loss), 6), "recompute": recompute,
             "dit_tflops_per_gpu": round(flops / (ms * 1e-3) / 1e12, 1), "frac_of_bf16_peak": round(flops / (ms * 1e-3) / PEAK_BF16_MFMA, 4),
             "saved_activation_gib": round(eng._train["saved"].numel() / 2 ** 30, 2),
-            "allreduce": {"world": world, "buckets": len(tr.reducer.bounds), "exchange": a.grad_exchange,
+            "allreduce": {"world": world, "collectives_issued": bool(tr.reducer.active), "buckets": len(tr.reducer.bounds), "exchange": a.grad_exchange,
                           "bucket_mib": [round((e - b) * 4 / 2 ** 20, 1) for b, e in tr.reducer.bounds],
                           "launched_during_backward": sum(1 for _, tag in log if isinstance(tag, int)),
                           "last_bucket_mib": round((tr.reducer.bounds[-1][1] - tr.reducer.bounds[-1][0]) * 4 / 2 ** 20, 1),
@@ -354,6 +356,8 @@ def main():
     ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce (bf16: half the xGMI bytes)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="NOT a measurement: the same script on the CPU emulator build of the kernels with "
                     "gloo and a tiny model (width 256, 2 blocks, 64^2) -- what tests/test_bench_dry_run.py uses to exercise the N > 1 path")
+    ap.add_argument("--force-dist", action="store_true", help="create the process group and issue every barrier / all-reduce even for a world of one "
+                    "(the one-GPU RCCL smoke run: same init, streams and collective calls as N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
     ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the informational objects may take before the line is printed without them")
@@ -378,9 +382,13 @@ def main():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    DIST["on"] = world > 1 or a.force_dist
+    if DIST["on"]:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")          # only --force-dist without a launcher gets here without one
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.dry_run_cpu:
             dist.init_process_group("gloo")
         else:
@@ -398,7 +406,7 @@ def main():
                 "data": "synthetic", "config": {"workload": f"obj-{a.res} training step (BASELINE.json configs[3]): B={a.train_batch} samples/GPU, "
                                                             f"4 input views, {a.train_views} rendered views, 460 M parameters, random init",
                                                 "parallelism": f"dp{world}"}, "train_step": tb, **dry_note}), flush=True)
-        if world > 1:
+        if DIST["on"]:
             torch.distributed.destroy_process_group()
         return
 
@@ -420,7 +428,7 @@ def main():
             return rendered, model.prepare_to_save(p), pc
 
     def barrier():
-        if world > 1:
+        if DIST["on"]:
             torch.distributed.barrier()
 
     loop_ms = None
@@ -460,7 +468,7 @@ def main():
         rendered, gaussians, _pc = step(prof=(PROF_KINDS[a.roofline_kernel], events[i]) if i in events else None)
     _sync(); barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if DIST["on"]:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -535,7 +543,7 @@ def main():
         watchdog.cancel()
         print(json.dumps(out), flush=True)
     watchdog.cancel()
-    if world > 1:
+    if DIST["on"]:
         torch.distributed.destroy_process_group()
 
 

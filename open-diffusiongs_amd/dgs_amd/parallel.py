@@ -24,12 +24,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(device=None, backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).  Returns (rank, world, local_rank)."""
+def init_distributed(device=None, backend=None, force=False):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).  Returns (rank, world, local_rank).
+    force=True creates the process group even for a world of one (the one-GPU RCCL smoke test: the same init, stream and
+    collective calls as N > 1, on the only hardware the builder's box has)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -86,9 +88,12 @@ def bucket_bounds(n, per, tail=()):
 class BucketedAllReduce:
     """Average `flat` over the ranks in large buckets, each enqueued as soon as the caller says its bytes are final."""
 
-    def __init__(self, flat, bucket_bytes=None, group=None, compress=None):
+    def __init__(self, flat, bucket_bytes=None, group=None, compress=None, force_collectives=False):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a world of one normally skips the collectives; force_collectives issues them anyway (a sum over one rank: the RCCL
+        # launch path, its stream ordering against the backward and the bf16 round trip run for real on a single GPU)
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         if bucket_bytes is None:                   # 32 MiB per rank: a ring step moves bucket / world per link
             bucket_bytes = (32 << 20) * max(self.world, 2)
         es = flat.element_size()
@@ -111,7 +116,7 @@ class BucketedAllReduce:
             self.launch_log = []
         while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][1] <= end_element:
             a, b = self.bounds[self.next_bucket]
-            if self.world > 1:
+            if self.active:
                 if self.compress == "bf16":
                     half = self.flat[a:b].to(torch.bfloat16)            # on the compute stream, behind the kernels that fill [a, b)
                     self.works.append((dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group, async_op=True), half, a, b))

@@ -27,14 +27,14 @@ class DataParallelTrainer:
     the backward writes there in place and reports finished groups to the bucketed all-reduce.  `close()` (or leaving the `with`
     block) hands the model back: a later plain `loss.backward()` then returns gradients through autograd again."""
 
-    def __init__(self, model, optimizer, bucket_bytes=None, accumulate_grad_batches=1, group=None, compress=None):
+    def __init__(self, model, optimizer, bucket_bytes=None, accumulate_grad_batches=1, group=None, compress=None, force_collectives=False):
         self.model, self.opt = model, optimizer
         self.accumulate = int(accumulate_grad_batches)
         eng = model.engine()
         self.fg = eng._train_state()["fg"]
         if next(model.parameters()).device != self.fg.flat.device:
             raise RuntimeError("DataParallelTrainer: the module's parameters must live on the engine's device (model.to(device))")
-        self.reducer = BucketedAllReduce(self.fg.flat, bucket_bytes, group=group, compress=compress)
+        self.reducer = BucketedAllReduce(self.fg.flat, bucket_bytes, group=group, compress=compress, force_collectives=force_collectives)
         self.world = self.reducer.world
         self._accum = torch.zeros_like(self.fg.flat) if self.accumulate > 1 else None
         self._summed_to = 0
