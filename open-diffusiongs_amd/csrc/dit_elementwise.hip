@@ -14,19 +14,33 @@ namespace dgs {
 // Two-pass statistics in registers (mean, then centred variance) like torch's fp32 LayerNorm.
 // ------------------------------------------------------------------------------------------------
 
-template <int VPL>   // float4 vectors per lane: width = 256 * VPL
+// The per-column operands (LayerNorm weight, adaLN shift / scale) do not depend on the statistics: they are requested right behind the
+// row itself, so the kernel is ONE memory round trip.  (As run-time tests of p.weight / p.shift inside the output loop the
+// compiler emitted, per 1 KiB of the row, branch -> load -> s_waitcnt vmcnt(0) -> store: four more dependent round trips behind the
+// reductions, ~2 of the kernel's 6.9 us at the DiT shape.)  Same arithmetic in the same order as before: outputs are bit-identical.
+template <int VPL, bool WEIGHT, bool MOD, bool F32OUT>   // float4 vectors per lane: width = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
+    const int b = blockIdx.y;                                  // the sample: grid.y (no per-row division in front of the operand loads)
+    const int local = blockIdx.x * 4 + (threadIdx.x >> 6), row = b * p.rows_per_batch + local;
+    if (local >= p.rows_per_batch || row >= p.rows) return;
     const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)row * p.width);
-    float4 v[VPL];
+    float4 v[VPL], w[WEIGHT ? VPL : 1], sh[MOD ? VPL : 1], sc[MOD ? VPL : 1];
     float sum = 0.f;
 #pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = xr[i * 64 + lane];
+#pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        v[i] = xr[i * 64 + lane];
-        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const int c4 = i * 64 + lane;   // float4 index inside the row
+        if constexpr (WEIGHT) w[i] = reinterpret_cast<const float4*>(p.weight)[c4];
+        if constexpr (MOD) {
+            sh[i] = reinterpret_cast<const float4*>(p.shift + (size_t)b * p.mod_stride)[c4];
+            sc[i] = reinterpret_cast<const float4*>(p.scale + (size_t)b * p.mod_stride)[c4];
+        }
     }
+    sched_fence();                      // every load is issued before the first use of the row (hipcc otherwise sinks half of them)
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(sum) / (float)p.width;
     float sq = 0.f;
 #pragma unroll
@@ -35,22 +49,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
         sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
     const float rstd = rsqrtf(wave_sum(sq) / (float)p.width + p.eps);
-    const int b = row / p.rows_per_batch;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c4 = i * 64 + lane;   // float4 index inside the row
+        const int c4 = i * 64 + lane;
         float4 y = make_float4(v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd);
-        if (p.weight) {
-            const float4 w = reinterpret_cast<const float4*>(p.weight)[c4];
-            y.x *= w.x; y.y *= w.y; y.z *= w.z; y.w *= w.w;
+        if constexpr (WEIGHT) { y.x *= w[i].x; y.y *= w[i].y; y.z *= w[i].z; y.w *= w[i].w; }
+        if constexpr (MOD) {
+            y.x = y.x * (1.0f + sc[i].x) + sh[i].x; y.y = y.y * (1.0f + sc[i].y) + sh[i].y;
+            y.z = y.z * (1.0f + sc[i].z) + sh[i].z; y.w = y.w * (1.0f + sc[i].w) + sh[i].w;
         }
-        if (p.shift) {
-            const float4 sh = reinterpret_cast<const float4*>(p.shift + (size_t)b * p.mod_stride)[c4];
-            const float4 sc = reinterpret_cast<const float4*>(p.scale + (size_t)b * p.mod_stride)[c4];
-            y.x = y.x * (1.0f + sc.x) + sh.x; y.y = y.y * (1.0f + sc.y) + sh.y;
-            y.z = y.z * (1.0f + sc.z) + sh.z; y.w = y.w * (1.0f + sc.w) + sh.w;
-        }
-        if (p.out_f32) reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)row * p.width)[c4] = y;
+        if constexpr (F32OUT) reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)row * p.width)[c4] = y;
         else reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)row * p.width)[c4] =
                  make_uint2(pack_bf2(y.x, y.y), pack_bf2(y.z, y.w));
     }
@@ -251,15 +259,24 @@ int launch_layernorm(const DgsDitLayerNormArgs* a, hipStream_t st) {
     p.rows = a->rows; p.width = a->width; p.mod_stride = a->mod_stride;
     p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->rows;
     p.out_f32 = a->out_f32; p.eps = a->eps; p.x = a->x; p.weight = a->weight; p.shift = a->shift; p.scale = a->scale; p.out = a->out;
-    const dim3 grid((a->rows + 3) / 4), block(256);
+    const dim3 grid((p.rows_per_batch + 3) / 4, (a->rows + p.rows_per_batch - 1) / p.rows_per_batch), block(256);
+    const bool w = a->weight != nullptr, m = a->shift != nullptr, f = a->out_f32 != 0;
+#define DGS_LN_CASE(V)                                                                                                                   \
+    case V:                                                                                                                              \
+        if (w) { if (m) { if (f) hipLaunchKernelGGL((layernorm_kernel<V, true, true, true>), grid, block, 0, st, p);                     \
+                          else hipLaunchKernelGGL((layernorm_kernel<V, true, true, false>), grid, block, 0, st, p); }                    \
+                 else   { if (f) hipLaunchKernelGGL((layernorm_kernel<V, true, false, true>), grid, block, 0, st, p);                    \
+                          else hipLaunchKernelGGL((layernorm_kernel<V, true, false, false>), grid, block, 0, st, p); } }                 \
+        else   { if (m) { if (f) hipLaunchKernelGGL((layernorm_kernel<V, false, true, true>), grid, block, 0, st, p);                    \
+                          else hipLaunchKernelGGL((layernorm_kernel<V, false, true, false>), grid, block, 0, st, p); }                   \
+                 else   { if (f) hipLaunchKernelGGL((layernorm_kernel<V, false, false, true>), grid, block, 0, st, p);                   \
+                          else hipLaunchKernelGGL((layernorm_kernel<V, false, false, false>), grid, block, 0, st, p); } }                \
+        break;
     switch (a->width / 256) {
-        case 1: hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((layernorm_kernel<3>), grid, block, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, p); break;
-        case 8: hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, st, p); break;
+        DGS_LN_CASE(1) DGS_LN_CASE(2) DGS_LN_CASE(3) DGS_LN_CASE(4) DGS_LN_CASE(8)
         default: return DGS_ERR_INVALID_ARGUMENT;
     }
+#undef DGS_LN_CASE
     return launch_ok();
 }
 

@@ -62,6 +62,18 @@ __device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b, float
 #endif
 }
 
+// Transposed copies ([feature][token], a lane owns ONE feature): the D-fragment layout gives lane (c, half) the tokens
+// 8 g + 4 half + {0..3} of its feature, i.e. 8-byte pieces; 32 features per wave-instruction = 32 cache lines for 512 bytes, and the
+// V third of the QKV tiles (and every tile of the training forward) left through four such instructions per block.  A half-wave
+// exchange (v_permlane32_swap) of the pieces of token groups g and g + 1 gives the lower lane tokens 8 g .. 8 g + 7 and the upper
+// lane 8 (g + 1) .. 8 (g + 1) + 7: one 16-byte store per lane, 32 contiguous bytes per feature and instruction, half the requests.
+// `tdst` = the feature's row at the block's first token (no half offset); u0 / u1 = this lane's pieces of groups g and g + 1.
+__device__ __forceinline__ void store_token_octet(bf16_t* tdst, int g, int half, uint2 u0, uint2 u1) {
+    half_swap(u0.x, u1.x);
+    half_swap(u0.y, u1.y);
+    *reinterpret_cast<uint4*>(tdst + 8 * (g + half)) = make_uint4(u0.x, u0.y, u1.x, u1.y);
+}
+
 constexpr int epi_strip_bytes(int nb) { return 32 * (32 * nb + 4) * 4; }     // LDS per wave
 
 
@@ -95,11 +107,12 @@ __device__ __forceinline__ void store_strip_impl(const P& p, const f32x16* acc, 
         for (int blk = 0; blk < NB; ++blk) {
             const int n = n0 + 32 * blk + c;
             const float bias = p.bias ? p.bias[n] : 0.0f;
-            bf16_t* tdst = p.vt + ((size_t)b * (p.N / 3) + (n - (p.N / 3) * 2)) * p.rows_per_batch + (m0 - b * p.rows_per_batch) + 4 * half;
+            bf16_t* tdst = p.vt + ((size_t)b * (p.N / 3) + (n - (p.N / 3) * 2)) * p.rows_per_batch + (m0 - b * p.rows_per_batch);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<uint2*>(tdst + 8 * g) = make_uint2(pack_bf2(acc[blk][4 * g] + bias, acc[blk][4 * g + 1] + bias),
-                                                                       pack_bf2(acc[blk][4 * g + 2] + bias, acc[blk][4 * g + 3] + bias));
+            for (int g = 0; g < 4; g += 2)
+                store_token_octet(tdst, g, half,
+                                  make_uint2(pack_bf2(acc[blk][4 * g] + bias, acc[blk][4 * g + 1] + bias), pack_bf2(acc[blk][4 * g + 2] + bias, acc[blk][4 * g + 3] + bias)),
+                                  make_uint2(pack_bf2(acc[blk][4 * g + 4] + bias, acc[blk][4 * g + 5] + bias), pack_bf2(acc[blk][4 * g + 6] + bias, acc[blk][4 * g + 7] + bias)));
         }
         return;
     }
@@ -172,11 +185,12 @@ __device__ __forceinline__ void store_strip_impl(const P& p, const f32x16* acc, 
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
-                bf16_t* tdst = p.vt + ((size_t)b * p.N + n0 + 32 * blk + c) * p.rows_per_batch + (m0 - b * p.rows_per_batch) + 4 * half;
+                bf16_t* tdst = p.vt + ((size_t)b * p.N + n0 + 32 * blk + c) * p.rows_per_batch + (m0 - b * p.rows_per_batch);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < 4; g += 2) {
                     const float* src = st + (4 * half + 8 * g) * S + 32 * blk + c;
-                    *reinterpret_cast<uint2*>(tdst + 8 * g) = make_uint2(pack_bf2(src[0], src[S]), pack_bf2(src[2 * S], src[3 * S]));
+                    store_token_octet(tdst, g, half, make_uint2(pack_bf2(src[0], src[S]), pack_bf2(src[2 * S], src[3 * S])),
+                                      make_uint2(pack_bf2(src[8 * S], src[9 * S]), pack_bf2(src[10 * S], src[11 * S])));
                 }
             }
         }

@@ -106,6 +106,10 @@ class BucketedAllReduce:
         if compress not in (None, "bf16"):
             raise ValueError("compress: None or 'bf16'")
         self.compress = compress
+        # world-of-one diagnostics: a buffer that receives every bucket THROUGH a collective that moves data on RCCL's stream
+        # (an all-gather over one rank = a copy there) at the moment the bucket is launched -- equal to `flat` after the step
+        # iff every bucket was final when its collective ran (set by the test: tests/test_rccl_world1_gpu.py)
+        self.probe = None
         self.next_bucket, self.works = 0, []
         self.launch_log = []          # (bucket index, tag) of the last step, in launch order (tests, diagnostics)
 
@@ -117,6 +121,9 @@ class BucketedAllReduce:
         while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][1] <= end_element:
             a, b = self.bounds[self.next_bucket]
             if self.active:
+                if self.probe is not None:
+                    assert self.world == 1, "the launch-time probe is a one-rank diagnostic"
+                    self.works.append((dist.all_gather_into_tensor(self.probe[a:b], self.flat[a:b], group=self.group, async_op=True), None, a, b))
                 if self.compress == "bf16":
                     half = self.flat[a:b].to(torch.bfloat16)            # on the compute stream, behind the kernels that fill [a, b)
                     self.works.append((dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group, async_op=True), half, a, b))

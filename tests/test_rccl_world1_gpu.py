@@ -4,10 +4,13 @@ collective of the N > 1 path actually issued (`force_collectives`): the async al
 the ctypes callback INSIDE dgs_dit_backward, on RCCL's stream, behind the compute stream's work so far; `finish()` waiting on the
 works before the optimizer; the bf16 exchange's cast / sum / copy-back; bench.py's barrier and max-over-ranks reduction.
 
-A sum over one rank is the identity, so the check is exact: the gradients of a step WITH the collectives equal, bit for bit, the
-gradients of the same step WITHOUT them (the backward is run-to-run deterministic, tools/train_determinism.py), which proves
-the stream ordering -- a bucket reduced before the kernels that fill it had run, or a weight update overtaking a collective,
-would show as a difference.  What a single GPU cannot show is xGMI traffic and scaling: no such number exists.
+Stream ordering is checked EXACTLY and inside one run: RCCL short-cuts an in-place all-reduce over one rank (no data moves), so
+beside it every bucket is also all-gathered (one rank: a copy performed on RCCL's stream, at the bucket's launch) into a probe
+buffer; after the step the probe must equal the flat gradient buffer bit for bit -- a bucket whose collective ran before the
+kernels that fill it had finished, or that was written again afterwards, differs.  Against the same step without collectives the
+gradients are compared at the step's own run-to-run spread (two plain runs: the rasterizer backward sums a Gaussian's tiles with
+fp32 atomics; only the DiT backward is bit-reproducible).  What a single GPU cannot show is xGMI traffic and scaling: no such
+number exists.
 """
 import os
 import socket
@@ -58,7 +61,7 @@ def _worker(port, out, backend="nccl"):
     rk = torch.tensor(cameras.default_fxfycxcy(res)).expand(B, RV, 4).contiguous().to(dev)
     target = torch.rand(B, RV, 3, res, res, generator=torch.Generator().manual_seed(2)).to(dev)
     results = {}
-    for name, kw in (("none", dict()), ("fp32", dict(force_collectives=True)), ("bf16", dict(force_collectives=True, compress="bf16"))):
+    for name, kw in (("none", dict()), ("none2", dict()), ("fp32", dict(force_collectives=True)), ("bf16", dict(force_collectives=True, compress="bf16"))):
         m = dn.DGSDenoiser(cfg, device=dev, lib=lib)
         m.reset_parameters(seed=4)
         m = m.to(dev)
@@ -66,25 +69,31 @@ def _worker(port, out, backend="nccl"):
         opt = torch.optim.SGD(m.parameters(), lr=0.0)
         # small buckets: several collectives leave DURING the backward (one per finished block group)
         with DataParallelTrainer(m, opt, bucket_bytes=bucket_bytes, **kw) as tr:
-            assert tr.reducer.active == (name != "none")
+            assert tr.reducer.active == (not name.startswith("none"))
+            if name == "fp32":
+                tr.reducer.probe = torch.full_like(tr.fg.flat, float("nan"))
             for _ in range(2):                                   # two steps: the reducer resets, works are not leaked
                 loss = tr.step(batch, t, target, rc2w, rk)
             if gpu:
                 torch.cuda.synchronize()
             results[name] = (float(loss), tr.fg.flat.clone(), list(tr.reducer.launch_log), len(tr.reducer.bounds))
+            if name == "fp32":
+                probe_equal = bool(torch.equal(tr.reducer.probe, tr.fg.flat))
+                probe_bad = int((tr.reducer.probe != tr.fg.flat).sum())
     # bench.py's timing plumbing on RCCL
     dist.barrier()
     tt = torch.tensor([1.25], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if gpu:
         torch.cuda.synchronize()
-    none, fp32, bf16 = results["none"], results["fp32"], results["bf16"]
+    none, none2, fp32, bf16 = results["none"], results["none2"], results["fp32"], results["bf16"]
+    rel = lambda x, y: float((x - y).norm() / y.norm())
     early = [b for b, tag in fp32[2] if isinstance(tag, int)]
     out.put(dict(
         loss=(none[0], fp32[0], bf16[0]),
-        fp32_bit_identical=bool(torch.equal(none[1], fp32[1])),
-        bf16_rel=float((bf16[1] - none[1]).norm() / none[1].norm()),
-        bf16_is_rounding=bool(torch.equal(bf16[1], none[1].to(torch.bfloat16).float())),
+        probe_equal=probe_equal, probe_bad=probe_bad,
+        run_to_run_rel=rel(none2[1], none[1]), fp32_rel=rel(fp32[1], none[1]), bf16_rel=rel(bf16[1], none[1]),
+        bf16_is_bf16=bool(torch.equal(bf16[1], bf16[1].to(torch.bfloat16).float())),
         finite=bool(torch.isfinite(fp32[1]).all()) and float(none[1].abs().max()) > 0.0,
         buckets=fp32[3], launched_during_backward=len(early), log=[(b, str(tag)) for b, tag in fp32[2]],
         max_reduce=float(tt.item())))
@@ -111,8 +120,9 @@ def _run(backend):
     print(r)
     assert r["finite"]
     assert r["loss"][0] == r["loss"][1] == r["loss"][2]                 # the forward does not depend on the exchange
-    assert r["fp32_bit_identical"], "gradients differ with the all-reduces issued: stream ordering between the backward and RCCL"
-    assert r["bf16_is_rounding"] or r["bf16_rel"] < 4e-3, r["bf16_rel"]   # a sum over one rank in bf16 = one bf16 rounding
+    assert r["probe_equal"], f"{r['probe_bad']} elements of a bucket were not final when its collective ran on RCCL's stream"
+    assert r["fp32_rel"] <= 4 * r["run_to_run_rel"] + 1e-7, r            # a sum over one rank: the step's own run-to-run spread
+    assert r["bf16_is_bf16"] and r["bf16_rel"] <= 4e-3 + 4 * r["run_to_run_rel"], r   # ... plus one bf16 rounding
     assert r["buckets"] >= 3 and r["launched_during_backward"] >= r["buckets"] - 1, r["log"]
     assert r["max_reduce"] == 1.25
 

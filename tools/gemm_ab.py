@@ -39,8 +39,18 @@ for name, N, K, epi in SHAPES:
     A, Wt, bias = bf(M, K), bf(N, K) * 0.05, torch.randn(N, generator=g, device=DEV)
     x0, gate = torch.randn(M, N, generator=g, device=DEV), torch.randn(1, N, generator=g, device=DEV)
 
-    def run(ops, x=None):
+    keep = {}                                                 # timed launches: preallocated outputs, nothing but the kernel
+
+    def run(ops, x=None, timed=False):
         kw = dict(rows_per_batch=M, valid_rows=L)
+        if timed and epi == _native.EPI_QKV:
+            if "qk" not in keep:
+                keep["qk"], keep["vt"] = torch.zeros(M, 2 * N // 3, dtype=torch.bfloat16, device=DEV), torch.zeros(1, N // 3, M, dtype=torch.bfloat16, device=DEV)
+            return ops.gemm(A, Wt, bias, epi, out=keep["qk"], vt=keep["vt"], **kw)
+        if timed and epi == _native.EPI_GELU_BF16:
+            if "o" not in keep:
+                keep["o"] = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            return ops.gemm(A, Wt, bias, epi, out=keep["o"], **kw)
         if epi == _native.EPI_GATE_RESIDUAL:
             ops.gemm(A, Wt, bias, epi, out=x, gate=gate, **kw)
             return x
@@ -60,14 +70,40 @@ for name, N, K, epi in SHAPES:
     xs = {"base": x0.clone(), "new": x0.clone()}
     ev = {k: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)] for k in xs}
     for _ in range(3):
-        run(base, xs["base"]); run(new, xs["new"])
+        run(base, xs["base"], True); run(new, xs["new"], True)
     for i in range(iters):
         for k, ops in (("base", base), ("new", new)):
             e0, e1 = ev[k][i]
-            e0.record(); run(ops, xs[k]); e1.record()
+            e0.record(); run(ops, xs[k], True); e1.record()
     sync()
     med = {k: sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in v)[iters // 2] for k, v in ev.items()}
     flops = 2.0 * L * N * K
     print(f"timing {name} [{M} x {N} x {K}]: base {med['base']:.1f} us ({flops / med['base'] / 1e6:.0f} TFLOP/s)  new {med['new']:.1f} us "
-          f"({flops / med['new'] / 1e6:.0f} TFLOP/s)  ratio {med['new'] / med['base']:.3f}  (median of {iters}; the QKV / fc1 lines include the "
-          f"output allocation)", flush=True)
+          f"({flops / med['new'] / 1e6:.0f} TFLOP/s)  ratio {med['new'] / med['base']:.3f}  (median of {iters}; preallocated outputs)", flush=True)
+
+
+# ---- training forward at 4 samples: every tile also leaves a transposed copy (`vt`: [sample][feature][token], the weight-gradient
+#      GEMMs' operand) -- QKV (V^T only), fc1 + GELU with aux (pre-activations) and vt, the LN-output style plain BF16 with vt ----
+if DEV != "cpu":
+    B4, M4 = 4, 4 * 4352
+    for name, N, K, epi in [("train qkv", 3 * W, W, _native.EPI_QKV), ("train fc1+gelu+vt", 4 * W, W, _native.EPI_GELU_BF16), ("train bf16+vt", W, W, _native.EPI_BF16)]:
+        A, Wt, bias = bf(M4, K), bf(N, K) * 0.05, torch.randn(N, generator=g, device=DEV)
+        res = {}
+        for k, ops in (("base", base), ("new", new)):
+            if epi == _native.EPI_QKV:
+                out, vt = torch.zeros(M4, 2 * N // 3, dtype=torch.bfloat16, device=DEV), torch.zeros(B4, N // 3, 4352, dtype=torch.bfloat16, device=DEV)
+                aux = None
+            else:
+                out, vt = torch.zeros(M4, N, dtype=torch.bfloat16, device=DEV), torch.zeros(B4, N, 4352, dtype=torch.bfloat16, device=DEV)
+                aux = torch.zeros(M4, N, dtype=torch.bfloat16, device=DEV) if epi == _native.EPI_GELU_BF16 else None
+            call = lambda ops=ops, out=out, vt=vt, aux=aux: ops.gemm(A, Wt, bias, epi, out=out, vt=vt, aux=aux, rows_per_batch=4352, valid_rows=L)
+            for _ in range(3):
+                call()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+            for e0, e1 in evs:
+                e0.record(); call(); e1.record()
+            sync()
+            res[k] = (sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)[10], out.clone(), vt.clone())
+        same = torch.equal(res["base"][1], res["new"][1]) and torch.equal(res["base"][2], res["new"][2])
+        print(f"{name} [{M4} x {N} x {K}]: outputs + transposed copies bit-identical: {same}; base {res['base'][0]:.1f} us  new {res['new'][0]:.1f} us  "
+              f"ratio {res['new'][0] / res['base'][0]:.3f}", flush=True)
