@@ -72,12 +72,20 @@ template <int V> struct Mode { static constexpr int value = V; };
 // side, coherent across XCDs), ordered by vmcnt(0) + barrier before the arrival counter is bumped.
 union PFrag { bf16x8 v; uint32_t u[4]; };
 
-constexpr int TAIL_REC = 66;          // floats per (key tile, query) record: max, sum, O[64]
+constexpr int TAIL_REC = 68;          // floats per (key tile, query) record: max, sum, 2 unused, O[64] (O 16-byte aligned: 9 stores per lane)
+// The tail tiles of a workgroup (one per wave: key tile qblk + nqb * wave) and the tail queries are copied into LDS by the main
+// loop's last rounds (LDS-DMA, no registers), so that the tail work behind the loop starts from LDS instead of a round trip of
+// fragment gathers at the moment all 256 workgroups leave their loops (DGS_ATTN_DBG stamps: 10.5 k cycles per workgroup, of 162 k).
+constexpr int TAIL_LDS_TILES = 5;                         // tiles staged per workgroup (waves 0..4); a wave beyond that reads global memory
+constexpr int TAIL_DMAS = 2 * TAIL_LDS_TILES + 1;         // per wave: its 1 KiB piece of every staged K and V^T tile + of the query tile
 
 __device__ __forceinline__ int pi16(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // one key tile of the tail queries, by one wave; rec = this tile's records [r][TAIL_REC]
-__device__ __forceinline__ void tail_tile(const AttnParams& p, int t, int r, const bf16_t* Qg, const bf16_t* Kg, const bf16_t* Vg, float* rec, int lane) {
+// `lds_k` != nullptr: the tile's K / V^T images and the tail queries' rows are in LDS (same layout as the ring tiles; foff = the
+// lane's fragment offsets of the main loop); otherwise the fragments are gathered from global memory.
+__device__ __forceinline__ void tail_tile(const AttnParams& p, int t, int r, const bf16_t* Qg, const bf16_t* Kg, const bf16_t* Vg, float* rec, int lane,
+                                          const char* lds_k = nullptr, const char* lds_v = nullptr, const char* lds_q = nullptr, const int* foff = nullptr) {
     const int l31 = lane & 31, half = lane >> 5;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
@@ -86,7 +94,9 @@ __device__ __forceinline__ void tail_tile(const AttnParams& p, int t, int r, con
     bf16x8 qf[4], kf[8], vf[8];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        uint4 raw = *reinterpret_cast<const uint4*>(Qg + (size_t)qld * p.ld_qk + (2 * ks + half) * 8);
+        uint4 raw;
+        if (lds_k) raw = *reinterpret_cast<const uint4*>(lds_q + foff[ks]);
+        else raw = *reinterpret_cast<const uint4*>(Qg + (size_t)qld * p.ld_qk + (2 * ks + half) * 8);
         if (!p.q_prescaled) {
             raw.x = scale_bf2(raw.x, p.scale_log2e); raw.y = scale_bf2(raw.y, p.scale_log2e);
             raw.z = scale_bf2(raw.z, p.scale_log2e); raw.w = scale_bf2(raw.w, p.scale_log2e);
@@ -94,9 +104,14 @@ __device__ __forceinline__ void tail_tile(const AttnParams& p, int t, int r, con
         qf[ks] = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            const int key = t * KB + pi16(l31 + 32 * blk);
-            kf[2 * ks + blk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)(key < p.L ? key : p.L - 1) * p.ld_qk + (2 * ks + half) * 8);
-            vf[2 * ks + blk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)(l31 + 32 * blk) * p.lpad + t * KB + 16 * ks + 8 * half);
+            if (lds_k) {
+                kf[2 * ks + blk] = *reinterpret_cast<const bf16x8*>(lds_k + foff[ks] + blk * 32 * 128);
+                vf[2 * ks + blk] = *reinterpret_cast<const bf16x8*>(lds_v + foff[ks] + blk * 32 * 128);
+            } else {
+                const int key = t * KB + pi16(l31 + 32 * blk);
+                kf[2 * ks + blk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)(key < p.L ? key : p.L - 1) * p.ld_qk + (2 * ks + half) * 8);
+                vf[2 * ks + blk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)(l31 + 32 * blk) * p.lpad + t * KB + 16 * ks + 8 * half);
+            }
         }
     }
     f32x16 s0 = zero16, s1 = zero16;
@@ -130,33 +145,39 @@ __device__ __forceinline__ void tail_tile(const AttnParams& p, int t, int r, con
         la = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[ks].v, la, 0, 0, 0);
     }
     if (l31 < r) {                             // lane owns query l31: d = db * 32 + 8 (rr >> 2) + 4 half + (rr & 3)
-        float* q = rec + l31 * TAIL_REC;
-        if (half == 0) { st_agent(q, mx); st_agent(q + 1, la[0]); }
+        float* q = rec + l31 * TAIL_REC;       // [max, sum, -, -, O[64]]: four consecutive d per accumulator group = one 16-byte store
+        if (half == 0) st_agent2(q, mx, la[0]);
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int d = 8 * (rr >> 2) + 4 * half + (rr & 3);
-            st_agent(q + 2 + d, o0[rr]);
-            st_agent(q + 2 + 32 + d, o1[rr]);
+        for (int g = 0; g < 4; ++g) {
+            st_agent4(q + 4 + 8 * g + 4 * half, o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]);
+            st_agent4(q + 4 + 32 + 8 * g + 4 * half, o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]);
         }
     }
 }
 
 // merge of the nrec per-tile records of one (sample, head), by the whole workgroup (512 threads)
+// An item is one (tail query, d) pair: r * 64 of them.  With the DiT's r = 2 that is 128 items for 512 threads: as one thread per
+// item walking all 65 records in two dependent LDS passes the merge took 15 k cycles of the LAST workgroup of every head
+// (DGS_ATTN_DBG stamps) -- 8 us at the very end of an 87 us kernel.  The records of a batch are therefore cut into G = 512 / items
+// slices (a power of two, at most 8); thread (slice g, item i) folds its slice into a running {max, sum, O} with the LDS reads of
+// four records in flight, and the G partial states of an item meet in LDS once, at the end.
 __device__ void tail_merge(const AttnParams& p, int bh, int nrec, int r, char* lds) {
     const int tid = threadIdx.x, head = bh % p.heads, b = bh / p.heads;
     // records of consecutive tiles are contiguous: pull them into LDS in batches (independent coalesced loads), then
-    // every thread folds the batch into the running {max, sum, O} of its (query, d) items
+    // every thread folds its slice of the batch into the running {max, sum, O} of its (query, d) item
     float* lbuf = reinterpret_cast<float*>(lds);
     const float* const recs = p.tail_ws + (size_t)bh * nrec * r * TAIL_REC;
-    const int per_rec = r * TAIL_REC;
+    const int per_rec = r * TAIL_REC, nitems = r * 64;
     const int cb = 15360 / per_rec;                            // tiles per batch (60 KiB of LDS)
+    int G = 1;
+    while (2 * G * nitems <= 512 && G < 8) G *= 2;             // slices of a batch; G == 1: one thread per item, items looped
     float Mr[4], lr[4], orr[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) { Mr[it] = -3.0e38f; lr[it] = 0.0f; orr[it] = 0.0f; }
     for (int c0 = 0; c0 < nrec; c0 += cb) {
         const int n = nrec - c0 < cb ? nrec - c0 : cb;
         __syncthreads();
-        const float2* src = reinterpret_cast<const float2*>(recs + (size_t)c0 * per_rec);       // 66 floats per record: 8-byte aligned
+        const float2* src = reinterpret_cast<const float2*>(recs + (size_t)c0 * per_rec);       // 68 floats per record
         const int n2 = n * per_rec / 2;
         for (int i0 = 0; i0 < n2; i0 += 10 * 512) {             // 10 independent loads in flight per thread
             float2 v[10];
@@ -172,22 +193,44 @@ __device__ void tail_merge(const AttnParams& p, int bh, int nrec, int r, char* l
             }
         }
         __syncthreads();
+        const int per_slice = (n + G - 1) / G;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int i = tid + it * 512;
-            if (i >= r * 64) break;
+            const int idx = tid + it * 512, g = idx / nitems, i = idx - g * nitems;
+            if (g >= G) break;
+            const int ca = g * per_slice, ce = ca + per_slice < n ? ca + per_slice : n;
+            if (ca >= ce) continue;
             const float* rec = lbuf + (i >> 6) * TAIL_REC;
             float M = Mr[it];
-            for (int c = 0; c < n; ++c) M = fmaxf(M, rec[c * per_rec]);
+#pragma unroll 4
+            for (int c = ca; c < ce; ++c) M = fmaxf(M, rec[c * per_rec]);
             const float w0 = fast_exp2(Mr[it] - M);
             float l = lr[it] * w0, o = orr[it] * w0;
-            for (int c = 0; c < n; ++c) {
+#pragma unroll 4
+            for (int c = ca; c < ce; ++c) {
                 const float w = fast_exp2(rec[c * per_rec] - M);
                 l += w * rec[c * per_rec + 1];
-                o += w * rec[c * per_rec + 2 + (i & 63)];
+                o += w * rec[c * per_rec + 4 + (i & 63)];
             }
             Mr[it] = M; lr[it] = l; orr[it] = o;
         }
+    }
+    if (G > 1) {                                               // the G partial states of an item: LDS, then slice 0 folds them in slice order
+        __syncthreads();
+        const int g = tid / nitems, i = tid - g * nitems;
+        float* part = lbuf;                                    // [G][nitems][3]
+        if (g < G) { part[(g * nitems + i) * 3] = Mr[0]; part[(g * nitems + i) * 3 + 1] = lr[0]; part[(g * nitems + i) * 3 + 2] = orr[0]; }
+        __syncthreads();
+        if (g != 0) return;
+        float M = Mr[0];
+        for (int k = 1; k < G; ++k) M = fmaxf(M, part[(k * nitems + i) * 3]);
+        float l = 0.0f, o = 0.0f;
+        for (int k = 0; k < G; ++k) {
+            const float w = fast_exp2(part[(k * nitems + i) * 3] - M);          // an empty slice: exp2(-3e38 - M) = 0
+            l += w * part[(k * nitems + i) * 3 + 1];
+            o += w * part[(k * nitems + i) * 3 + 2];
+        }
+        Mr[0] = M; lr[0] = l; orr[0] = o;
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -300,6 +343,24 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     const bf16_t* const vsrc = Vg + (size_t)R * p.lpad + chunk * 8;
     auto stage_k = [&](int tile, int slot) { glds16(ksrc + (size_t)tile * KB * p.ld_qk, kring + slot * KV_TILE_BYTES + wave * 1024); };
     auto stage_v = [&](int tile, int slot) { glds16(vsrc + (size_t)tile * KB, vring + slot * KV_TILE_BYTES + wave * 1024); };
+    // tail staging (see TAIL_LDS_TILES): [K j | V^T j] x TAIL_LDS_TILES behind the rings, then the tail queries' rows as one more
+    // K-shaped tile (LDS row R = query nfull * 32 + R, unpermuted: the B operand wants query = lane & 31).  Every wave issues
+    // exactly TAIL_DMAS pieces (a tile index beyond the last tile is clamped: a harmless duplicate), so the counted waits of the
+    // iterations around the issue are compile-time.
+    const int tail_r = p.L - p.nfull * 32;
+    char* const tail_lds = lds + 2 * RING * KV_TILE_BYTES;
+    char* const tail_q = tail_lds + 2 * TAIL_LDS_TILES * KV_TILE_BYTES;
+    auto stage_tail = [&]() {
+#pragma unroll
+        for (int j = 0; j < TAIL_LDS_TILES; ++j) {
+            const int tt = min(qblk + p.nqb * j, ntiles - 1);
+            glds16(ksrc + (size_t)tt * KB * p.ld_qk, tail_lds + (2 * j) * KV_TILE_BYTES + wave * 1024);
+            glds16(vsrc + (size_t)tt * KB, tail_lds + (2 * j + 1) * KV_TILE_BYTES + wave * 1024);
+        }
+        const int qrow = min(p.nfull * 32 + R, p.lpad - 1);
+        glds16(Qg + (size_t)qrow * p.ld_qk + chunk * 8, tail_q + wave * 1024);
+    };
+    int tail_age = tail_r ? -1 : 99;       // -1: still to be staged; 0 / 1: its pieces may be in flight across this iteration's wait; >= 2: landed
     // per-lane fragment address inside a tile: fragment i = 2 ks + blk -> row l31 + 32 blk, 16-byte slot (2 ks + half) ^ swizzle
     const int kswz = (l31 >> 1) & 7;
     int foff[4];
@@ -368,6 +429,12 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
             if (t + RING < ntiles) { stage_k(t + RING, slot); ++issued; }
             if (t + RING - 1 < ntiles) { stage_v(t + RING - 1, (slot + RING - 1) & (RING - 1)); ++issued; }
         }
+        // the tail pieces go out BEHIND this iteration's own DMAs, in the first iteration of the generic rounds at the end of the loop
+        // (K / V^T are L2-resident by then); they may stay in flight across this wait and the next one -- two iterations, like a ring
+        // tile -- because memory operations retire in order: "at most TAIL_DMAS + own outstanding" still means everything older landed
+        if constexpr (!FAST && MODE != 2) {
+            if (tail_age < 0) { stage_tail(); tail_age = 0; }
+        }
         if (LIVE == 1 || (LIVE == 2 && wave_live)) {
             bf16x8 vf[8];
             PFrag pf[4];
@@ -434,7 +501,12 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
                 wait_vmcnt<2>();
                 raw_barrier();
             } else {
-                if (issued == 2) wait_vmcnt<2>();
+                if (tail_age == 0 || tail_age == 1) {
+                    if (issued == 2) wait_vmcnt<2 + TAIL_DMAS>();
+                    else if (issued == 1) wait_vmcnt<1 + TAIL_DMAS>();
+                    else wait_vmcnt<TAIL_DMAS>();
+                    ++tail_age;
+                } else if (issued == 2) wait_vmcnt<2>();
                 else wait_vmcnt<0>();
                 if (!(dbg & 2)) raw_barrier();
             }
@@ -509,10 +581,20 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     }
     // ---- tail queries: wave w takes key tile qblk + nqb * w (K / V^T are L2-resident by now).  Its record stores are
     //      issued BEFORE the output stores so that the counted wait below covers exactly them. ----
-    const int tail_r = p.L - p.nfull * 32, bh = b * p.heads + head;
-    if (tail_r)
-        for (int tt = qblk + p.nqb * wave; tt < ntiles; tt += p.nqb * NW)
-            tail_tile(p, tt, tail_r, Qg, Kg, Vg, p.tail_ws + ((size_t)bh * ntiles + tt) * tail_r * TAIL_REC, lane);
+    const int bh = b * p.heads + head;
+    if (tail_r) {
+        if (tail_age < 0) stage_tail();                 // a single-tile sequence: no iteration with a wait came by
+        wait_vmcnt<0>();                                // every wave's pieces of the staged tiles have landed ...
+        raw_barrier();                                  // ... and are visible to the wave that reads them
+        bool staged = wave < TAIL_LDS_TILES;
+        for (int tt = qblk + p.nqb * wave; tt < ntiles; tt += p.nqb * NW) {
+            float* const rec = p.tail_ws + ((size_t)bh * ntiles + tt) * tail_r * TAIL_REC;
+            if (staged) tail_tile(p, tt, tail_r, Qg, Kg, Vg, rec, lane, tail_lds + (2 * wave) * KV_TILE_BYTES, tail_lds + (2 * wave + 1) * KV_TILE_BYTES, tail_q, foff);
+            else tail_tile(p, tt, tail_r, Qg, Kg, Vg, rec, lane);
+            staged = false;
+        }
+    }
+    MAIN_STAMP(7);
     if (wave_live) {                                    // lane owns query q, d = db*32 + 8 g + 4 half + (0..3)
         if (p.lse2 && half == 0) p.lse2[((size_t)b * p.heads + head) * p.lpad + q] = lse_out;
         bf16_t* orow = p.out + (row0 + q) * (size_t)(p.heads * 64) + head * 64;
@@ -542,7 +624,9 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     }
     wait_lgkmcnt0();
     raw_barrier();
+    MAIN_STAMP(5);
     if (*flag) tail_merge(p, bh, ntiles, tail_r, lds);
+    MAIN_STAMP(6);
 }
 
 }  // namespace dgs
@@ -586,7 +670,8 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     hipStream_t st = static_cast<hipStream_t>(stream);
     // 64 KiB of rings; DGS_ATTN_LDS_PAD (bytes) adds unused LDS to cap the workgroups per CU (measurement aid)
     static const int lds_pad = getenv("DGS_ATTN_LDS_PAD") ? atoi(getenv("DGS_ATTN_LDS_PAD")) : 0;
-    const int lds_bytes = 2 * RING * KV_TILE_BYTES + lds_pad;
+    // + the staged tail tiles and the tail queries' tile when L % 32 != 0: 64 + 80 + 8 = 152 KiB (one workgroup per CU either way)
+    const int lds_bytes = 2 * RING * KV_TILE_BYTES + (r ? (2 * TAIL_LDS_TILES + 1) * KV_TILE_BYTES : 0) + lds_pad;
     static int lds_attr = 0;
     if (lds_attr != lds_bytes) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
@@ -603,8 +688,9 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
         long long mn = host[0], mx = host[0]; double sum = 0;
         for (int i = 0; i < n; ++i) { mn = host[i] < mn ? host[i] : mn; mx = host[i] > mx ? host[i] : mx; sum += host[i]; }
         const int ntiles = (a->L + KB - 1) / KB;
-        if (dbg & 8) fprintf(stderr, "[attn dbg] main wg0 stamps: prologue(load wait + tail tile) %lld, first tile %lld, loop %lld, epilogue stores %lld\n", host[4113] - host[4112],
-                             host[4114] - host[4113], host[4115] - host[4114], host[4116] - host[4115]);
+        if (dbg & 8) fprintf(stderr, "[attn dbg] main wg0 stamps: prologue (load wait) %lld, first tile %lld, loop %lld, pack + tail tile %lld, output stores issued %lld, "
+                             "record drain + barrier + counter %lld, merge (if last) %lld\n", host[4113] - host[4112],
+                             host[4114] - host[4113], host[4115] - host[4114], host[4119] - host[4115], host[4116] - host[4119], host[4117] - host[4116], host[4118] - host[4117]);
         fprintf(stderr, "[attn dbg] L=%d loop cycles per wave: min %lld avg %.0f max %lld  -> per tile %.0f / %.0f / %.0f\n", a->L, mn, sum / n, mx,
                 (double)mn / ntiles, sum / n / ntiles, (double)mx / ntiles);
     }

@@ -223,6 +223,27 @@ __device__ __forceinline__ void st_agent(float* ptr, float v) {
     __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+// 8- and 16-byte forms of the store (one instruction per 2 / 4 floats; 16-byte aligned for the latter).  The compiler does not
+// count inline-asm memory operations in its own s_waitcnt bookkeeping: an uncounted OLDER or YOUNGER entry in the in-order queue
+// only makes its waits stricter, and the code that needs these stores performed waits with an explicit wait_vmcnt.
+__device__ __forceinline__ void st_agent2(float* ptr, float a, float b) {
+#ifdef HIPEMU
+    ptr[0] = a; ptr[1] = b;
+#else
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+#endif
+}
+__device__ __forceinline__ void st_agent4(float* ptr, float a, float b, float c, float d) {
+#ifdef HIPEMU
+    ptr[0] = a; ptr[1] = b; ptr[2] = c; ptr[3] = d;
+#else
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+#endif
+}
 __device__ __forceinline__ float2 ld_agent2(const float2* ptr) {
 #ifdef HIPEMU
     return *ptr;

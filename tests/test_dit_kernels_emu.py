@@ -88,7 +88,8 @@ def test_gemm_qkv_epilogue(ops):
 
 
 # 520 / 600: enough key tiles for the branch-free steady-state rounds; at 600 the last workgroup also has waves without queries
-@pytest.mark.parametrize("L,prescaled", [(128, False), (130, False), (130, True), (67, True), (258, False), (520, True), (600, True), (20, False)])
+# 97 / 130 / 67 / 132: 1, 2, 3, 4 tail queries = 8, 4, 2, 2 record slices in the merge of the tail records; 520 / 600 / 20: one thread per item
+@pytest.mark.parametrize("L,prescaled", [(128, False), (130, False), (130, True), (67, True), (258, False), (520, True), (600, True), (20, False), (97, False), (132, True)])
 def test_attention(ops, L, prescaled):
     g = torch.Generator().manual_seed(3)
     B, heads = 2, 2
