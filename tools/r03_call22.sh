@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round 3, call 22: attention prologue with the counted wait (A/B vs HEAD), the learned-token side jobs behind a full round of tiles
+# (fc1 / fc2), and who fills large tensors in a training step.
+set -u
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/r03v
+mkdir -p $out
+cd $R
+L=open-diffusiongs_amd/lib
+timeout 600 python -m pytest tests/test_dit_gpu.py -m gpu -q -x -k "attention" 2>&1 | grep -v "Warning\|amdgpu.ids" | tail -3 > $out/pytest_attention.txt; cat $out/pytest_attention.txt
+timeout 300 python tools/attn_ab.py $L/libdgs_hip_base.so 2>&1 | grep -v amdgpu.ids > $out/attn_ab.txt; cat $out/attn_ab.txt
+timeout 300 python tools/gemm_tailwgs_ab.py 2>&1 | grep -v amdgpu.ids > $out/gemm_tailwgs_ab.txt; cat $out/gemm_tailwgs_ab.txt
+FILL_MIN_MIB=16 timeout 400 python tools/find_fills.py 2>&1 | grep -v amdgpu.ids | tail -40 > $out/find_fills.txt; cat $out/find_fills.txt | cut -c1-250
