@@ -297,7 +297,11 @@ def train_bench(a, dev, rank, world, steps, warmup):
     model.reset_parameters(seed=0)          # identical replicas on every rank
     model = model.to(dev)                   # fp32 master parameters + optimizer state on the GPU
     model.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=not DRY["on"])
+    if a.optimizer == "fused":      # AdamW + refresh of the engine's bf16 / transposed weight copies in one launch (include/dgs_optim.h)
+        from dgs_amd.optim import FusedAdamW
+        opt = FusedAdamW(model, lr=1e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+    else:                           # torch's multi-tensor AdamW, then ~600 torch copies for the refresh
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05, fused=not DRY["on"])
     tr = DataParallelTrainer(model, opt, bucket_bytes=(a.bucket_mb << 20) if a.bucket_mb > 0 else None, compress=a.grad_exchange if a.grad_exchange != "fp32" else None,
                              force_collectives=a.force_dist)
     batch, t = synth.make_batch(B, res, V=V, device=dev, seed=100 + rank, with_t=True)
@@ -328,7 +332,7 @@ def train_bench(a, dev, rank, world, steps, warmup):
     log = tr.reducer.launch_log
     tr.close()
     return {"ms_per_step": round(ms, 2), "samples_per_s": round(B * world / (ms * 1e-3), 2), "batch_per_gpu": B, "rendered_views": RV,
-            "steps": steps, "warmup": warmup, "loss": round(float(loss), 6), "recompute": recompute,
+            "steps": steps, "warmup": warmup, "loss": round(float(loss), 6), "recompute": recompute, "optimizer": a.optimizer,
             "dit_tflops_per_gpu": round(flops / (ms * 1e-3) / 1e12, 1), "frac_of_bf16_peak": round(flops / (ms * 1e-3) / PEAK_BF16_MFMA, 4),
             "saved_activation_gib": round(eng._train["saved"].numel() / 2 ** 30, 2),
             "allreduce": {"world": world, "collectives_issued": bool(tr.reducer.active), "buckets": len(tr.reducer.bounds), "exchange": a.grad_exchange,
@@ -336,7 +340,7 @@ def train_bench(a, dev, rank, world, steps, warmup):
                           "launched_during_backward": sum(1 for _, tag in log if isinstance(tag, int)),
                           "last_bucket_mib": round((tr.reducer.bounds[-1][1] - tr.reducer.bounds[-1][0]) * 4 / 2 ** 20, 1),
                           "gradient_bytes": int(tr.fg.flat.numel() * 4)},
-            "note": "DataParallelTrainer.step end to end: fwd + raster + MSE + bwd (+ overlapped all-reduce) + fused AdamW + weight refresh"}
+            "note": "DataParallelTrainer.step end to end: fwd + raster + MSE + bwd (+ overlapped all-reduce) + AdamW + weight refresh (betas / eps of diffusionGS_rel.yaml)"}
 
 
 def main():
@@ -353,6 +357,8 @@ def main():
     ap.add_argument("--train-views", type=int, default=10)
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--bucket-mb", type=int, default=0, help="all-reduce bucket size; 0 = 32 MiB per rank (dgs_amd/parallel.py)")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"], help="training step: dgs_amd.optim.FusedAdamW (one launch: AdamW + the "
+                    "engine's weight copies) or torch.optim.AdamW + the torch-copy refresh")
     ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce (bf16: half the xGMI bytes)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="NOT a measurement: the same script on the CPU emulator build of the kernels with "
                     "gloo and a tiny model (width 256, 2 blocks, 64^2) -- what tests/test_bench_dry_run.py uses to exercise the N > 1 path")

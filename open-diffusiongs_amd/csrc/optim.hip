@@ -1,0 +1,134 @@
+// optim.hip -- AdamW step + refresh of the engine's weight copies in one launch (include/dgs_optim.h).
+//
+// HBM-bound elementwise work: per parameter 16 bytes read (p, g, m, v) and 12 + 2 (+ 2) written.  A tile is 4,096 consecutive
+// elements of a flat tensor, or a 64 x 64 block of a matrix that also keeps a transposed bf16 copy (the block goes through LDS
+// once so that the transposed rows leave as 16-byte stores too).  256 threads, 16 bytes per lane and access, no atomics, nothing
+// depends on the order of the tiles.
+#include "dgs_device.h"
+#include "dgs_optim.h"
+#include "dit_common.h"
+
+namespace dgs {
+
+struct AdamWHyper { float decay, one_minus_b1, b2, one_minus_b2, inv_bc2_sqrt, eps, step_size; };
+
+__device__ __forceinline__ float adamw_one(float& p, float g, float& m, float& v, const AdamWHyper& h) {
+    p = p * h.decay;
+    m = m + (g - m) * h.one_minus_b1;
+    v = v * h.b2 + (h.one_minus_b2 * g) * g;
+    const float denom = sqrtf(v) * h.inv_bc2_sqrt + h.eps;
+    p = p - h.step_size * (m / denom);
+    return p;
+}
+
+__global__ __launch_bounds__(256) void adamw_refresh_kernel(const DgsAdamWTensor* __restrict__ tab, int n_tensors, AdamWHyper h) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64][64 + 8];     // bf16 block for the transposed copy (rows padded: 144 B)
+    const int tid = threadIdx.x, bid = blockIdx.x;
+    // the tensor this tile belongs to: the last entry whose first_tile <= bid (uniform: scalar loads)
+    int lo = 0, hi = n_tensors - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_tile <= bid) lo = mid; else hi = mid - 1;
+    }
+    const DgsAdamWTensor t = tab[lo];
+    const int local = bid - t.first_tile;
+    if (t.copy_t == nullptr) {
+        // ---- flat tile: elements [local * 4096, +4096) ----
+        const long long n = t.rows * t.cols, base = (long long)local * 4096;
+        const bool vec = (n & 3) == 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long i = base + (long long)j * 1024 + tid * 4;
+            if (i >= n) break;
+            if (vec) {
+                float4 p = *reinterpret_cast<const float4*>(t.p + i);
+                const float4 g = *reinterpret_cast<const float4*>(t.g + i);
+                float4 m = *reinterpret_cast<const float4*>(t.m + i), v = *reinterpret_cast<const float4*>(t.v + i);
+                adamw_one(p.x, g.x, m.x, v.x, h); adamw_one(p.y, g.y, m.y, v.y, h);
+                adamw_one(p.z, g.z, m.z, v.z, h); adamw_one(p.w, g.w, m.w, v.w, h);
+                *reinterpret_cast<float4*>(t.p + i) = p;
+                *reinterpret_cast<float4*>(t.m + i) = m;
+                *reinterpret_cast<float4*>(t.v + i) = v;
+                if (t.copy_kind == DGS_OPTIM_COPY_BF16)
+                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(t.copy) + i) = make_uint2(pack_bf2(p.x, p.y), pack_bf2(p.z, p.w));
+                else if (t.copy_kind == DGS_OPTIM_COPY_F32) *reinterpret_cast<float4*>(static_cast<float*>(t.copy) + i) = p;
+            } else {
+                for (int e = 0; e < 4 && i + e < n; ++e) {
+                    float p = t.p[i + e], m = t.m[i + e], v = t.v[i + e];
+                    adamw_one(p, t.g[i + e], m, v, h);
+                    t.p[i + e] = p; t.m[i + e] = m; t.v[i + e] = v;
+                    if (t.copy_kind == DGS_OPTIM_COPY_BF16) static_cast<bf16_t*>(t.copy)[i + e] = (bf16_t)(pack_bf2(p, 0.0f) & 0xffffu);
+                    else if (t.copy_kind == DGS_OPTIM_COPY_F32) static_cast<float*>(t.copy)[i + e] = p;
+                }
+            }
+        }
+        return;
+    }
+    // ---- 64 x 64 block of a matrix with a transposed copy ----
+    const int tiles_c = (int)(t.cols / 64);
+    const int r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
+    const int c4 = (tid & 15) * 4, rr = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = rr + 16 * j;
+        const long long i = (long long)(r0 + r) * t.cols + c0 + c4;
+        float4 p = *reinterpret_cast<const float4*>(t.p + i);
+        const float4 g = *reinterpret_cast<const float4*>(t.g + i);
+        float4 m = *reinterpret_cast<const float4*>(t.m + i), v = *reinterpret_cast<const float4*>(t.v + i);
+        adamw_one(p.x, g.x, m.x, v.x, h); adamw_one(p.y, g.y, m.y, v.y, h);
+        adamw_one(p.z, g.z, m.z, v.z, h); adamw_one(p.w, g.w, m.w, v.w, h);
+        *reinterpret_cast<float4*>(t.p + i) = p;
+        *reinterpret_cast<float4*>(t.m + i) = m;
+        *reinterpret_cast<float4*>(t.v + i) = v;
+        const uint2 b = make_uint2(pack_bf2(p.x, p.y), pack_bf2(p.z, p.w));
+        if (t.copy_kind == DGS_OPTIM_COPY_BF16) *reinterpret_cast<uint2*>(static_cast<bf16_t*>(t.copy) + i) = b;
+        else if (t.copy_kind == DGS_OPTIM_COPY_F32) *reinterpret_cast<float4*>(static_cast<float*>(t.copy) + i) = p;
+        *reinterpret_cast<uint2*>(&tile[r][c4]) = b;
+    }
+    __syncthreads();
+    // transposed: thread -> column c of the block, 16 consecutive rows: 32 contiguous bytes of copy_t[c0 + c][r0 + ...]
+    const int c = tid >> 2, rq = (tid & 3) * 16;
+    unsigned short u[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) u[e] = tile[rq + e][c];
+    bf16_t* dst = static_cast<bf16_t*>(t.copy_t) + (long long)(c0 + c) * t.rows + r0 + rq;
+    auto pk = [&](int e) { return (uint32_t)u[e] | ((uint32_t)u[e + 1] << 16); };
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pk(0), pk(2), pk(4), pk(6));
+    *reinterpret_cast<uint4*>(dst + 8) = make_uint4(pk(8), pk(10), pk(12), pk(14));
+}
+
+}  // namespace dgs
+
+extern "C" int32_t dgs_adamw_plan(DgsAdamWTensor* tab, int32_t n) {
+    if (!tab || n <= 0) return -1;
+    long long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        DgsAdamWTensor& t = tab[i];
+        if (!t.p || !t.g || !t.m || !t.v || t.rows <= 0 || t.cols <= 0) return -1;
+        if (t.copy_kind < DGS_OPTIM_COPY_NONE || t.copy_kind > DGS_OPTIM_COPY_F32 || (t.copy_kind != DGS_OPTIM_COPY_NONE && !t.copy)) return -1;
+        t.first_tile = (int32_t)tiles;
+        if (t.copy_t) {
+            if (t.rows % 64 || t.cols % 64) return -1;
+            tiles += (t.rows / 64) * (t.cols / 64);
+        } else {
+            tiles += (t.rows * t.cols + 4095) / 4096;
+        }
+        if (tiles > 0x7fffffffLL) return -1;
+    }
+    return (int32_t)tiles;
+}
+
+extern "C" int dgs_adamw_step(const DgsAdamWArgs* a, dgs_stream_t stream) {
+    if (!a || !a->tensors || a->n_tensors <= 0 || a->n_tiles <= 0 || !(a->bias_correction1 > 0.0f) || !(a->bias_correction2_sqrt > 0.0f))
+        return DGS_ERR_INVALID_ARGUMENT;
+    dgs::AdamWHyper h;
+    h.decay = 1.0f - a->lr * a->weight_decay;
+    h.one_minus_b1 = 1.0f - a->beta1;
+    h.b2 = a->beta2;
+    h.one_minus_b2 = 1.0f - a->beta2;
+    h.inv_bc2_sqrt = 1.0f / a->bias_correction2_sqrt;
+    h.eps = a->eps;
+    h.step_size = a->lr / a->bias_correction1;
+    hipLaunchKernelGGL(dgs::adamw_refresh_kernel, dim3(a->n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), a->tensors, a->n_tensors, h);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # or an A/B side (tools/ab_build.sh).  Never a fallback: whatever is named must exist and pass the ABI check.
 LIB_PATH = os.environ.get("DGS_AMD_LIBRARY") or os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
 
-ABI_VERSION = 3          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
+ABI_VERSION = 4          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
 c_float_p = ctypes.POINTER(ctypes.c_float)
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
@@ -361,8 +361,33 @@ def _declare_loss(L):
     return L
 
 
+class DgsAdamWTensor(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("copy", ctypes.c_void_p),
+                ("copy_t", ctypes.c_void_p), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("copy_kind", ctypes.c_int32),
+                ("first_tile", ctypes.c_int32)]
+
+
+class DgsAdamWArgs(ctypes.Structure):
+    _fields_ = [("tensors", ctypes.c_void_p), ("n_tensors", ctypes.c_int32), ("n_tiles", ctypes.c_int32), ("lr", ctypes.c_float),
+                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float),
+                ("bias_correction1", ctypes.c_float), ("bias_correction2_sqrt", ctypes.c_float)]
+
+
+OPTIM_COPY_NONE, OPTIM_COPY_BF16, OPTIM_COPY_F32 = 0, 1, 2
+# every symbol include/dgs_optim.h declares (checked by tests/test_abi.py)
+OPTIM_SYMBOLS = ["dgs_adamw_plan", "dgs_adamw_step"]
+
+
+def _declare_optim(L):
+    L.dgs_adamw_plan.restype = ctypes.c_int32
+    L.dgs_adamw_plan.argtypes = [ctypes.POINTER(DgsAdamWTensor), ctypes.c_int32]
+    L.dgs_adamw_step.restype = ctypes.c_int
+    L.dgs_adamw_step.argtypes = [ctypes.POINTER(DgsAdamWArgs), ctypes.c_void_p]
+    return L
+
+
 _declare_raster = _declare
 
 
 def _declare(L):  # noqa: F811  (raster + DiT + sampler + loss prototypes on one library)
-    return _declare_loss(_declare_sampler(_declare_dit(_declare_raster(L))))
+    return _declare_optim(_declare_loss(_declare_sampler(_declare_dit(_declare_raster(L)))))

@@ -190,30 +190,37 @@ class DitEngine:
                ("dec_ln_w", "image_token_decoder.layernorm.weight"), ("dec_w", "image_token_decoder.linear.weight"))
 
     @torch.no_grad()
+    def weight_destinations(self):
+        """state-dict key -> (engine tensor that holds its copy [same shape, bf16 or fp32], transposed bf16 copy or None): the ONE
+        description of where a parameter's value has to go after it changed -- `refresh_weights` walks it with torch copies, the
+        fused optimizer step (dgs_amd/optim.py) hands it to the kernel that updates the parameter."""
+        k, W, L = self._keep, self.width, self.layers
+        tk = self._train["tkeep"] if self._train is not None else None
+        dst = {key: (k[name], None) for name, key in self._DIRECT}
+        dst["gaussians_pos_embedding"] = (k["pos_emb"], None)
+        for i in range(L):
+            p = f"transformer.{i}."
+            for short, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+                dst[p + key + ".weight"] = (k[f"{i}.{short}_w"], tk[f"{i}.{short}"] if tk is not None else None)
+                dst[p + key + ".bias"] = (k[f"{i}.{short}_b"], None)
+            dst[p + "adaLN_modulation.1.weight"] = (k["ada_w"][6 * W * i:6 * W * (i + 1)], None)
+            dst[p + "adaLN_modulation.1.bias"] = (k["ada_b"][6 * W * i:6 * W * (i + 1)], None)
+        o = 6 * W * L
+        for j, head in enumerate(("upsampler", "image_token_decoder")):
+            dst[head + ".adaLN_modulation.1.weight"] = (k["ada_w"][o + 2 * W * j:o + 2 * W * (j + 1)], None)
+            dst[head + ".adaLN_modulation.1.bias"] = (k["ada_b"][o + 2 * W * j:o + 2 * W * (j + 1)], None)
+        if tk is not None:
+            dst["image_token_decoder.linear.weight"] = (k["dec_w"], tk["dec"])
+        return dst
+
     def refresh_weights(self, state_dict):
         """Copy (and convert to bf16 / transpose) the current parameter values INTO the engine's existing device buffers:
         what has to happen after every optimizer step.  Pointers, workspaces, the activation arenas and the flat gradient
         buffer all stay as they are."""
-        sd, k, W, L = state_dict, self._keep, self.width, self.layers
-        for name, key in self._DIRECT:
-            k[name].copy_(sd[key])
-        k["pos_emb"].copy_(sd["gaussians_pos_embedding"].reshape(self.ng, W))
-        tk = self._train["tkeep"] if self._train is not None else None
-        for i in range(L):
-            p = f"transformer.{i}."
-            for short, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
-                k[f"{i}.{short}_w"].copy_(sd[p + key + ".weight"])
-                k[f"{i}.{short}_b"].copy_(sd[p + key + ".bias"])
-                if tk is not None:
-                    tk[f"{i}.{short}"].copy_(k[f"{i}.{short}_w"].t())
-            k["ada_w"][6 * W * i:6 * W * (i + 1)].copy_(sd[p + "adaLN_modulation.1.weight"])
-            k["ada_b"][6 * W * i:6 * W * (i + 1)].copy_(sd[p + "adaLN_modulation.1.bias"])
-        o = 6 * W * L
-        for j, head in enumerate(("upsampler", "image_token_decoder")):
-            k["ada_w"][o + 2 * W * j:o + 2 * W * (j + 1)].copy_(sd[head + ".adaLN_modulation.1.weight"])
-            k["ada_b"][o + 2 * W * j:o + 2 * W * (j + 1)].copy_(sd[head + ".adaLN_modulation.1.bias"])
-        if tk is not None:
-            tk["dec"].copy_(k["dec_w"].t())
+        for key, (copy, copy_t) in self.weight_destinations().items():
+            copy.copy_(state_dict[key].reshape(copy.shape))
+            if copy_t is not None:
+                copy_t.copy_(copy.t())
 
     def _workspace(self, B, V, H, W):
         need = int(self.lib.dgs_dit_workspace_bytes(ctypes.byref(self.model), B, V, H, W))

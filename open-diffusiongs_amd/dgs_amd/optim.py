@@ -1,0 +1,107 @@
+"""AdamW step + refresh of the engine's weight copies in ONE launch (include/dgs_optim.h, csrc/optim.hip).
+
+The reference trains with `torch.optim.AdamW(lr=1e-5, betas=[0.9, 0.99], eps=1e-8)` (diffusionGS/configs/diffusionGS_rel.yaml:57-62,
+diffusionGS/utils/scheduler.py:34-53).  On a bf16-MFMA engine an optimizer step is followed by bringing every device-resident operand
+copy of the weights up to date; as torch ops that is a multi-tensor AdamW (one launch per ~50 tensors) plus ~600 cast /
+transposed-copy / copy launches per step (3.2 + 1.2 ms of a 91 ms step, `profiles/r03_final_train_step_kernel_stats.txt`).
+`FusedAdamW.step()` reads p, g, m, v once and writes p, m, v and every copy: same arithmetic as torch's single-tensor AdamW in fp32.
+
+Drop-in where `DataParallelTrainer` takes an optimizer: `.step()`, `.zero_grad()`, `.param_groups` (one group: lr / betas / eps /
+weight_decay may be changed between steps, e.g. by an LR scheduler), `.state_dict()` / `.load_state_dict()`.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _native
+from .dit import _stream
+
+
+class FusedAdamW:
+    refreshes_engine = True          # DataParallelTrainer: the engine's weight copies are written by step() itself
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.model = model
+        self.lib = getattr(model, "_lib", None) or _native.lib()
+        self.param_groups = [dict(params=list(model.parameters()), lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps),
+                                  weight_decay=float(weight_decay))]
+        self.step_count = 0
+        self._named = [(n, p) for n, p in model.named_parameters()]
+        dev = self._named[0][1].device
+        sizes = [(p.numel() + 63) // 64 * 64 for _, p in self._named]          # 256-byte aligned slices
+        self.exp_avg = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self._offsets, o = [], 0
+        for s in sizes:
+            self._offsets.append(o)
+            o += s
+        self._table = None          # (device table, n_tensors, n_tiles, the pointers it was built from)
+
+    # -- torch.optim.Optimizer surface the trainer / a scheduler touches ---------------------------------
+    def zero_grad(self, set_to_none=True):
+        """The backward overwrites every gradient (dgs_dit_backward writes, never accumulates): nothing to clear."""
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
+                    param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+    # -- the table of tensors (rebuilt when a pointer changed: new .grad tensors, a rebuilt engine) --------
+    def _plan(self):
+        eng = self.model.engine()
+        ptrs = (id(eng), id(eng._train)) + tuple((p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0) for _, p in self._named)
+        if self._table is not None and self._table[3] == ptrs:
+            return self._table
+        dst = eng.weight_destinations()
+        entries = []
+        for (name, p), off in zip(self._named, self._offsets):
+            if p.grad is None:
+                continue                          # a parameter that received no gradient is left alone, like torch.optim
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                raise RuntimeError(f"FusedAdamW: {name}: fp32 contiguous master parameters and gradients only")
+            e = _native.DgsAdamWTensor()
+            e.p, e.g = p.data_ptr(), p.grad.data_ptr()
+            e.m, e.v = self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off
+            rows, cols = (int(p.shape[0]), p.numel() // int(p.shape[0])) if p.dim() >= 2 else (1, p.numel())
+            e.rows, e.cols = rows, cols
+            copy, copy_t = dst.get(name, (None, None))
+            if copy is not None:
+                if copy.numel() != p.numel() or not copy.is_contiguous():
+                    raise RuntimeError(f"FusedAdamW: engine copy of {name} has another layout")
+                e.copy = copy.data_ptr()
+                e.copy_kind = _native.OPTIM_COPY_BF16 if copy.dtype == torch.bfloat16 else _native.OPTIM_COPY_F32
+            if copy_t is not None:
+                if tuple(copy_t.shape) != (cols, rows) or copy_t.dtype != torch.bfloat16 or not copy_t.is_contiguous():
+                    raise RuntimeError(f"FusedAdamW: transposed engine copy of {name} has another layout")
+                e.copy_t = copy_t.data_ptr()
+            entries.append(e)
+        host = (_native.DgsAdamWTensor * len(entries))(*entries)
+        n_tiles = int(self.lib.dgs_adamw_plan(host, len(entries)))
+        if n_tiles <= 0:
+            raise RuntimeError("FusedAdamW: dgs_adamw_plan rejected the tensor table")
+        raw = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.exp_avg.device)
+        self._table = (raw, len(entries), n_tiles, ptrs)
+        return self._table
+
+    @torch.no_grad()
+    def step(self):
+        g = self.param_groups[0]
+        raw, n, n_tiles, _ = self._plan()
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        a = _native.DgsAdamWArgs()
+        a.tensors, a.n_tensors, a.n_tiles = raw.data_ptr(), n, n_tiles
+        a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = g["lr"], b1, b2, g["eps"], g["weight_decay"]
+        a.bias_correction1 = 1.0 - b1 ** self.step_count
+        a.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** self.step_count)
+        rc = self.lib.dgs_adamw_step(ctypes.byref(a), _stream(self.exp_avg.device))
+        if rc != 0:
+            raise RuntimeError(f"dgs_adamw_step: {_native.status_string(self.lib, rc)} (status {rc})")
+        # the parameters were written through raw pointers: their version counters did not move, and the engine's copies are
+        # already up to date -- DGSDenoiser.engine() must not refresh them again

@@ -118,5 +118,11 @@ class DataParallelTrainer:
                     self._accum += self.fg.flat
         self.reducer.finish(average=False)
         self.opt.step()
-        m.engine()                                             # weights changed: refresh the bf16 / transposed copies in place
+        # weights changed: the engine's bf16 / transposed copies have to follow.  dgs_amd.optim.FusedAdamW writes them in the same launch
+        # as the update; for any other optimizer they are refreshed EXPLICITLY -- DGSDenoiser.engine() only notices parameter version
+        # counters, and an optimizer is free not to move them (foreach / fused implementations, `p.data` updates, EMA swaps)
+        if getattr(self.opt, "refreshes_engine", False):
+            m.engine()
+        else:
+            m.refresh_engine_weights()
         return total / K

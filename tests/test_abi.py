@@ -22,7 +22,8 @@ def _declared(header):
 def test_every_declared_symbol_is_exported():
     build_mod.build_hip()
     lib = _native.lib()
-    for header, table in (("dgs_raster.h", _native.RASTER_SYMBOLS), ("dgs_dit.h", _native.DIT_SYMBOLS), ("dgs_sampler.h", _native.SAMPLER_SYMBOLS), ("dgs_loss.h", _native.LOSS_SYMBOLS)):
+    for header, table in (("dgs_raster.h", _native.RASTER_SYMBOLS), ("dgs_dit.h", _native.DIT_SYMBOLS), ("dgs_sampler.h", _native.SAMPLER_SYMBOLS), ("dgs_loss.h", _native.LOSS_SYMBOLS),
+                          ("dgs_optim.h", _native.OPTIM_SYMBOLS)):
         names = _declared(header)
         assert names, header
         for n in names:
@@ -37,8 +38,8 @@ def test_ctypes_structs_match_c_layout():
     structs = ["DgsRasterForwardArgs", "DgsRasterBackwardArgs", "DgsDitGemmArgs", "DgsDitAttentionArgs", "DgsDitLayerNormArgs",
                "DgsDitRowLinearArgs", "DgsDitLayerWeights", "DgsDitModel", "DgsDitForwardArgs", "DgsSamplerStepArgs", "DgsMseArgs",
                "DgsDitLayerNormBackwardArgs", "DgsDitRowLinearBackwardArgs", "DgsDitGateMulArgs", "DgsDitAttentionBackwardArgs",
-               "DgsDitBackwardArgs", "DgsDitRunBlocksArgs", "DgsResizeArgs"]
-    src = '#include <stdio.h>\n#include "dgs_dit.h"\n#include "dgs_sampler.h"\n#include "dgs_loss.h"\nint main(){' + "".join(
+               "DgsDitBackwardArgs", "DgsDitRunBlocksArgs", "DgsResizeArgs", "DgsAdamWTensor", "DgsAdamWArgs"]
+    src = '#include <stdio.h>\n#include "dgs_dit.h"\n#include "dgs_sampler.h"\n#include "dgs_loss.h"\n#include "dgs_optim.h"\nint main(){' + "".join(
         f'printf("%zu\\n", sizeof({s}));' for s in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
