@@ -406,7 +406,7 @@ def main():
         tb = train_bench(a, dev, rank, world, a.steps, a.warmup)
         if rank == 0:
             print(json.dumps({
-                "metric": "training samples/sec (DiT fwd+bwd + GS raster fwd+bwd + grad all-reduce + AdamW) at 256^2",
+                "metric": f"training samples/sec (DiT fwd+bwd + GS raster fwd+bwd + grad all-reduce + AdamW) at {a.res}^2",
                 "value": tb["samples_per_s"], "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": tb["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                 "data": "synthetic", "config": {"workload": f"obj-{a.res} training step (BASELINE.json configs[3]): B={a.train_batch} samples/GPU, "
