@@ -13,11 +13,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
+def _run(*flags, gpus=2):
     env = dict(os.environ, OMP_NUM_THREADS="4")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "1", *flags],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry-run-cpu", "--steps", "1", "--warmup", "1", *flags],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -43,3 +43,12 @@ def test_two_rank_inference_step_through_respawn():
     assert d["n_gpus"] == 2 and d["unit"] == "renders/s" and "dry_run" in d and d["value"] > 0
     assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) <= 0.006                                  # B = 1, 4 views, 2 ranks
     assert d["config"]["parallelism"] == "dp2" and d["cpu_baseline"] is None
+
+
+def test_one_rank_with_the_process_group_forced():
+    """`--force-dist` (the one-GPU RCCL smoke run of profiles/r03_train_rccl_world1.json) on gloo: a process group of one rank, every
+    barrier / max-over-ranks reduction / gradient bucket issued."""
+    d = _run("--mode", "train", "--train-batch", "1", "--bucket-mb", "1", "--force-dist", gpus=1)
+    ar = d["train_step"]["allreduce"]
+    assert d["n_gpus"] == 1 and ar["world"] == 1 and ar["collectives_issued"] is True and ar["buckets"] >= 3
+    assert d["train_step"]["optimizer"] == "fused"

@@ -162,3 +162,68 @@ def test_accumulate_grad_batches_equals_one_large_batch():
     assert p.exitcode == 0
     assert abs(l1 - l2) < 1e-6 * max(1.0, abs(l1))
     assert np.abs(g1 - g2).max() <= 2e-3 * np.abs(g1).max()
+
+
+def _fused_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "..", "open-diffusiongs_amd"), os.path.join(here, "..")):
+        sys.path.insert(0, os.path.abspath(p))
+    from dgs_amd import denoiser as dn
+    from dgs_amd.optim import FusedAdamW
+    from dgs_amd.parallel import init_distributed
+    from dgs_amd.train import DataParallelTrainer
+    from dit_util import synth_inputs
+    from emu_util import emu_lib
+    from oracle import dit_oracle as D
+    init_distributed(backend="gloo")
+    cfg = D.Cfg(width=256, num_layers=1)
+    m = dn.DGSDenoiser(dict(width=256, in_channels=9, patch_size=8, num_layers=1), device="cpu", lib=emu_lib())
+    m.reset_parameters(seed=1)
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 2, 2, 16, seed=9)
+    sl = slice(rank, rank + 1) if world > 1 else slice(0, 2)
+    batch = dict(image=images[sl], ray_o=ray_o[sl], ray_d=ray_d[sl], c2w=c2w[sl], fxfycxcy=k[sl])
+    target = torch.rand(2, 2, 3, 16, 16, generator=torch.Generator().manual_seed(3))[sl]
+    tr = DataParallelTrainer(m, FusedAdamW(m, lr=1e-2, betas=(0.9, 0.99), weight_decay=0.05), bucket_bytes=1 << 20)
+    for _ in range(2):
+        tr.step(batch, t[sl], target)
+    p = torch.cat([q.detach().reshape(-1) for q in m.parameters()])
+    eng = m.engine()
+    n = "transformer.0.mlp.fc1.weight"
+    copy, copy_t = eng.weight_destinations()[n]
+    ok = bool(torch.equal(copy, dict(m.named_parameters())[n].detach().to(torch.bfloat16)) and torch.equal(copy_t, copy.t()))
+    out.put((rank, p.numpy(), ok))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_fused_adamw_keeps_the_replicas_identical():
+    """Two ranks x one sample with the one-launch AdamW + weight refresh: after two steps both replicas hold the SAME parameters (the
+    averaged gradients are identical bits on both ranks, the update is deterministic) and they match one process x two samples; the
+    engine's bf16 / transposed copies follow on every rank."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_fused_worker, args=(0, 1, _free_port(), q1))
+    p1.start()
+    single = q1.get(timeout=300)
+    p1.join(60)
+    assert res[0][2] and res[1][2] and single[2]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    # Adam normalises the step, so gradient noise of 2e-3 (bf16 operands, another summation order) can move a parameter by up to
+    # ~lr where the gradient is tiny: compare against the size of the update, not of the parameter
+    assert np.abs(res[0][1] - single[1]).max() <= 2.5e-2
+    assert np.abs(res[0][1] - single[1]).mean() <= 2e-3
