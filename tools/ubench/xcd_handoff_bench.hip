@@ -7,6 +7,9 @@
 //                       consumer: spin on the flag, agent-scope ACQUIRE fence (invalidates), plain loads
 //     mode 1  "sc1":    payload stored with sc1 (performed at the memory side), s_waitcnt vmcnt(0), flag store;
 //                       consumer: spin on the flag, payload loaded with sc1 (agent-scope relaxed atomic loads: bypass the L2s)
+//     mode 2  "sc1dma": producer as mode 1; the consumer pulls the payload into LDS with sc1 LDS-DMA (global_load_lds_dwordx4 sc1:
+//                       1 KiB per wave-instruction, no registers) in 64 KiB chunks and checks it there -- how a GEMM stage of a
+//                       persistent pipeline would read the previous stage's tiles
 // 256 workgroups of 256 threads, one per CU (LDS pad); workgroup p < 128 produces for consumer p + 128 (same XCD: the dispatcher
 // places block b on XCD b % 8) or p + 129 (the next XCD); XCC_ID is read back to check that.  Every workgroup stamps the constant
 // 100 MHz clock: producer start / flag stored, consumer flag seen / payload read.  `rounds` hand-offs per pair through the SAME
@@ -82,6 +85,24 @@ __global__ __launch_bounds__(256) void handoff_kernel(char* payload, unsigned* f
             if (bail) break;
             const unsigned long long s2 = wall_clock64();
             if (mode == 0) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            if (mode == 2) {
+                char* lbuf = reinterpret_cast<char*>(pad) + 1024;                     // 64 KiB chunk behind the pad word
+                const int wave = tid >> 6, lane = tid & 63;
+                for (int c0 = 0; c0 < bytes; c0 += 65536) {
+                    const int n = bytes - c0 < 65536 ? bytes - c0 : 65536;
+                    for (int piece = wave; piece * 1024 < n; piece += 4)              // lane i's 16 bytes land at the piece's base + 16 i
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(buf + c0 + piece * 1024 + lane * 16),
+                                                         (__attribute__((address_space(3))) void*)(lbuf + piece * 1024), 16, 0, 16 /* sc1 */);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    for (int i = tid * 16; i < n; i += 256 * 16) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(lbuf + i);
+                        const int gi = c0 + i;
+                        if (v.x != (unsigned)r || v.y != (unsigned)gi || v.w != (unsigned)(r * 2654435761u + gi)) ++errors;
+                    }
+                    __syncthreads();
+                }
+            } else
             for (int i = tid * 16; i < bytes; i += 256 * 16) {
                 uint4 v;
                 if (mode == 0) v = *reinterpret_cast<const uint4*>(buf + i);
@@ -119,7 +140,7 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(handoff_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     printf("# hand-off between two workgroups of one launch, %d rounds per pair, 128 pairs at once; background dirty stores %d KiB per workgroup and round\n", rounds, dirty_kb);
     printf("# mode   placement  payload    producer write+release   flag -> seen   consumer acquire+read   errors   (us, mean over pairs and rounds)\n");
-    for (int mode = 0; mode < 2; ++mode)
+    for (int mode = 0; mode < 3; ++mode)
         for (int shift = 0; shift < 2; ++shift)
             for (int bytes : {4096, 65536, 1 << 20}) {
                 hipMemset(flags, 0, (G / 2) * 128);
@@ -139,7 +160,7 @@ int main(int argc, char** argv) {
                     same += h[p].xcc == h[c].xcc;
                 }
                 const double k = 1.0 / (G / 2) / rounds / 100.0;                       // 100 MHz ticks -> us
-                printf("%-6s %-10s %7d B   %10.2f               %8.2f       %10.2f            %llu   (%d of 128 pairs on one XCD)\n", mode ? "sc1" : "fence",
+                printf("%-6s %-10s %7d B   %10.2f               %8.2f       %10.2f            %llu   (%d of 128 pairs on one XCD)\n", mode == 0 ? "fence" : mode == 1 ? "sc1" : "sc1dma",
                        shift ? "next XCD" : "same XCD", bytes, wr * k, hand * k, rd * k, err, same);
             }
     return 0;
