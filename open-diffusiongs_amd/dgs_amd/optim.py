@@ -6,8 +6,9 @@ copy of the weights up to date; as torch ops that is a multi-tensor AdamW (one l
 transposed-copy / copy launches per step (3.2 + 1.2 ms of a 91 ms step, `profiles/r03_final_train_step_kernel_stats.txt`).
 `FusedAdamW.step()` reads p, g, m, v once and writes p, m, v and every copy: same arithmetic as torch's single-tensor AdamW in fp32.
 
-Drop-in where `DataParallelTrainer` takes an optimizer: `.step()`, `.zero_grad()`, `.param_groups` (one group: lr / betas / eps /
-weight_decay may be changed between steps, e.g. by an LR scheduler), `.state_dict()` / `.load_state_dict()`.
+A `torch.optim.Optimizer` (one parameter group: lr / betas / eps / weight_decay may be changed between steps), so the reference's
+`CosineAnnealingLR(optim, ...)` (configs/diffusionGS_rel.yaml:64-68, utils/scheduler.py `parse_scheduler`) and Lightning's checkpointing
+take it as they take torch's: `.step()`, `.zero_grad()`, `.param_groups`, `.state_dict()` / `.load_state_dict()`.
 """
 import ctypes
 import math
@@ -18,14 +19,14 @@ from . import _native
 from .dit import _stream
 
 
-class FusedAdamW:
+class FusedAdamW(torch.optim.Optimizer):
     refreshes_engine = True          # DataParallelTrainer: the engine's weight copies are written by step() itself
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(list(model.parameters()), dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps),
+                                                        weight_decay=float(weight_decay)))
         self.model = model
         self.lib = getattr(model, "_lib", None) or _native.lib()
-        self.param_groups = [dict(params=list(model.parameters()), lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps),
-                                  weight_decay=float(weight_decay))]
         self.step_count = 0
         self._named = [(n, p) for n, p in model.named_parameters()]
         dev = self._named[0][1].device
@@ -40,9 +41,13 @@ class FusedAdamW:
 
     # -- torch.optim.Optimizer surface the trainer / a scheduler touches ---------------------------------
     def zero_grad(self, set_to_none=True):
-        """The backward overwrites every gradient (dgs_dit_backward writes, never accumulates): nothing to clear."""
+        """Under DataParallelTrainer the backward OVERWRITES every gradient in the flat buffer (dgs_dit_backward writes, never
+        accumulates): nothing to clear, and the `.grad` views must stay.  Anywhere else: torch's semantics."""
+        if not getattr(self.model, "_grads_in_place", False):
+            super().zero_grad(set_to_none=set_to_none)
 
     def state_dict(self):
+        """The moments live in two flat buffers (the layout follows model.named_parameters()), not in per-parameter `state` entries."""
         return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
                     param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
 

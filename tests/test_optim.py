@@ -22,9 +22,9 @@ def _case(dev, lib, cfg, steps=3):
     topt = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05, foreach=False, fused=False)
     fopt = FusedAdamW(m, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
     g = torch.Generator().manual_seed(0)
+    # the reference's scheduler (configs/diffusionGS_rel.yaml:64-68) drives both: FusedAdamW is a torch.optim.Optimizer
+    scheds = [torch.optim.lr_scheduler.CosineAnnealingLR(o, T_max=4, eta_min=1e-4) for o in (topt, fopt)]
     for step in range(steps):
-        if step == 2:                                    # a scheduler moved the learning rate
-            topt.param_groups[0]["lr"] = fopt.param_groups[0]["lr"] = 1e-3
         for p, r in zip(m.parameters(), ref):
             gr = (torch.randn(p.shape, generator=g) * (0.1 + step)).to(dev)
             if p.grad is None:
@@ -34,6 +34,12 @@ def _case(dev, lib, cfg, steps=3):
             r.grad = gr.clone()
         topt.step()
         fopt.step()
+        for sc in scheds:
+            sc.step()
+        assert abs(topt.param_groups[0]["lr"] - fopt.param_groups[0]["lr"]) < 1e-12 and fopt.param_groups[0]["lr"] < 3e-3
+    sd = fopt.state_dict()                               # round trip of the checkpoint form
+    fopt.load_state_dict(sd)
+    assert sd["step"] == steps and sd["param_groups"][0]["betas"] == (0.9, 0.99)
     return m, eng, names, ref, topt, fopt
 
 
