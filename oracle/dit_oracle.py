@@ -145,9 +145,10 @@ def patchify(posed, ps):
     return x.reshape(b * v, (H // ps) * (W // ps), ps * ps * c)
 
 
-def image_to_gaussians(sd, cfg, images, ray_o, ray_d, t, return_tokens=False):
+def image_to_gaussians(sd, cfg, images, ray_o, ray_d, t, return_tokens=False, checkpoint_blocks=False):
     """denoiser.py:306-416 (obj) / denoiser_scene.py mirror.  Returns (dict(xyz, features, scaling, rotation, opacity),
-    img_aligned_xyz[b,v,3,H,W])."""
+    img_aligned_xyz[b,v,3,H,W]).  checkpoint_blocks: every block under torch.utils.checkpoint, as the reference itself runs them
+    (denoiser.py:348-354) -- same values and gradients, one block's activations alive at a time."""
     if cfg.ray_pe_type == "relative_plk":
         o_dot_d = torch.sum(-ray_o * ray_d, dim=2, keepdim=True)
         nearest = ray_o + o_dot_d * ray_d
@@ -166,7 +167,11 @@ def image_to_gaussians(sd, cfg, images, ray_o, ray_d, t, return_tokens=False):
     x = F.layer_norm(x, (cfg.width,), sd["transformer_input_layernorm.weight"], None, 1e-5)
     heads = cfg.width // cfg.dim_heads
     for i in range(cfg.num_layers):
-        x = dit_block(x, cvec, sd, f"transformer.{i}.", heads)
+        if checkpoint_blocks and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            x = checkpoint(dit_block, x, cvec, sd, f"transformer.{i}.", heads, use_reentrant=False)
+        else:
+            x = dit_block(x, cvec, sd, f"transformer.{i}.", heads)
     g_tok, i_tok = x.split([cfg.n_gaussians, v * n_patches], dim=1)
     gaussians = head(g_tok, cvec, sd, "upsampler.")
     img_g = head(i_tok, cvec, sd, "image_token_decoder.").reshape(b, -1, cfg.gs_channels)

@@ -48,9 +48,10 @@ def golden_case(kind, tag="hip256"):
 FIELDS = ("xyz", "features", "scaling", "rotation", "opacity")
 
 
-def oracle_gradients(sd, cfg, images, ray_o, ray_d, t, wts, dev):
+def oracle_gradients(sd, cfg, images, ray_o, ray_d, t, wts, dev, checkpoint_blocks=False):
     """Parameter gradients of sum_k <out_k, wts_k> by torch autograd through the fp32 oracle evaluated on `dev`, ONE SAMPLE AT A
-    TIME (at L = 4098 the oracle's attention matrices are ~26 GB per sample) and summed over samples in fp64.
+    TIME (at L = 4098 the oracle's attention matrices are ~26 GB per sample) and summed over samples in fp64.  checkpoint_blocks:
+    every block under torch.utils.checkpoint (L = 16,386: 24 blocks x 2 score matrices of 17 GB would not fit; one block's do).
     Returns (outputs per field [B, ...] fp32, {state-dict key: gradient fp64})."""
     B = images.shape[0]
     leaf = {k: v.to(dev).requires_grad_(True) for k, v in sd.items()}
@@ -58,7 +59,7 @@ def oracle_gradients(sd, cfg, images, ray_o, ray_d, t, wts, dev):
     outs = {k: [] for k in FIELDS}
     for b in range(B):
         s = slice(b, b + 1)
-        ref, _ = D.image_to_gaussians(leaf, cfg, images[s].to(dev), ray_o[s].to(dev), ray_d[s].to(dev), t[s].to(dev))
+        ref, _ = D.image_to_gaussians(leaf, cfg, images[s].to(dev), ray_o[s].to(dev), ray_d[s].to(dev), t[s].to(dev), checkpoint_blocks=checkpoint_blocks)
         sum((ref[k] * wts[k][s]).sum() for k in FIELDS).backward()
         for k, v in leaf.items():
             if v.grad is not None:

@@ -58,6 +58,16 @@ def test_full_size_256_product_default_exp(regime, views):
     assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV, exact=False, rtol=2e-3)
 
 
+@pytest.mark.parametrize("exact,rtol", [(True, 2e-4), (False, 2e-3)], ids=["exact_exp", "product_default"])
+def test_full_size_512_vs_oracle(exact, rtol):
+    """BASELINE configs[4] (512^2, P = 1,048,578 Gaussians, 1,024 tiles, trained-like regime: N ~ 7 M instances, the list forms of
+    the binning incl. the 1,024-thread per-tile sort): every gradient of one view against the oracle's fp64-accumulated sums
+    (backward.cu:399-557 blend, :144-274,346-396 preprocess; rasterizer_impl.cu:340-434)."""
+    sc = synth.gaussian_scene(512, regime="trained", seed=0)
+    cams, _, _ = synth.render_cameras(512, 4, phase_deg=10)
+    assert_backward_parity(_backend(), sc, cams[:1], 512, 512, DEV, exact=exact, rtol=rtol)
+
+
 def test_precomputed_colors_and_long_lists():
     H, W = 32, 48
     sc, cams = small_scene(120, W, H, seed=8, n_views=2)
