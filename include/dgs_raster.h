@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 4   /* bumped with every change of a struct or prototype in the include directory (round 2 = 2, unversioned) */
+#define DGS_ABI_VERSION 5   /* bumped with every change of a struct or prototype in the include directory (round 2 = 2, unversioned) */
 #define DGS_TILE 16 /* cuda_rasterizer/config.h:14-15 */
 
 typedef void* dgs_stream_t; /* hipStream_t */
@@ -88,16 +88,24 @@ typedef struct DgsRasterForwardArgs {
     dgs_alloc_fn img_alloc;   void* img_user;      /* size: dgs_raster_image_bytes(W,H,V)       */
     dgs_alloc_fn binning_alloc; void* binning_user;/* size: dgs_raster_binning_bytes(num_rendered) */
     /* async mode: if binning_capacity > 0, binning_alloc is called ONCE up front with
-     * dgs_raster_binning_bytes(binning_capacity) and the call never synchronises; an
-     * overflow sets *status_dev = DGS_ERR_BINNING_OVERFLOW and renders nothing.         */
+     * dgs_raster_binning_bytes(binning_capacity) and the call never synchronises, reads nothing back and may be captured in a
+     * hipGraph (the reference's blocking read of num_rendered, rasterizer_impl.cu:281, is gone); more instances than the
+     * capacity set status_dev[1] = DGS_ERR_BINNING_OVERFLOW and the image is filled with NaN (nothing plausible is rendered).
+     * The backward of such a call takes binning_capacity as its `num_rendered`.                                              */
     int64_t binning_capacity;
-    int32_t* num_rendered_dev;   /* device int64-compatible pair: [0]=num_rendered (low 32 bits), [1]=status; may be NULL in sync mode */
+    int32_t* num_rendered_dev;   /* device int32[4], written by the call in both modes when not NULL: [0] = num_rendered (low 32 bits),
+                                    [1] = status (DgsStatus), [2] = longest tile list, [3] = 0                               */
+    int64_t longest_hint;        /* async mode, IN: the longest tile list the caller expects (a previous call of this shape), 0 =
+                                    unknown.  Sizes the LDS of the per-tile sort; a longer list only changes the form that runs   */
     /* ---- result ---- */
     int64_t num_rendered;        /* host, OUT (sync mode); -1 in async mode             */
-    int32_t binning_form;        /* per-tile ordering algorithm. 0: chosen from the instance statistics (default);
-                                    tests / measurement: 1 instance list + depth-rank bitmap sort, 2 per-tile scan of the
-                                    depth-ordered Gaussians, 3 instance list + per-tile bitonic sort in LDS.  All forms
-                                    produce the reference's lists bit for bit.                                       */
+    int64_t longest_list;        /* host, OUT (sync mode); -1 in async mode             */
+    int32_t binning_form;        /* per-tile ordering algorithm. 0: chosen from the instance statistics (on the host in the sync mode;
+                                    in the async mode every form is launched and the device returns from the others at once);
+                                    1 instance list + depth-rank bitmap sort, 2 per-tile scan of the depth-ordered Gaussians,
+                                    3 instance list + per-tile sort in LDS (falls back to 1 when a list does not fit): that form
+                                    only is launched -- what an async caller passes from dgs_raster_binning_form() of the
+                                    previous call's statistics.  All forms produce the reference's lists bit for bit.  */
     int32_t exact_exp;           /* exponential of a (pixel, Gaussian) pair in the blend loop.  0 (default): the hardware's
                                     v_exp_f32 -- what the reference's `exp()` compiles to under its fast-math build; 1: a fixed
                                     IEEE sequence the CPU oracle restates (oracle exp_mode 1), every float of the result
@@ -154,6 +162,10 @@ size_t dgs_raster_image_bytes(int32_t width, int32_t height, int32_t V);
 size_t dgs_raster_binning_bytes(int64_t num_rendered);
 
 int dgs_raster_forward(DgsRasterForwardArgs* args, dgs_stream_t stream);
+/* The ordering form a call with these instance statistics picks (1..3, see DgsRasterForwardArgs.binning_form; `binning_form` 0 =
+ * no preference): the host-side twin of the choice the kernels make in the async mode. */
+int dgs_raster_binning_form(int32_t binning_form, int64_t num_rendered, int64_t longest_list, int32_t P, int32_t width, int32_t height,
+                            int32_t V);
 int dgs_raster_backward(const DgsRasterBackwardArgs* args, dgs_stream_t stream);
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, dgs_stream_t stream);
@@ -173,7 +185,7 @@ int dgs_rays_from_c2w(int32_t n, const float* c2w, const float* fxfycxcy, int32_
 /* Introspection for the parity tests: copies a named array of the forward state out of the
  * opaque buffers into `dst` (device pointer, `dst_bytes` capacity).  Names: "depths", "means2D",
  * "conic_opacity", "rgb", "tiles_touched", "clamped", "cov3D", "ranges", "n_contrib", "final_T",
- * "point_list".  Returns the number of bytes written or a negative DgsStatus.            */
+ * "point_list", "list_len", "tile_work", "tile_scanned" (and "tile_stats", "tile_stats_bwd": zero in the product library).  Returns the number of bytes written or a negative DgsStatus.            */
 int64_t dgs_raster_state_read(const char* name, int32_t P, int32_t width, int32_t height, int32_t V,
                               int64_t num_rendered, const void* geom_buffer, const void* binning_buffer,
                               const void* img_buffer, void* dst, int64_t dst_bytes, dgs_stream_t stream);

@@ -50,7 +50,7 @@ struct BwdParams {
 template <bool FAST_EXP>
 __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     __shared__ uint32_t s_id[256];
-    __shared__ uint2 s_stat[4];
+    __shared__ uint2 s_stat[kRasterStats ? 4 : 1];
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
     __shared__ float4 s_rgbc[256];                        // colour, alpha cut-off on `power`
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
             uint32_t word = lst[0];
             Entry ea = load(word & 255u), eb;
-            st_entries += tot;
+            if constexpr (kRasterStats) st_entries += tot;
             uint32_t k = 0;
             for (; __ballot(k < tot) != 0ull; k += 4) {
                 const uint32_t word_next = lst[(k >> 2) + 1u];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                 ea = load(word_next & 255u);    step(k + 3u, word >> 24, eb);
                 word = word_next;
             }
-            st_trips += k;
+            if constexpr (kRasterStats) st_trips += k;
         }
         __syncthreads();
         // entry `tid`: the tile's sums, one atomic per value
@@ -229,14 +229,16 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             }
         }
     }
-    uint32_t ent = (lane & 15) == 0 ? st_entries : 0u;
+    if constexpr (kRasterStats) {
+        uint32_t ent = (lane & 15) == 0 ? st_entries : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ent += (uint32_t)__shfl_xor((int)ent, o);
-    if (lane == 0) s_stat[wave] = make_uint2(ent, st_trips);
-    __syncthreads();
-    if (tid == 0)
-        p.im.tile_stats[(size_t)p.V * p.T + vt] = make_uint4(s_stat[0].x + s_stat[1].x + s_stat[2].x + s_stat[3].x,
-                                                             s_stat[0].y + s_stat[1].y + s_stat[2].y + s_stat[3].y, 0u, (uint32_t)rounds);
+        for (int o = 32; o > 0; o >>= 1) ent += (uint32_t)__shfl_xor((int)ent, o);
+        if (lane == 0) s_stat[wave] = make_uint2(ent, st_trips);
+        __syncthreads();
+        if (tid == 0)
+            p.im.tile_stats[(size_t)p.V * p.T + vt] = make_uint4(s_stat[0].x + s_stat[1].x + s_stat[2].x + s_stat[3].x,
+                                                                 s_stat[0].y + s_stat[1].y + s_stat[2].y + s_stat[3].y, 0u, (uint32_t)rounds);
+    }
 }
 
 // backward.cu:20-139 for one Gaussian of one view.  dRGB already has the clamp mask applied.  Adds into dsh[M][3] and dmean.

@@ -6,6 +6,17 @@
 
 namespace dgs {
 
+// Per-tile measurement counters of the two blend kernels (ImageState::tile_stats: cell-list entries walked, wave loop trips): compiled
+// into the tools' library (-DDGS_INSTRUMENT, lib/libdgs_hip_instr.so) and the emulator build only.  In the product library every
+// `if constexpr (kRasterStats)` branch is discarded -- no counters, no cross-lane reduce, no store in the hottest loops of the
+// rasterizer; tile_stats then stays zero-filled.  bench.py counts a call's pair evaluations with the tools' library and times the
+// product library.
+#if defined(DGS_INSTRUMENT) || defined(HIPEMU)
+constexpr bool kRasterStats = true;
+#else
+constexpr bool kRasterStats = false;
+#endif
+
 // ---- small column-major 3x3 helper with glm's product order (type_mat3x3.inl:486-519) ----
 struct M3 { float c[3][3]; };
 __device__ __forceinline__ M3 m3_cols(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {

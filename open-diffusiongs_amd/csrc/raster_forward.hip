@@ -394,6 +394,10 @@ __host__ __device__ __forceinline__ int binning_form_of(int bin_mode, int bitoni
     if (num_rendered * 10 >= T * P * V) return kFormScan;
     return fits ? kFormBitonic : kFormRankSort;
 }
+// the scan is on demand: T x P is its worst case, not its cost; tile coordinates are packed in 8 bits each (rank_rects_kernel)
+__host__ __device__ __forceinline__ bool scan_form_possible(int gx, int gy, long long T, long long P) {
+    return gx <= 255 && gy <= 255 && T * P <= (1ll << 31);
+}
 __device__ __forceinline__ int binning_form(const FwdParams& p) {
     return binning_form_of(p.bin_mode, p.bitonic_cap, (long long)(uint32_t)p.im.totals[0], (long long)(uint32_t)p.im.totals[2], p.T, p.P, p.V);
 }
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ uint4 s_cnt[16];                           // [cell] entries of the batch the cell keeps, per staging wave
     __shared__ uint8_t s_list[17][256];                   // [cell] their batch indices, front to back (+ one row: the walk reads a group ahead)
     __shared__ uint32_t s_walk[4];
-    __shared__ uint2 s_stat[4];
+    __shared__ uint2 s_stat[kRasterStats ? 4 : 1];
     __shared__ uint32_t s_ring[SCAN ? kRing : 1];         // scan form: list entries found, not yet staged
     __shared__ uint32_t s_scan[4];
     if (binning_is_scan(p) != SCAN) return;               // async mode launches both forms
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     uint32_t st_entries = 0, st_trips = 0, st_batches = 0;      // tile_stats (measurement): per lane its cell's entries, per wave its loop trips
     for (int i = 0; i < rounds; ++i) {
         if (__syncthreads_count(done) == 256) break;
-        ++st_batches;
+        if constexpr (kRasterStats) ++st_batches;
         const uint32_t pos = rg.x + (uint32_t)i * 256u + (uint32_t)tid;
         const uint32_t need = min(256u, rg.y - rg.x - (uint32_t)i * 256u);
         if (SCAN) {
@@ -902,7 +906,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
             const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
             uint32_t word = lst[0];
             Entry ea = load(word & 255u), eb;
-            st_entries += tot;
+            if constexpr (kRasterStats) st_entries += tot;
             uint32_t k = 0;
             for (; __ballot(k < tot) != 0ull; k += 4) {
                 const uint32_t word_next = lst[(k >> 2) + 1u];
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
                 ea = load(word_next & 255u);    step(k + 3u, word >> 24, eb);
                 word = word_next;
             }
-            st_trips += k;
+            if constexpr (kRasterStats) st_trips += k;
         }
     }
     if (inside) {
@@ -921,24 +925,32 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
         p.im.final_T[(size_t)v * HW + pid] = T;
         p.im.n_contrib[(size_t)v * HW + pid] = last_contributor;
         float* out = p.out_color + (size_t)v * 3 * HW;
-        out[pid] = C0 + T * p.bg[0];
-        out[HW + pid] = C1 + T * p.bg[1];
-        out[2 * HW + pid] = C2 + T * p.bg[2];
+        // a call that failed on the device (async mode: more instances than the binning buffer holds; prefiltered + a culled point)
+        // has no host to report to before its output is consumed: the image is NaN, not a plausible background
+        const float bad = __uint_as_float(0x7FC00000u);
+        out[pid] = ok ? C0 + T * p.bg[0] : bad;
+        out[HW + pid] = ok ? C1 + T * p.bg[1] : bad;
+        out[2 * HW + pid] = ok ? C2 + T * p.bg[2] : bad;
     }
     // how far into its list the tile got: what the backward replays, and what it ranks its launch order by
     uint32_t walked = last_contributor;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) walked = max(walked, (uint32_t)__shfl_xor((int)walked, o));
-    uint32_t ent = (lane & 15) == 0 ? st_entries : 0u;                 // one lane per 16-lane row: the row's cell
+    if constexpr (kRasterStats) {
+        uint32_t ent = (lane & 15) == 0 ? st_entries : 0u;             // one lane per 16-lane row: the row's cell
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ent += (uint32_t)__shfl_xor((int)ent, o);
-    if (lane == 0) { s_walk[wave] = walked; s_stat[wave] = make_uint2(ent, st_trips); }
+        for (int o = 32; o > 0; o >>= 1) ent += (uint32_t)__shfl_xor((int)ent, o);
+        if (lane == 0) s_stat[wave] = make_uint2(ent, st_trips);
+    }
+    if (lane == 0) s_walk[wave] = walked;
     __syncthreads();
     if (tid == 0) {
         p.im.tile_work[vt] = max(max(s_walk[0], s_walk[1]), max(s_walk[2], s_walk[3]));
         p.im.tile_cursor[vt] = SCAN ? ts.found : rg.y - rg.x;          // entries of the tile's list that exist in point_list
-        p.im.tile_stats[vt] = make_uint4(s_stat[0].x + s_stat[1].x + s_stat[2].x + s_stat[3].x, s_stat[0].y + s_stat[1].y + s_stat[2].y + s_stat[3].y,
-                                         SCAN ? ts.next_rank : 0u, st_batches);
+        p.im.tile_scanned[vt] = SCAN ? ts.next_rank : 0u;              // depth ranks the tile tested (scan form)
+        if constexpr (kRasterStats)
+            p.im.tile_stats[vt] = make_uint4(s_stat[0].x + s_stat[1].x + s_stat[2].x + s_stat[3].x, s_stat[0].y + s_stat[1].y + s_stat[2].y + s_stat[3].y,
+                                             SCAN ? ts.next_rank : 0u, st_batches);
     }
 }
 
@@ -1034,6 +1046,14 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     }
 
     const int VT = V * p.T;
+    constexpr int kBitonicMax = 16384;                             // 128 KiB of LDS
+    // once per process, before anything is enqueued (a stream capture must not meet it): the per-tile LDS sort's dynamic LDS size
+    static const bool lds_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
+    if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
     // tile_count and totals are neighbours in the image state (ImageState::carve): one fill
     hipMemsetAsync(p.im.tile_count, 0, (size_t)(reinterpret_cast<char*>(p.im.totals + 4) - reinterpret_cast<char*>(p.im.tile_count)), st);
     const dim3 gridP((P + 255) / 256, V);
@@ -1050,10 +1070,9 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
 
     // binning form (binning_form_of): the host only rules forms out; the choice itself is made from the instance statistics --
     // on the host in the sync mode (it has just read them back), on the device in the async mode
-    const bool can_scan = p.gx <= 255 && p.gy <= 255 && (long long)p.T * P <= (1ll << 31);   // the scan is on demand: T x P is its worst case, not its cost
+    const bool can_scan = scan_form_possible(p.gx, p.gy, p.T, P);
     p.bin_mode = a->binning_form;
     if (p.bin_mode < 0 || p.bin_mode > 3 || (p.bin_mode == 0 && !can_scan) || (p.bin_mode == kFormScan && !can_scan)) p.bin_mode = can_scan ? 0 : kFormBitonic;
-    constexpr int kBitonicMax = 16384;                             // 128 KiB of LDS
     int forms = 0;                                                 // bit f set: form f has to be launched
     // The forms that work on depth ranks need the radix sort of the P depth keys (12 launches, ~0.17 ms at 256^2 x 4 views).  In
     // the sync mode it is worth having it in flight while the host waits for the statistics -- but only if it will be needed:
@@ -1078,6 +1097,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         if (hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
         if (tot[1] != 0) return tot[1];
         a->num_rendered = (int64_t)(uint32_t)tot[0];
+        a->longest_list = (int64_t)(uint32_t)tot[2];
         bbuf = a->binning_alloc(dgs_raster_binning_bytes(a->num_rendered), a->binning_user);
         if (!bbuf) return DGS_ERR_ALLOC;
         p.bn = BinningState::carve(bbuf, (size_t)(a->num_rendered < 1 ? 1 : a->num_rendered), nullptr);
@@ -1086,11 +1106,26 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         p.bitonic_cap = cap;
         last_form = binning_form_of(p.bin_mode, p.bitonic_cap, a->num_rendered, (uint32_t)tot[2], p.T, P, V);
         forms = 1 << last_form;
-    } else {
-        a->num_rendered = -1;
         if (a->num_rendered_dev)
-            hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-        p.bitonic_cap = kBitonicMax;
+            hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    } else {
+        // nothing is read back: the statistics go to the caller's device words (it reads them when it likes -- dgs_amd/raster.py
+        // copies them to pinned host memory behind the call and looks at them before the NEXT call), every kernel of a form the
+        // device does not pick returns at once.  A forced form (binning_form != 0: the caller's knowledge of the previous call of
+        // this shape) launches that form only -- scan and rank sort are always valid, the LDS sort falls back to the rank sort on
+        // the device when a list does not fit (both are launched).  All forms produce the same lists bit for bit.
+        a->num_rendered = -1;
+        a->longest_list = -1;
+        if (a->num_rendered_dev)
+            hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        // LDS the per-tile sort is launched with: for the longest list the caller expects (+ 50 %), else the maximum; a list that
+        // does not fit sends the call to the rank sort on the device
+        int cap = kBitonicMax;
+        if (a->longest_hint > 0) {
+            cap = 2048;
+            while (cap < a->longest_hint + a->longest_hint / 2 && cap < kBitonicMax) cap <<= 1;
+        }
+        p.bitonic_cap = cap;
         forms = p.bin_mode ? (1 << p.bin_mode) | (p.bin_mode == kFormBitonic ? 1 << kFormRankSort : 0)
                            : (1 << kFormRankSort) | (1 << kFormScan) | (1 << kFormBitonic);
     }
@@ -1110,12 +1145,6 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         hipLaunchKernelGGL(tile_sort_kernel, dim3(p.T, V), dim3(256), (size_t)wwords * 4, st, p, wwords);
     }
     if (forms & (1 << kFormBitonic)) {
-        static const bool lds_ok =
-            hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
-        if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
         const size_t lds = (size_t)p.bitonic_cap * 8 + 2 * kBuckets * 4;
         if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(VT), dim3(1024), lds, st, p);
         else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(VT), dim3(256), lds, st, p);
@@ -1125,6 +1154,16 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         else hipLaunchKernelGGL((blend_forward_kernel<false, true>), dim3(VT), dim3(256), 0, st, p);
     }
     return check(st, a->debug);
+}
+
+int dgs_raster_binning_form(int32_t binning_form, int64_t num_rendered, int64_t longest_list, int32_t P, int32_t W, int32_t H, int32_t V) {
+    if (P < 0 || W <= 0 || H <= 0 || V < 1 || num_rendered < 0 || longest_list < 0) return DGS_ERR_INVALID_ARGUMENT;
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const long long T = (long long)gx * gy;
+    const bool can_scan = scan_form_possible(gx, gy, T, P);
+    int mode = binning_form;
+    if (mode < 0 || mode > 3 || (mode == 0 && !can_scan) || (mode == kFormScan && !can_scan)) mode = can_scan ? 0 : kFormBitonic;
+    return binning_form_of(mode, 16384, num_rendered, longest_list, T, P, V);
 }
 
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
@@ -1163,6 +1202,7 @@ int64_t dgs_raster_state_read(const char* name, int32_t P, int32_t W, int32_t H,
     else if (is("final_T")) { src = im.final_T; bytes = HW * 4; }
     else if (is("list_len")) { src = im.tile_cursor; bytes = T * 4; }       // entries of each tile's list present in point_list
     else if (is("tile_work")) { src = im.tile_work; bytes = T * 4; }
+    else if (is("tile_scanned")) { src = im.tile_scanned; bytes = T * 4; }
     else if (is("tile_stats")) { src = im.tile_stats; bytes = T * 16; }                // forward blend: see raster_state.h
     else if (is("tile_stats_bwd")) { src = im.tile_stats + T; bytes = T * 16; }
     else if (is("point_list")) { src = bn.point_list; bytes = (size_t)(N < 0 ? 0 : N) * 4; }

@@ -81,8 +81,10 @@ struct ImageState {
     int32_t* totals;               // [4]     {num_rendered, status, longest tile list, -}
     uint32_t* tile_order;          // [V*T]   launch order of the per-tile kernels (workgroup b works on tile tile_order[b])
     uint32_t* tile_work;           // [V*T]   list entries the forward blend walked before the tile was finished
-    uint4* tile_stats;             // [2][V*T] measurement (forward, backward): {cell-list entries walked (x 16 pixels = pair evaluations),
-                                   //          wave loop trips (x 64 lanes = lane slots issued), depth ranks scanned (scan form), batches}
+    uint32_t* tile_scanned;        // [V*T]   depth ranks the forward blend tested for the tile (scan form; else 0)
+    uint4* tile_stats;             // [2][V*T] measurement (forward, backward), tools' / emulator build only (kRasterStats), else zero:
+                                   //          {cell-list entries walked (x 16 pixels = pair evaluations), wave loop trips (x 64 lanes = lane
+                                   //          slots issued), depth ranks scanned (scan form), batches}
     static ImageState carve(void* buf, size_t W, size_t H, size_t V, size_t* bytes) {
         Carver c(buf);
         ImageState s;
@@ -95,6 +97,7 @@ struct ImageState {
         s.ranges = c.take<uint2>(V * T);
         s.tile_order = c.take<uint32_t>(V * T);
         s.tile_work = c.take<uint32_t>(V * T);
+        s.tile_scanned = c.take<uint32_t>(V * T);
         s.tile_stats = c.take<uint4>(2 * V * T);
         if (bytes) *bytes = c.bytes();
         return s;

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # or an A/B side (tools/ab_build.sh).  Never a fallback: whatever is named must exist and pass the ABI check.
 LIB_PATH = os.environ.get("DGS_AMD_LIBRARY") or os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
 
-ABI_VERSION = 4          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
+ABI_VERSION = 5          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
+DGS_ERR_BINNING_OVERFLOW = -7    # include/dgs_raster.h DgsStatus
 c_float_p = ctypes.POINTER(ctypes.c_float)
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
@@ -31,8 +32,8 @@ class DgsRasterForwardArgs(ctypes.Structure):
         ("geom_alloc", ALLOC_FN), ("geom_user", ctypes.c_void_p),
         ("img_alloc", ALLOC_FN), ("img_user", ctypes.c_void_p),
         ("binning_alloc", ALLOC_FN), ("binning_user", ctypes.c_void_p),
-        ("binning_capacity", ctypes.c_int64), ("num_rendered_dev", ctypes.c_void_p),
-        ("num_rendered", ctypes.c_int64), ("binning_form", ctypes.c_int32), ("exact_exp", ctypes.c_int32),
+        ("binning_capacity", ctypes.c_int64), ("num_rendered_dev", ctypes.c_void_p), ("longest_hint", ctypes.c_int64),
+        ("num_rendered", ctypes.c_int64), ("longest_list", ctypes.c_int64), ("binning_form", ctypes.c_int32), ("exact_exp", ctypes.c_int32),
     ]
 
 
@@ -58,7 +59,7 @@ class DgsRasterBackwardArgs(ctypes.Structure):
 
 # every symbol include/dgs_raster.h declares (checked by tests/test_abi.py)
 RASTER_SYMBOLS = ["dgs_abi_version", "dgs_status_string", "dgs_raster_geom_bytes", "dgs_raster_image_bytes",
-                  "dgs_raster_binning_bytes", "dgs_raster_forward", "dgs_raster_backward", "dgs_mark_visible",
+                  "dgs_raster_binning_bytes", "dgs_raster_forward", "dgs_raster_binning_form", "dgs_raster_backward", "dgs_mark_visible",
                   "dgs_raster_state_read", "dgs_cameras_from_c2w", "dgs_rays_from_c2w"]
 
 
@@ -74,6 +75,8 @@ def _declare(L):
     L.dgs_raster_binning_bytes.argtypes = [ctypes.c_int64]
     L.dgs_raster_forward.restype = ctypes.c_int
     L.dgs_raster_forward.argtypes = [ctypes.POINTER(DgsRasterForwardArgs), ctypes.c_void_p]
+    L.dgs_raster_binning_form.restype = ctypes.c_int
+    L.dgs_raster_binning_form.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
     if hasattr(L, "dgs_raster_backward"):
         L.dgs_raster_backward.restype = ctypes.c_int
         L.dgs_raster_backward.argtypes = [ctypes.POINTER(DgsRasterBackwardArgs), ctypes.c_void_p]

@@ -31,9 +31,58 @@ def _prep(t, device):
     return t.contiguous()
 
 
+class _AsyncPlan:
+    """What the backend knows about the calls of ONE shape (P, W, H, V, views per set, device): the instance statistics the device
+    reported for the calls so far.  They size the next call's binning buffer and pick its ordering form, so that the call itself
+    reads nothing back (the reference blocks on `num_rendered` in every forward, rasterizer_impl.cu:281).
+
+    capacity  2 x the most instances any call of this shape produced (the buffer is torch memory: a cached block after the first
+              call); a call that needs more flags DGS_ERR_BINNING_OVERFLOW on the device and renders NaN -- it cannot tell the host
+              in time -- and the NEXT call of the shape raises, with the capacity already raised.
+    form      dgs_raster_binning_form() of the latest statistics that have arrived (any form is correct for any scene -- the lists
+              are bit-identical -- a stale one only costs time).
+    Statistics travel device -> pinned host words behind each call; `poll` looks at the ones whose copy has finished."""
+
+    MARGIN = 2.0
+
+    def __init__(self):
+        self.capacity, self.form, self.longest, self.seen_max = 0, 0, 0, 0
+        self.pending = []          # (event or None, host int32[4], capacity the call ran with)
+        self.overflowed = None     # (instances, capacity) of a call that did not fit, until it has been reported
+        self.calls = {"sync": 0, "async": 0}
+
+    def note(self, lib, n, longest, P, W, H, V):
+        self.seen_max = max(self.seen_max, int(n))
+        self.longest = int(longest)
+        self.capacity = max(self.capacity, int(self.MARGIN * self.seen_max) + 1024)
+        self.form = int(lib.dgs_raster_binning_form(0, int(n), int(longest), P, W, H, V))
+
+    def poll(self, lib, P, W, H, V, wait=False):
+        keep = []
+        for ev, host, cap in self.pending:
+            if ev is not None and not wait and not ev.query():
+                keep.append((ev, host, cap))
+                continue
+            if ev is not None and wait:
+                ev.synchronize()
+            n, status, longest = int(host[0]) & 0xFFFFFFFF, int(host[1]), int(host[2]) & 0xFFFFFFFF
+            self.note(lib, n, longest, P, W, H, V)
+            if status == _native.DGS_ERR_BINNING_OVERFLOW:
+                self.overflowed = (n, cap)
+            elif status != 0:
+                raise RuntimeError(f"dgs rasterizer: an earlier asynchronous call failed on the device: {_native.status_string(lib, status)} (status {status})")
+        self.pending = keep
+        if self.overflowed is not None:
+            n, cap = self.overflowed
+            self.overflowed = None
+            raise RuntimeError(f"dgs rasterizer: an earlier asynchronous render produced {n} instances but its binning buffer held {cap}: "
+                               f"that call's image is NaN.  The capacity is now {self.capacity}; run the step again")
+
+
 class RasterBackend:
     def __init__(self, lib=None, exact_exp=None):
         self.lib = lib if lib is not None else _native.lib()
+        self._plans = {}             # (P, W, H, V, views_per_set, device) -> _AsyncPlan
         # exponential of the blend loops (dgs_raster.h `exact_exp`): False = the hardware's v_exp_f32 (product default), True = the
         # fixed IEEE sequence the CPU oracle restates (floats bit-identical with the oracle: what the bit-exact parity tests select)
         self.exact_exp = bool(int(os.environ.get("DGS_RASTER_EXACT_EXP", "0") or 0)) if exact_exp is None else bool(exact_exp)
@@ -70,11 +119,24 @@ class RasterBackend:
         num_rendered, color, radii, geom, binning, img = out
         return num_rendered, color[0], radii[0], geom, binning, img
 
+    def plan_for(self, P, W, H, V, views_per_set, device):
+        return self._plans.setdefault((int(P), int(W), int(H), int(V), int(views_per_set), str(device)), _AsyncPlan())
+
+    def check_async(self, wait=True):
+        """Look at the statistics of every asynchronous call so far (wait=True: block until their copies have arrived) and raise if
+        one of them failed on the device -- the place for a caller to turn a NaN image into an exception at a moment of its choosing
+        (end of a sampling loop, end of a training step)."""
+        for (P, W, H, V, _vps, _dev), plan in self._plans.items():
+            plan.poll(self.lib, P, W, H, V, wait=wait)
+
     def forward_views(self, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                       viewmatrix, projmatrix, campos, tanfov, tanfovx, tanfovy, image_height, image_width, sh, degree,
-                      prefiltered, debug, views_per_set=1, raw_activations=False, binning_capacity=0):
+                      prefiltered, debug, views_per_set=1, raw_activations=False, binning_capacity=0, planned=False):
         """Batched entry: means3D [S,P,3] (other per-Gaussian inputs [S,P,...]); viewmatrix/projmatrix [V,4,4];
-        campos [V,3]; tanfov optional [V,2] tensor.  Returns (num_rendered, color[V,3,H,W], radii[V,P], geom, binning, img)."""
+        campos [V,3]; tanfov optional [V,2] tensor.  Returns (num_rendered, color[V,3,H,W], radii[V,P], geom, binning, img).
+        planned=True (the product's render path: Renderer.forward): no host synchronisation -- the binning capacity and the ordering
+        form come from the `_AsyncPlan` of this shape; the FIRST call of a shape runs the synchronous form to learn them.  The
+        returned `num_rendered` is then the capacity the binning buffer was carved with (what the backward takes)."""
         device = means3D.device
         S, P = int(means3D.shape[0]), int(means3D.shape[1])
         V = int(viewmatrix.shape[0])
@@ -108,15 +170,44 @@ class RasterBackend:
         a.radii = ctypes.c_void_p(radii.data_ptr())
         cbs = [self._allocator(holder, k, device) for k in ("geom", "img", "binning")]
         a.geom_alloc, a.img_alloc, a.binning_alloc = cbs
-        a.binning_capacity = int(binning_capacity)
         a.binning_form = int(os.environ.get("DGS_RASTER_BIN", "0") or 0)     # tests / measurement only (dgs_raster.h)
         a.exact_exp = int(self.exact_exp)
+        plan = self.plan_for(P, W, H, V, views_per_set, device) if planned else None
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if plan is not None:
+            if not capturing:
+                plan.poll(self.lib, P, W, H, V)
+            binning_capacity = plan.capacity          # 0 before the first call of the shape: the synchronous form, which reports N
+            if binning_capacity > 0 and a.binning_form == 0:
+                a.binning_form, a.longest_hint = plan.form, plan.longest
+            if capturing and binning_capacity <= 0:
+                raise RuntimeError("dgs rasterizer: the first render of a shape synchronises (it learns the binning capacity); run the step "
+                                   "once before capturing it in a graph")
+        a.binning_capacity = int(binning_capacity)
         ndev = None
         if binning_capacity > 0:
-            ndev = torch.zeros(2, dtype=torch.int32, device=device)
+            ndev = torch.empty(4, dtype=torch.int32, device=device)
             a.num_rendered_dev = ctypes.c_void_p(ndev.data_ptr())
         rc = self.lib.dgs_raster_forward(ctypes.byref(a), self._stream(device))
         self._check(rc)
+        if plan is not None:
+            if binning_capacity > 0:          # statistics -> pinned host words behind the call; looked at by a later call's poll()
+                plan.calls["async"] += 1
+                if device.type == "cuda":
+                    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+                    host.copy_(ndev, non_blocking=True)
+                    ev = None
+                    if not capturing:
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(device))
+                    plan.pending.append((ev, host, int(binning_capacity)))
+                    if capturing:
+                        plan.graph_stats = plan.pending.pop()[1]       # rewritten by every replay: the graph's owner polls it (dgs_amd/graph.py)
+                else:
+                    plan.pending.append((None, ndev.clone(), int(binning_capacity)))
+                return int(binning_capacity), out_color, radii, holder["geom"], holder["binning"], holder["img"]
+            plan.calls["sync"] += 1
+            plan.note(self.lib, int(a.num_rendered), int(a.longest_list), P, W, H, V)
         num_rendered = int(a.num_rendered) if binning_capacity <= 0 else ndev
         return num_rendered, out_color, radii, holder["geom"], holder["binning"], holder["img"]
 
@@ -231,7 +322,7 @@ class RasterBackend:
         degree = int(round(M ** 0.5)) - 1
         out = self.forward_views(bg, xyz, None, opacity.reshape(B, -1), scaling, rotation, 1.0, None, view, proj, campos,
                                  tanfov, 0.0, 0.0, height, width, features, degree, False, False, views_per_set=V,
-                                 raw_activations=True)
+                                 raw_activations=True, planned=True)
         return out[1].reshape(B, V, 3, int(height), int(width))
 
     # -- _C.mark_visible ------------------------------------------------------------------
@@ -274,7 +365,7 @@ class _RenderViews(torch.autograd.Function):
         xyz_, sh_, sc_, ro_, op_ = f(xyz), f(features), f(scaling), f(rotation), f(opacity).reshape(B, -1)
         n, color, radii, geom, binning, img = backend.forward_views(
             bg, xyz_, None, op_, sc_, ro_, 1.0, None, view, proj, campos, tanfov, 0.0, 0.0, height, width, sh_, degree,
-            False, False, views_per_set=V, raw_activations=True)
+            False, False, views_per_set=V, raw_activations=True, planned=True)
         ctx.backend, ctx.meta = backend, (B, V, int(height), int(width), degree, n)
         ctx.save_for_backward(bg, xyz_, sh_, sc_, ro_, op_, view, proj, campos, tanfov, radii, geom, binning, img)
         return color.reshape(B, V, 3, int(height), int(width))

@@ -1,0 +1,107 @@
+"""The product's render path without a host synchronisation (dgs_amd/raster.py `_AsyncPlan`, dgs_raster.h async mode), on the CPU
+emulation of the kernels: the reference blocks on `num_rendered` in every forward (rasterizer_impl.cu:281); here the first call of a
+shape learns the instance statistics and every later one runs from the plan -- same images and gradients bit for bit, a forced
+ordering form from the previous call's statistics, NaN + a deferred exception when a scene outgrows the capacity."""
+import numpy as np
+import pytest
+import torch
+
+from dgs_amd import cameras, synth
+from dgs_amd.raster import RasterBackend, _AsyncPlan, render_views_autograd
+from emu_util import emu_lib
+
+CPU = torch.device("cpu")
+
+
+def _scene(res, regime, seed, n_views=2):
+    sc = synth.gaussian_scene(res, regime=regime, seed=seed, activated=False)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32)
+    raw = [t(sc[k])[None] for k in ("xyz", "shs", "scales", "rotations", "opacities")]
+    c2w = t(cameras.ring_cameras(n_views, phase_deg=10))[None]
+    k = t(cameras.default_fxfycxcy(res)).expand(1, n_views, 4).contiguous()
+    return raw, c2w, k
+
+
+@pytest.mark.parametrize("regime", ["small", "init"])
+def test_planned_calls_equal_the_synchronous_call(regime):
+    res = 64
+    be = RasterBackend(lib=emu_lib())
+    raw, c2w, k = _scene(res, regime, 0)
+    first = be.render_views(*raw, res, res, c2w, k)                  # learns the statistics (synchronous form)
+    plan = be.plan_for(raw[0].shape[1], res, res, 2, 2, CPU)
+    assert plan.calls == {"sync": 1, "async": 0} and plan.capacity >= 2 * plan.seen_max > 0 and plan.form in (1, 2, 3)
+    assert plan.form == (2 if regime == "init" else 3)              # dense scenes scan, sparse ones sort their lists in LDS
+    second = be.render_views(*raw, res, res, c2w, k)                 # runs from the plan: nothing read back
+    third = be.render_views(*raw, res, res, c2w, k)
+    assert plan.calls == {"sync": 1, "async": 2}
+    assert torch.equal(first, second) and torch.equal(first, third)
+    be.check_async()
+
+
+def test_planned_autograd_equals_synchronous_gradients():
+    res = 64
+    raw, c2w, k = _scene(res, "trained", 3)
+    w = torch.randn(1, 2, 3, res, res, generator=torch.Generator().manual_seed(0)) / (3 * res * res)
+    grads = []
+    be = RasterBackend(lib=emu_lib())
+    for _ in range(2):                                               # call 1: synchronous form; call 2: from the plan
+        leaves = [x.clone().requires_grad_(True) for x in raw]
+        img = render_views_autograd(be, *leaves, res, res, c2w, k)
+        (img * w).sum().backward()
+        grads.append([x.grad.clone() for x in leaves] + [img.detach()])
+    assert be.plan_for(raw[0].shape[1], res, res, 2, 2, CPU).calls == {"sync": 1, "async": 1}
+    for a, b in zip(*grads):
+        # the backward sums a Gaussian's tiles with fp32 atomics; the emulator runs workgroups in a fixed order
+        assert torch.equal(a, b)
+
+
+def test_stale_form_is_still_correct_and_refreshed():
+    """The plan's form comes from the PREVIOUS call's statistics: a sparse scene rendered with the dense scene's form (and the other
+    way round) gives the same bits; the call after it has the right form again."""
+    res = 64
+    be = RasterBackend(lib=emu_lib())
+    dense, c2w, k = _scene(res, "init", 1)
+    sparse, _, _ = _scene(res, "small", 1)
+    ref_sparse = RasterBackend(lib=emu_lib()).render_views(*sparse, res, res, c2w, k)
+    ref_dense = RasterBackend(lib=emu_lib()).render_views(*dense, res, res, c2w, k)
+    plan = be.plan_for(dense[0].shape[1], res, res, 2, 2, CPU)
+    be.render_views(*dense, res, res, c2w, k)
+    assert plan.form == 2
+    assert torch.equal(be.render_views(*sparse, res, res, c2w, k), ref_sparse)      # scan form on a sparse scene
+    assert torch.equal(be.render_views(*sparse, res, res, c2w, k), ref_sparse)
+    assert plan.form == 3
+    assert torch.equal(be.render_views(*dense, res, res, c2w, k), ref_dense)        # LDS-sort hint on a dense scene (falls back on the device)
+    be.render_views(*dense, res, res, c2w, k)
+    assert plan.form == 2
+
+
+def test_overflow_is_nan_and_raises_on_the_next_call(monkeypatch):
+    res = 64
+    be = RasterBackend(lib=emu_lib())
+    sparse, c2w, k = _scene(res, "small", 2)
+    dense, _, _ = _scene(res, "init", 2)
+    monkeypatch.setattr(_AsyncPlan, "MARGIN", 1.0)
+    be.render_views(*sparse, res, res, c2w, k)
+    plan = be.plan_for(sparse[0].shape[1], res, res, 2, 2, CPU)
+    cap = plan.capacity
+    img = be.render_views(*dense, res, res, c2w, k)                  # far more instances than the sparse scene's capacity
+    assert torch.isnan(img).all()
+    with pytest.raises(RuntimeError, match="binning buffer"):
+        be.render_views(*dense, res, res, c2w, k)
+    assert plan.capacity > cap
+    ok = be.render_views(*dense, res, res, c2w, k)                   # the capacity has been raised: renders
+    assert torch.isfinite(ok).all()
+    assert torch.equal(ok, RasterBackend(lib=emu_lib()).render_views(*dense, res, res, c2w, k))
+
+
+def test_binning_form_helper_matches_the_kernels_choice():
+    lib = emu_lib()
+    P, W, H, V = 16386, 64, 64, 2
+    T = 16
+    tenth = -(-T * P * V // 10)
+    assert lib.dgs_raster_binning_form(0, tenth, 100, P, W, H, V) == 2                 # a tenth of all pairs: scan
+    assert lib.dgs_raster_binning_form(0, tenth - 1, 100, P, W, H, V) == 3             # below: lists, sorted in LDS ...
+    assert lib.dgs_raster_binning_form(0, 1000, 16385, P, W, H, V) == 1                # ... unless one does not fit
+    assert lib.dgs_raster_binning_form(3, 1000, 16385, P, W, H, V) == 1
+    assert lib.dgs_raster_binning_form(1, 10 ** 9, 5, P, W, H, V) == 1
+    assert lib.dgs_raster_binning_form(0, -1, 5, P, W, H, V) < 0
