@@ -184,10 +184,14 @@ def raster_roofline(dev, res, V, iters=10):
       waves issued (four 16-lane rows walk their cells' lists in lockstep)."""
     import numpy as np
     import torch
-    from dgs_amd import cameras, synth
-    from dgs_amd.raster import default_backend, render_views_autograd
+    from dgs_amd import _native, cameras, synth
+    from dgs_amd.raster import RasterBackend, default_backend, render_views_autograd
     be = default_backend()
-    out = {"views": V, "resolution": res, "exact_exp": bool(be.exact_exp),
+    # pair-evaluation counters (tile_stats) exist in the tools' build only (csrc/raster_common.h kRasterStats): ONE untimed forward +
+    # backward on it counts what the call walks -- the same kernels minus the counters are what is timed below
+    instr = os.path.join(ROOT, "open-diffusiongs_amd", "lib", "libdgs_hip_instr.so")
+    be_count = RasterBackend(lib=_native.open_library(instr), exact_exp=be.exact_exp) if os.path.exists(instr) else None
+    out = {"views": V, "resolution": res, "exact_exp": bool(be.exact_exp), "pair_counts_from": "lib/libdgs_hip_instr.so" if be_count else None,
            "hbm": {"bound": "hbm", "peak": PEAK_HBM / 1e9, "unit": "GB/s"}, "valu": {"bound": "valu", "peak": PEAK_FP32_VALU / 1e12, "unit": "TFLOP/s"}}
     tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
     traffic = pmc_traffic("raster")
@@ -201,16 +205,20 @@ def raster_roofline(dev, res, V, iters=10):
         P = int(leaves[0].shape[1])
         view, proj, campos, tanfov = be.cameras_from_c2w(c2w, k, res, res)
         det = [x.detach() for x in leaves]
-        fwd = lambda: be.forward_views(torch.ones(3, device=dev), det[0], None, det[4].reshape(1, -1), det[2], det[3], 1.0, None, view, proj,
-                                       campos, tanfov, 0.0, 0.0, res, res, det[1], 0, False, False, views_per_set=V, raw_activations=True)
-        N, _color, radii, geom, binning, img = fwd()
+        fwd_on = lambda b, planned: b.forward_views(torch.ones(3, device=dev), det[0], None, det[4].reshape(1, -1), det[2], det[3], 1.0, None, view, proj,
+                                                    campos, tanfov, 0.0, 0.0, res, res, det[1], 0, False, False, views_per_set=V, raw_activations=True,
+                                                    planned=planned)
+        fwd = lambda: fwd_on(be, True)          # the product's call: planned, no host synchronisation after the first call of the shape
+        bc = be_count or be
+        N, _color, radii, geom, binning, img = fwd_on(bc, False)
         N = int(N)
-        rd = lambda name, cnt: be.state_read(name, P, res, res, V, N, geom, binning, img, torch.int32, cnt).long()
-        be.backward_views(torch.ones(3, device=dev), det[0], radii, None, det[4].reshape(1, -1), det[2], det[3], 1.0, None, view, proj, campos,
+        rd = lambda name, cnt: bc.state_read(name, P, res, res, V, N, geom, binning, img, torch.int32, cnt).long()
+        bc.backward_views(torch.ones(3, device=dev), det[0], radii, None, det[4].reshape(1, -1), det[2], det[3], 1.0, None, view, proj, campos,
                           tanfov, 0.0, 0.0, w.reshape(V, 3, res, res), det[1], 0, geom, N, binning, img, False, views_per_set=V, raw_activations=True)
         sf, sb = rd("tile_stats", V * T * 4).reshape(V * T, 4).sum(0).tolist(), rd("tile_stats_bwd", V * T * 4).reshape(V * T, 4).sum(0).tolist()
         walked, listed = int(rd("tile_work", V * T).sum()), int(rd("list_len", V * T).sum())
-        scanned = sf[2]
+        scanned = int(rd("tile_scanned", V * T).sum())
+        counted = be_count is not None
         inst = 0 if scanned else N                                       # the list forms materialise and sort all N instances
         bytes_f = V * (104 * P + 20 * res * res) + 44 * walked + 4 * listed + 4 * scanned + 44 * inst
         bytes_b = V * (251 * P + 20 * res * res) + 44 * walked
@@ -222,9 +230,10 @@ def raster_roofline(dev, res, V, iters=10):
             render_views_autograd(be, *leaves, res, res, c2w, k).backward(w)
 
         rec = {"P": P, "N_per_view": N // V, "binning": "scan" if scanned else "list", "entries_walked_per_view": walked // V,
-               "entries_listed_per_view": listed // V, "ranks_scanned_per_view": scanned // V,
-               "pair_evals_forward": 16 * sf[0], "pair_evals_backward": 16 * sb[0],
-               "lane_use_forward": round(16 * sf[0] / max(64 * sf[1], 1), 3), "lane_use_backward": round(16 * sb[0] / max(64 * sb[1], 1), 3)}
+               "entries_listed_per_view": listed // V, "ranks_scanned_per_view": scanned // V}
+        if counted:
+            rec.update({"pair_evals_forward": 16 * sf[0], "pair_evals_backward": 16 * sb[0],
+                        "lane_use_forward": round(16 * sf[0] / max(64 * sf[1], 1), 3), "lane_use_backward": round(16 * sb[0] / max(64 * sb[1], 1), 3)})
         for name, fn, nbytes, flops in (("forward", fwd, bytes_f, flop_f), ("forward_backward", fb, bytes_f + bytes_b, flop_f + flop_b)):
             for _ in range(3):
                 fn()
@@ -236,9 +245,10 @@ def raster_roofline(dev, res, V, iters=10):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
             rec[name] = {"ms": round(ms, 4), "views_per_s": round(V / ms * 1e3, 1), "algorithmic_bytes": int(nbytes),
-                         "hbm_achieved": round(nbytes / ms / 1e6, 1), "hbm_frac": round(nbytes / (ms * 1e-3) / PEAK_HBM, 4),
-                         "valu_achieved": round(flops / (ms * 1e-3) / 1e12, 2), "valu_frac": round(flops / (ms * 1e-3) / PEAK_FP32_VALU, 4),
-                         "pair_evals_per_s": round((16 * sf[0] + (16 * sb[0] if name != "forward" else 0)) / (ms * 1e-3), 0)}
+                         "hbm_achieved": round(nbytes / ms / 1e6, 1), "hbm_frac": round(nbytes / (ms * 1e-3) / PEAK_HBM, 4)}
+            if counted:
+                rec[name].update({"valu_achieved": round(flops / (ms * 1e-3) / 1e12, 2), "valu_frac": round(flops / (ms * 1e-3) / PEAK_FP32_VALU, 4),
+                                  "pair_evals_per_s": round((16 * sf[0] + (16 * sb[0] if name != "forward" else 0)) / (ms * 1e-3), 0)})
             if traffic and traffic.get("raster", {}).get(regime, {}).get(name) is not None:
                 rec[name]["traffic"] = traffic["raster"][regime][name]
         out[regime] = rec
@@ -302,8 +312,9 @@ def train_bench(a, dev, rank, world, steps, warmup):
         opt = FusedAdamW(model, lr=1e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
     else:                           # torch's multi-tensor AdamW, then ~600 torch copies for the refresh
         opt = torch.optim.AdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05, fused=not DRY["on"])
+    # gradient_clip_val: 0.5 (configs/diffusionGS_rel.yaml:76-77): the reference's optimizer step is clip + AdamW
     tr = DataParallelTrainer(model, opt, bucket_bytes=(a.bucket_mb << 20) if a.bucket_mb > 0 else None, compress=a.grad_exchange if a.grad_exchange != "fp32" else None,
-                             force_collectives=a.force_dist)
+                             force_collectives=a.force_dist, max_grad_norm=a.clip if a.clip > 0 else None)
     batch, t = synth.make_batch(B, res, V=V, device=dev, seed=100 + rank, with_t=True)
     rc2w = torch.tensor(np.stack([cameras.ring_cameras(RV, phase_deg=5.0 + 7 * b) for b in range(B)])).to(dev)
     rk = torch.tensor(cameras.default_fxfycxcy(res)).expand(B, RV, 4).contiguous().to(dev)
@@ -313,17 +324,31 @@ def train_bench(a, dev, rank, world, steps, warmup):
     if DIST["on"]:
         torch.distributed.barrier()
     _sync()
+    if not DRY["on"]:
+        tr.reducer.timing = {}                      # events around finish(): GPU time the compute stream waits for collectives
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.step(batch, t, target, rc2w, rk)
+    t_enq = time.perf_counter()
     _sync()
+    t_local = time.perf_counter() - t0
     if DIST["on"]:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [t_local / steps * 1e3]
+    ranks_seen = 1
     if DIST["on"]:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tl = torch.tensor([t_local], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(tl) for _ in range(world)]
+        torch.distributed.all_gather(allt, tl)
+        rank_ms = [float(x.item()) / steps * 1e3 for x in allt]
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        torch.distributed.all_reduce(one)               # every rank adds 1: the number of ranks that really took part
+        ranks_seen = int(one.item())
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
+    exposed = tr.reducer.exposed_ms() if not DRY["on"] else None
     eng = model.engine()
     L = eng.num_tokens(V, res, res)
     ms = elapsed / steps * 1e3
@@ -335,12 +360,18 @@ def train_bench(a, dev, rank, world, steps, warmup):
             "steps": steps, "warmup": warmup, "loss": round(float(loss), 6), "recompute": recompute, "optimizer": a.optimizer,
             "dit_tflops_per_gpu": round(flops / (ms * 1e-3) / 1e12, 1), "frac_of_bf16_peak": round(flops / (ms * 1e-3) / PEAK_BF16_MFMA, 4),
             "saved_activation_gib": round(eng._train["saved"].numel() / 2 ** 30, 2),
+            "gradient_clip_val": a.clip if a.clip > 0 else None,
+            "grad_norm_before_clip": round(float(tr.last_grad_sumsq.sqrt()), 6) if tr.last_grad_sumsq is not None else None,
+            "host_enqueue_ms_per_step": round((t_enq - t0) / steps * 1e3, 2),
+            "per_rank_ms": {"min": round(min(rank_ms), 2), "max": round(max(rank_ms), 2)}, "ranks_seen": ranks_seen,
+            "parameter_broadcast_bytes": int(tr.broadcast_bytes),
             "allreduce": {"world": world, "collectives_issued": bool(tr.reducer.active), "buckets": len(tr.reducer.bounds), "exchange": a.grad_exchange,
+                          "exposed_ms_per_step": round(exposed, 3) if exposed is not None else None,
                           "bucket_mib": [round((e - b) * 4 / 2 ** 20, 1) for b, e in tr.reducer.bounds],
                           "launched_during_backward": sum(1 for _, tag in log if isinstance(tag, int)),
                           "last_bucket_mib": round((tr.reducer.bounds[-1][1] - tr.reducer.bounds[-1][0]) * 4 / 2 ** 20, 1),
                           "gradient_bytes": int(tr.fg.flat.numel() * 4)},
-            "note": "DataParallelTrainer.step end to end: fwd + raster + MSE + bwd (+ overlapped all-reduce) + AdamW + weight refresh (betas / eps of diffusionGS_rel.yaml)"}
+            "note": "DataParallelTrainer.step end to end: fwd + raster + MSE + bwd (+ overlapped all-reduce) + global-norm clip + AdamW + weight refresh (betas / eps / gradient_clip_val of diffusionGS_rel.yaml)"}
 
 
 def main():
@@ -356,6 +387,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--train-views", type=int, default=10)
     ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--clip", type=float, default=0.5, help="training step: global-norm gradient clip (gradient_clip_val of configs/diffusionGS_rel.yaml:76-77); 0 = none")
     ap.add_argument("--bucket-mb", type=int, default=0, help="all-reduce bucket size; 0 = 32 MiB per rank (dgs_amd/parallel.py)")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"], help="training step: dgs_amd.optim.FusedAdamW (one launch: AdamW + the "
                     "engine's weight copies) or torch.optim.AdamW + the torch-copy refresh")
@@ -364,6 +396,10 @@ def main():
                     "gloo and a tiny model (width 256, 2 blocks, 64^2) -- what tests/test_bench_dry_run.py uses to exercise the N > 1 path")
     ap.add_argument("--force-dist", action="store_true", help="create the process group and issue every barrier / all-reduce even for a world of one "
                     "(the one-GPU RCCL smoke run: same init, streams and collective calls as N > 1)")
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): the timed steps are replays of DGSDenoiser.forward captured as ONE hipGraph "
+                    "(dgs_amd/graph.py), except the steps that carry the roofline kernel's HIP events (every 4th), which are enqueued eagerly; 0: every step eager")
+    ap.add_argument("--preheat-s", type=float, default=2.0, help="seconds of the same step run (untimed) before the warm-up steps: a timed region of "
+                    "~0.15 s that starts from idle clocks measures the DVFS ramp, not the kernels (BENCH_r03 vs the builder's runs: -8 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
     ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the informational objects may take before the line is printed without them")
@@ -437,12 +473,52 @@ def main():
         if DIST["on"]:
             torch.distributed.barrier()
 
+    from dgs_amd.dit import DitOps
+    clock = {}
+    if not a.dry_run_cpu:
+        clock["at_start_mhz"] = round(DitOps().shader_clock_mhz(dev), 0)      # before any load: the idle / ramping state
+
+    use_graph = bool(a.graph) and not a.dry_run_cpu
+    graph_step = None
+    if use_graph:
+        # DGSDenoiser.forward as one captured graph: same kernels (the capture goes through the same C calls), one host call per step
+        gb = {k: batch[k] for k in ("image", "ray_o", "ray_d", "c2w", "fxfycxcy")}
+        graphed = model.graphed(gb, t)
+
+        def graph_step():
+            rendered, gaussians = graphed.replay()
+            return rendered, gaussians, 0
+
+    def timed_loop(n, fn):
+        """n steps of fn: (wall ms per step incl. the final synchronisation, host ms per step until the last step was ENQUEUED, GPU ms
+        per step between two events on the stream)."""
+        e0, e1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not a.dry_run_cpu else (None, None)
+        _sync()
+        w0 = time.perf_counter()
+        if e0 is not None:
+            e0.record()
+        for _ in range(n):
+            fn()
+        if e1 is not None:
+            e1.record()
+        w1 = time.perf_counter()
+        _sync()
+        w2 = time.perf_counter()
+        return (w2 - w0) / n * 1e3, (w1 - w0) / n * 1e3, (e0.elapsed_time(e1) / n if e0 is not None else None)
+
+    # pre-heat (untimed): the same step until the clocks have settled
+    if not a.dry_run_cpu and a.preheat_s > 0:
+        h0 = time.perf_counter()
+        while time.perf_counter() - h0 < a.preheat_s:
+            for _ in range(10):
+                (graph_step or step)()
+            _sync()
+        clock["after_preheat_mhz"] = round(DitOps().shader_clock_mhz(dev), 0)
+
     loop_ms = None
     if not a.no_extras:
         # Informational (SURVEY.md 8d): the reference's 30-step sampling loop end to end -- DGSDenoiser.forward + the device
-        # sampler step (dgs_amd/sampler.py) per iteration; one untimed loop, one timed.  Not part of `value`.  It runs BEFORE the
-        # warm-up + timed region: behind tens of seconds of host-side set-up the GPU starts from its idle clocks, and a timed region
-        # of 0.15 s that begins 20 ms later measured 3-4 % slower per step than this loop's steps (which also carry the sampler).
+        # sampler step (dgs_amd/sampler.py) per iteration; one untimed loop, one timed.  Not part of `value`.
         from dgs_amd import sampler as sm
         diffusion = sm.create_diffusion("30", device=dev)
         loop_batch = dict(batch)
@@ -452,30 +528,60 @@ def main():
             _sync()
             l0 = time.perf_counter()
             with torch.no_grad():
-                diffusion.p_sample_loop(model, loop_batch)
+                diffusion.p_sample_loop(model, loop_batch, use_graph=use_graph)
             _sync()
             if timed:
                 loop_ms = (time.perf_counter() - l0) * 1e3
 
+    variants = None
+    if not a.no_extras and not a.dry_run_cpu:
+        # the step both ways, 20 steps each, untimed region: what the graph buys on this box, and how far the host runs ahead
+        variants = {}
+        for name, fn in (("eager", step), ("graph", graph_step)):
+            if fn is None:
+                continue
+            for _ in range(3):
+                fn()
+            wall, host, gpu = timed_loop(20, fn)
+            variants[name] = {"ms_per_step": round(wall, 3), "host_enqueue_ms_per_step": round(host, 3), "gpu_ms_per_step": round(gpu, 3)}
+
+    run_step = graph_step or step
     for _ in range(a.warmup):
-        step()
+        run_step()
     nl = MODEL_CFG["num_layers"]
     per_step = {"attention": nl, "gemm_qkv": nl, "gemm_gate_residual": 2 * nl, "gemm_fc1_gelu": nl, "layernorm": 2 * nl}[a.roofline_kernel]
     # HIP events around every launch of the roofline kernel on every 4th step of the timed region: an event record is a packet
-    # of its own between two kernels (~2 us), 48 of them per step were 1.5 % of the step they measure
+    # of its own between two kernels (~2 us), 48 of them per step were 1.5 % of the step they measure.  Those steps are enqueued
+    # eagerly (events cannot be re-armed inside a captured graph); the others are graph replays
     prof_steps = [] if a.dry_run_cpu else [i for i in range(a.steps) if i % 4 == 0]
     events = {i: [torch.cuda.Event(enable_timing=True) for _ in range(2 * per_step)] for i in prof_steps}
     for ev in events.values():  # materialise the HIP event handles before the timed region
         for e in ev:
             e.record()
+    g0, g1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if not a.dry_run_cpu else (None, None)
     barrier(); _sync()
     t0 = time.perf_counter()
+    if g0 is not None:
+        g0.record()
     for i in range(a.steps):
-        rendered, gaussians, _pc = step(prof=(PROF_KINDS[a.roofline_kernel], events[i]) if i in events else None)
+        if i in events:
+            rendered, gaussians, _pc = step(prof=(PROF_KINDS[a.roofline_kernel], events[i]))
+        else:
+            rendered, gaussians, _pc = run_step()
+    if g1 is not None:
+        g1.record()
+    t_enq = time.perf_counter()
     _sync(); barrier()
     elapsed = time.perf_counter() - t0
+    local_ms = elapsed / a.steps * 1e3
+    if not a.dry_run_cpu:
+        clock["after_timed_region_mhz"] = round(DitOps().shader_clock_mhz(dev), 0)
+    rank_ms = [local_ms]
     if DIST["on"]:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        torch.distributed.all_gather(allt, tt)
+        rank_ms = [float(x.item()) / a.steps * 1e3 for x in allt]
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -503,8 +609,19 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_MFMA, 4), "traffic": tr_bytes,
                          "launches_timed": len(kern_ms), "avg_launch_us": round(avg_s * 1e6, 2),
                          "step_frac_of_peak": round(dit_flops(L, MODEL_CFG["width"], nl) * B / (ms * 1e-3) / PEAK_BF16_MFMA, 4)},
+            # what the timed region looked like from the host and from the device (rank 0): `host_enqueue_ms` = until the last step
+            # was enqueued (the host runs ahead of the device by ms_per_step - this), `gpu_ms` = between two events on the stream,
+            # `shader_clock_mhz` = s_memtime / s_memrealtime of a probe kernel at three moments, `per_rank_ms` = every rank's own time
+            "timed_region": {"graph_replays": sum(1 for i in range(a.steps) if i not in events) if use_graph else 0,
+                             "eager_steps_with_events": len(events), "preheat_s": a.preheat_s if not a.dry_run_cpu else 0.0,
+                             "host_enqueue_ms_per_step": round((t_enq - t0) / a.steps * 1e3, 3),
+                             "gpu_ms_per_step": round(g0.elapsed_time(g1) / a.steps, 3) if g0 is not None else None,
+                             "shader_clock_mhz": clock, "per_rank_ms": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
+                             "ranks_seen": len(rank_ms)},
             **dry_note,
         }
+        if variants:
+            out["step_variants"] = variants
         if loop_ms is not None:
             out["sampling_loop_30_steps"] = {"ms_per_loop": round(loop_ms, 2), "renders_per_s": round(B * V * 30 / (loop_ms * 1e-3), 1),
                                              "note": "per GPU; informational, not part of value"}

@@ -344,6 +344,11 @@ int dgs_dit_run_blocks(const DgsDitModel* m, const DgsDitRunBlocksArgs* a, dgs_s
  * unnoticed.  tests/ call it in front of the kernels under test. */
 int dgs_debug_poison_lds(dgs_stream_t stream);
 
+/* Measurement hook (bench.py's `clock` object): 256 workgroups run a dependent fp32 chain for `microseconds` of the constant 100 MHz
+ * clock (s_memrealtime); out (device int64[3]) receives {shader-clock cycles (s_memtime) workgroup 0 counted, 100 MHz ticks it
+ * counted, 0}: effective shader clock = out[0] / out[1] x 100 MHz at the moment the stream reaches the probe. */
+int dgs_debug_clock_probe(int64_t* out, int32_t microseconds, dgs_stream_t stream);
+
 int32_t dgs_dit_lpad(int32_t L);   /* padded rows per sample */
 size_t dgs_dit_workspace_bytes(const DgsDitModel* m, int32_t B, int32_t V, int32_t H, int32_t W);
 int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a, dgs_stream_t stream);

@@ -50,6 +50,12 @@ typedef struct DgsAdamWArgs {
     float lr, beta1, beta2, eps, weight_decay;
     float bias_correction1;        /* 1 - beta1 ^ step  (computed by the caller, in double)          */
     float bias_correction2_sqrt;   /* sqrt(1 - beta2 ^ step)                                        */
+    /* Global-norm gradient clip folded into the step (the reference trains with `gradient_clip_val: 0.5`,
+     * diffusionGS/configs/diffusionGS_rel.yaml:76-77 = Lightning's norm clip = torch.nn.utils.clip_grad_norm_): every gradient is
+     * read as g * min(1, max_grad_norm / (sqrt(*grad_sumsq) + 1e-6)); the gradient tensors themselves are not rewritten.
+     * max_grad_norm <= 0: no clip (grad_sumsq is not read). */
+    const float* grad_sumsq;       /* DEVICE float[1]: sum of squares of ALL gradients (dgs_sumsq_partials + dgs_sumsq_finish) */
+    float max_grad_norm;
 } DgsAdamWArgs;
 
 /* HOST: fills `first_tile` of every entry of a host-side table and returns the launch's tile count (< 0: invalid table, e.g. a
@@ -58,6 +64,13 @@ int32_t dgs_adamw_plan(DgsAdamWTensor* host_tensors, int32_t n_tensors);
 
 /* One launch: AdamW step on every tensor of the table + its copies. */
 int dgs_adamw_step(const DgsAdamWArgs* args, dgs_stream_t stream);
+
+/* Sum of squares of a gradient buffer, in two deterministic stages: dgs_sumsq_partials WRITES one partial per 65,536 consecutive
+ * elements of x[0, n) into partials[0, dgs_sumsq_count(n)) (x 16-byte aligned) -- callable per bucket of a larger buffer, as each
+ * bucket becomes final, in any order; dgs_sumsq_finish adds `count` partials in index order into total[0].  Same bits every run. */
+int32_t dgs_sumsq_count(int64_t n);
+int dgs_sumsq_partials(const float* x, int64_t n, float* partials, dgs_stream_t stream);
+int dgs_sumsq_finish(const float* partials, int32_t count, float* total, dgs_stream_t stream);
 
 #ifdef __cplusplus
 }

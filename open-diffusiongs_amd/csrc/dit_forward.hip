@@ -62,6 +62,23 @@ __global__ __launch_bounds__(256) void poison_lds_kernel(int words) {
     if (w[(threadIdx.x * 97) % words] != 0x7FC07FC0u) __builtin_trap();      // keeps the stores
 }
 
+// dgs_debug_clock_probe: every workgroup runs a dependent fp32 chain until `ticks` ticks of the constant 100 MHz clock have passed;
+// workgroup 0 reports how many shader-clock cycles that took.
+__global__ __launch_bounds__(256) void clock_probe_kernel(long long* out, int ticks) {
+    const long long w0 = wall_stamp(), c0 = cycle_stamp();
+    float x = (float)threadIdx.x;
+    long long w1 = w0;
+    while (w1 - w0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) x = __builtin_fmaf(x, 1.0000001f, 0.5f);
+        w1 = wall_stamp();
+        if (w1 == w0) break;                                           // emulator: no clocks
+    }
+    const long long c1 = cycle_stamp();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+    if (x == 123.456f) out[2] = 1;                                     // keeps the chain
+}
+
 static int token_count(const DgsDitModel* m, int V, int H, int W) { return m->n_gaussians + V * (H / m->patch) * (W / m->patch); }
 
 }  // namespace dgs
@@ -143,6 +160,12 @@ extern "C" int dgs_debug_poison_lds(dgs_stream_t stream) {
     static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(dgs::poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess;
     if (!ok) return DGS_ERR_DEVICE;
     hipLaunchKernelGGL(dgs::poison_lds_kernel, dim3(2048), dim3(256), kBytes, static_cast<hipStream_t>(stream), kBytes / 4);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+extern "C" int dgs_debug_clock_probe(int64_t* out, int32_t microseconds, dgs_stream_t stream) {
+    if (!out || microseconds <= 0 || microseconds > 100000) return DGS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(dgs::clock_probe_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<long long*>(out), microseconds * 100);
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }
 

@@ -10,7 +10,56 @@
 
 namespace dgs {
 
-struct AdamWHyper { float decay, one_minus_b1, b2, one_minus_b2, inv_bc2_sqrt, eps, step_size; };
+struct AdamWHyper { float decay, one_minus_b1, b2, one_minus_b2, inv_bc2_sqrt, eps, step_size; const float* grad_sumsq; float max_grad_norm; };
+
+// ---- gradient norm for the global-norm clip (Lightning `gradient_clip_val`, torch.nn.utils.clip_grad_norm_) ----
+// One partial per kSumsqChunk consecutive elements, WRITTEN (not accumulated) by the workgroup that owns the chunk: lanes sum their
+// elements in a fixed order, the wave and the workgroup combine in a fixed order -- the same bits every run, whatever the launch
+// order of the buckets' calls.  dgs_sumsq_finish adds the partials in index order (fp64) into one fp32 word the AdamW launch reads.
+constexpr int kSumsqChunk = 65536;
+
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ x, long long n, float* __restrict__ partials) {
+    __shared__ float s_w[4];
+    const long long base = (long long)blockIdx.x * kSumsqChunk;
+    const int tid = threadIdx.x;
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int j = 0; j < kSumsqChunk / 1024; ++j) {
+        const long long i = base + (long long)j * 1024 + tid * 4;
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (i + e < n) acc += x[i + e] * x[i + e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((tid & 63) == 0) s_w[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partials, int count, float* __restrict__ total) {
+    __shared__ double s_t[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) acc += (double)partials[i];
+    s_t[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_t[threadIdx.x] += s_t[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = (float)s_t[0];
+}
+
+// the clip coefficient of torch.nn.utils.clip_grad_norm_: max_norm / (total_norm + 1e-6), clamped to 1
+__device__ __forceinline__ float clip_coef(const AdamWHyper& h) {
+    if (h.grad_sumsq == nullptr) return 1.0f;
+    const float c = h.max_grad_norm / (sqrtf(h.grad_sumsq[0]) + 1.0e-6f);
+    return c < 1.0f ? c : 1.0f;
+}
 
 __device__ __forceinline__ float adamw_one(float& p, float g, float& m, float& v, const AdamWHyper& h) {
     p = p * h.decay;
@@ -32,6 +81,7 @@ __global__ __launch_bounds__(256) void adamw_refresh_kernel(const DgsAdamWTensor
     }
     const DgsAdamWTensor t = tab[lo];
     const int local = bid - t.first_tile;
+    const float gc = clip_coef(h);                                 // 1 without a clip: g * 1.0f is g
     if (t.copy_t == nullptr) {
         // ---- flat tile: elements [local * 4096, +4096) ----
         const long long n = t.rows * t.cols, base = (long long)local * 4096;
@@ -44,8 +94,8 @@ __global__ __launch_bounds__(256) void adamw_refresh_kernel(const DgsAdamWTensor
                 float4 p = *reinterpret_cast<const float4*>(t.p + i);
                 const float4 g = *reinterpret_cast<const float4*>(t.g + i);
                 float4 m = *reinterpret_cast<const float4*>(t.m + i), v = *reinterpret_cast<const float4*>(t.v + i);
-                adamw_one(p.x, g.x, m.x, v.x, h); adamw_one(p.y, g.y, m.y, v.y, h);
-                adamw_one(p.z, g.z, m.z, v.z, h); adamw_one(p.w, g.w, m.w, v.w, h);
+                adamw_one(p.x, g.x * gc, m.x, v.x, h); adamw_one(p.y, g.y * gc, m.y, v.y, h);
+                adamw_one(p.z, g.z * gc, m.z, v.z, h); adamw_one(p.w, g.w * gc, m.w, v.w, h);
                 *reinterpret_cast<float4*>(t.p + i) = p;
                 *reinterpret_cast<float4*>(t.m + i) = m;
                 *reinterpret_cast<float4*>(t.v + i) = v;
@@ -55,7 +105,7 @@ __global__ __launch_bounds__(256) void adamw_refresh_kernel(const DgsAdamWTensor
             } else {
                 for (int e = 0; e < 4 && i + e < n; ++e) {
                     float p = t.p[i + e], m = t.m[i + e], v = t.v[i + e];
-                    adamw_one(p, t.g[i + e], m, v, h);
+                    adamw_one(p, t.g[i + e] * gc, m, v, h);
                     t.p[i + e] = p; t.m[i + e] = m; t.v[i + e] = v;
                     if (t.copy_kind == DGS_OPTIM_COPY_BF16) static_cast<bf16_t*>(t.copy)[i + e] = (bf16_t)(pack_bf2(p, 0.0f) & 0xffffu);
                     else if (t.copy_kind == DGS_OPTIM_COPY_F32) static_cast<float*>(t.copy)[i + e] = p;
@@ -75,8 +125,8 @@ __global__ __launch_bounds__(256) void adamw_refresh_kernel(const DgsAdamWTensor
         float4 p = *reinterpret_cast<const float4*>(t.p + i);
         const float4 g = *reinterpret_cast<const float4*>(t.g + i);
         float4 m = *reinterpret_cast<const float4*>(t.m + i), v = *reinterpret_cast<const float4*>(t.v + i);
-        adamw_one(p.x, g.x, m.x, v.x, h); adamw_one(p.y, g.y, m.y, v.y, h);
-        adamw_one(p.z, g.z, m.z, v.z, h); adamw_one(p.w, g.w, m.w, v.w, h);
+        adamw_one(p.x, g.x * gc, m.x, v.x, h); adamw_one(p.y, g.y * gc, m.y, v.y, h);
+        adamw_one(p.z, g.z * gc, m.z, v.z, h); adamw_one(p.w, g.w * gc, m.w, v.w, h);
         *reinterpret_cast<float4*>(t.p + i) = p;
         *reinterpret_cast<float4*>(t.m + i) = m;
         *reinterpret_cast<float4*>(t.v + i) = v;
@@ -105,6 +155,11 @@ extern "C" int32_t dgs_adamw_plan(DgsAdamWTensor* tab, int32_t n) {
     for (int i = 0; i < n; ++i) {
         DgsAdamWTensor& t = tab[i];
         if (!t.p || !t.g || !t.m || !t.v || t.rows <= 0 || t.cols <= 0) return -1;
+        // the kernel moves 16 bytes per lane (8 for a bf16 copy): a tensor that is a view at an odd element offset has no such alignment
+        const auto misaligned = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) != 0; };
+        if (misaligned(t.p, 16) || misaligned(t.g, 16) || misaligned(t.m, 16) || misaligned(t.v, 16)) return -1;
+        if (t.copy && misaligned(t.copy, t.copy_kind == DGS_OPTIM_COPY_BF16 ? 8 : 16)) return -1;
+        if (t.copy_t && misaligned(t.copy_t, 16)) return -1;
         if (t.copy_kind < DGS_OPTIM_COPY_NONE || t.copy_kind > DGS_OPTIM_COPY_F32 || (t.copy_kind != DGS_OPTIM_COPY_NONE && !t.copy)) return -1;
         t.first_tile = (int32_t)tiles;
         if (t.copy_t) {
@@ -129,6 +184,23 @@ extern "C" int dgs_adamw_step(const DgsAdamWArgs* a, dgs_stream_t stream) {
     h.inv_bc2_sqrt = 1.0f / a->bias_correction2_sqrt;
     h.eps = a->eps;
     h.step_size = a->lr / a->bias_correction1;
+    h.grad_sumsq = a->max_grad_norm > 0.0f ? a->grad_sumsq : nullptr;
+    h.max_grad_norm = a->max_grad_norm;
+    if (a->max_grad_norm > 0.0f && !a->grad_sumsq) return DGS_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(dgs::adamw_refresh_kernel, dim3(a->n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), a->tensors, a->n_tensors, h);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+extern "C" int32_t dgs_sumsq_count(int64_t n) { return n <= 0 ? 0 : (int32_t)((n + dgs::kSumsqChunk - 1) / dgs::kSumsqChunk); }
+
+extern "C" int dgs_sumsq_partials(const float* x, int64_t n, float* partials, dgs_stream_t stream) {
+    if (!x || !partials || n <= 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return DGS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(dgs::sumsq_partials_kernel, dim3(dgs_sumsq_count(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long long)n, partials);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+extern "C" int dgs_sumsq_finish(const float* partials, int32_t count, float* total, dgs_stream_t stream) {
+    if (!partials || !total || count <= 0) return DGS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(dgs::sumsq_finish_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials, count, total);
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }

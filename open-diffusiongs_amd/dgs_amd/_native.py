@@ -264,7 +264,7 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
-               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds",
+               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds", "dgs_debug_clock_probe",
                "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes",
                "dgs_dit_workspace_bytes_for_tokens"]
 
@@ -297,6 +297,8 @@ def _declare_dit(L):
     L.dgs_dit_saved_bytes.argtypes = L.dgs_dit_saved_bytes.argtypes + [ctypes.c_int32]
     L.dgs_debug_poison_lds.restype = ctypes.c_int
     L.dgs_debug_poison_lds.argtypes = [ctypes.c_void_p]
+    L.dgs_debug_clock_probe.restype = ctypes.c_int
+    L.dgs_debug_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
     L.dgs_dit_run_blocks.restype = ctypes.c_int
     L.dgs_dit_run_blocks.argtypes = [ctypes.POINTER(DgsDitModel), ctypes.POINTER(DgsDitRunBlocksArgs), ctypes.c_void_p]
     L.dgs_dit_forward_train.restype = ctypes.c_int
@@ -373,12 +375,13 @@ class DgsAdamWTensor(ctypes.Structure):
 class DgsAdamWArgs(ctypes.Structure):
     _fields_ = [("tensors", ctypes.c_void_p), ("n_tensors", ctypes.c_int32), ("n_tiles", ctypes.c_int32), ("lr", ctypes.c_float),
                 ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float),
-                ("bias_correction1", ctypes.c_float), ("bias_correction2_sqrt", ctypes.c_float)]
+                ("bias_correction1", ctypes.c_float), ("bias_correction2_sqrt", ctypes.c_float),
+                ("grad_sumsq", ctypes.c_void_p), ("max_grad_norm", ctypes.c_float)]
 
 
 OPTIM_COPY_NONE, OPTIM_COPY_BF16, OPTIM_COPY_F32 = 0, 1, 2
 # every symbol include/dgs_optim.h declares (checked by tests/test_abi.py)
-OPTIM_SYMBOLS = ["dgs_adamw_plan", "dgs_adamw_step"]
+OPTIM_SYMBOLS = ["dgs_adamw_plan", "dgs_adamw_step", "dgs_sumsq_count", "dgs_sumsq_partials", "dgs_sumsq_finish"]
 
 
 def _declare_optim(L):
@@ -386,6 +389,12 @@ def _declare_optim(L):
     L.dgs_adamw_plan.argtypes = [ctypes.POINTER(DgsAdamWTensor), ctypes.c_int32]
     L.dgs_adamw_step.restype = ctypes.c_int
     L.dgs_adamw_step.argtypes = [ctypes.POINTER(DgsAdamWArgs), ctypes.c_void_p]
+    L.dgs_sumsq_count.restype = ctypes.c_int32
+    L.dgs_sumsq_count.argtypes = [ctypes.c_int64]
+    L.dgs_sumsq_partials.restype = ctypes.c_int
+    L.dgs_sumsq_partials.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    L.dgs_sumsq_finish.restype = ctypes.c_int
+    L.dgs_sumsq_finish.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     return L
 
 

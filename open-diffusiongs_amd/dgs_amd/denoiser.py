@@ -109,9 +109,12 @@ class Renderer(nn.Module):
         self.scaling_modifier = None
         self.gaussians_model = GaussianModel(config.gaussians_sh_degree, self.scaling_modifier)
 
+    def backend(self):
+        return self._backend if self._backend is not None else default_backend()
+
     def forward(self, xyz, features, scaling, rotation, opacity, height, width, C2W, fxfycxcy, deferred=True):
         f = lambda t: t.float()      # custom_fwd(cast_inputs=float32), renderer.py:34
-        backend = self._backend if self._backend is not None else default_backend()
+        backend = self.backend()
         if torch.is_grad_enabled() and any(t.requires_grad for t in (xyz, features, scaling, rotation, opacity)):
             from .raster import render_views_autograd      # training: DeferredGaussianRender's role, gs_core.py:949-1064
             return render_views_autograd(backend, f(xyz), f(features), f(scaling), f(rotation), f(opacity), height, width,
@@ -274,6 +277,7 @@ class DGSDenoiser(nn.Module):
         self._block_hook = None          # set by a data-parallel trainer: called per finished gradient group during backward
         self._grads_in_place = False     # set by a trainer that made the .grad tensors views of the flat gradient buffer
         self.activation_budget_bytes = None   # None: 60 % of the device's free memory when the first training forward runs
+        self._graphs = {}                # shape key -> dgs_amd.graph.GraphedForward
         if c.pretrained_model_name_or_path:
             self._load_pretrained(c.pretrained_model_name_or_path)
 
@@ -352,6 +356,23 @@ class DGSDenoiser(nn.Module):
         rendered = self.render_gaussians(params, input_batch["c2w"], input_batch["fxfycxcy"], input_batch["image"].shape[3],
                                          input_batch["image"].shape[4])
         return rendered, self.prepare_to_save(params)
+
+    def graphed(self, input_batch, timesteps):
+        """`forward` at these shapes as one captured hipGraph (dgs_amd/graph.py): built on first use per shape (two eager warm-up
+        calls + the capture), then `graphed(batch, t)(batch, t)` copies the inputs into the graph's tensors and replays.  Inference
+        only; outputs are the graph's own tensors (overwritten by the next replay)."""
+        from .graph import GraphedForward
+        key = GraphedForward.shape_key(input_batch, timesteps)
+        g = self._graphs.get(key)
+        if g is None:
+            self.engine()                    # weights up to date before anything is captured
+            g = self._graphs[key] = GraphedForward(self, input_batch, timesteps)
+        else:
+            self.engine()                    # parameter versions moved (optimizer step, load_state_dict): copies refreshed in place
+        return g
+
+    def drop_graphs(self):
+        self._graphs = {}
 
     def prepare_to_save(self, gaussians_parameters):   # denoiser.py:290-304
         out = []

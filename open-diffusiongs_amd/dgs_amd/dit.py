@@ -39,6 +39,14 @@ class DitOps:
         LDS-DMA cannot pass on the previous launch's data."""
         self._check(self.lib.dgs_debug_poison_lds(ctypes.c_void_p(torch.cuda.current_stream(torch.device(device)).cuda_stream)))
 
+    def shader_clock_mhz(self, device="cuda:0", microseconds=20):
+        """Measurement hook (dgs_debug_clock_probe): the effective shader clock where the stream stands, from the two hardware
+        counters (s_memtime: shader clock, s_memrealtime: constant 100 MHz).  Synchronises."""
+        out = torch.zeros(3, dtype=torch.int64, device=device)
+        self._check(self.lib.dgs_debug_clock_probe(_p(out), int(microseconds), _stream(torch.device(device))))
+        c, w, _ = out.tolist()
+        return 100.0 * c / w if w > 0 else 0.0
+
     def gemm(self, A, W, bias=None, epilogue=_native.EPI_BF16, out=None, gate=None, rows_per_batch=0, vt=None, valid_rows=0,
              resid=None, aux=None, shape=None, k_per_batch=0, a_batch_stride=0, w_batch_stride=0, lda=None, ldw=None, algo=0,
              q_scale=0.0, splitk=False):

@@ -47,15 +47,35 @@ class FusedAdamW(torch.optim.Optimizer):
             super().zero_grad(set_to_none=set_to_none)
 
     def state_dict(self):
-        """The moments live in two flat buffers (the layout follows model.named_parameters()), not in per-parameter `state` entries."""
-        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
-                    param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
+        """torch's layout -- {'state': {param index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [indices]}]} --
+        so that generic tooling (Lightning checkpoints, optimizer-state inspection) reads it like torch.optim.AdamW's.  The moments
+        themselves live in two flat buffers (the layout follows model.named_parameters()); the entries are copies of their slices."""
+        state = {}
+        for i, ((_, p), off) in enumerate(zip(self._named, self._offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[off:off + n].reshape(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].reshape(p.shape).clone()}
+        groups = [dict({k: v for k, v in g.items() if k != "params"}, params=list(range(len(self._named)))) for g in self.param_groups]
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if "state" not in sd:             # round 3's private layout: flat buffers
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        else:
+            steps = set()
+            for i, ((_, p), off) in enumerate(zip(self._named, self._offsets)):
+                e = sd["state"].get(i, sd["state"].get(str(i)))
+                if e is None:
+                    continue
+                n = p.numel()
+                self.exp_avg[off:off + n].copy_(e["exp_avg"].reshape(-1)); self.exp_avg_sq[off:off + n].copy_(e["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(e["step"])))
+            if len(steps) > 1:
+                raise ValueError("FusedAdamW: one step count for all parameters (per-parameter counts differ in this state dict)")
+            self.step_count = steps.pop() if steps else 0
         for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+            g.update({k: v for k, v in s.items() if k != "params"})
 
     # -- the table of tensors (rebuilt when a pointer changed: new .grad tensors, a rebuilt engine) --------
     def _plan(self):
@@ -94,8 +114,19 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table = (raw, len(entries), n_tiles, ptrs)
         return self._table
 
-    @torch.no_grad()
-    def step(self):
+    def step(self, closure=None, grad_sumsq=None, max_grad_norm=None):
+        """closure: torch.optim.Optimizer's protocol (Lightning's loop and precision plugins call `optimizer.step(closure=...)`): run
+        under grad mode first, its loss returned.  grad_sumsq (device float[1]) + max_grad_norm: the global-norm clip folded into the
+        launch (dgs_optim.h; DataParallelTrainer computes the sum of squares bucket by bucket as the gradients become final)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        with torch.no_grad():
+            self._step(grad_sumsq, max_grad_norm)
+        return loss
+
+    def _step(self, grad_sumsq, max_grad_norm):
         g = self.param_groups[0]
         raw, n, n_tiles, _ = self._plan()
         self.step_count += 1
@@ -105,6 +136,11 @@ class FusedAdamW(torch.optim.Optimizer):
         a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = g["lr"], b1, b2, g["eps"], g["weight_decay"]
         a.bias_correction1 = 1.0 - b1 ** self.step_count
         a.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** self.step_count)
+        if max_grad_norm is not None and max_grad_norm > 0:
+            if grad_sumsq is None:
+                raise ValueError("FusedAdamW.step: max_grad_norm needs grad_sumsq (the device word holding the gradients' sum of squares)")
+            self._keep_sumsq = grad_sumsq
+            a.grad_sumsq, a.max_grad_norm = grad_sumsq.data_ptr(), float(max_grad_norm)
         rc = self.lib.dgs_adamw_step(ctypes.byref(a), _stream(self.exp_avg.device))
         if rc != 0:
             raise RuntimeError(f"dgs_adamw_step: {_native.status_string(self.lib, rc)} (status {rc})")

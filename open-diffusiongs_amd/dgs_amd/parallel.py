@@ -43,6 +43,63 @@ def init_distributed(device=None, backend=None, force=False):
     return rank, world, local
 
 
+def broadcast_parameters(module, src=0, group=None, bucket_bytes=256 << 20):
+    """DDP's init-time parameter (and buffer) broadcast (torch DistributedDataParallel._sync_module_states; Lightning wraps the
+    model in DDP before the first step): every rank leaves with rank `src`'s values, whatever it was constructed or loaded with.
+    Few large messages (xGMI: large messages fill all links): tensors are packed into flat buckets of `bucket_bytes`."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    sent, i = 0, 0
+    while i < len(tensors):
+        dtype, dev = tensors[i].dtype, tensors[i].device
+        chunk, nbytes = [], 0
+        while i < len(tensors) and tensors[i].dtype == dtype and tensors[i].device == dev and (not chunk or nbytes + tensors[i].numel() * tensors[i].element_size() <= bucket_bytes):
+            chunk.append(tensors[i]); nbytes += tensors[i].numel() * tensors[i].element_size(); i += 1
+        flat = torch.cat([t.reshape(-1) for t in chunk])
+        dist.broadcast(flat, src=src, group=group)
+        o = 0
+        for t in chunk:
+            t.copy_(flat[o:o + t.numel()].view_as(t)); o += t.numel()
+        sent += nbytes
+    return sent
+
+
+class GradNorm:
+    """Sum of squares of the flat gradient buffer for the global-norm clip (torch.nn.utils.clip_grad_norm_ / Lightning
+    `gradient_clip_val`, configs/diffusionGS_rel.yaml:76-77), computed bucket by bucket as each bucket becomes final (behind its
+    all-reduce, on the reducer's side stream: hidden behind the backward) -- not as another pass over 1.84 GB at the end.  Two
+    deterministic stages (include/dgs_optim.h): one partial per 65,536 elements, written; `total()` adds them in index order."""
+    CHUNK = 65536
+
+    def __init__(self, flat, lib):
+        import ctypes
+        self.flat, self.lib, self._c = flat, lib, ctypes
+        self.count = int(lib.dgs_sumsq_count(flat.numel()))
+        self.partials = torch.zeros(self.count, dtype=torch.float32, device=flat.device)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=flat.device)
+
+    def _stream(self):
+        c = self._c
+        return c.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream) if self.flat.is_cuda else None
+
+    def add(self, a, b):
+        """flat[a:b] is final: (re)write its partials.  a is a multiple of 65,536 (every bucket boundary but the buffer's end is)."""
+        assert a % self.CHUNK == 0 and b > a
+        c = self._c
+        rc = self.lib.dgs_sumsq_partials(c.c_void_p(self.flat.data_ptr() + 4 * a), b - a, c.c_void_p(self.partials.data_ptr() + 4 * (a // self.CHUNK)), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"dgs_sumsq_partials: status {rc}")
+
+    def total(self):
+        """-> device float[1]: sum of squares over the whole buffer (every bucket added since the last call)."""
+        c = self._c
+        rc = self.lib.dgs_sumsq_finish(c.c_void_p(self.partials.data_ptr()), self.count, c.c_void_p(self.sumsq.data_ptr()), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"dgs_sumsq_finish: status {rc}")
+        return self.sumsq
+
+
 class FlatGrads:
     """One contiguous fp32 gradient buffer with a named view per parameter, laid out in BACKWARD completion order
     (heads first, block L-1 ... block 0, embedding last) so that finished prefixes are contiguous buckets."""
@@ -88,8 +145,12 @@ def bucket_bounds(n, per, tail=()):
 class BucketedAllReduce:
     """Average `flat` over the ranks in large buckets, each enqueued as soon as the caller says its bytes are final."""
 
-    def __init__(self, flat, bucket_bytes=None, group=None, compress=None, force_collectives=False):
+    def __init__(self, flat, bucket_bytes=None, group=None, compress=None, force_collectives=False, norm=None):
         self.flat, self.group = flat, group
+        self.norm = norm              # GradNorm: partial sums of squares of each bucket as it becomes final (global-norm clip)
+        self.side = torch.cuda.Stream(flat.device) if flat.is_cuda else None      # behind-the-collective work: bf16 copy-back, norm partials
+        self._deferred = []           # CPU tensors (gloo tests): the same work, done in finish() behind each wait
+        self.timing = None            # set to {} by a caller that wants `exposed_ms` (GPU time finish() waited for collectives)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # a world of one normally skips the collectives; force_collectives issues them anyway (a sum over one rank: the RCCL
         # launch path, its stream ordering against the backward and the bf16 round trip run for real on a single GPU)
@@ -101,7 +162,12 @@ class BucketedAllReduce:
         # the buffer is in backward-completion order: the LAST bucket's collective starts when the backward ends and nothing
         # overlaps it -- keep it (and its predecessors, which have little backward left to hide behind) small
         tail = [min(per, (m << 20) // es) for m in (128, 64, 32, 32)] if bucket_bytes > (32 << 20) else []
+        if norm is not None:          # bucket starts on partial boundaries
+            per = max(GradNorm.CHUNK, per // GradNorm.CHUNK * GradNorm.CHUNK)
+            tail = [max(GradNorm.CHUNK, t // GradNorm.CHUNK * GradNorm.CHUNK) for t in tail]
         self.bounds = bucket_bounds(flat.numel(), per, tail)
+        if norm is not None and any(a % GradNorm.CHUNK for a, _ in self.bounds):      # tiny buffers with an odd tail: one bucket
+            self.bounds = [(0, flat.numel())]
         assert self.bounds[0][0] == 0 and self.bounds[-1][1] == flat.numel() and all(a[1] == b[0] for a, b in zip(self.bounds, self.bounds[1:]))
         if compress not in (None, "bf16"):
             raise ValueError("compress: None or 'bf16'")
@@ -120,26 +186,71 @@ class BucketedAllReduce:
             self.launch_log = []
         while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][1] <= end_element:
             a, b = self.bounds[self.next_bucket]
+            work, half = None, None
             if self.active:
                 if self.probe is not None:
                     assert self.world == 1, "the launch-time probe is a one-rank diagnostic"
-                    self.works.append((dist.all_gather_into_tensor(self.probe[a:b], self.flat[a:b], group=self.group, async_op=True), None, a, b))
+                    self.works.append(dist.all_gather_into_tensor(self.probe[a:b], self.flat[a:b], group=self.group, async_op=True))
                 if self.compress == "bf16":
                     half = self.flat[a:b].to(torch.bfloat16)            # on the compute stream, behind the kernels that fill [a, b)
-                    self.works.append((dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group, async_op=True), half, a, b))
+                    work = dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 else:
-                    self.works.append((dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, a, b))
+                    work = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._after_bucket(work, half, a, b)
             self.launch_log.append((self.next_bucket, tag))
             self.next_bucket += 1
+
+    def _after_bucket(self, work, half, a, b):
+        """What follows a bucket's collective -- the bf16 copy-back (the half-size copy is released right there) and the bucket's
+        norm partials -- on a SIDE stream that waits for the collective: the compute stream (the backward of the earlier blocks)
+        is not held up.  finish() joins the side stream."""
+        if work is None and half is None and self.norm is None:
+            return
+        if self.side is None:
+            self._deferred.append((work, half, a, b))
+            return
+        cur = torch.cuda.current_stream(self.flat.device)
+        self.side.wait_stream(cur)                                     # a world of one: the bucket is final behind the kernels enqueued so far
+        with torch.cuda.stream(self.side):
+            if work is not None:
+                work.wait()                                            # stream-side wait: the host does not block
+            if half is not None:
+                self.flat[a:b].copy_(half)
+                half.record_stream(self.side)
+            if self.norm is not None:
+                self.norm.add(a, b)
 
     def finish(self, average=True):
         """Launch what is left, wait for everything; average=True turns sums into means (a caller that already folded
         1 / world into its loss scale passes False and saves the pass over the buffer).  Resets for the next step."""
         self.ready_up_to(self.flat.numel(), tag="finish")
-        for w, half, a, b in self.works:
+        e0 = e1 = None
+        if self.timing is not None and self.side is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                                                # behind the last kernel of the backward
+        for w in self.works:                                           # the one-rank probe's gathers
             w.wait()
+        for work, half, a, b in self._deferred:
+            if work is not None:
+                work.wait()
             if half is not None:
                 self.flat[a:b].copy_(half)
+            if self.norm is not None:
+                self.norm.add(a, b)
+        if self.side is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        if e1 is not None:
+            e1.record()                                                # [e0, e1] on the compute stream = time it idled for collectives
+            self.timing.setdefault("events", []).append((e0, e1))
         if self.world > 1 and average:
             self.flat.mul_(1.0 / self.world)
-        self.works, self.next_bucket = [], 0
+        self.works, self._deferred, self.next_bucket = [], [], 0
+
+    def exposed_ms(self):
+        """Mean GPU time per step the compute stream waited in finish() for collectives (and the work behind them) that the backward
+        did not hide.  Needs `timing = {}` before the steps; synchronises."""
+        ev = (self.timing or {}).get("events", [])
+        if not ev:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)

@@ -123,17 +123,29 @@ class SpacedDiffusion:
         return out
 
     @torch.no_grad()
-    def p_sample_loop(self, model, input_batch, clip_denoised=True, keep_last_only=True):
+    def p_sample_loop(self, model, input_batch, clip_denoised=True, keep_last_only=True, use_graph=None):
         """p_sample_loop / p_sample_loop_progressive (gaussian_diffusion.py:520-603) with the model protocol of
         p_mean_variance (:348-352): batch["image"] = cat(image[:, :1], image_noisy); render, gaussians = model(batch, t).
-        Returns the last step's dict {"sample", "pred_xstart", "input_batch", "denoiser_output_dict"}."""
+        Returns the last step's dict {"sample", "pred_xstart", "input_batch", "denoiser_output_dict"}.
+        use_graph (default: on a GPU, when the model offers `graphed`): the 30 forwards of the loop are replays of one captured
+        hipGraph (dgs_amd/graph.py) -- same kernels, same results; the outputs of the last step are cloned out of the graph's tensors."""
         x = input_batch["image_noisy"]
         B = x.shape[0]
         final = None
+        if use_graph is None:
+            use_graph = x.is_cuda and hasattr(model, "graphed") and keep_last_only
         for i in reversed(range(self.num_timesteps)):
             t = torch.full((B,), i, dtype=torch.int64, device=x.device)
             input_batch["image"] = torch.cat([input_batch["image"][:, 0:1], input_batch["image_noisy"]], dim=1)
-            render, gaussians = model(input_batch, self.model_timesteps(t))
+            if use_graph:
+                mt = self.model_timesteps(t)
+                render, gaussians = model.graphed(input_batch, mt)(input_batch, mt)
+                if i == 0:
+                    render = render.clone()
+                    for gm in gaussians:          # GaussianModel containers over the graph's output tensors
+                        gm.set_data(gm._xyz.clone(), gm.get_features.clone(), gm._scaling.clone(), gm._rotation.clone(), gm._opacity.clone())
+            else:
+                render, gaussians = model(input_batch, self.model_timesteps(t))
             pred = torch.empty_like(x) if (i == 0 or not keep_last_only) else None
             x = self.step(render.float(), input_batch["image_noisy"].float(), t, clip_denoised=clip_denoised, pred_xstart=pred)
             input_batch["image_noisy"] = x

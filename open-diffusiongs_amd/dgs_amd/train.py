@@ -19,7 +19,7 @@ collective reduces them in place and nothing is copied in or out.  Averaging is 
 import torch
 
 from . import losses
-from .parallel import BucketedAllReduce
+from .parallel import BucketedAllReduce, GradNorm, broadcast_parameters
 
 
 class DataParallelTrainer:
@@ -27,14 +27,28 @@ class DataParallelTrainer:
     the backward writes there in place and reports finished groups to the bucketed all-reduce.  `close()` (or leaving the `with`
     block) hands the model back: a later plain `loss.backward()` then returns gradients through autograd again."""
 
-    def __init__(self, model, optimizer, bucket_bytes=None, accumulate_grad_batches=1, group=None, compress=None, force_collectives=False):
+    def __init__(self, model, optimizer, bucket_bytes=None, accumulate_grad_batches=1, group=None, compress=None, force_collectives=False,
+                 max_grad_norm=None, broadcast_from=0):
+        """max_grad_norm: global-norm gradient clip (Lightning `gradient_clip_val`; the reference trains with 0.5,
+        configs/diffusionGS_rel.yaml:76-77) -- the norm's partial sums are taken bucket by bucket behind each bucket's all-reduce and
+        the scale is applied inside the optimizer launch (FusedAdamW) or as one in-place scale of the flat buffer (any other optimizer).
+        broadcast_from: the rank whose parameters every rank starts from (DDP's init-time broadcast); None skips it."""
         self.model, self.opt = model, optimizer
         self.accumulate = int(accumulate_grad_batches)
+        self.max_grad_norm = float(max_grad_norm) if max_grad_norm else None
+        self.broadcast_bytes = 0
+        if broadcast_from is not None:
+            self.broadcast_bytes = broadcast_parameters(model, src=broadcast_from, group=group)
+            if self.broadcast_bytes:
+                model.refresh_engine_weights()
         eng = model.engine()
         self.fg = eng._train_state()["fg"]
         if next(model.parameters()).device != self.fg.flat.device:
             raise RuntimeError("DataParallelTrainer: the module's parameters must live on the engine's device (model.to(device))")
-        self.reducer = BucketedAllReduce(self.fg.flat, bucket_bytes, group=group, compress=compress, force_collectives=force_collectives)
+        self.norm = GradNorm(self.fg.flat, getattr(model, "_lib", None) or eng.lib) if self.max_grad_norm else None
+        self.last_grad_sumsq = None      # device float[1] of the last step (its square root is the norm BEFORE clipping, as clip_grad_norm_ returns)
+        self.reducer = BucketedAllReduce(self.fg.flat, bucket_bytes, group=group, compress=compress, force_collectives=force_collectives,
+                                         norm=self.norm)
         self.world = self.reducer.world
         self._accum = torch.zeros_like(self.fg.flat) if self.accumulate > 1 else None
         self._summed_to = 0
@@ -117,7 +131,16 @@ class DataParallelTrainer:
                 else:
                     self._accum += self.fg.flat
         self.reducer.finish(average=False)
-        self.opt.step()
+        if self.norm is not None:
+            self.last_grad_sumsq = self.norm.total()
+            if getattr(self.opt, "refreshes_engine", False):          # FusedAdamW: the scale rides in the update launch
+                self.opt.step(grad_sumsq=self.last_grad_sumsq, max_grad_norm=self.max_grad_norm)
+            else:                                                      # torch.nn.utils.clip_grad_norm_ on the flat buffer (the .grad views)
+                coef = (self.max_grad_norm / (self.last_grad_sumsq.sqrt() + 1e-6)).clamp(max=1.0)
+                self.fg.flat.mul_(coef)
+                self.opt.step()
+        else:
+            self.opt.step()
         # weights changed: the engine's bf16 / transposed copies have to follow.  dgs_amd.optim.FusedAdamW writes them in the same launch
         # as the update; for any other optimizer they are refreshed EXPLICITLY -- DGSDenoiser.engine() only notices parameter version
         # counters, and an optimizer is free not to move them (foreach / fused implementations, `p.data` updates, EMA swaps)

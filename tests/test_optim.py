@@ -37,9 +37,16 @@ def _case(dev, lib, cfg, steps=3):
         for sc in scheds:
             sc.step()
         assert abs(topt.param_groups[0]["lr"] - fopt.param_groups[0]["lr"]) < 1e-12 and fopt.param_groups[0]["lr"] < 3e-3
-    sd = fopt.state_dict()                               # round trip of the checkpoint form
+    sd = fopt.state_dict()                               # round trip of the checkpoint form: torch's layout (state / param_groups)
+    tsd = topt.state_dict()
+    assert set(sd) == set(tsd) == {"state", "param_groups"} and sd["param_groups"][0]["betas"] == (0.9, 0.99)
+    assert sd["param_groups"][0]["params"] == tsd["param_groups"][0]["params"] and set(sd["state"]) == set(tsd["state"])
+    assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == steps
+    assert sd["state"][3]["exp_avg"].shape == tsd["state"][3]["exp_avg"].shape
+    before = (fopt.exp_avg.clone(), fopt.exp_avg_sq.clone())
+    fopt.exp_avg.zero_(); fopt.exp_avg_sq.zero_(); fopt.step_count = 0
     fopt.load_state_dict(sd)
-    assert sd["step"] == steps and sd["param_groups"][0]["betas"] == (0.9, 0.99)
+    assert fopt.step_count == steps and torch.equal(fopt.exp_avg, before[0]) and torch.equal(fopt.exp_avg_sq, before[1])
     return m, eng, names, ref, topt, fopt
 
 
@@ -84,7 +91,81 @@ def test_plan_rejects_bad_tables():
     assert lib.dgs_adamw_plan((_native.DgsAdamWTensor * 1)(e), 1) < 0
     e.copy_t = None
     assert lib.dgs_adamw_plan((_native.DgsAdamWTensor * 1)(e), 1) == 2          # flat: ceil(6144 / 4096) tiles
+    assert x.data_ptr() % 16 == 0
+    for field in ("p", "g", "m", "v"):                    # a view at an odd element offset: no 16-byte alignment for the float4 accesses
+        setattr(e, field, x.data_ptr() + 4)
+        assert lib.dgs_adamw_plan((_native.DgsAdamWTensor * 1)(e), 1) < 0, field
+        setattr(e, field, x.data_ptr())
+    e.copy, e.copy_kind = x.data_ptr() + 4, _native.OPTIM_COPY_BF16              # bf16 copy: 8-byte stores
+    assert lib.dgs_adamw_plan((_native.DgsAdamWTensor * 1)(e), 1) < 0
+    e.copy = x.data_ptr() + 8
+    assert lib.dgs_adamw_plan((_native.DgsAdamWTensor * 1)(e), 1) == 2
     assert lib.dgs_adamw_step(None, None) != 0
+
+
+def test_step_takes_a_closure_like_torch_optimizers():
+    """Lightning's loop calls optimizer.step(closure=...): the closure runs first (under grad mode), its loss is returned."""
+    from emu_util import emu_lib
+    dev = torch.device("cpu")
+    m = dn.DGSDenoiser(CFG, device=dev, lib=emu_lib())
+    m.reset_parameters(seed=2)
+    opt = FusedAdamW(m, lr=1e-3)
+    calls = []
+
+    def closure():
+        assert torch.is_grad_enabled()
+        for p in m.parameters():
+            p.grad = torch.ones_like(p)
+        calls.append(1)
+        return torch.tensor(3.5)
+
+    w0 = m.transformer[0].attn.qkv.weight.detach().clone()
+    assert float(opt.step(closure=closure)) == 3.5 and calls == [1]
+    assert not torch.equal(w0, m.transformer[0].attn.qkv.weight.detach())
+
+
+def test_sumsq_and_clip_match_clip_grad_norm_on_the_emulator():
+    """dgs_sumsq_partials / dgs_sumsq_finish + the clip folded into dgs_adamw_step == torch.nn.utils.clip_grad_norm_(params, 0.5) followed by
+    torch.optim.AdamW (Lightning's `gradient_clip_val: 0.5`, configs/diffusionGS_rel.yaml:76-77), for a norm above AND below the bound."""
+    from emu_util import emu_lib
+    from dgs_amd.parallel import GradNorm
+    lib = emu_lib()
+    dev = torch.device("cpu")
+    for scale, clipped in ((1.0, True), (1e-6, False)):
+        m = dn.DGSDenoiser(CFG, device=dev, lib=lib)
+        m.reset_parameters(seed=4)
+        eng = m.engine()
+        fg = eng._train_state()["fg"]
+        ref = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+        g = torch.Generator().manual_seed(1)
+        fg.flat.copy_(torch.randn(fg.flat.shape, generator=g) * scale)
+        views = eng.grad_views()
+        for (n, p), r in zip(m.named_parameters(), ref):
+            p.grad = views[n].reshape(p.shape)
+            r.grad = p.grad.clone()
+        # padding between the slices of the flat buffer is not a gradient: it stays zero in the trainer (never written)
+        mask = torch.zeros_like(fg.flat, dtype=torch.bool)
+        for n in fg.names:
+            off, numel, _ = fg.offsets[n]
+            mask[off:off + numel] = True
+        fg.flat.mul_(mask)
+        norm = GradNorm(fg.flat, lib)
+        half = (fg.flat.numel() // 2) // GradNorm.CHUNK * GradNorm.CHUNK
+        norm.add(half, fg.flat.numel())                   # buckets in any order
+        norm.add(0, half)
+        total = norm.total()
+        want = torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        assert abs(float(total.sqrt()) - float(want)) <= 1e-5 * float(want)
+        assert (float(want) > 0.5) == clipped
+        topt = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05, foreach=False, fused=False)
+        fopt = FusedAdamW(m, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+        topt.step()
+        fopt.step(grad_sumsq=total, max_grad_norm=0.5)
+        for (n, p), r in zip(m.named_parameters(), ref):
+            err = float((p.detach() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-12))
+            assert err < 2e-6, (n, err, clipped)
+    with pytest.raises(ValueError):
+        fopt.step(max_grad_norm=0.5)
 
 
 @pytest.mark.gpu

@@ -227,3 +227,73 @@ def test_fused_adamw_keeps_the_replicas_identical():
     # ~lr where the gradient is tiny: compare against the size of the update, not of the parameter
     assert np.abs(res[0][1] - single[1]).max() <= 2.5e-2
     assert np.abs(res[0][1] - single[1]).mean() <= 2e-3
+
+
+def _clip_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "..", "open-diffusiongs_amd"), os.path.join(here, "..")):
+        sys.path.insert(0, os.path.abspath(p))
+    from dgs_amd import denoiser as dn
+    from dgs_amd.optim import FusedAdamW
+    from dgs_amd.parallel import init_distributed
+    from dgs_amd.train import DataParallelTrainer
+    from dit_util import synth_inputs
+    from emu_util import emu_lib
+    from oracle import dit_oracle as D
+    init_distributed(backend="gloo")
+    cfg = D.Cfg(width=256, num_layers=1)
+    m = dn.DGSDenoiser(dict(width=256, in_channels=9, patch_size=8, num_layers=1), device="cpu", lib=emu_lib())
+    m.reset_parameters(seed=1 + 10 * rank)           # the ranks START from different weights: the trainer's broadcast makes them rank 0's
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 2, 2, 16, seed=9)
+    sl = slice(rank, rank + 1)
+    batch = dict(image=images[sl], ray_o=ray_o[sl], ray_d=ray_d[sl], c2w=c2w[sl], fxfycxcy=k[sl])
+    target = torch.rand(2, 2, 3, 16, 16, generator=torch.Generator().manual_seed(3))[sl]
+    res = {}
+    for kind in ("fused", "sgd"):
+        m.reset_parameters(seed=1 + 10 * rank)
+        m.refresh_engine_weights()
+        opt = FusedAdamW(m, lr=1e-2, betas=(0.9, 0.99), weight_decay=0.0) if kind == "fused" else torch.optim.SGD(m.parameters(), lr=1.0)
+        with DataParallelTrainer(m, opt, bucket_bytes=1 << 20, max_grad_norm=1e-3, compress="bf16" if kind == "sgd" else None) as tr:
+            start = torch.cat([q.detach().reshape(-1) for q in m.parameters()]).clone()
+            assert tr.broadcast_bytes > 0
+            tr.step(batch, t[sl], target)
+            norm = float(tr.last_grad_sumsq.sqrt())
+            grads = torch.cat([q.grad.reshape(-1) for q in m.parameters()]).clone()
+        end = torch.cat([q.detach().reshape(-1) for q in m.parameters()])
+        res[kind] = (start.numpy(), end.numpy(), norm, grads.numpy())
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_global_norm_clip_two_ranks():
+    """DDP's init-time parameter broadcast (ranks constructed with different seeds leave the trainer's constructor with rank 0's values)
+    and the global-norm clip (Lightning gradient_clip_val, configs/diffusionGS_rel.yaml:76-77): the norm is the norm of the AVERAGED
+    gradient, identical on both ranks; with SGD(lr = 1) the step is exactly -clip_coef * gradient, so its length is max_grad_norm."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_clip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=400) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    r0, r1 = res[0][1], res[1][1]
+    for kind in ("fused", "sgd"):
+        np.testing.assert_array_equal(r0[kind][0], r1[kind][0])          # same start: rank 1 took rank 0's parameters
+        np.testing.assert_array_equal(r0[kind][1], r1[kind][1])          # same end: identical averaged gradients, identical norm, deterministic update
+        assert r0[kind][2] == r1[kind][2] and r0[kind][2] > 1e-3          # the norm before clipping, above the bound
+    g = r0["fused"][3].astype(np.float64)                                # FusedAdamW reads g * coef: the gradient tensors keep their values
+    assert abs(np.sqrt((g * g).sum()) - r0["fused"][2]) <= 1e-5 * r0["fused"][2]
+    start, end, norm, g = r0["sgd"]                                      # any other optimizer: the flat buffer (= the .grad views) is
+    g = g.astype(np.float64)                                             # scaled in place, like torch.nn.utils.clip_grad_norm_
+    assert abs(np.sqrt((g * g).sum()) - 1e-3 * norm / (norm + 1e-6)) <= 1e-8
+    step = (end.astype(np.float64) - start)
+    np.testing.assert_allclose(step, -g, atol=1.2e-7)                    # SGD(lr = 1): the step IS the clipped gradient (to the fp32 rounding of p - g, p <= 1)
