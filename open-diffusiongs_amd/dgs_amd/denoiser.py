@@ -11,7 +11,6 @@ load_state_dict); compute is ONE C call into libdgs_hip.so for the DiT (dgs_amd.
 for all (sample, view) rasterizations (dgs_amd.raster).  There is no PyTorch fallback.
 """
 import copy
-import warnings
 import math
 from dataclasses import dataclass, fields
 
@@ -169,23 +168,24 @@ def _aligned_to_points(d_aligned, ps):
     return x.reshape(B, V * H * W, C)
 
 
-class _PendingGuard:
-    """Marks the engine's single activation arena as in use between a training forward and its backward."""
+class _ArenaGuard:
+    """Holds one of the engine's activation arenas between a training forward and its backward; dies with the autograd graph."""
 
-    def __init__(self, eng):
-        self.eng = eng
-        eng.pending_backward = id(self)      # a token, not a reference: the guard must die with the autograd graph
+    def __init__(self, eng, arena):
+        self.eng, self.arena = eng, arena
 
     def release(self):
-        if self.eng.pending_backward == id(self):
-            self.eng.pending_backward = False
+        if self.arena is not None:
+            self.eng.release_arena(self.arena)
+            self.arena = None
 
     __del__ = release
 
 
 class _DitFunction(torch.autograd.Function):
-    """image_to_gaussians under torch autograd: forward = dgs_dit_forward_train (activations saved in the engine's arena;
+    """image_to_gaussians under torch autograd: forward = dgs_dit_forward_train (activations saved in one of the engine's arenas;
     per-block recompute when the module's checkpoint policy says so, denoiser.py:348-354), backward = dgs_dit_backward.
+    Several forwards may be pending (each holds its own arena until its backward has run or its graph is dropped).
     The parameter gradients land in the engine's flat fp32 buffer (dgs_amd.parallel.FlatGrads); autograd receives COPIES
     of its slices in named_parameters() order (so .grad accumulation over several backward passes is correct), unless a
     trainer owns the buffer (module._grads_in_place: the .grad tensors ARE views of it and nothing is copied)."""
@@ -193,12 +193,9 @@ class _DitFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, names, images, ray_o, ray_d, t, *params):
         eng = module.engine()
-        if eng.pending_backward:
-            raise RuntimeError("DGSDenoiser: a second training forward before the backward of the first one would overwrite "
-                               "its saved activations (one activation arena per engine); call backward() first")
         B, V, _, H, W = images.shape
-        out, aligned = eng.forward_train(images, ray_o, ray_d, t, recompute=module.recompute_policy(B, V, H, W))
-        ctx.guard = _PendingGuard(eng)     # released by backward, or when the graph (and with it ctx) is dropped unused
+        out, aligned = eng.forward_train(images, ray_o, ray_d, t, recompute=module.recompute_policy(B, V, H, W), keep_busy=True)
+        ctx.guard = _ArenaGuard(eng, eng._train["current"])     # released by backward, or when the graph (and with it ctx) is dropped unused
         ctx.engine, ctx.module, ctx.names, ctx.param_shapes = eng, module, names, [tuple(p.shape) for p in params]
         return out["xyz"], out["features"], out["scaling"], out["rotation"], out["opacity"], aligned
 
@@ -206,7 +203,10 @@ class _DitFunction(torch.autograd.Function):
     def backward(ctx, dxyz, dfeat, dscal, drot, dopa, daligned):
         eng, module = ctx.engine, ctx.module
         z = lambda g, like: g if g is not None else torch.zeros(like, device=eng.device)
-        B, V, H, W = eng._train["shape"]
+        arena = ctx.guard.arena
+        if arena is None:
+            raise RuntimeError("DGSDenoiser: backward through the same forward twice (its activations were released by the first)")
+        B, V, H, W = arena["shape"]
         P = eng.ng + V * H * W
         dxyz = z(dxyz, (B, P, 3))
         if daligned is not None:      # img_aligned_xyz is a rearranged view of xyz[:, n_gaussians:] (denoiser.py:401-409)
@@ -214,7 +214,7 @@ class _DitFunction(torch.autograd.Function):
             dxyz[:, eng.ng:] += _aligned_to_points(daligned.to(dxyz.dtype), eng.patch)
         try:
             eng.backward(dxyz, z(dfeat, (B, P, 1, 3)), z(dscal, (B, P, 3)), z(drot, (B, P, 4)), z(dopa, (B, P, 1)),
-                         block_hook=module._block_hook)
+                         block_hook=module._block_hook, arena=arena)
         finally:
             ctx.guard.release()
         if module._grads_in_place:
@@ -299,10 +299,17 @@ class DGSDenoiser(nn.Module):
                     p.zero_()
 
     def _load_pretrained(self, path):   # denoiser.py:256-282
-        ckpt = torch.load(path, map_location="cpu")
+        """The checkpoint layouts the reference reads: {'model': {'denoiser.<key>': ...}} (its live branch, :259-267), a Lightning
+        checkpoint {'state_dict': {'shape_model.<key>': ...}} (what its training writes and pipline_obj.py:66-70 loads at the system
+        level; the branch is commented out at :269-280) and a flat state dict (optionally 'shape_model.'-prefixed); always strict."""
+        ckpt = torch.load(path, map_location="cpu") if not isinstance(path, dict) else path
         if "model" in ckpt:
             ckpt = {k.replace("denoiser.", ""): v for k, v in ckpt["model"].items()
                     if k.startswith("denoiser.") and not k.startswith("denoiser.loss_computer")}
+        elif "state_dict" in ckpt:
+            ckpt = {k[len("shape_model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("shape_model.")}
+        elif any(k.startswith("shape_model.") for k in ckpt):
+            ckpt = {k[len("shape_model."):]: v for k, v in ckpt.items() if k.startswith("shape_model.")}
         self.load_state_dict(ckpt, strict=True)
 
     # -- engine -------------------------------------------------------------------------------------------
@@ -383,25 +390,25 @@ class DGSDenoiser(nn.Module):
                                      for k in ("xyz", "features", "scaling", "rotation", "opacity"))))
         return out
 
+    MAX_DIFFERENTIABLE_BATCH = 4      # samples per dgs_dit_forward_train / dgs_dit_backward call (include/dgs_dit.h)
+
     def image_to_gaussians(self, images, ray_o, ray_d, t, training=False):   # denoiser.py:306-416
         ng = self.cfg.n_gaussians
         differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())   # in train AND eval mode
-        if differentiable and not self.training and (images.shape[0] > 4 or (self._engine is not None and self._engine.pending_backward)):
-            # an eval-mode caller that did not wrap inference in no_grad(): the differentiable path takes at most 4 samples per call
-            # and owns ONE activation arena -- serve it from the inference engine (the reference's inference entry points all run
-            # under no_grad, so nobody differentiates this result)
-            if not getattr(self, "_warned_eval_grad", False):
-                warnings.warn("DGSDenoiser (eval mode, grad enabled): batch > 4 or a pending backward -- running the inference engine, "
-                              "the outputs of this call are not differentiable; wrap inference in torch.no_grad()")
-                self._warned_eval_grad = True
-            differentiable = False
         if differentiable:
-            if images.shape[0] > 4:
-                raise RuntimeError("DGSDenoiser: the differentiable path (forward that saves activations + backward) handles at most 4 "
-                                   "samples per call; use gradient accumulation (DataParallelTrainer accumulate_grad_batches) or a "
-                                   "smaller per-GPU batch")
+            B, mb = images.shape[0], self.MAX_DIFFERENTIABLE_BATCH
+            if B > mb and self._grads_in_place:
+                # a trainer made the .grad tensors views of the flat buffer, which every backward call OVERWRITES: it splits its
+                # batch itself (DataParallelTrainer: micro-batches of <= 4 inside one optimizer step)
+                raise RuntimeError(f"DGSDenoiser: under a trainer with in-place gradients one call takes at most {mb} samples "
+                                   "(DataParallelTrainer.step splits larger per-rank batches into micro-batches itself)")
             names = [n for n, _ in self.named_parameters()]
-            outs = _DitFunction.apply(self, names, images, ray_o, ray_d, t, *[p for _, p in self.named_parameters()])
+            plist = [p for _, p in self.named_parameters()]
+            parts = []
+            for b0 in range(0, B, mb):      # a call takes <= 4 samples: larger batches run as chunks, each with its own activation arena,
+                sl = slice(b0, b0 + mb)     # and autograd sums their parameter gradients
+                parts.append(_DitFunction.apply(self, names, images[sl], ray_o[sl], ray_d[sl], t[sl], *plist))
+            outs = parts[0] if len(parts) == 1 else tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(6))
             xyz, aligned = outs[0], outs[5]
             if self.cfg.clip_xyz and training:        # denoiser.py:397-398 (no shipped caller passes training=True)
                 xyz = torch.cat((xyz[:, :ng], xyz[:, ng:].clamp(-1.0, 1.0)), dim=1)

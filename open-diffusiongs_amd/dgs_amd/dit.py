@@ -188,7 +188,6 @@ class DitEngine:
         self.model = m
         self._ws, self._ws_shape = None, None
         self._train = None           # lazily built: transposed weights, gradient buffer, arenas
-        self.pending_backward = False
         self.refresh_weights(sd)
 
     # state-dict key of every engine tensor (adaLN tensors are stacked: see refresh_weights)
@@ -348,7 +347,9 @@ class DitEngine:
         for name in ("t_w0", "t_b0", "t_w1", "t_b1", "tok_w", "pos_emb", "in_ln_w", "head_ada_w", "head_ada_b", "up_ln_w", "up_w", "dec_ln_w", "dec_w"):
             setattr(gr, name, fg.view(name).data_ptr())
         gr.layer = ctypes.cast(lgr, ctypes.POINTER(DgsDitLayerGrads))
-        self._train = dict(tkeep=tkeep, layersT=layersT, mt=mt, fg=fg, lgr=lgr, gr=gr, saved=None, bws=None, shape=None)
+        # activation arenas: one per training forward whose backward has not run yet (`forward_train` takes a free one of the
+        # right shape or allocates one); `saved` / `shape` / `recompute` / `ray_d` mirror the most recently used arena
+        self._train = dict(tkeep=tkeep, layersT=layersT, mt=mt, fg=fg, lgr=lgr, gr=gr, saved=None, bws=None, shape=None, arenas=[])
         return self._train
 
     def grad_views(self):
@@ -376,20 +377,54 @@ class DitEngine:
         """Bytes of the activation arena of one training forward (save-all, or the reference's per-block recompute mode)."""
         return int(self.lib.dgs_dit_saved_bytes(ctypes.byref(self.model), B, V, H, W, int(bool(recompute))))
 
-    def forward_train(self, images, ray_o, ray_d, t, recompute=False):
+    def _arena(self, B, V, H, W, recompute, keep_busy):
+        """A free activation arena for this shape (allocated on first need).  keep_busy=False (the engine-level API: forward_train
+        then backward, one pass at a time) reuses THE arena of the shape; True (autograd: several forwards may be pending) marks it
+        busy until `release_arena`."""
+        tr = self._train_state()
+        for ar in tr["arenas"]:
+            if ar["shape"] == (B, V, H, W) and ar["recompute"] == recompute and not ar["busy"]:
+                break
+        else:
+            if not keep_busy:                # shape changed: drop the idle arenas of other shapes before allocating
+                tr["arenas"][:] = [x for x in tr["arenas"] if x["busy"]]
+                tr["saved"] = tr["bws"] = None
+            m = ctypes.byref(self.model)
+            ar = dict(shape=(B, V, H, W), recompute=recompute, busy=False, ray_d=None,
+                      saved=torch.zeros(self.saved_bytes(B, V, H, W, recompute), dtype=torch.uint8, device=self.device),
+                      bws=torch.zeros(int(self.lib.dgs_dit_backward_workspace_bytes(m, B, V, H, W)), dtype=torch.uint8, device=self.device))
+            tr["arenas"].append(ar)
+        ar["busy"] = bool(keep_busy)
+        tr["saved"], tr["bws"], tr["shape"], tr["recompute"], tr["current"] = ar["saved"], ar["bws"], ar["shape"], ar["recompute"], ar
+        return ar
+
+    def release_arena(self, ar, drop_extra=True):
+        """The backward of the forward that took `ar` has run (or its graph was dropped).  Idle duplicates of a shape -- arenas that
+        only existed because several forwards were pending at once -- are freed."""
+        ar["busy"] = False
+        if drop_extra:
+            tr, seen = self._train, set()
+            keep = []
+            for x in tr["arenas"]:
+                key = (x["shape"], x["recompute"])
+                if x["busy"] or key not in seen:
+                    keep.append(x)
+                if not x["busy"]:
+                    seen.add(key)
+            tr["arenas"][:] = keep
+
+    @property
+    def pending_backward(self):
+        return any(ar["busy"] for ar in (self._train or {}).get("arenas", []))
+
+    def forward_train(self, images, ray_o, ray_d, t, recompute=False, keep_busy=False):
         """image_to_gaussians that keeps what `backward` needs.  recompute=False: every activation is saved, nothing is
         recomputed; True: only block inputs are kept and `backward` re-runs each block (torch.utils.checkpoint's role,
-        denoiser.py:348-354).  Returns (dict, aligned_xyz)."""
+        denoiser.py:348-354).  Returns (dict, aligned_xyz); the arena the pass used is `self._train["current"]`."""
         dev = self.device
-        tr = self._train_state()
         B, V, _, H, W = images.shape
         recompute = bool(recompute)
-        if tr["shape"] != (B, V, H, W) or tr.get("recompute") != recompute:
-            m = ctypes.byref(self.model)
-            tr["saved"] = tr["bws"] = None       # release before allocating the new arenas
-            tr["saved"] = torch.zeros(self.saved_bytes(B, V, H, W, recompute), dtype=torch.uint8, device=dev)
-            tr["bws"] = torch.zeros(int(self.lib.dgs_dit_backward_workspace_bytes(m, B, V, H, W)), dtype=torch.uint8, device=dev)
-            tr["shape"], tr["recompute"] = (B, V, H, W), recompute
+        ar = self._arena(B, V, H, W, recompute, keep_busy)
         img = images[:, :, :3].to(dev, torch.float32).contiguous()
         ro, rd = ray_o.to(dev, torch.float32).contiguous(), ray_d.to(dev, torch.float32).contiguous()
         tt = t.to(dev, torch.int64).contiguous()
@@ -403,26 +438,29 @@ class DitEngine:
         a.xyz, a.features, a.scaling, a.rotation, a.opacity = (_p(out[k]) for k in ("xyz", "features", "scaling", "rotation", "opacity"))
         a.aligned_xyz = _p(aligned)
         a.train_recompute = int(recompute)
-        rc = self.lib.dgs_dit_forward_train(ctypes.byref(self.model), ctypes.byref(a), _p(tr["saved"]), tr["saved"].numel(), _stream(dev))
+        rc = self.lib.dgs_dit_forward_train(ctypes.byref(self.model), ctypes.byref(a), _p(ar["saved"]), ar["saved"].numel(), _stream(dev))
         if rc != 0:
+            ar["busy"] = False
             raise RuntimeError(f"dgs dit forward_train: {_native.status_string(self.lib, rc)} (status {rc})")
-        tr["ray_d"] = rd
+        ar["ray_d"] = rd
         return out, aligned
 
-    def backward(self, dxyz, dfeatures, dscaling, drotation, dopacity, block_hook=None):
-        """Gradients of every parameter into the flat buffer (overwritten).  Must follow `forward_train`.
+    def backward(self, dxyz, dfeatures, dscaling, drotation, dopacity, block_hook=None, arena=None):
+        """Gradients of every parameter into the flat buffer (overwritten).  Must follow `forward_train` (arena: the one that
+        forward used; default the most recent).
         block_hook(stage) is called on the host as soon as a group of gradients has been ENQUEUED on the current stream
         (stage = layers: heads, layers-1..0: that block incl. its adaLN Linear, -1: the rest) -- the place to start a bucket's all-reduce."""
         tr = self._train_state()
-        B, V, H, W = tr["shape"]
+        ar = arena if arena is not None else tr["current"]
+        B, V, H, W = ar["shape"]
         dev = self.device
         g = [x.to(dev, torch.float32).contiguous() for x in (dxyz, dfeatures, dscaling, drotation, dopacity)]
         a = _native.DgsDitBackwardArgs()
         a.B, a.V, a.H, a.W = B, V, H, W
-        a.ray_d = _p(tr["ray_d"])
-        a.saved, a.saved_bytes, a.workspace, a.workspace_bytes = _p(tr["saved"]), tr["saved"].numel(), _p(tr["bws"]), tr["bws"].numel()
+        a.ray_d = _p(ar["ray_d"])
+        a.saved, a.saved_bytes, a.workspace, a.workspace_bytes = _p(ar["saved"]), ar["saved"].numel(), _p(ar["bws"]), ar["bws"].numel()
         a.dxyz, a.dfeatures, a.dscaling, a.drotation, a.dopacity = (_p(x) for x in g)
-        a.recompute = int(tr.get("recompute", False))
+        a.recompute = int(ar["recompute"])
         errors = []
         if block_hook is not None:
             def _cb(_user, stage):

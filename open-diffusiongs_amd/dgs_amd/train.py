@@ -50,8 +50,9 @@ class DataParallelTrainer:
         self.reducer = BucketedAllReduce(self.fg.flat, bucket_bytes, group=group, compress=compress, force_collectives=force_collectives,
                                          norm=self.norm)
         self.world = self.reducer.world
-        self._accum = torch.zeros_like(self.fg.flat) if self.accumulate > 1 else None
+        self._accum = torch.zeros_like(self.fg.flat) if self.accumulate > 1 else None      # allocated lazily too when a batch needs splitting
         self._summed_to = 0
+        self._use_accum = False
         self._last_micro = True
         self._layers = eng.layers
         model._grads_in_place = True
@@ -97,7 +98,7 @@ class DataParallelTrainer:
         if not self._last_micro:
             return
         end = self._end_of_stage(stage)
-        if self._accum is not None and end > self._summed_to:      # fold in the earlier micro-batches, slice by slice
+        if self._use_accum and end > self._summed_to:             # fold in the earlier micro-batches, slice by slice
             self.fg.flat[self._summed_to:end] += self._accum[self._summed_to:end]
             self._summed_to = end
         self.reducer.ready_up_to(end, tag=stage)
@@ -115,8 +116,20 @@ class DataParallelTrainer:
         nb = batch["image"].shape[0]
         assert nb % K == 0, "batch size must be a multiple of accumulate_grad_batches"
         mb = nb // K
+        limit = getattr(m, "MAX_DIFFERENTIABLE_BATCH", 4)
+        if mb > limit:
+            # one dgs_dit_forward_train / dgs_dit_backward call takes <= 4 samples: a larger per-rank batch (the reference's scene
+            # configurations: 12 at 512^2, 24 at 256^2; configs/diffusionGS_scene_512.yaml:16) runs as micro-batches inside THIS
+            # optimizer step -- same gradient (mean over the whole batch), one all-reduce, one clip, one update
+            c = -(-mb // limit)
+            while mb % c:
+                c += 1
+            K, mb = K * c, mb // c
+            if self._accum is None:
+                self._accum = torch.zeros_like(self.fg.flat)
         total = 0.0
         self._summed_to = 0
+        self._use_accum = K > 1
         for j in range(K):
             sl = slice(j * mb, (j + 1) * mb)
             self._last_micro = j == K - 1

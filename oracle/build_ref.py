@@ -65,17 +65,59 @@ GLUE_SRC = "/root/reference/diffusionGS/models/gsrenderer"
 GLUE_DST = os.path.join(OUT, "py", "diffusionGS", "models", "gsrenderer")
 
 
+DIFF_SRC = "/root/reference/diffusionGS/models/diffusion"
+DIFF_DST = os.path.join(OUT, "py", "diffusionGS", "models", "diffusion")
+DIFF_FILES = ("__init__.py", "gaussian_diffusion.py", "respace.py", "diffusion_utils.py")
+SYSTEM_SRC = "/root/reference/diffusionGS/systems/diffusion_gs_system.py"
+UTILS_SRC = "/root/reference/diffusionGS/systems/utils.py"
+CALLERS_DST = os.path.join(OUT, "py", "ref_callers.py")
+
+
+def _function_source(path, name, cls=None):
+    """Verbatim source text of a function (or of a method of `cls`) of a reference file, dedented to module level."""
+    import ast
+    import textwrap
+    text = open(path).read()
+    tree = ast.parse(text)
+    body = tree.body
+    if cls is not None:
+        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    fn = next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == name)
+    lines = text.splitlines()[fn.lineno - 1:fn.end_lineno]
+    return textwrap.dedent("\n".join(lines)) + "\n", (fn.lineno, fn.end_lineno)
+
+
 def build_py():
-    """Step 3: the reference's Python render glue, byte for byte, as package diffusionGS.models.gsrenderer under oracle/_ref/py."""
+    """Step 3: the reference's Python callers of the hot path, byte for byte, under the git-ignored oracle/_ref/py:
+      * diffusionGS/models/gsrenderer/{gs_core.py, renderer.py}   the render glue (oracle/ref_glue.py `load`)
+      * diffusionGS/models/diffusion/*.py                          the sampler: create_diffusion, p_sample_loop_progressive
+                                                                   (gaussian_diffusion.py:560-603 -> model(input_batch, t) at :350,359)
+      * ref_callers.py                                             two functions sliced out by source range: `TransformInput`
+                                                                   (systems/utils.py:621-757) and `PointDiffusionSystem.forward`
+                                                                   (systems/diffusion_gs_system.py:71-116) -- their files import the
+                                                                   whole training stack (Lightning, skimage, cv2, LPIPS), the
+                                                                   functions themselves need torch only."""
     if not os.path.isdir(GLUE_SRC):
         return all(os.path.exists(os.path.join(GLUE_DST, f)) for f in ("gs_core.py", "renderer.py"))
     os.makedirs(GLUE_DST, exist_ok=True)
-    d = os.path.join(OUT, "py")
-    for part in ("diffusionGS", "models", "gsrenderer"):
-        d = os.path.join(d, part)
-        open(os.path.join(d, "__init__.py"), "a").close()
+    os.makedirs(DIFF_DST, exist_ok=True)
+    for sub in ("gsrenderer", "diffusion"):
+        d = os.path.join(OUT, "py")
+        for part in ("diffusionGS", "models", sub):
+            d = os.path.join(d, part)
+            if not (sub == "diffusion" and part == "diffusion"):      # the diffusion package has its own __init__.py
+                open(os.path.join(d, "__init__.py"), "a").close()
     for f in ("gs_core.py", "renderer.py"):
         shutil.copyfile(os.path.join(GLUE_SRC, f), os.path.join(GLUE_DST, f))
+    for f in DIFF_FILES:
+        shutil.copyfile(os.path.join(DIFF_SRC, f), os.path.join(DIFF_DST, f))
+    ti, ti_lines = _function_source(UTILS_SRC, "TransformInput")
+    fw, fw_lines = _function_source(SYSTEM_SRC, "forward", cls="PointDiffusionSystem")
+    with open(CALLERS_DST, "w") as fh:
+        fh.write("# GENERATED by oracle/build_ref.py from /root/reference (git-ignored, test infrastructure): verbatim source ranges\n"
+                 "from typing import Any, Dict\n\nimport torch\n\n"
+                 f"# ---- diffusionGS/systems/utils.py:{ti_lines[0]}-{ti_lines[1]} ----\n{ti}\n\n"
+                 f"# ---- diffusionGS/systems/diffusion_gs_system.py:{fw_lines[0]}-{fw_lines[1]} (PointDiffusionSystem.forward) ----\n{fw}")
     return True
 
 

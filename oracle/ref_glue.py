@@ -77,3 +77,28 @@ def load():
     assert os.path.realpath(os.path.dirname(dgr.__file__)).startswith(os.path.realpath(pkg)), "diff_gaussian_rasterization is not the drop-in"
     _loaded = importlib.import_module("diffusionGS.models.gsrenderer.renderer")
     return _loaded
+
+
+def diffusion_available():
+    return os.path.exists(os.path.join(PY, "diffusionGS", "models", "diffusion", "gaussian_diffusion.py")) and os.path.exists(os.path.join(PY, "ref_callers.py"))
+
+
+def load_diffusion():
+    """-> the reference's `diffusionGS.models.diffusion` package (create_diffusion, SpacedDiffusion, GaussianDiffusion), verbatim."""
+    if not diffusion_available():
+        raise RuntimeError("oracle/_ref/py/diffusionGS/models/diffusion is missing: run oracle/build_ref.py where /root/reference exists")
+    if PY not in sys.path:
+        sys.path.insert(0, PY)
+    for name in ("diffusionGS", "diffusionGS.models"):          # namespace skeleton (the gsrenderer loader may have made it already)
+        importlib.import_module(name)
+    return importlib.import_module("diffusionGS.models.diffusion")
+
+
+def load_callers():
+    """-> module with the reference's `TransformInput` and `PointDiffusionSystem.forward` (as a plain function of `self`), verbatim
+    source ranges (oracle/build_ref.py)."""
+    if not diffusion_available():
+        raise RuntimeError("oracle/_ref/py/ref_callers.py is missing: run oracle/build_ref.py where /root/reference exists")
+    if PY not in sys.path:
+        sys.path.insert(0, PY)
+    return importlib.import_module("ref_callers")

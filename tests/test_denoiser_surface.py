@@ -133,11 +133,11 @@ def test_img_aligned_xyz_is_differentiable():
         assert torch.allclose(p.grad, g1[n], rtol=1e-5, atol=1e-7), n
 
 
-def test_gradient_accumulation_and_pending_forward():
-    """Two backward passes before zero_grad accumulate g1 + g2 in .grad (autograd receives copies of the flat buffer's
-    slices); a second training forward before the first one's backward is refused (one activation arena); a forward whose
-    graph is dropped unused releases the arena; eval mode with grad enabled is differentiable too."""
-    import pytest
+def test_gradient_accumulation_and_pending_forwards():
+    """Two backward passes before zero_grad accumulate g1 + g2 in .grad (autograd receives copies of the flat buffer's slices);
+    SEVERAL training forwards may be pending -- each holds its own activation arena until its backward ran or its graph was
+    dropped -- so the sum of two forwards' losses differentiates like the two losses one by one (eval mode with grad enabled too:
+    frozen-norm fine-tuning, guidance); arenas that only existed for the overlap are freed again."""
     m = _tiny_model(seed=7)
     cfg = D.Cfg(width=256, num_layers=1)
     images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 2, 2, 16, seed=5)
@@ -153,17 +153,51 @@ def test_gradient_accumulation_and_pending_forward():
     loss(f(slice(1, 2))).backward()
     for n, p in m.named_parameters():
         assert torch.allclose(p.grad, g1[n] + g2[n], rtol=1e-5, atol=1e-8), n
+    eng = m.engine()
+    for mode in (m.train, m.eval):
+        mode()
+        m.zero_grad()
+        a, b = f(slice(0, 1)), f(slice(1, 2))                   # two forwards pending at once
+        assert eng.pending_backward and sum(ar["busy"] for ar in eng._train["arenas"]) == 2
+        assert a.xyz.grad_fn is not None and b.xyz.grad_fn is not None
+        (loss(a) + loss(b)).backward()                           # ONE backward through both
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.grad, g1[n] + g2[n], rtol=1e-5, atol=1e-8), (n, m.training)
+        assert not eng.pending_backward and len(eng._train["arenas"]) == 1      # the second arena was only needed for the overlap
     a = f(slice(0, 1))
-    with pytest.raises(RuntimeError, match="second training forward"):
-        f(slice(1, 2))
+    assert eng.pending_backward
     del a                                                       # graph dropped without backward: arena released
     import gc; gc.collect()
-    m.eval()
-    b = f(slice(1, 2))
-    assert b.xyz.grad_fn is not None
-    loss(b).backward()
+    assert not eng.pending_backward
     with torch.no_grad():
         assert f(slice(0, 1)).xyz.grad_fn is None
+
+
+def test_differentiable_batches_above_four_run_as_chunks():
+    """dgs_dit_forward_train takes <= 4 samples per call; a larger batch (the reference's scene configurations train with 12 / 24
+    per rank) goes through image_to_gaussians as chunks under autograd: same outputs and the same parameter gradients as the
+    samples one by one; under a trainer with in-place gradients the split is the trainer's job."""
+    m = _tiny_model(seed=11)
+    cfg = D.Cfg(width=256, num_layers=1)
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 6, 2, 16, seed=5)
+    loss = lambda p: (p.xyz ** 2).sum() + (p.opacity ** 2).sum() + (p.features ** 2).sum()
+    ref_out, ref = [], None
+    for b in range(6):
+        sl = slice(b, b + 1)
+        p, _ = m.image_to_gaussians(images[sl], ray_o[sl], ray_d[sl], t[sl])
+        ref_out.append(p.xyz.detach())
+        loss(p).backward()
+    ref = {n: q.grad.clone() for n, q in m.named_parameters()}
+    m.zero_grad()
+    p, aligned = m.image_to_gaussians(images, ray_o, ray_d, t)     # 6 samples: chunks of 4 + 2
+    assert p.xyz.shape[0] == 6 and aligned.shape[0] == 6 and torch.equal(p.xyz.detach(), torch.cat(ref_out))
+    loss(p).backward()
+    for n, q in m.named_parameters():
+        assert torch.allclose(q.grad, ref[n], rtol=2e-4, atol=1e-6 * float(ref[n].abs().max())), n
+    m._grads_in_place = True
+    with pytest.raises(RuntimeError, match="micro-batches"):
+        m.image_to_gaussians(images, ray_o, ray_d, t)
+    m._grads_in_place = False
 
 
 def test_engine_survives_optimizer_steps_in_place():
@@ -228,3 +262,52 @@ def test_run_layers_matches_oracle_blocks():
     assert rel_l2(m.run_layers(0, 1)(odd, c[:1]), ref7) < 2e-2
     with pytest.raises(RuntimeError):
         m.run_layers(0, 1, views=3)(odd, c[:1])            # 5 image tokens are not 3 views of anything
+
+
+@pytest.mark.parametrize("scene", [False, True], ids=["obj", "scene"])
+def test_checkpoint_files_round_trip(tmp_path, scene):
+    """BASELINE configs[1]'s load path (the checkpoint itself is unreachable offline): the three file layouts the reference reads --
+    the Lightning checkpoint its training writes and pipline_obj.py:66-70 loads at the SYSTEM level ({'state_dict': {'shape_model.<key>'}}),
+    denoiser.py:259-267's {'model': {'denoiser.<key>'}} and a flat state dict -- written by torch.save, read back through
+    `pretrained_model_name_or_path` / load_state_dict(strict=True), for the obj ([2, W]) and scene ([1, 2, W]) embedding shapes; the
+    engine built from the loaded weights computes what the saved model computed."""
+    cls = dn.DGSDenoiserScene if scene else dn.DGSDenoiser
+    cfgd = dict(OBJ_CFG, num_layers=1, ray_pe_type="plk" if scene else "relative_plk")
+    src = cls(cfgd, device="cpu", lib=emu_lib())
+    src.reset_parameters(seed=31)
+    assert tuple(src.gaussians_pos_embedding.shape) == ((1, 2, 256) if scene else (2, 256))
+    cfg = D.Cfg(width=256, num_layers=1, scene=scene, ray_pe_type=cfgd["ray_pe_type"])
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 1, 2, 16, seed=3)
+    with torch.no_grad():
+        want, _ = src.image_to_gaussians(images, ray_o, ray_d, t)
+
+    class System(torch.nn.Module):                      # the reference's LightningModule keeps the denoiser as `shape_model` (:43)
+        def __init__(self, m):
+            super().__init__()
+            self.shape_model = m
+            self.loss_computer = torch.nn.Linear(2, 2)  # stands for the LPIPS weights a real checkpoint also holds
+
+    sd = src.state_dict()
+    files = {"lightning": {"state_dict": System(src).state_dict(), "epoch": 3, "global_step": 1234},
+             "model": {"model": {**{"denoiser." + k_: v for k_, v in sd.items()}, "denoiser.loss_computer.w": torch.zeros(1), "other.x": torch.zeros(1)}},
+             "flat": dict(sd)}
+    for name, content in files.items():
+        path = str(tmp_path / f"{name}.ckpt")
+        torch.save(content, path)
+        m = cls(dict(cfgd, pretrained_model_name_or_path=path), device="cpu", lib=emu_lib())     # denoiser.py:256-282
+        for (n_, a), (_, b) in zip(m.state_dict().items(), sd.items()):
+            assert torch.equal(a, b), (name, n_)
+        with torch.no_grad():
+            got, _ = m.image_to_gaussians(images, ray_o, ray_d, t)
+        assert all(torch.equal(got[f], want[f]) for f in ("xyz", "features", "scaling", "rotation", "opacity")), name
+    # pipline_obj.py:66-70: the system-level strict load of the Lightning file
+    fresh = System(cls(cfgd, device="cpu", lib=emu_lib()))
+    fresh.load_state_dict(torch.load(str(tmp_path / "lightning.ckpt"), map_location="cpu")["state_dict"])
+    assert torch.equal(fresh.shape_model.gaussians_pos_embedding, src.gaussians_pos_embedding)
+    # the other model family's checkpoint does not load (embedding shapes differ), nor does a file with a missing key
+    other = (dn.DGSDenoiser if scene else dn.DGSDenoiserScene)(dict(cfgd, ray_pe_type="relative_plk" if scene else "plk"), device="cpu", lib=emu_lib())
+    with pytest.raises(RuntimeError):
+        other._load_pretrained(str(tmp_path / "lightning.ckpt"))
+    broken = {k_: v for k_, v in sd.items() if k_ != "transformer.0.mlp.fc2.bias"}
+    with pytest.raises(RuntimeError):
+        cls(cfgd, device="cpu", lib=emu_lib())._load_pretrained(broken)

@@ -145,6 +145,25 @@ def _accum_worker(rank, world, port, out):
         tr = DataParallelTrainer(m, torch.optim.SGD(m.parameters(), lr=0.0), bucket_bytes=1 << 20, accumulate_grad_batches=accumulate)
         loss = tr.step(batch, t, target)
         res.append((float(loss), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()))
+    # a per-rank batch above the 4 samples one C call takes (the reference's scene configs: 12 / 24 per rank): the trainer splits it
+    # into micro-batches inside ONE optimizer step; then a small batch again (the accumulator of the split step must not leak into it)
+    big = synth_inputs(cfg, 6, 2, 16, seed=9)
+    bb = dict(image=big[0], ray_o=big[1], ray_d=big[2], c2w=big[4], fxfycxcy=big[5])
+    tb = torch.rand(6, 2, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    m = dn.DGSDenoiser(dict(width=256, in_channels=9, patch_size=8, num_layers=1), device="cpu", lib=emu_lib())
+    m.reset_parameters(seed=1)
+    tr = DataParallelTrainer(m, torch.optim.SGD(m.parameters(), lr=0.0), bucket_bytes=1 << 20)
+    loss6 = tr.step(bb, big[3], tb)
+    g6 = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy().copy()
+    loss2 = tr.step(batch, t, target)
+    g2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy().copy()
+    tr.close()
+    m.zero_grad()
+    from dgs_amd import losses
+    p6, _ = m.image_to_gaussians(bb["image"], bb["ray_o"], bb["ray_d"], big[3])       # autograd: chunks of 4 + 2, gradients summed by torch
+    l6, _, _ = losses.mse_psnr(m.render_gaussians(p6, bb["c2w"], bb["fxfycxcy"], 16, 16), tb, lib=emu_lib())
+    l6.backward()
+    res.append((float(loss6), g6, float(l6), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy(), float(loss2), g2))
     out.put(res)
 
 
@@ -157,11 +176,16 @@ def test_accumulate_grad_batches_equals_one_large_batch():
     q = ctx.Queue()
     p = ctx.Process(target=_accum_worker, args=(0, 1, _free_port(), q))
     p.start()
-    (l1, g1), (l2, g2) = q.get(timeout=300)
+    (l1, g1), (l2, g2), (l6, g6, l6_ref, g6_ref, l2b, g2b) = q.get(timeout=600)
     p.join(60)
     assert p.exitcode == 0
     assert abs(l1 - l2) < 1e-6 * max(1.0, abs(l1))
     assert np.abs(g1 - g2).max() <= 2e-3 * np.abs(g1).max()
+    # batch of 6 in one trainer step (split 2 x 3) == autograd over the same batch (chunks 4 + 2)
+    assert abs(l6 - l6_ref) < 1e-5 * max(1.0, abs(l6_ref))
+    assert np.abs(g6 - g6_ref).max() <= 2e-3 * np.abs(g6_ref).max()
+    # and the next, small step is clean
+    assert abs(l2b - l1) < 1e-6 * max(1.0, abs(l1)) and np.abs(g2b - g1).max() <= 1e-6 * np.abs(g1).max()
 
 
 def _fused_worker(rank, world, port, out):

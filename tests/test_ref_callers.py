@@ -1,0 +1,176 @@
+"""The REFERENCE's own callers of the hot path, run unchanged on top of the product (SURVEY.md 8b "what calls it"):
+
+  * its sampler -- `create_diffusion("30").p_sample_loop_progressive(model=DGSDenoiser, ...)` (gaussian_diffusion.py:560-603, which
+    calls `model(input_batch, t)` through respace.py's `_WrappedModel` at :350,359) -- against `dgs_amd.sampler`;
+  * its training forward -- `PointDiffusionSystem.forward` (systems/diffusion_gs_system.py:71-116: TransformInput, q_sample,
+    `shape_model.image_to_gaussians`, `shape_model.render_gaussians`, the loss computer) with Lightning and the LPIPS / SSIM networks
+    out of the picture -- against the product's own calls on the same noisy inputs, forward and backward.
+
+The reference sources are copied / sliced verbatim into the git-ignored oracle/_ref/py at build time (oracle/build_ref.py, step 3:
+`/root/reference` does not exist on the GPU box, the directory travels with the snapshot); nothing of them is on the product path.
+Runs on the CPU emulation of the kernels here and on the gfx950 build under `-m gpu`."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from dgs_amd import cameras, denoiser as dn, losses, sampler as sm
+from oracle import ref_glue
+
+needs_ref = pytest.mark.skipif(not ref_glue.diffusion_available(), reason="oracle/_ref/py not built (oracle/build_ref.py needs /root/reference)")
+
+
+def _model(device, lib, width, layers, seed=3):
+    m = dn.DGSDenoiser(dict(width=width, in_channels=9, patch_size=8, num_layers=layers), device=device, lib=lib)
+    m.reset_parameters(seed=seed)
+    with torch.no_grad():
+        m.image_token_decoder.linear.weight.mul_(5.0)            # renders that depend visibly on the inputs
+    return m.to(device)
+
+
+def _batch(B, V, res, device, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.rand(B, V, 3, res, res, generator=g)
+    c2w = torch.tensor(np.stack([cameras.ring_cameras(V, phase_deg=11.0 * b) for b in range(B)]), dtype=torch.float32)
+    k = torch.tensor(cameras.default_fxfycxcy(res), dtype=torch.float32).expand(B, V, 4).contiguous()
+    return {k_: v.to(device) for k_, v in dict(image=image, c2w=c2w, fxfycxcy=k).items()}
+
+
+def _sampler_case(device, lib, width, layers, res):
+    callers = ref_glue.load_callers()
+    refd = ref_glue.load_diffusion()
+    m = _model(device, lib, width, layers).eval()
+    B, V = 2, 3
+    base = _batch(B, V, res, device)
+    base["ray_o"], base["ray_d"] = callers.TransformInput(base["image"], base["c2w"], base["fxfycxcy"])   # the reference's own rays
+    x_T = torch.randn(B, V - 1, 3, res, res, generator=torch.Generator().manual_seed(5)).to(device)
+
+    def fresh():
+        b = {k: v.clone() for k, v in base.items()}
+        b["image_noisy"] = x_T.clone()
+        return b
+
+    # ---- the reference's loop, driving the product's model ----
+    rd = refd.create_diffusion("30")
+    torch.manual_seed(11)
+    ref_steps = []
+    for out in rd.p_sample_loop_progressive(m, shape=(B,), input_batch=fresh(), clip_denoised=True, device=device):
+        ref_steps.append((out["sample"].clone(), out["pred_xstart"].clone()))
+    assert len(ref_steps) == 30
+    ref_final = out
+    # ---- the product's sampler, step by step with the same noise stream (th.randn_like(x) behind the model call, :504) ----
+    d = sm.create_diffusion("30", device=device, lib=lib)
+    torch.manual_seed(11)
+    b = fresh()
+    x = b["image_noisy"]
+    worst = 0.0
+    for n, i in enumerate(reversed(range(d.num_timesteps))):
+        t = torch.full((B,), i, dtype=torch.int64, device=device)
+        b["image"] = torch.cat([b["image"][:, 0:1], b["image_noisy"]], dim=1)
+        with torch.no_grad():
+            render, _ = m(b, d.model_timesteps(t))
+        pred = torch.empty_like(x)
+        x = d.step(render.float(), b["image_noisy"].float(), t, clip_denoised=True, pred_xstart=pred)
+        b["image_noisy"] = x
+        if n < 3:       # the first steps: both loops have seen bit-identical inputs so far -- the sampler arithmetic alone
+            assert float((x - ref_steps[n][0]).abs().max()) <= 2e-6 * max(1.0, float(ref_steps[n][0].abs().max())), n
+            assert float((pred - ref_steps[n][1]).abs().max()) <= 2e-6, n
+        worst = max(worst, float((x - ref_steps[n][0]).abs().max()))
+    assert worst <= 1e-4, worst                                   # 30 steps: differences of 1e-7 go through the model each step
+    # ---- and the product's own loop (graph replays on the GPU) ----
+    torch.manual_seed(11)
+    mine = d.p_sample_loop(m, fresh(), clip_denoised=True)
+    assert float((mine["sample"] - ref_final["sample"]).abs().max()) <= 1e-4
+    assert float((mine["pred_xstart"] - ref_final["pred_xstart"]).abs().max()) <= 1e-4
+    r_ref, r_mine = ref_final["denoiser_output_dict"]["render_images"], mine["denoiser_output_dict"]["render_images"]
+    assert float((r_ref - r_mine).abs().max()) <= 1e-4
+    g_ref, g_mine = ref_final["denoiser_output_dict"]["pred_gaussians"], mine["denoiser_output_dict"]["pred_gaussians"]
+    assert len(g_ref) == len(g_mine) == B and float((g_ref[0].get_xyz - g_mine[0].get_xyz).abs().max()) <= 1e-3
+
+
+class _LossComputer:
+    """LossComputer.forward's signature and return tuple (utils/losses.py:261-369) with the terms the product has on the device; the
+    LPIPS / SSIM networks (out of scope, no weights offline) contribute zeros."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __call__(self, rendering, target, masks_all, masks, ray_o, img_aligned_xyz=None, gt_img_aligned_xyz=None):
+        _loss, l2, _psnr = losses.mse_psnr(rendering, target, lib=self.lib)
+        pd, xyz = losses.points_losses(img_aligned_xyz, ray_o, gt_img_aligned_xyz, masks, lib=self.lib)
+        z = torch.zeros_like(l2)
+        return l2, z, z, pd, xyz
+
+
+def _system_case(device, lib, width, layers, res):
+    callers = ref_glue.load_callers()
+    refd = ref_glue.load_diffusion()
+    m = _model(device, lib, width, layers, seed=4).train()
+    B, V_in, V_all = 2, 4, 6
+    g = torch.Generator().manual_seed(2)
+    allv = _batch(B, V_all, res, device, seed=1)
+    batch = {"rgbs_input": allv["image"][:, :V_in].clone(), "c2ws_input": allv["c2w"][:, :V_in], "fxfycxcys_input": allv["fxfycxcy"][:, :V_in],
+             "depths_input": (1.5 + torch.rand(B, V_in, 1, res, res, generator=g)).to(device),
+             "c2ws": allv["c2w"], "fxfycxcys": allv["fxfycxcy"], "rgbs": allv["image"],
+             "masks": torch.ones(B, V_all, 1, res, res, device=device), "masks_input": (torch.rand(B, V_in, 1, res, res, generator=g) > 0.3).float().to(device)}
+    clean = batch["rgbs_input"].clone()
+    system = types.SimpleNamespace(
+        cfg=types.SimpleNamespace(noise_scheduler=types.SimpleNamespace(num_train_timesteps=1000)),
+        diffusion_training=refd.create_diffusion(str(1000), predict_xstart=True), shape_model=m, loss_computer=_LossComputer(lib))
+    torch.manual_seed(21)
+    out = callers.forward(system, batch)                          # PointDiffusionSystem.forward, verbatim
+    for k in ("loss_diffusion", "loss_lpips", "loss_ssim", "loss_xyz", "loss_pointsdist"):
+        assert out[k].dim() == 0 and torch.isfinite(out[k]), k
+    assert out["noise_pred"].shape == (B, V_all, 3, res, res) and out["timesteps"].dtype == torch.int64
+    x_t = out["x_t"]
+    assert torch.equal(x_t[:, 0], clean[:, 0]) and not torch.equal(x_t[:, 1:], clean[:, 1:])       # view 0 stays clean, the others carry q_sample's noise
+    loss = out["loss_diffusion"] + 0.5 * out["loss_pointsdist"] + 0.1 * out["loss_xyz"]           # lambda-weighted sum, training_step :118-124
+    m.zero_grad()
+    loss.backward()
+    gref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    assert all(torch.isfinite(v).all() for v in gref.values()) and float(gref["transformer.0.attn.qkv.weight"].abs().max()) > 0
+    # ---- the same step as the product's own calls on the same noisy inputs: HIP rays, HIP losses ----
+    be = m.gs_renderer.backend()
+    ray_o, ray_d = be.rays_from_c2w(batch["c2ws_input"], batch["fxfycxcys_input"], res, res)
+    m.zero_grad()
+    params, aligned = m.image_to_gaussians(x_t.detach(), ray_o, ray_d, out["timesteps"])
+    rendered = m.render_gaussians(params, batch["c2ws"], batch["fxfycxcys"], res, res)
+    l2 = losses.mse_psnr(rendered, batch["rgbs"], lib=lib)[0]
+    pd, xyz = losses.points_losses(aligned, ray_o, ray_o + ray_d * batch["depths_input"], batch["masks_input"], lib=lib)
+    assert float((rendered.detach() - out["noise_pred"].detach()).abs().max()) <= 2e-4                          # rays differ by 1e-6 (kernel vs torch)
+    assert abs(float(l2) - float(out["loss_diffusion"])) <= 1e-5 * max(1.0, abs(float(l2)))
+    assert abs(float(pd.mean()) - float(out["loss_pointsdist"])) <= 1e-4 * max(1.0, abs(float(pd.mean())))
+    assert abs(float(xyz) - float(out["loss_xyz"])) <= 1e-4 * max(1.0, abs(float(xyz)))
+    (l2 + 0.5 * pd.mean() + 0.1 * xyz).backward()
+    bad = []
+    for n, p in m.named_parameters():
+        den = float(gref[n].abs().max())
+        if float((p.grad - gref[n]).abs().max()) > 5e-3 * den + 1e-9:
+            bad.append(n)
+    assert not bad, bad[:6]
+
+
+@needs_ref
+def test_reference_sampler_over_the_product_emulated():
+    from emu_util import emu_lib
+    _sampler_case(torch.device("cpu"), emu_lib(), 256, 1, 16)
+
+
+@needs_ref
+def test_reference_system_forward_over_the_product_emulated():
+    from emu_util import emu_lib
+    _system_case(torch.device("cpu"), emu_lib(), 256, 1, 16)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_reference_sampler_over_the_product_gpu():
+    """64^2, the shipped architecture (width 1024, 24 blocks, L = 194 at 3 views): 30 steps of the reference's loop and of the product's."""
+    _sampler_case(torch.device("cuda:0"), None, 1024, 24, 64)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_reference_system_forward_over_the_product_gpu():
+    _system_case(torch.device("cuda:0"), None, 1024, 4, 64)
