@@ -396,7 +396,7 @@ def main():
                     "gloo and a tiny model (width 256, 2 blocks, 64^2) -- what tests/test_bench_dry_run.py uses to exercise the N > 1 path")
     ap.add_argument("--force-dist", action="store_true", help="create the process group and issue every barrier / all-reduce even for a world of one "
                     "(the one-GPU RCCL smoke run: same init, streams and collective calls as N > 1)")
-    ap.add_argument("--graph", type=int, default=1, help="1 (default): the timed steps are replays of DGSDenoiser.forward captured as ONE hipGraph "
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DGS_GRAPH", "1")), help="1 (default): the timed steps are replays of DGSDenoiser.forward captured as ONE hipGraph "
                     "(dgs_amd/graph.py), except the steps that carry the roofline kernel's HIP events (every 4th), which are enqueued eagerly; 0: every step eager")
     ap.add_argument("--preheat-s", type=float, default=2.0, help="seconds of the same step run (untimed) before the warm-up steps: a timed region of "
                     "~0.15 s that starts from idle clocks measures the DVFS ramp, not the kernels (BENCH_r03 vs the builder's runs: -8 %%)")
@@ -480,14 +480,19 @@ def main():
 
     use_graph = bool(a.graph) and not a.dry_run_cpu
     graph_step = None
+    graph_error = None
     if use_graph:
         # DGSDenoiser.forward as one captured graph: same kernels (the capture goes through the same C calls), one host call per step
         gb = {k: batch[k] for k in ("image", "ray_o", "ray_d", "c2w", "fxfycxcy")}
-        graphed = model.graphed(gb, t)
+        try:
+            graphed = model.graphed(gb, t)
 
-        def graph_step():
-            rendered, gaussians = graphed.replay()
-            return rendered, gaussians, 0
+            def graph_step():
+                rendered, gaussians = graphed.replay()
+                return rendered, gaussians, 0
+        except Exception as e:                      # noqa: BLE001 -- the eager step is the same work: measure that, and say why
+            graph_error, use_graph = f"{type(e).__name__}: {str(e)[:300]}", False
+            model.drop_graphs()
 
     def timed_loop(n, fn):
         """n steps of fn: (wall ms per step incl. the final synchronisation, host ms per step until the last step was ENQUEUED, GPU ms
@@ -612,7 +617,7 @@ def main():
             # what the timed region looked like from the host and from the device (rank 0): `host_enqueue_ms` = until the last step
             # was enqueued (the host runs ahead of the device by ms_per_step - this), `gpu_ms` = between two events on the stream,
             # `shader_clock_mhz` = s_memtime / s_memrealtime of a probe kernel at three moments, `per_rank_ms` = every rank's own time
-            "timed_region": {"graph_replays": sum(1 for i in range(a.steps) if i not in events) if use_graph else 0,
+            "timed_region": {"graph_replays": sum(1 for i in range(a.steps) if i not in events) if use_graph else 0, "graph_error": graph_error,
                              "eager_steps_with_events": len(events), "preheat_s": a.preheat_s if not a.dry_run_cpu else 0.0,
                              "host_enqueue_ms_per_step": round((t_enq - t0) / a.steps * 1e3, 3),
                              "gpu_ms_per_step": round(g0.elapsed_time(g1) / a.steps, 3) if g0 is not None else None,

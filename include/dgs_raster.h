@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 5   /* bumped with every change of a struct or prototype in the include directory (round 2 = 2, unversioned) */
+#define DGS_ABI_VERSION 6   /* bumped with every change of a struct or prototype in the include directory (round 2 = 2, unversioned) */
 #define DGS_TILE 16 /* cuda_rasterizer/config.h:14-15 */
 
 typedef void* dgs_stream_t; /* hipStream_t */
@@ -95,6 +95,8 @@ typedef struct DgsRasterForwardArgs {
     int64_t binning_capacity;
     int32_t* num_rendered_dev;   /* device int32[4], written by the call in both modes when not NULL: [0] = num_rendered (low 32 bits),
                                     [1] = status (DgsStatus), [2] = longest tile list, [3] = 0                               */
+    int32_t* num_rendered_host;  /* PINNED host int32[4] or NULL: the same four words, copied behind the call (an asynchronous D2H copy on the
+                                    stream: valid once the stream has passed it -- record an event behind the call)                 */
     int64_t longest_hint;        /* async mode, IN: the longest tile list the caller expects (a previous call of this shape), 0 =
                                     unknown.  Sizes the LDS of the per-tile sort; a longer list only changes the form that runs   */
     /* ---- result ---- */

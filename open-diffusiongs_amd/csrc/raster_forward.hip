@@ -1108,6 +1108,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         forms = 1 << last_form;
         if (a->num_rendered_dev)
             hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        if (a->num_rendered_host)
+            hipMemcpyAsync(a->num_rendered_host, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
     } else {
         // nothing is read back: the statistics go to the caller's device words (it reads them when it likes -- dgs_amd/raster.py
         // copies them to pinned host memory behind the call and looks at them before the NEXT call), every kernel of a form the
@@ -1118,6 +1120,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         a->longest_list = -1;
         if (a->num_rendered_dev)
             hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        if (a->num_rendered_host)
+            hipMemcpyAsync(a->num_rendered_host, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         // LDS the per-tile sort is launched with: for the longest list the caller expects (+ 50 %), else the maximum; a list that
         // does not fit sends the call to the rank sort on the device
         int cap = kBitonicMax;

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # or an A/B side (tools/ab_build.sh).  Never a fallback: whatever is named must exist and pass the ABI check.
 LIB_PATH = os.environ.get("DGS_AMD_LIBRARY") or os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
 
-ABI_VERSION = 5          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
+ABI_VERSION = 6          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
 DGS_ERR_BINNING_OVERFLOW = -7    # include/dgs_raster.h DgsStatus
 c_float_p = ctypes.POINTER(ctypes.c_float)
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
@@ -32,7 +32,7 @@ class DgsRasterForwardArgs(ctypes.Structure):
         ("geom_alloc", ALLOC_FN), ("geom_user", ctypes.c_void_p),
         ("img_alloc", ALLOC_FN), ("img_user", ctypes.c_void_p),
         ("binning_alloc", ALLOC_FN), ("binning_user", ctypes.c_void_p),
-        ("binning_capacity", ctypes.c_int64), ("num_rendered_dev", ctypes.c_void_p), ("longest_hint", ctypes.c_int64),
+        ("binning_capacity", ctypes.c_int64), ("num_rendered_dev", ctypes.c_void_p), ("num_rendered_host", ctypes.c_void_p), ("longest_hint", ctypes.c_int64),
         ("num_rendered", ctypes.c_int64), ("longest_list", ctypes.c_int64), ("binning_form", ctypes.c_int32), ("exact_exp", ctypes.c_int32),
     ]
 

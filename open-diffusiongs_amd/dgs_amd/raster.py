@@ -44,12 +44,28 @@ class _AsyncPlan:
     Statistics travel device -> pinned host words behind each call; `poll` looks at the ones whose copy has finished."""
 
     MARGIN = 2.0
+    SLOTS = 64                     # pinned host words for the statistics of that many calls in flight
 
     def __init__(self):
         self.capacity, self.form, self.longest, self.seen_max = 0, 0, 0, 0
         self.pending = []          # (event or None, host int32[4], capacity the call ran with)
         self.overflowed = None     # (instances, capacity) of a call that did not fit, until it has been reported
         self.calls = {"sync": 0, "async": 0}
+        self.host = None           # pinned int32[SLOTS + 1, 4]: allocated ONCE, outside any stream capture (a pinned allocation is not a
+        self.slot = 0              # stream operation: inside a capture it invalidates the capture); row SLOTS belongs to a captured graph
+
+    def host_words(self, for_graph):
+        if self.host is None:
+            self.host = torch.empty(self.SLOTS + 1, 4, dtype=torch.int32, pin_memory=True)
+        if for_graph:
+            return self.host[self.SLOTS]
+        if len(self.pending) >= self.SLOTS:          # every slot holds an unread result: wait for the oldest
+            ev = self.pending[0][0]
+            if ev is not None:
+                ev.synchronize()
+        w = self.host[self.slot]
+        self.slot = (self.slot + 1) % self.SLOTS
+        return w
 
     def note(self, lib, n, longest, P, W, H, V):
         self.seen_max = max(self.seen_max, int(n))
@@ -59,6 +75,8 @@ class _AsyncPlan:
 
     def poll(self, lib, P, W, H, V, wait=False):
         keep = []
+        if len(self.pending) >= self.SLOTS:
+            wait = True                                  # the ring of host words is full
         for ev, host, cap in self.pending:
             if ev is not None and not wait and not ev.query():
                 keep.append((ev, host, cap))
@@ -184,30 +202,35 @@ class RasterBackend:
                 raise RuntimeError("dgs rasterizer: the first render of a shape synchronises (it learns the binning capacity); run the step "
                                    "once before capturing it in a graph")
         a.binning_capacity = int(binning_capacity)
-        ndev = None
+        ndev = host = None
         if binning_capacity > 0:
-            ndev = torch.empty(4, dtype=torch.int32, device=device)
-            a.num_rendered_dev = ctypes.c_void_p(ndev.data_ptr())
+            if plan is not None and device.type == "cuda":
+                # statistics -> pinned host words, copied by the library behind the call (a plain asynchronous D2H copy on the stream: a
+                # memcpy node when the call is being captured); looked at by a later call's poll()
+                host = plan.host_words(for_graph=capturing)
+                a.num_rendered_host = ctypes.c_void_p(host.data_ptr())
+            else:
+                ndev = torch.empty(4, dtype=torch.int32, device=device)
+                a.num_rendered_dev = ctypes.c_void_p(ndev.data_ptr())
         rc = self.lib.dgs_raster_forward(ctypes.byref(a), self._stream(device))
         self._check(rc)
         if plan is not None:
-            if binning_capacity > 0:          # statistics -> pinned host words behind the call; looked at by a later call's poll()
+            if binning_capacity > 0:
                 plan.calls["async"] += 1
-                if device.type == "cuda":
-                    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-                    host.copy_(ndev, non_blocking=True)
-                    ev = None
-                    if not capturing:
+                if host is not None:
+                    if capturing:
+                        plan.graph_stats = host       # rewritten by every replay: the graph's owner polls it (dgs_amd/graph.py)
+                    else:
                         ev = torch.cuda.Event()
                         ev.record(torch.cuda.current_stream(device))
-                    plan.pending.append((ev, host, int(binning_capacity)))
-                    if capturing:
-                        plan.graph_stats = plan.pending.pop()[1]       # rewritten by every replay: the graph's owner polls it (dgs_amd/graph.py)
+                        plan.pending.append((ev, host, int(binning_capacity)))
                 else:
                     plan.pending.append((None, ndev.clone(), int(binning_capacity)))
                 return int(binning_capacity), out_color, radii, holder["geom"], holder["binning"], holder["img"]
             plan.calls["sync"] += 1
             plan.note(self.lib, int(a.num_rendered), int(a.longest_list), P, W, H, V)
+            if device.type == "cuda":
+                plan.host_words(for_graph=True)       # the pinned words exist before anybody captures a call of this shape
         num_rendered = int(a.num_rendered) if binning_capacity <= 0 else ndev
         return num_rendered, out_color, radii, holder["geom"], holder["binning"], holder["img"]
 

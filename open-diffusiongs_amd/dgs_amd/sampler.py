@@ -13,6 +13,7 @@ There is no CPU fallback: without the HIP library `step` raises.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -132,8 +133,8 @@ class SpacedDiffusion:
         x = input_batch["image_noisy"]
         B = x.shape[0]
         final = None
-        if use_graph is None:
-            use_graph = x.is_cuda and hasattr(model, "graphed") and keep_last_only
+        if use_graph is None:        # DGS_GRAPH=0: the eager loop everywhere (a debugging switch)
+            use_graph = x.is_cuda and hasattr(model, "graphed") and keep_last_only and os.environ.get("DGS_GRAPH", "1") != "0"
         for i in reversed(range(self.num_timesteps)):
             t = torch.full((B,), i, dtype=torch.int64, device=x.device)
             input_batch["image"] = torch.cat([input_batch["image"][:, 0:1], input_batch["image_noisy"]], dim=1)
