@@ -190,7 +190,12 @@ def raster_roofline(dev, res, V, iters=10):
     # pair-evaluation counters (tile_stats) exist in the tools' build only (csrc/raster_common.h kRasterStats): ONE untimed forward +
     # backward on it counts what the call walks -- the same kernels minus the counters are what is timed below
     instr = os.path.join(ROOT, "open-diffusiongs_amd", "lib", "libdgs_hip_instr.so")
-    be_count = RasterBackend(lib=_native.open_library(instr), exact_exp=be.exact_exp) if os.path.exists(instr) else None
+    be_count = None
+    if os.path.exists(instr):
+        try:
+            be_count = RasterBackend(lib=_native.open_library(instr), exact_exp=be.exact_exp)
+        except RuntimeError as e:                 # a stale tools' build (ABI mismatch): no pair counts, the timings stand
+            print(f"[bench] {e}", file=sys.stderr, flush=True)
     out = {"views": V, "resolution": res, "exact_exp": bool(be.exact_exp), "pair_counts_from": "lib/libdgs_hip_instr.so" if be_count else None,
            "hbm": {"bound": "hbm", "peak": PEAK_HBM / 1e9, "unit": "GB/s"}, "valu": {"bound": "valu", "peak": PEAK_FP32_VALU / 1e12, "unit": "TFLOP/s"}}
     tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
@@ -643,13 +648,19 @@ def main():
     watchdog.daemon = True
     watchdog.start()
     x0 = time.perf_counter()
+    stage = lambda name: print(f"[bench] {name} ({time.perf_counter() - x0:.1f} s)", file=sys.stderr, flush=True) if rank == 0 else None
     if not a.no_extras:
         try:
+            stage("extras: raster roofline")
             rr = raster_roofline(dev, res, V) if rank == 0 else None
+            stage("extras: scene 512")
             s512 = scene_512(dev) if rank == 0 else None
             del model, eng
+            graph_step = graphed = run_step = None      # the captured graph holds the model's buffers
             torch.cuda.empty_cache()
+            stage("extras: training step")
             tb = train_bench(a, dev, rank, world, a.train_steps, 2)      # every rank: the step has a collective
+            stage("extras: done")
         except Exception as e:                                          # noqa: BLE001 -- whatever it was, the line goes out
             emit_and_leave(f"{type(e).__name__}: {e}")
         if rank == 0:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 6   /* bumped with every change of a struct or prototype in the include directory (round 2 = 2, unversioned) */
+#define DGS_ABI_VERSION 7   /* bumped with every change of a struct or prototype in the include directory (round 2 = 2, unversioned) */
 #define DGS_TILE 16 /* cuda_rasterizer/config.h:14-15 */
 
 typedef void* dgs_stream_t; /* hipStream_t */
@@ -154,6 +154,13 @@ typedef struct DgsRasterBackwardArgs {
     float* dL_dscales;    /* [S,P,3]  or NULL */
     float* dL_drotations; /* [S,P,4]  or NULL */
     int32_t exact_exp;    /* as DgsRasterForwardArgs.exact_exp: must equal the forward's */
+    /* Deterministic form (the product's default; dgs_amd/raster.py): `scratch` = dgs_raster_backward_scratch_bytes(...) bytes of device
+     * memory (contents irrelevant, nothing is read before it is written).  Every (tile, Gaussian) instance then has a slot of its
+     * own, a tile STORES its sums there and a gather adds a Gaussian's slots in a fixed order: no floating-point atomic anywhere,
+     * the same bits on every run.  NULL: the sums of a Gaussian's tiles meet in fp32 atomics (the reference's way, backward.cu:
+     * 10 atomicAdd per pair; here one per tile and value) -- run-to-run differences of the order of 1e-7 relative.            */
+    void* scratch;
+    size_t scratch_bytes;
 } DgsRasterBackwardArgs;
 
 int dgs_abi_version(void);
@@ -169,6 +176,9 @@ int dgs_raster_forward(DgsRasterForwardArgs* args, dgs_stream_t stream);
 int dgs_raster_binning_form(int32_t binning_form, int64_t num_rendered, int64_t longest_list, int32_t P, int32_t width, int32_t height,
                             int32_t V);
 int dgs_raster_backward(const DgsRasterBackwardArgs* args, dgs_stream_t stream);
+/* Bytes of DgsRasterBackwardArgs.scratch: 36 per instance slot (num_rendered as passed to the backward: the forward's count, or the
+ * binning capacity of an asynchronous forward) + 4 per (view, Gaussian) + 8 per tile. */
+size_t dgs_raster_backward_scratch_bytes(int32_t P, int32_t width, int32_t height, int32_t V, int64_t num_rendered);
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, dgs_stream_t stream);
 

@@ -12,6 +12,16 @@
 //                                                              instead of <= 256; 16x4 strips the Gaussian's ellipse cannot
 //                                                              reach are skipped on a scalar bit test; the replay starts at
 //                                                              the tile's deepest contributor
+//                                                            DETERMINISTIC form (DgsRasterBackwardArgs.scratch, the product's
+//                                                              default): no atomic at all.  A (tile, Gaussian) instance has a slot
+//                                                              of its own, Gaussian-major -- slot = (exclusive scan of
+//                                                              tiles_touched)[Gaussian] + index of the tile in the Gaussian's
+//                                                              rectangle --, the tile STORES its nine sums there, and
+//                                                              gather_partials_kernel adds a Gaussian's slots in rectangle
+//                                                              order.  Which slots a tile wrote needs no flag and no fill: a
+//                                                              tile's list is sorted by (depth bits, index), it replays the
+//                                                              first `todo` entries, so it wrote Gaussian g iff key(g) <= the
+//                                                              key of its deepest replayed entry (8 bytes per tile)
 //   computeCov2DCUDA     backward.cu:144-274                 preprocess_backward_kernel: ONE thread per (set, Gaussian)
 //   preprocessCUDA bwd   backward.cu:346-396 (+ SH :20-139,    walks the views of its set, so gradients of the views of a
 //     computeCov3D :278-341)                                   set are summed in registers in a fixed order -- no atomics,
@@ -31,7 +41,69 @@ struct BwdParams {
     ImageState im;
     BinningState bn;
     float *dL_dmean2D, *dL_dconic, *dL_dcolors, *dL_dcov3D, *dL_dopacity, *dL_dmeans3D, *dL_dsh, *dL_dscales, *dL_drots;
+    // deterministic form (null: the atomic form): see BwdScratch
+    uint32_t* slot_base;         // [V*P + 1]   exclusive scan of tiles_touched: first slot of (view, Gaussian)
+    unsigned long long* last_key;// [V*T]       (depth bits << 32 | Gaussian) of the deepest entry the tile replayed; 0: none
+    float4* slot_a;              // [slots]     {colour r, g, b, mean2D x}
+    float4* slot_b;              // [slots]     {mean2D y, conic xx, conic xy, conic yy}
+    float* slot_c;               // [slots]     opacity
 };
+
+// Scratch of the deterministic backward, carved from ONE caller-owned buffer (dgs_raster_backward_scratch_bytes).
+struct BwdScratch {
+    uint32_t* slot_base; uint32_t* block_sums; unsigned long long* last_key; float4* slot_a; float4* slot_b; float* slot_c;
+    static BwdScratch carve(void* buf, size_t P, size_t V, size_t T, size_t slots, size_t* bytes) {
+        Carver c(buf);
+        BwdScratch s;
+        s.slot_base = c.take<uint32_t>(P * V + 1);
+        s.block_sums = c.take<uint32_t>((P * V + 4095) / 4096 + 1);
+        s.last_key = c.take<unsigned long long>(V * T);
+        s.slot_a = c.take<float4>(slots);
+        s.slot_b = c.take<float4>(slots);
+        s.slot_c = c.take<float>(slots);
+        if (bytes) *bytes = c.bytes();
+        return s;
+    }
+};
+
+// ---- exclusive scan of tiles_touched over all (view, Gaussian): two launches, 4,096 elements per workgroup ----
+__global__ __launch_bounds__(256) void touched_block_sums_kernel(const uint32_t* touched, size_t n, uint32_t* block_sums) {
+    __shared__ uint32_t scratch[8];
+    const size_t base = (size_t)blockIdx.x * 4096;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const size_t i = base + (size_t)r * 256 + threadIdx.x;
+        sum += i < n ? touched[i] : 0u;
+    }
+    uint32_t total;
+    (void)block_exclusive_scan<256>(sum, scratch, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void touched_scan_kernel(const uint32_t* touched, size_t n, const uint32_t* block_sums, uint32_t* slot_base) {
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t s_base;
+    // the workgroups in front of this one
+    uint32_t before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += block_sums[b];
+    uint32_t total;
+    (void)block_exclusive_scan<256>(before, scratch, &total);
+    if (threadIdx.x == 0) s_base = total;
+    __syncthreads();
+    // thread t owns 16 CONSECUTIVE elements (the scan is over the element order)
+    const size_t first = (size_t)blockIdx.x * 4096 + (size_t)threadIdx.x * 16;
+    uint32_t c[16], mine = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { c[e] = first + e < n ? touched[first + e] : 0u; mine += c[e]; }
+    uint32_t run = s_base + block_exclusive_scan<256>(mine, scratch, &total);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (first + e < n) slot_base[first + e] = run;
+        run += c[e];
+    }
+    if (first <= n && n < first + 16) slot_base[n] = run;     // the end: first slot behind the last Gaussian (n % 16 elements of this thread counted)
+}
 
 // grid V*T (workgroup b takes tile tile_order[b]), 256 threads = 4 wave64.  backward.cu:399-557.
 //
@@ -47,7 +119,7 @@ struct BwdParams {
 // Measured per 4 views at 256^2, trained-like / random-init regime, forward + backward: one atomic per wave per value 4.14 /
 // 2.49 ms; 16 x 4 strip masks 3.45 / 2.11; + combining a tile's four strips in LDS 3.00 / 1.88; + launch order by work 2.33 /
 // 1.70; cells: see DESIGN.md.  (One wave per tile with four pixels per lane lost: a latency chain.)
-template <bool FAST_EXP>
+template <bool FAST_EXP, bool DET>
 __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     __shared__ uint32_t s_id[256];
     __shared__ uint2 s_stat[kRasterStats ? 4 : 1];
@@ -216,7 +288,24 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             bool any = false;
 #pragma unroll
             for (int q = 0; q < 9; ++q) { c9[q] = s_acc[q][tid]; any = any || c9[q] != 0.f; }
-            if (any) {
+            if constexpr (DET) {
+                // every replayed entry STORES its sums (zeros too) into the slot of (Gaussian, this tile): Gaussian-major, the tile's
+                // index inside the Gaussian's rectangle (the forward's tile_rect on the same state: the same rectangle)
+                if (idx >= 0) {
+                    if (any) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) s_acc[q][tid] = 0.f;
+                    }
+                    const uint32_t id = s_id[tid];
+                    const size_t gv = vo + id;
+                    int x0, y0, x1, y1;
+                    tile_rect(s_xy[tid].x, s_xy[tid].y, p.radii[gv], p.gx, p.gy, &x0, &y0, &x1, &y1);
+                    const size_t slot = (size_t)p.slot_base[gv] + (size_t)((by - y0) * (x1 - x0) + (bx - x0));
+                    p.slot_a[slot] = make_float4(c9[0], c9[1], c9[2], c9[3]);
+                    p.slot_b[slot] = make_float4(c9[4], c9[5], c9[6], c9[7]);
+                    p.slot_c[slot] = c9[8];
+                }
+            } else if (any) {
 #pragma unroll
                 for (int q = 0; q < 9; ++q) s_acc[q][tid] = 0.f;
                 const uint32_t id = s_id[tid];
@@ -227,6 +316,17 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                 atomicAdd(p.dL_dconic + 4 * gv, c9[5]); atomicAdd(p.dL_dconic + 4 * gv + 1, c9[6]); atomicAdd(p.dL_dconic + 4 * gv + 3, c9[7]);
                 atomicAdd(p.dL_dopacity + gs, c9[8]);
             }
+        }
+    }
+    if constexpr (DET) {
+        // what this tile replayed: the first `todo` entries of its list, which is sorted by (depth bits, Gaussian index)
+        if (tid == 0) {
+            unsigned long long key = 0ull;
+            if (todo > 0) {
+                const uint32_t id = p.bn.point_list[rg.x + todo - 1u];
+                key = ((unsigned long long)__float_as_uint(p.g.depths[vo + id]) << 32) | id;
+            }
+            p.last_key[vt] = key;
         }
     }
     if constexpr (kRasterStats) {
@@ -315,6 +415,47 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* work,
     atomicMax(&smax, mx);
     __syncthreads();
     deal_tiles(work, n, smax, order, s_class, scratch);
+}
+
+// Deterministic form: grid ceil(S*P / 256), one thread per (set, Gaussian).  For every view of the set it adds the slots of the tiles
+// that replayed the Gaussian, in rectangle order (row-major), and writes the view's dL_dmean2D / dL_dconic / dL_dcolors rows; the
+// per-set sums (opacity; colours when they are precomputed) run over the views in view order.  Every output element is written.
+__global__ __launch_bounds__(256) void gather_partials_kernel(BwdParams p, int S) {
+    const size_t si = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (si >= (size_t)S * p.P) return;
+    const int s = (int)(si / p.P), idx = (int)(si % p.P);
+    const bool colors_per_set = p.colors_pre != nullptr;
+    float op_sum = 0.f, col_sum[3] = {0.f, 0.f, 0.f};
+    const int v0 = s * p.vps, v1 = min(p.V, v0 + p.vps);
+    for (int v = v0; v < v1; ++v) {
+        const size_t gi = (size_t)v * p.P + idx;
+        float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int radius = p.radii[gi];
+        if (radius > 0) {
+            const float2 m = p.g.means2D[gi];
+            int x0, y0, x1, y1;
+            tile_rect(m.x, m.y, radius, p.gx, p.gy, &x0, &y0, &x1, &y1);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(p.g.depths[gi]) << 32) | (uint32_t)idx;
+            const unsigned long long* lk = p.last_key + (size_t)v * p.T;
+            size_t slot = p.slot_base[gi];
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x, ++slot) {
+                    if (key <= lk[y * p.gx + x]) {
+                        const float4 sa = p.slot_a[slot], sb = p.slot_b[slot];
+                        a[0] += sa.x; a[1] += sa.y; a[2] += sa.z; a[3] += sa.w;
+                        a[4] += sb.x; a[5] += sb.y; a[6] += sb.z; a[7] += sb.w;
+                        a[8] += p.slot_c[slot];
+                    }
+                }
+        }
+        p.dL_dmean2D[3 * gi] = a[3]; p.dL_dmean2D[3 * gi + 1] = a[4]; p.dL_dmean2D[3 * gi + 2] = 0.f;
+        p.dL_dconic[4 * gi] = a[5]; p.dL_dconic[4 * gi + 1] = a[6]; p.dL_dconic[4 * gi + 2] = 0.f; p.dL_dconic[4 * gi + 3] = a[7];
+        if (!colors_per_set) { p.dL_dcolors[3 * gi] = a[0]; p.dL_dcolors[3 * gi + 1] = a[1]; p.dL_dcolors[3 * gi + 2] = a[2]; }
+        else { col_sum[0] += a[0]; col_sum[1] += a[1]; col_sum[2] += a[2]; }
+        op_sum += a[8];
+    }
+    p.dL_dopacity[si] = op_sum;
+    if (colors_per_set) { p.dL_dcolors[3 * si] = col_sum[0]; p.dL_dcolors[3 * si + 1] = col_sum[1]; p.dL_dcolors[3 * si + 2] = col_sum[2]; }
 }
 
 // grid ceil(S*P / 256).  One thread per (set, Gaussian); loops over the views of the set.
@@ -520,10 +661,30 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
     p.dL_dopacity = a->dL_dopacity; p.dL_dmeans3D = a->dL_dmeans3D; p.dL_dsh = a->dL_dsh; p.dL_dscales = a->dL_dscales;
     p.dL_drots = a->dL_drotations;
 
+    const size_t nv = (size_t)V * P, ns = (size_t)S * P, ncol = (a->colors_precomp ? ns : nv) * 3;
+    const bool det = a->scratch != nullptr;
+    if (det) {
+        // ---- deterministic form: slots instead of atomics, nothing to fill ----
+        const size_t slots = (size_t)(a->num_rendered < 1 ? 1 : a->num_rendered);
+        size_t need = 0;
+        const BwdScratch sc = BwdScratch::carve(a->scratch, (size_t)P, (size_t)V, (size_t)p.T, slots, &need);
+        if (a->scratch_bytes < need) return DGS_ERR_ALLOC;
+        p.slot_base = sc.slot_base; p.last_key = sc.last_key; p.slot_a = sc.slot_a; p.slot_b = sc.slot_b; p.slot_c = sc.slot_c;
+        const unsigned nb = (unsigned)((nv + 4095) / 4096);
+        hipLaunchKernelGGL(touched_block_sums_kernel, dim3(nb), dim3(256), 0, st, p.g.tiles_touched, nv, sc.block_sums);
+        hipLaunchKernelGGL(touched_scan_kernel, dim3(nb), dim3(256), 0, st, p.g.tiles_touched, nv, sc.block_sums, sc.slot_base);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_work, V * p.T, p.im.tile_order);
+        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_kernel<false, true>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((blend_backward_kernel<true, true>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
+        if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
+        hipLaunchKernelGGL(gather_partials_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
+        hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
+        if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
+        return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+    }
     // The four tensors the blend kernel accumulates into start from zero (the reference's torch::zeros, rasterize_points.cu:148-156);
     // everything else is written in full by preprocess_backward_kernel.  A caller that lays the four out back to back
     // (dgs_amd/raster.py does) gets ONE fill instead of four.
-    const size_t nv = (size_t)V * P, ns = (size_t)S * P, ncol = (a->colors_precomp ? ns : nv) * 3;
     if (p.dL_dconic == p.dL_dmean2D + nv * 3 && p.dL_dcolors == p.dL_dconic + nv * 4 && p.dL_dopacity == p.dL_dcolors + ncol) {
         hipMemsetAsync(p.dL_dmean2D, 0, (nv * 7 + ncol + ns) * sizeof(float), st);
     } else {
@@ -534,11 +695,19 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
     }
     if (a->num_rendered != 0) hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_work, V * p.T, p.im.tile_order);
     if (a->num_rendered != 0) {
-        if (p.exact_exp) hipLaunchKernelGGL(blend_backward_kernel<false>, dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(blend_backward_kernel<true>, dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
+        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_kernel<false, false>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((blend_backward_kernel<true, false>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
     }
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
+extern "C" size_t dgs_raster_backward_scratch_bytes(int32_t P, int32_t width, int32_t height, int32_t V, int64_t num_rendered) {
+    if (P <= 0 || width <= 0 || height <= 0 || V < 1) return 0;
+    const size_t T = (size_t)((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
+    size_t b = 0;
+    BwdScratch::carve(nullptr, (size_t)P, (size_t)V, T, (size_t)(num_rendered < 1 ? 1 : num_rendered), &b);
+    return b;
 }

@@ -17,6 +17,15 @@ constexpr bool kRasterStats = true;
 constexpr bool kRasterStats = false;
 #endif
 
+// auxiliary.h:46-56 (getRect): the tile rectangle [x0, x1) x [y0, y1) of a Gaussian from its pixel position and radius
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int* x0, int* y0, int* x1, int* y1) {
+    const float r = (float)radius;
+    *x0 = min(gx, max(0, f2i_sat((px - r) / (float)kTile)));
+    *y0 = min(gy, max(0, f2i_sat((py - r) / (float)kTile)));
+    *x1 = min(gx, max(0, f2i_sat((px + r + (float)(kTile - 1)) / (float)kTile)));
+    *y1 = min(gy, max(0, f2i_sat((py + r + (float)(kTile - 1)) / (float)kTile)));
+}
+
 // ---- small column-major 3x3 helper with glm's product order (type_mat3x3.inl:486-519) ----
 struct M3 { float c[3][3]; };
 __device__ __forceinline__ M3 m3_cols(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {

@@ -45,15 +45,6 @@ __device__ __forceinline__ void view_tanfov(const FwdParams& p, int v, float* tx
     else { *tx = p.tanfovx; *ty = p.tanfovy; }
 }
 
-// auxiliary.h:46-56
-__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int* x0, int* y0, int* x1, int* y1) {
-    const float r = (float)radius;
-    *x0 = min(gx, max(0, f2i_sat((px - r) / (float)kTile)));
-    *y0 = min(gy, max(0, f2i_sat((py - r) / (float)kTile)));
-    *x1 = min(gx, max(0, f2i_sat((px + r + (float)(kTile - 1)) / (float)kTile)));
-    *y1 = min(gy, max(0, f2i_sat((py + r + (float)(kTile - 1)) / (float)kTile)));
-}
-
 // forward.cu:20-71, degree 0..3.  sh points at this Gaussian's M coefficients (3 floats each).
 __device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, float dx, float dy, float dz, float* out, unsigned* clamp_bits) {
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # or an A/B side (tools/ab_build.sh).  Never a fallback: whatever is named must exist and pass the ABI check.
 LIB_PATH = os.environ.get("DGS_AMD_LIBRARY") or os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
 
-ABI_VERSION = 6          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
+ABI_VERSION = 7          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
 DGS_ERR_BINNING_OVERFLOW = -7    # include/dgs_raster.h DgsStatus
 c_float_p = ctypes.POINTER(ctypes.c_float)
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
@@ -53,13 +53,14 @@ class DgsRasterBackwardArgs(ctypes.Structure):
         ("dL_dmeans2D", ctypes.c_void_p), ("dL_dconic", ctypes.c_void_p), ("dL_dcolors", ctypes.c_void_p),
         ("dL_dcov3D", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p), ("dL_dmeans3D", ctypes.c_void_p),
         ("dL_dsh", ctypes.c_void_p), ("dL_dscales", ctypes.c_void_p), ("dL_drotations", ctypes.c_void_p),
-        ("exact_exp", ctypes.c_int32),
+        ("exact_exp", ctypes.c_int32), ("scratch", ctypes.c_void_p), ("scratch_bytes", ctypes.c_size_t),
     ]
 
 
 # every symbol include/dgs_raster.h declares (checked by tests/test_abi.py)
 RASTER_SYMBOLS = ["dgs_abi_version", "dgs_status_string", "dgs_raster_geom_bytes", "dgs_raster_image_bytes",
-                  "dgs_raster_binning_bytes", "dgs_raster_forward", "dgs_raster_binning_form", "dgs_raster_backward", "dgs_mark_visible",
+                  "dgs_raster_binning_bytes", "dgs_raster_forward", "dgs_raster_binning_form", "dgs_raster_backward",
+                  "dgs_raster_backward_scratch_bytes", "dgs_mark_visible",
                   "dgs_raster_state_read", "dgs_cameras_from_c2w", "dgs_rays_from_c2w"]
 
 
@@ -80,6 +81,8 @@ def _declare(L):
     if hasattr(L, "dgs_raster_backward"):
         L.dgs_raster_backward.restype = ctypes.c_int
         L.dgs_raster_backward.argtypes = [ctypes.POINTER(DgsRasterBackwardArgs), ctypes.c_void_p]
+        L.dgs_raster_backward_scratch_bytes.restype = ctypes.c_size_t
+        L.dgs_raster_backward_scratch_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]
     L.dgs_mark_visible.restype = ctypes.c_int
     L.dgs_mark_visible.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p]
@@ -98,8 +101,15 @@ def _declare(L):
 
 
 def open_library(path):
-    """Open a library exporting the dgs C ABI and attach prototypes."""
-    return _declare(ctypes.CDLL(path))
+    """Open a library exporting the dgs C ABI and attach prototypes.  Whatever build it is (product, tools' instrumented build, CPU
+    emulation), it has to speak THIS binding's struct layouts: a stale build is refused, not called with misaligned structs."""
+    L = ctypes.CDLL(path)
+    L.dgs_abi_version.restype = ctypes.c_int
+    if L.dgs_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"dgs_amd: ABI version mismatch: {path} reports {L.dgs_abi_version()}, this binding is written for {ABI_VERSION} "
+                           f"(include/dgs_raster.h DGS_ABI_VERSION) -- rebuild it (`python -m dgs_amd.build`, `DGS_INSTRUMENT=1 python -m dgs_amd.build`, "
+                           f"tests/hipemu/build_emu.py)")
+    return _declare(L)
 
 
 _lib = None

@@ -68,4 +68,7 @@ def _build(force, verbose, obj_dir, lib_path, extra):
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv, verbose=True))
+    # both builds, always: the tools' library has to follow every ABI change of the product's (bench.py counts with it)
+    if os.environ.get("DGS_INSTRUMENT", "0") in ("", "0"):
+        print(build_hip(force="--force" in sys.argv, verbose=True, instrument=False))
+    print(build_hip(force="--force" in sys.argv, verbose=True, instrument=True))

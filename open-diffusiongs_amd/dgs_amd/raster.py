@@ -104,6 +104,11 @@ class RasterBackend:
         # exponential of the blend loops (dgs_raster.h `exact_exp`): False = the hardware's v_exp_f32 (product default), True = the
         # fixed IEEE sequence the CPU oracle restates (floats bit-identical with the oracle: what the bit-exact parity tests select)
         self.exact_exp = bool(int(os.environ.get("DGS_RASTER_EXACT_EXP", "0") or 0)) if exact_exp is None else bool(exact_exp)
+        # backward without floating-point atomics (dgs_raster.h `scratch`): on unless its scratch (36 bytes per instance slot) would
+        # exceed `deterministic_budget` bytes -- then the atomic form runs, and `last_backward_deterministic` says so
+        self.deterministic = os.environ.get("DGS_RASTER_DETERMINISTIC", "1") != "0"
+        self.deterministic_budget = int(float(os.environ.get("DGS_RASTER_DETERMINISTIC_GIB", "64")) * 2 ** 30)
+        self.last_backward_deterministic = None
 
     # -- helpers ---------------------------------------------------------------------------
     @staticmethod
@@ -298,6 +303,13 @@ class RasterBackend:
         a.dL_dsh = _ptr(out["sh"]) if M else None
         a.dL_dscales, a.dL_drotations = (_ptr(out["scales"]), _ptr(out["rotations"])) if use_sr else (None, None)
         a.exact_exp = int(self.exact_exp)
+        scratch = None
+        if self.deterministic and int(num_rendered) > 0:
+            nbytes = int(self.lib.dgs_raster_backward_scratch_bytes(P, W, H, V, int(num_rendered)))
+            if nbytes <= self.deterministic_budget:
+                scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                a.scratch, a.scratch_bytes = ctypes.c_void_p(scratch.data_ptr()), nbytes
+        self.last_backward_deterministic = scratch is not None
         rc = self.lib.dgs_raster_backward(ctypes.byref(a), self._stream(device))
         self._check(rc)
         return out

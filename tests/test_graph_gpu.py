@@ -65,7 +65,10 @@ def test_graph_replays_equal_the_eager_step():
         want, want_g = m(batch2, t2)
         want, want_xyz = want.clone(), want_g[0]._xyz.clone()
         got, got_g = g(batch2, t2)
-        assert torch.equal(got, want) and torch.equal(got_g[0]._xyz, want_xyz) and not torch.equal(got, ref_render)
+        torch.cuda.synchronize()
+        diag = dict(stats=g._stats.tolist(), capacity=g._plan.capacity, seen_max=g._plan.seen_max, form=g._plan.form,
+                    xyz_equal=bool(torch.equal(got_g[0]._xyz, want_xyz)), nan_frac=float(torch.isnan(got).float().mean()))
+        assert torch.equal(got, want) and torch.equal(got_g[0]._xyz, want_xyz) and not torch.equal(got, ref_render), diag
         # weights change (load_state_dict / optimizer step): the engine's copies are refreshed in place, the SAME graph sees them
         sd = {k: v.clone() for k, v in m.state_dict().items()}
         sd["transformer.1.mlp.fc2.weight"] = sd["transformer.1.mlp.fc2.weight"] * 1.5

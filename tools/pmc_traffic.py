@@ -57,6 +57,60 @@ def collect(counter, out_dir, cmd):
     return rows
 
 
+# the four block GEMMs of the sampling step at one sample (L = 4098 valid rows, width 1024): kernel-name fragment -> (family,
+# algorithmic bytes per launch = A read + W read + output written (+ residual read), 2-byte operands)
+_L, _W = 4098, 1024
+DIT_FAMILIES = {
+    "gemm_sliced_kernel<4, 256, 8, 0, 256>": ("gemm_qkv", _L * _W * 2 + 3 * _W * _W * 2 + _L * 3 * _W * 2),
+    "gemm_sliced_kernel<1, 256, 8, 0, 256>": ("gemm_fc1_gelu", _L * _W * 2 + 4 * _W * _W * 2 + _L * 4 * _W * 2),
+    "gemm_sliced_kernel<2, 128, 4, 0, 128>": ("gemm_fc2_gate_residual", _L * 4 * _W * 2 + 4 * _W * _W * 2 + 2 * _L * _W * 4),
+    "gemm_bf16_kernel<2, 64>": ("gemm_proj_gate_residual", _L * _W * 2 + _W * _W * 2 + 2 * _L * _W * 4),
+    "layernorm_kernel<4, false, true, false>": ("layernorm_modulate", _L * _W * 4 + _L * _W * 2),
+}
+
+
+def collect_with_durations(counters, out_dir, cmd):
+    """One PMC pass with several SQ counters + the kernel trace of the same run: per kernel {counter: sum, calls, dur_ns: sum}."""
+    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out_dir, "--"] + cmd,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    rows = {}
+    for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            d = rows.setdefault(r.get("Kernel_Name", "?"), {"calls": 0, "dur_ns": 0.0})
+            c = r.get("Counter_Name")
+            d[c] = d.get(c, 0.0) + float(r.get("Counter_Value", 0) or 0)
+            if c == counters[0]:
+                d["calls"] += 1
+                try:
+                    d["dur_ns"] += float(r.get("End_Timestamp", 0)) - float(r.get("Start_Timestamp", 0))
+                except (TypeError, ValueError):
+                    pass
+    return rows
+
+
+def mfma_busy(raw, bench, out):
+    """Matrix-pipe occupancy of the DiT kernels (`north_star`: "rocprof-evidenced MFMA utilisation for the DiT path"):
+    SQ_VALU_MFMA_BUSY_CYCLES per dispatch / (1,024 SIMDs x the dispatch's duration x the shader clock).  The counter is summed over
+    the chip's SIMDs... the clock is not in the trace, so the table gives busy cycles per SIMD and per microsecond (= the fraction of
+    a 1 GHz clock; divide by the clock in GHz that bench.py's `shader_clock_mhz` reports for the fraction of peak issue slots)."""
+    rows = collect_with_durations(["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES"], os.path.join(raw, "dit_mfma"), bench)
+    table = {}
+    for name, d in rows.items():
+        if "dgs::" not in name or not d["calls"]:
+            continue
+        busy = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / d["calls"]
+        dur_us = d["dur_ns"] / d["calls"] / 1e3 if d["dur_ns"] else None
+        table[name[:90]] = {"launches": d["calls"], "mfma_busy_cycles_per_launch": busy, "mfma_insts_per_launch": d.get("SQ_INSTS_MFMA", 0.0) / d["calls"],
+                            "avg_us_under_pmc": dur_us,
+                            "busy_cycles_per_simd_per_us": (busy / 1024.0 / dur_us) if dur_us else None}
+    out["dit_mfma"] = table
+    lines = [f"{'kernel':72s} {'launches':>8s} {'MFMA busy cyc/launch':>22s} {'MFMA insts':>12s} {'avg us (PMC run)':>17s} {'busy cyc / SIMD / us':>21s}"]
+    for k, v in sorted(table.items(), key=lambda kv: -(kv[1]["mfma_busy_cycles_per_launch"] or 0)):
+        lines.append(f"{k[:72]:72s} {v['launches']:8d} {v['mfma_busy_cycles_per_launch']:22.0f} {v['mfma_insts_per_launch']:12.0f} "
+                     f"{(v['avg_us_under_pmc'] or 0):17.2f} {(v['busy_cycles_per_simd_per_us'] or 0):21.1f}")
+    open(os.path.join(ROOT, "gpurun_out", "dit_pmc.txt"), "w").write("\n".join(lines) + "\n")
+
+
 def calibrate(raw):
     """tools/ubench/fetch_calib_bench under --pmc FETCH_SIZE: what the counter reports for patterns of known byte counts (streaming,
     one 16-byte piece per 128- / 64-byte line, the blend's record gather).  `reported_bytes` is the RAW counter (KiB x 1024, no
@@ -93,7 +147,7 @@ def main():
            "kernel_source_sha": kernel_source_sha(), "family_sha": {f: kernel_source_sha(f) for f in FAMILIES},
            "git_head": head or None, "dit": {}, "raster": {}, "kernels": {}}
     py = sys.executable
-    bench = [py, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras"]
+    bench = [py, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras", "--graph", "0", "--preheat-s", "0"]
     f = collect("FETCH_SIZE", os.path.join(raw, "dit_fetch"), bench)
     w = collect("WRITE_SIZE", os.path.join(raw, "dit_write"), bench)
     for name in sorted(set(f) | set(w)):
@@ -105,6 +159,14 @@ def main():
         if "attention_fwd_kernel" in name and fb is not None and wb is not None:
             out["dit"]["attention"] = {"fetch_bytes_per_launch": int(fb), "write_bytes_per_launch": int(wb),
                                        "traffic_bytes_per_launch": int(fb + wb), "algorithmic_bytes_per_launch": 4098 * 1024 * 2 * 4}
+        for frag, (fam, algo) in DIT_FAMILIES.items():
+            if frag in name and fb is not None and wb is not None:
+                out["dit"][fam] = {"fetch_bytes_per_launch": int(fb), "write_bytes_per_launch": int(wb), "traffic_bytes_per_launch": int(fb + wb),
+                                   "algorithmic_bytes_per_launch": int(algo), "traffic_over_algorithmic": round((fb + wb) / algo, 3)}
+    try:
+        mfma_busy(raw, bench, out)
+    except Exception as e:                      # noqa: BLE001 -- an annex
+        out["dit_mfma"] = {"error": f"{type(e).__name__}: {e}"}
     iters = 3
     for regime in ("init", "trained"):
         out["raster"][regime] = {}
@@ -123,7 +185,7 @@ def main():
         out["fetch_calibration"] = {"error": f"{type(e).__name__}: {e}"}
     path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
-    print(json.dumps({k: out[k] for k in ("dit", "raster", "fetch_calibration")}, indent=1))
+    print(json.dumps({k: out[k] for k in ("dit", "dit_mfma", "raster", "fetch_calibration")}, indent=1))
     print("wrote", path, "-> copy to profiles/pmc_traffic.json")
 
 
