@@ -403,7 +403,7 @@ def main():
                     "(the one-GPU RCCL smoke run: same init, streams and collective calls as N > 1)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("DGS_GRAPH", "1")), help="1 (default): the timed steps are replays of DGSDenoiser.forward captured as ONE hipGraph "
                     "(dgs_amd/graph.py), except the steps that carry the roofline kernel's HIP events (every 4th), which are enqueued eagerly; 0: every step eager")
-    ap.add_argument("--preheat-s", type=float, default=2.0, help="seconds of the same step run (untimed) before the warm-up steps: a timed region of "
+    ap.add_argument("--preheat-s", type=float, default=1.0, help="seconds of the same step run (untimed) before the warm-up steps: a timed region of "
                     "~0.15 s that starts from idle clocks measures the DVFS ramp, not the kernels (BENCH_r03 vs the builder's runs: -8 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")

@@ -129,7 +129,11 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     __shared__ uint32_t s_max[4];
     __shared__ uint4 s_cnt[16];                           // [cell] entries of the batch the cell keeps, per staging wave
     __shared__ uint8_t s_list[17][256];                   // [cell] their batch indices, back to front (+ one row: read-ahead)
-    __shared__ float s_acc[9][256];                       // [value][entry] sums over the tile's pixels
+    // [wave copy][value][entry] sums over the tile's pixels.  Atomic form: ONE copy, the sixteen cells' ds_add_f32 meet in it in whatever
+    // order the four waves get there (fp32: the sum's last bit depends on that order).  Deterministic form: a copy per wave -- inside
+    // a wave the adds happen in program order -- and the four copies are added in wave order when the batch is done.
+    constexpr int NACC = DET ? 4 : 1;
+    __shared__ float s_acc[NACC][9][256];
     const uint32_t vt = p.im.tile_order[blockIdx.x];           // order_tiles_kernel: most replayed entries first
     const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T), s = v / p.vps;
     const int bx = tile % p.gx, by = tile / p.gx;
@@ -165,7 +169,9 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
     if (lane == 0) s_max[wave] = mc;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) s_acc[k][tid] = 0.f;
+    for (int w = 0; w < NACC; ++w)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_acc[w][k][tid] = 0.f;
     __syncthreads();
     const uint32_t todo = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));   // <= rg.y - rg.x
     const int rounds = (int)((todo + 255u) / 256u);
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                         for (int q = 0; q < 9; ++q) c9[q] = row_sum_to_lane15(take ? c9[q] : 0.f);
                         if ((lane & 15) == 15 && ((takers >> (16 * row)) & 0xFFFFull) != 0ull) {
 #pragma unroll
-                            for (int q = 0; q < 9; ++q) lds_add(&s_acc[q][j], c9[q]);
+                            for (int q = 0; q < 9; ++q) lds_add(&s_acc[DET ? wave : 0][q][j], c9[q]);
                         }
                     }
                 }
@@ -287,14 +293,20 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             float c9[9];
             bool any = false;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) { c9[q] = s_acc[q][tid]; any = any || c9[q] != 0.f; }
+            for (int q = 0; q < 9; ++q) {
+                if constexpr (DET) c9[q] = ((s_acc[0][q][tid] + s_acc[1][q][tid]) + s_acc[2][q][tid]) + s_acc[3][q][tid];
+                else c9[q] = s_acc[0][q][tid];
+                any = any || c9[q] != 0.f;
+            }
             if constexpr (DET) {
                 // every replayed entry STORES its sums (zeros too) into the slot of (Gaussian, this tile): Gaussian-major, the tile's
                 // index inside the Gaussian's rectangle (the forward's tile_rect on the same state: the same rectangle)
                 if (idx >= 0) {
                     if (any) {
 #pragma unroll
-                        for (int q = 0; q < 9; ++q) s_acc[q][tid] = 0.f;
+                        for (int w = 0; w < NACC; ++w)
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) s_acc[w][q][tid] = 0.f;
                     }
                     const uint32_t id = s_id[tid];
                     const size_t gv = vo + id;
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                 }
             } else if (any) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) s_acc[q][tid] = 0.f;
+                for (int q = 0; q < 9; ++q) s_acc[0][q][tid] = 0.f;
                 const uint32_t id = s_id[tid];
                 const size_t gv = vo + id, gs = (size_t)s * p.P + id;
                 float* dc = p.dL_dcolors + 3 * (colors_per_set ? gs : gv);

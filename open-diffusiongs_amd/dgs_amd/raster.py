@@ -104,9 +104,10 @@ class RasterBackend:
         # exponential of the blend loops (dgs_raster.h `exact_exp`): False = the hardware's v_exp_f32 (product default), True = the
         # fixed IEEE sequence the CPU oracle restates (floats bit-identical with the oracle: what the bit-exact parity tests select)
         self.exact_exp = bool(int(os.environ.get("DGS_RASTER_EXACT_EXP", "0") or 0)) if exact_exp is None else bool(exact_exp)
-        # backward without floating-point atomics (dgs_raster.h `scratch`): on unless its scratch (36 bytes per instance slot) would
-        # exceed `deterministic_budget` bytes -- then the atomic form runs, and `last_backward_deterministic` says so
-        self.deterministic = os.environ.get("DGS_RASTER_DETERMINISTIC", "1") != "0"
+        # backward without floating-point atomics (dgs_raster.h `scratch`; DGS_RASTER_DETERMINISTIC=1 or `backend.deterministic = True`):
+        # bit-reproducible gradients for 36 bytes of scratch per instance slot and, in dense scenes, time; if
+        # the scratch would exceed `deterministic_budget` bytes the atomic form runs and `last_backward_deterministic` says so
+        self.deterministic = os.environ.get("DGS_RASTER_DETERMINISTIC", "0") not in ("", "0")
         self.deterministic_budget = int(float(os.environ.get("DGS_RASTER_DETERMINISTIC_GIB", "64")) * 2 ** 30)
         self.last_backward_deterministic = None
 

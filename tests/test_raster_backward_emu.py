@@ -11,6 +11,18 @@ from util_scene import small_scene
 DEV = torch.device("cpu")
 
 
+@pytest.fixture(params=["atomic", "deterministic"], autouse=True)
+def backward_form(request):
+    """Both forms of the backward (dgs_raster.h `scratch`): one fp32 atomic per value per (tile, Gaussian), or per-instance slots + an
+    ordered gather (no floating-point atomic).  Every test of this file runs with each."""
+    be = emu_backend()
+    old = be.deterministic
+    be.deterministic = request.param == "deterministic"
+    yield request.param
+    assert be.last_backward_deterministic in (None, request.param == "deterministic")
+    be.deterministic = old
+
+
 @pytest.mark.parametrize("deg,seed,H,W,views", [(0, 1, 40, 56, 1), (3, 3, 33, 17, 2), (1, 5, 48, 48, 3)])
 def test_backward_matches_oracle(deg, seed, H, W, views):
     sc, cams = small_scene(200, W, H, seed=seed, sh_degree=deg, n_views=views)

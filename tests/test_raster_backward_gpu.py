@@ -70,8 +70,9 @@ def test_full_size_512_vs_oracle(exact, rtol):
 
 @pytest.mark.parametrize("regime", ["trained", "init"])
 def test_backward_is_bit_reproducible_256(regime):
-    """The deterministic form (the product default: every (tile, Gaussian) instance stores its sums into a slot of its own, a gather
-    adds them in rectangle order; no floating-point atomic): two backward passes give identical bits, in the list forms (trained-like)
+    """The deterministic form (`backend.deterministic = True`: every (tile, Gaussian) instance stores its sums into a slot of its own, a
+    gather adds them in rectangle order, a tile's waves accumulate in LDS copies of their own; no floating-point atomic whose order
+    is left to the hardware): two backward passes give identical bits, in the list forms (trained-like)
     and the on-demand scan form (random-init regime), 4 views at 256^2; the atomic form (reference's way) stays within 1e-5 of it."""
     from dgs_amd import cameras
     from dgs_amd.raster import RasterBackend, render_views_autograd
@@ -89,7 +90,7 @@ def test_backward_is_bit_reproducible_256(regime):
         return [x.grad.clone() for x in leaves]
 
     be = RasterBackend()
-    assert be.deterministic
+    be.deterministic = True
     runs = [grads(be) for _ in range(3)]
     assert be.last_backward_deterministic
     for r in runs[1:]:
