@@ -584,6 +584,12 @@ def main():
     _sync(); barrier()
     elapsed = time.perf_counter() - t0
     local_ms = elapsed / a.steps * 1e3
+    # the timed steps produced what they claim: no deferred device-side failure (asynchronous renders report one call late), finite images
+    if not a.dry_run_cpu:
+        if use_graph:
+            graphed.check(wait=True)
+        model.gs_renderer.backend().check_async(wait=True)
+        assert bool(torch.isfinite(rendered).all()), "the timed region rendered non-finite images"
     if not a.dry_run_cpu:
         clock["after_timed_region_mhz"] = round(DitOps().shader_clock_mhz(dev), 0)
     rank_ms = [local_ms]

@@ -177,7 +177,7 @@ int dgs_raster_binning_form(int32_t binning_form, int64_t num_rendered, int64_t 
                             int32_t V);
 int dgs_raster_backward(const DgsRasterBackwardArgs* args, dgs_stream_t stream);
 /* Bytes of DgsRasterBackwardArgs.scratch: 36 per instance slot (num_rendered as passed to the backward: the forward's count, or the
- * binning capacity of an asynchronous forward) + 4 per (view, Gaussian) + 8 per tile. */
+ * binning capacity of an asynchronous forward) + 20 per (view, Gaussian) + 8 per tile. */
 size_t dgs_raster_backward_scratch_bytes(int32_t P, int32_t width, int32_t height, int32_t V, int64_t num_rendered);
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, dgs_stream_t stream);

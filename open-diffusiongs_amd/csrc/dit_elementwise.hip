@@ -297,6 +297,20 @@ int launch_rowlinear(const DgsDitRowLinearArgs* a, hipStream_t st) {
     return launch_ok();
 }
 
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* dst, size_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = z;
+}
+
+int launch_zero_fill(void* dst, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return DGS_OK;
+    if ((bytes & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return DGS_ERR_INVALID_ARGUMENT;
+    const size_t n16 = bytes / 16;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, st, static_cast<uint4*>(dst), n16);
+    return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
+}
+
 int launch_timestep(const int64_t* t, float* emb, int B, hipStream_t st) {
     hipLaunchKernelGGL(timestep_freq_kernel, dim3(B), dim3(128), 0, st, t, emb, B);
     return launch_ok();

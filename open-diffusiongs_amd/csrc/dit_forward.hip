@@ -200,7 +200,7 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     }
 
     // ---- tokens: embed + patchify -> tokenizer GEMM -> learned tokens -> input LayerNorm (denoiser.py:312-347) ----
-    if (hipMemsetAsync(ws.emb, 0, (size_t)M * kin * sizeof(bf16_t), st) != hipSuccess) return DGS_ERR_DEVICE;
+    DGS_TRY(launch_zero_fill(ws.emb, (size_t)M * kin * sizeof(bf16_t), st));       // a kernel, not a memset node: dit_kernels.h
     EmbedParams ep;
     ep.B = B; ep.V = V; ep.H = H; ep.W = Wd; ep.ps = m->patch; ep.lpad = lpad; ep.relative_plk = m->relative_plk;
     ep.images = a->images; ep.ray_o = a->ray_o; ep.ray_d = a->ray_d; ep.out = ws.emb;

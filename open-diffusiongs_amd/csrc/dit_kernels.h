@@ -36,6 +36,10 @@ struct GsParams {
 int launch_layernorm(const DgsDitLayerNormArgs* a, hipStream_t st);
 int launch_rowlinear(const DgsDitRowLinearArgs* a, hipStream_t st);
 int launch_timestep(const int64_t* t, float* emb, int B, hipStream_t st);
+// zero `bytes` bytes (a multiple of 16, 16-byte aligned) with a kernel of the library's own.  NOT hipMemsetAsync: inside a captured
+// hipGraph a memset NODE stopped zeroing its destination as soon as the process issued an eager hipMemsetAsync elsewhere (ROCm 7.2,
+// profiles/r04_graph_memset_node_debug.txt), and a plain kernel is also the shorter launch (2 us against ~5 for the runtime's fill)
+int launch_zero_fill(void* dst, size_t bytes, hipStream_t st);
 int launch_embed(const EmbedParams& p, hipStream_t st);
 int launch_pos_embed(const float* pe, float* x, int B, int lpad, int L, int ng, int width, hipStream_t st);
 int launch_gather_tokens(const float* x, float* out, int B, int lpad, int L, int ng, int width, hipStream_t st);

@@ -47,11 +47,13 @@ struct BwdParams {
     float4* slot_a;              // [slots]     {colour r, g, b, mean2D x}
     float4* slot_b;              // [slots]     {mean2D y, conic xx, conic xy, conic yy}
     float* slot_c;               // [slots]     opacity
+    float* op_view;              // [V*P]       per-view opacity sums (added over the views of a set, in view order, by preprocess_backward_kernel)
+    float* col_view;             // [V*P*3]     per-view colour sums when colours are per set (precomputed colours); else null
 };
 
 // Scratch of the deterministic backward, carved from ONE caller-owned buffer (dgs_raster_backward_scratch_bytes).
 struct BwdScratch {
-    uint32_t* slot_base; uint32_t* block_sums; unsigned long long* last_key; float4* slot_a; float4* slot_b; float* slot_c;
+    uint32_t* slot_base; uint32_t* block_sums; unsigned long long* last_key; float4* slot_a; float4* slot_b; float* slot_c; float* op_view; float* col_view;
     static BwdScratch carve(void* buf, size_t P, size_t V, size_t T, size_t slots, size_t* bytes) {
         Carver c(buf);
         BwdScratch s;
@@ -61,6 +63,8 @@ struct BwdScratch {
         s.slot_a = c.take<float4>(slots);
         s.slot_b = c.take<float4>(slots);
         s.slot_c = c.take<float>(slots);
+        s.op_view = c.take<float>(P * V);
+        s.col_view = c.take<float>(3 * P * V);
         if (bytes) *bytes = c.bytes();
         return s;
     }
@@ -429,45 +433,46 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* work,
     deal_tiles(work, n, smax, order, s_class, scratch);
 }
 
-// Deterministic form: grid ceil(S*P / 256), one thread per (set, Gaussian).  For every view of the set it adds the slots of the tiles
-// that replayed the Gaussian, in rectangle order (row-major), and writes the view's dL_dmean2D / dL_dconic / dL_dcolors rows; the
-// per-set sums (opacity; colours when they are precomputed) run over the views in view order.  Every output element is written.
-__global__ __launch_bounds__(256) void gather_partials_kernel(BwdParams p, int S) {
-    const size_t si = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (si >= (size_t)S * p.P) return;
-    const int s = (int)(si / p.P), idx = (int)(si % p.P);
-    const bool colors_per_set = p.colors_pre != nullptr;
-    float op_sum = 0.f, col_sum[3] = {0.f, 0.f, 0.f};
-    const int v0 = s * p.vps, v1 = min(p.V, v0 + p.vps);
-    for (int v = v0; v < v1; ++v) {
-        const size_t gi = (size_t)v * p.P + idx;
-        float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int radius = p.radii[gi];
-        if (radius > 0) {
-            const float2 m = p.g.means2D[gi];
-            int x0, y0, x1, y1;
-            tile_rect(m.x, m.y, radius, p.gx, p.gy, &x0, &y0, &x1, &y1);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(p.g.depths[gi]) << 32) | (uint32_t)idx;
-            const unsigned long long* lk = p.last_key + (size_t)v * p.T;
-            size_t slot = p.slot_base[gi];
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x, ++slot) {
-                    if (key <= lk[y * p.gx + x]) {
-                        const float4 sa = p.slot_a[slot], sb = p.slot_b[slot];
-                        a[0] += sa.x; a[1] += sa.y; a[2] += sa.z; a[3] += sa.w;
-                        a[4] += sb.x; a[5] += sb.y; a[6] += sb.z; a[7] += sb.w;
-                        a[8] += p.slot_c[slot];
-                    }
-                }
-        }
-        p.dL_dmean2D[3 * gi] = a[3]; p.dL_dmean2D[3 * gi + 1] = a[4]; p.dL_dmean2D[3 * gi + 2] = 0.f;
-        p.dL_dconic[4 * gi] = a[5]; p.dL_dconic[4 * gi + 1] = a[6]; p.dL_dconic[4 * gi + 2] = 0.f; p.dL_dconic[4 * gi + 3] = a[7];
-        if (!colors_per_set) { p.dL_dcolors[3 * gi] = a[0]; p.dL_dcolors[3 * gi + 1] = a[1]; p.dL_dcolors[3 * gi + 2] = a[2]; }
-        else { col_sum[0] += a[0]; col_sum[1] += a[1]; col_sum[2] += a[2]; }
-        op_sum += a[8];
+// Deterministic form: grid (ceil(P / 256), V), one thread per (view, Gaussian).  It adds the slots of the tiles that replayed the
+// Gaussian, in rectangle order (row-major), and writes the view's dL_dmean2D / dL_dconic / dL_dcolors rows and its opacity (and,
+// with per-set colours, colour) sums -- which preprocess_backward_kernel adds over the views of a set in view order.  Every output
+// element is written.  The tiles' keys sit in LDS (8 bytes per tile): a Gaussian of the random-init regime tests ~50 of them.
+template <bool LDS_KEYS>
+__global__ __launch_bounds__(256) void gather_partials_kernel(BwdParams p) {
+    DGS_DYNAMIC_LDS(smem);
+    const int v = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long* lk = p.last_key + (size_t)v * p.T;
+    if (LDS_KEYS) {
+        unsigned long long* s_lk = reinterpret_cast<unsigned long long*>(smem);
+        for (int i = threadIdx.x; i < p.T; i += 256) s_lk[i] = lk[i];
+        __syncthreads();
+        lk = s_lk;
     }
-    p.dL_dopacity[si] = op_sum;
-    if (colors_per_set) { p.dL_dcolors[3 * si] = col_sum[0]; p.dL_dcolors[3 * si + 1] = col_sum[1]; p.dL_dcolors[3 * si + 2] = col_sum[2]; }
+    if (idx >= p.P) return;
+    const size_t gi = (size_t)v * p.P + idx;
+    float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int radius = p.radii[gi];
+    if (radius > 0) {
+        const float2 m = p.g.means2D[gi];
+        int x0, y0, x1, y1;
+        tile_rect(m.x, m.y, radius, p.gx, p.gy, &x0, &y0, &x1, &y1);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(p.g.depths[gi]) << 32) | (uint32_t)idx;
+        size_t slot = p.slot_base[gi];
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x, ++slot) {
+                if (key <= lk[y * p.gx + x]) {
+                    const float4 sa = p.slot_a[slot], sb = p.slot_b[slot];
+                    a[0] += sa.x; a[1] += sa.y; a[2] += sa.z; a[3] += sa.w;
+                    a[4] += sb.x; a[5] += sb.y; a[6] += sb.z; a[7] += sb.w;
+                    a[8] += p.slot_c[slot];
+                }
+            }
+    }
+    p.dL_dmean2D[3 * gi] = a[3]; p.dL_dmean2D[3 * gi + 1] = a[4]; p.dL_dmean2D[3 * gi + 2] = 0.f;
+    p.dL_dconic[4 * gi] = a[5]; p.dL_dconic[4 * gi + 1] = a[6]; p.dL_dconic[4 * gi + 2] = 0.f; p.dL_dconic[4 * gi + 3] = a[7];
+    if (p.colors_pre == nullptr) { p.dL_dcolors[3 * gi] = a[0]; p.dL_dcolors[3 * gi + 1] = a[1]; p.dL_dcolors[3 * gi + 2] = a[2]; }
+    else { p.col_view[3 * gi] = a[0]; p.col_view[3 * gi + 1] = a[1]; p.col_view[3 * gi + 2] = a[2]; }
+    p.op_view[gi] = a[8];
 }
 
 // grid ceil(S*P / 256).  One thread per (set, Gaussian); loops over the views of the set.
@@ -482,6 +487,16 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
     const int nsh = p.shs ? 3 * p.M : 0;
     for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
     const int v0 = s * p.vps, v1 = min(p.V, v0 + p.vps);
+    if (p.op_view) {     // deterministic form: the per-set sums over the views of the set, in view order (gather_partials_kernel wrote the per-view terms)
+        float o = 0.f, c3[3] = {0.f, 0.f, 0.f};
+        for (int v = v0; v < v1; ++v) {
+            const size_t gi = (size_t)v * p.P + idx;
+            o += p.op_view[gi];
+            if (p.colors_pre) { c3[0] += p.col_view[3 * gi]; c3[1] += p.col_view[3 * gi + 1]; c3[2] += p.col_view[3 * gi + 2]; }
+        }
+        p.dL_dopacity[si] = o;
+        if (p.colors_pre) { p.dL_dcolors[3 * si] = c3[0]; p.dL_dcolors[3 * si + 1] = c3[1]; p.dL_dcolors[3 * si + 2] = c3[2]; }
+    }
     for (int v = v0; v < v1; ++v) {
         const size_t gi = (size_t)v * p.P + idx;
         if (!(p.radii[gi] > 0)) {                  // culled in this view: its dL_dcov3D row is zero (the buffer is not pre-filled)
@@ -682,6 +697,7 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
         const BwdScratch sc = BwdScratch::carve(a->scratch, (size_t)P, (size_t)V, (size_t)p.T, slots, &need);
         if (a->scratch_bytes < need) return DGS_ERR_ALLOC;
         p.slot_base = sc.slot_base; p.last_key = sc.last_key; p.slot_a = sc.slot_a; p.slot_b = sc.slot_b; p.slot_c = sc.slot_c;
+        p.op_view = sc.op_view; p.col_view = sc.col_view;
         const unsigned nb = (unsigned)((nv + 4095) / 4096);
         hipLaunchKernelGGL(touched_block_sums_kernel, dim3(nb), dim3(256), 0, st, p.g.tiles_touched, nv, sc.block_sums);
         hipLaunchKernelGGL(touched_scan_kernel, dim3(nb), dim3(256), 0, st, p.g.tiles_touched, nv, sc.block_sums, sc.slot_base);
@@ -689,7 +705,9 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
         if (p.exact_exp) hipLaunchKernelGGL((blend_backward_kernel<false, true>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((blend_backward_kernel<true, true>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
         if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
-        hipLaunchKernelGGL(gather_partials_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
+        const dim3 gridPV((unsigned)((P + 255) / 256), (unsigned)V);
+        if (p.T <= 4096) hipLaunchKernelGGL((gather_partials_kernel<true>), gridPV, dim3(256), (size_t)p.T * 8, st, p);
+        else hipLaunchKernelGGL((gather_partials_kernel<false>), gridPV, dim3(256), 0, st, p);
         hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
         if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
         return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;

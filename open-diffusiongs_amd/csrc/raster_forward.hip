@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys
 // Exclusive scan of the V*T tile counts -> [start,end) ranges into the packed instance list (one workgroup), and the launch
 // order of the per-tile kernels (deal_tiles, by list length).
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2* ranges, uint32_t* cursor, int n,
-                                                         int32_t* totals, long long capacity, uint32_t* order, int gx, int gy) {
+                                                         int32_t* totals, long long capacity, uint32_t* order, int gx, int gy,
+                                                         int32_t* stats_dev, int32_t* stats_host) {
     __shared__ uint32_t scratch[20];
     __shared__ uint32_t smax;
     __shared__ uint32_t s_class[1024];
@@ -367,6 +368,11 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2
         totals[0] = (int32_t)carry;
         totals[2] = (int32_t)smax;
         if (capacity >= 0 && (long long)carry > capacity) totals[1] = DGS_ERR_BINNING_OVERFLOW;
+        // the caller's copies of the four words (DgsRasterForwardArgs.num_rendered_dev / num_rendered_host), written by this kernel:
+        // the host copy is a store into pinned, device-visible host memory -- no memcpy node in a captured call
+        const int32_t st1 = totals[1];
+        if (stats_dev) { stats_dev[0] = (int32_t)carry; stats_dev[1] = st1; stats_dev[2] = (int32_t)smax; stats_dev[3] = 0; }
+        if (stats_host) { stats_host[0] = (int32_t)carry; stats_host[1] = st1; stats_host[2] = (int32_t)smax; stats_host[3] = 0; }
     }
     deal_tiles(count, n, smax, order, s_class, scratch);
 }
@@ -945,6 +951,13 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     }
 }
 
+// tile_count .. totals (ImageState::carve lays them out back to back) start from zero: a kernel of the library's own, not
+// hipMemsetAsync (a memset NODE of a captured graph stopped zeroing once the process had issued an eager hipMemsetAsync elsewhere;
+// and this is the shorter launch)
+__global__ __launch_bounds__(1024) void zero_words_kernel(uint32_t* dst, int n) {
+    for (int i = threadIdx.x; i < n; i += 1024) dst[i] = 0u;
+}
+
 __global__ void mark_visible_kernel(int P, const float* means, const float* vm, uint8_t* present) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -1046,7 +1059,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
                             kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
     if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
     // tile_count and totals are neighbours in the image state (ImageState::carve): one fill
-    hipMemsetAsync(p.im.tile_count, 0, (size_t)(reinterpret_cast<char*>(p.im.totals + 4) - reinterpret_cast<char*>(p.im.tile_count)), st);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, (int)(reinterpret_cast<uint32_t*>(p.im.totals + 4) - p.im.tile_count));
     const dim3 gridP((P + 255) / 256, V);
     const bool lds_tiles = p.T <= 4096;
     if (lds_tiles) hipLaunchKernelGGL((preprocess_kernel<true>), gridP, dim3(256), (size_t)p.T * 4, st, p);
@@ -1055,7 +1068,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     if (rc) return rc;
 
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, p.im.ranges, p.im.tile_cursor, VT, p.im.totals,
-                       async ? (long long)a->binning_capacity : -1LL, p.im.tile_order, p.gx, p.gy);
+                       async ? (long long)a->binning_capacity : -1LL, p.im.tile_order, p.gx, p.gy, a->num_rendered_dev, a->num_rendered_host);
     rc = check(st, a->debug);
     if (rc) return rc;
 
@@ -1097,10 +1110,6 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         p.bitonic_cap = cap;
         last_form = binning_form_of(p.bin_mode, p.bitonic_cap, a->num_rendered, (uint32_t)tot[2], p.T, P, V);
         forms = 1 << last_form;
-        if (a->num_rendered_dev)
-            hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-        if (a->num_rendered_host)
-            hipMemcpyAsync(a->num_rendered_host, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
     } else {
         // nothing is read back: the statistics go to the caller's device words (it reads them when it likes -- dgs_amd/raster.py
         // copies them to pinned host memory behind the call and looks at them before the NEXT call), every kernel of a form the
@@ -1109,10 +1118,6 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         // the device when a list does not fit (both are launched).  All forms produce the same lists bit for bit.
         a->num_rendered = -1;
         a->longest_list = -1;
-        if (a->num_rendered_dev)
-            hipMemcpyAsync(a->num_rendered_dev, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-        if (a->num_rendered_host)
-            hipMemcpyAsync(a->num_rendered_host, p.im.totals, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         // LDS the per-tile sort is launched with: for the longest list the caller expects (+ 50 %), else the maximum; a list that
         // does not fit sends the call to the rank sort on the device
         int cap = kBitonicMax;

@@ -50,10 +50,18 @@ class GraphedForward:
     def shape_key(input_batch, timesteps):
         return tuple((k, tuple(input_batch[k].shape), input_batch[k].dtype) for k in _INPUT_KEYS) + (tuple(timesteps.shape), timesteps.dtype)
 
-    def _check_previous(self):
+    def check(self, wait=True):
+        """Raise if the latest replay failed on the device (wait=True: block until it has finished)."""
+        self._check_previous(wait=wait)
+
+    def _check_previous(self, wait=False):
         """The previous replay's instance statistics (in pinned memory once its event has passed): a scene that outgrew the captured
         binning capacity rendered NaN -- raise, as the eager path does on its next call."""
-        if self._event is None or self._stats is None or not self._event.query():
+        if self._event is None or self._stats is None:
+            return
+        if wait:
+            self._event.synchronize()
+        elif not self._event.query():
             return
         self._event = None
         n, status = int(self._stats[0]) & 0xFFFFFFFF, int(self._stats[1])

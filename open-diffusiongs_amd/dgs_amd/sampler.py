@@ -142,6 +142,7 @@ class SpacedDiffusion:
                 mt = self.model_timesteps(t)
                 render, gaussians = model.graphed(input_batch, mt)(input_batch, mt)
                 if i == 0:
+                    model.graphed(input_batch, mt).check(wait=True)       # a deferred device-side failure of the replays surfaces here
                     render = render.clone()
                     for gm in gaussians:          # GaussianModel containers over the graph's output tensors
                         gm.set_data(gm._xyz.clone(), gm.get_features.clone(), gm._scaling.clone(), gm._rotation.clone(), gm._opacity.clone())
