@@ -33,6 +33,7 @@ import subprocess
 import sys
 import threading
 import time
+import types
 
 # dmabuf IPC is the only mode this pool's host driver supports: without it RCCL's cross-process buffer exchange fails with
 # `hipIpcGetMemHandle: invalid argument`.  Set before the HIP runtime loads, whoever launched this process.
@@ -590,6 +591,12 @@ def main():
             graphed.check(wait=True)
         model.gs_renderer.backend().check_async(wait=True)
         assert bool(torch.isfinite(rendered).all()), "the timed region rendered non-finite images"
+        # the last step's outputs are the captured graph's own tensors: keep copies for the PSNR check behind the informational objects
+        # (the graph is dropped there to free its memory)
+        rendered = rendered.clone()
+        g0_ = gaussians[0]
+        gaussians = [types.SimpleNamespace(_xyz=g0_._xyz.clone(), _features_dc=g0_._features_dc.clone(), _scaling=g0_._scaling.clone(),
+                                           _rotation=g0_._rotation.clone(), _opacity=g0_._opacity.clone())]
     if not a.dry_run_cpu:
         clock["after_timed_region_mhz"] = round(DitOps().shader_clock_mhz(dev), 0)
     rank_ms = [local_ms]

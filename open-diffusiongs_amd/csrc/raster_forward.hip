@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys
 // order of the per-tile kernels (deal_tiles, by list length).
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2* ranges, uint32_t* cursor, int n,
                                                          int32_t* totals, long long capacity, uint32_t* order, int gx, int gy,
-                                                         int32_t* stats_dev, int32_t* stats_host) {
+                                                         int32_t* stats_dev, int32_t* stats_host, int list_cap) {
     __shared__ uint32_t scratch[20];
     __shared__ uint32_t smax;
     __shared__ uint32_t s_class[1024];
@@ -368,6 +368,9 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2
         totals[0] = (int32_t)carry;
         totals[2] = (int32_t)smax;
         if (capacity >= 0 && (long long)carry > capacity) totals[1] = DGS_ERR_BINNING_OVERFLOW;
+        // async call that launched the per-tile LDS sort ALONE (its caller named the longest list it expects): a longer list has no
+        // kernel to go to -- the same deferred failure as an instance overflow (NaN image, raised by the next call, which sizes for it)
+        if (list_cap > 0 && smax > (uint32_t)list_cap) totals[1] = DGS_ERR_BINNING_OVERFLOW;
         // the caller's copies of the four words (DgsRasterForwardArgs.num_rendered_dev / num_rendered_host), written by this kernel:
         // the host copy is a store into pinned, device-visible host memory -- no memcpy node in a captured call
         const int32_t st1 = totals[1];
@@ -1067,16 +1070,24 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     int rc = check(st, a->debug);
     if (rc) return rc;
 
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, p.im.ranges, p.im.tile_cursor, VT, p.im.totals,
-                       async ? (long long)a->binning_capacity : -1LL, p.im.tile_order, p.gx, p.gy, a->num_rendered_dev, a->num_rendered_host);
-    rc = check(st, a->debug);
-    if (rc) return rc;
-
     // binning form (binning_form_of): the host only rules forms out; the choice itself is made from the instance statistics --
     // on the host in the sync mode (it has just read them back), on the device in the async mode
     const bool can_scan = scan_form_possible(p.gx, p.gy, p.T, P);
     p.bin_mode = a->binning_form;
     if (p.bin_mode < 0 || p.bin_mode > 3 || (p.bin_mode == 0 && !can_scan) || (p.bin_mode == kFormScan && !can_scan)) p.bin_mode = can_scan ? 0 : kFormBitonic;
+    // async + the LDS sort named + the longest list the caller expects: that kernel alone (no radix sort, no rank-sort fallback in
+    // the launch sequence); its LDS is sized for 1.5 x the expectation
+    int bitonic_only_cap = 0;
+    if (async && p.bin_mode == kFormBitonic && a->longest_hint > 0) {
+        bitonic_only_cap = 2048;
+        while (bitonic_only_cap < a->longest_hint + a->longest_hint / 2 && bitonic_only_cap < kBitonicMax) bitonic_only_cap <<= 1;
+    }
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, p.im.ranges, p.im.tile_cursor, VT, p.im.totals,
+                       async ? (long long)a->binning_capacity : -1LL, p.im.tile_order, p.gx, p.gy, a->num_rendered_dev, a->num_rendered_host,
+                       bitonic_only_cap);
+    rc = check(st, a->debug);
+    if (rc) return rc;
+
     int forms = 0;                                                 // bit f set: form f has to be launched
     // The forms that work on depth ranks need the radix sort of the P depth keys (12 launches, ~0.17 ms at 256^2 x 4 views).  In
     // the sync mode it is worth having it in flight while the host waits for the statistics -- but only if it will be needed:
@@ -1118,15 +1129,10 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         // the device when a list does not fit (both are launched).  All forms produce the same lists bit for bit.
         a->num_rendered = -1;
         a->longest_list = -1;
-        // LDS the per-tile sort is launched with: for the longest list the caller expects (+ 50 %), else the maximum; a list that
-        // does not fit sends the call to the rank sort on the device
-        int cap = kBitonicMax;
-        if (a->longest_hint > 0) {
-            cap = 2048;
-            while (cap < a->longest_hint + a->longest_hint / 2 && cap < kBitonicMax) cap <<= 1;
-        }
-        p.bitonic_cap = cap;
-        forms = p.bin_mode ? (1 << p.bin_mode) | (p.bin_mode == kFormBitonic ? 1 << kFormRankSort : 0)
+        // LDS the per-tile sort is launched with: for the longest list the caller expects (+ 50 %) -- then it is launched alone and a
+        // longer list is a deferred failure (scan_tiles_kernel) --, else the maximum with the rank sort beside it as the device's fallback
+        p.bitonic_cap = bitonic_only_cap ? bitonic_only_cap : kBitonicMax;
+        forms = p.bin_mode ? (1 << p.bin_mode) | (p.bin_mode == kFormBitonic && !bitonic_only_cap ? 1 << kFormRankSort : 0)
                            : (1 << kFormRankSort) | (1 << kFormScan) | (1 << kFormBitonic);
     }
 

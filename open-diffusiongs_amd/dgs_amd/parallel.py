@@ -165,9 +165,12 @@ class BucketedAllReduce:
         if norm is not None:          # bucket starts on partial boundaries
             per = max(GradNorm.CHUNK, per // GradNorm.CHUNK * GradNorm.CHUNK)
             tail = [max(GradNorm.CHUNK, t // GradNorm.CHUNK * GradNorm.CHUNK) for t in tail]
-        self.bounds = bucket_bounds(flat.numel(), per, tail)
-        if norm is not None and any(a % GradNorm.CHUNK for a, _ in self.bounds):      # tiny buffers with an odd tail: one bucket
-            self.bounds = [(0, flat.numel())]
+        if norm is not None:          # every bucket STARTS on a partial boundary: lay the buckets out on the length rounded up, clamp the end
+            n = flat.numel()
+            up = -(-n // GradNorm.CHUNK) * GradNorm.CHUNK
+            self.bounds = [(a, min(b, n)) for a, b in bucket_bounds(up, per, tail) if a < n]
+        else:
+            self.bounds = bucket_bounds(flat.numel(), per, tail)
         assert self.bounds[0][0] == 0 and self.bounds[-1][1] == flat.numel() and all(a[1] == b[0] for a, b in zip(self.bounds, self.bounds[1:]))
         if compress not in (None, "bf16"):
             raise ValueError("compress: None or 'bf16'")

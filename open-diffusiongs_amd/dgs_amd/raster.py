@@ -86,15 +86,16 @@ class _AsyncPlan:
             n, status, longest = int(host[0]) & 0xFFFFFFFF, int(host[1]), int(host[2]) & 0xFFFFFFFF
             self.note(lib, n, longest, P, W, H, V)
             if status == _native.DGS_ERR_BINNING_OVERFLOW:
-                self.overflowed = (n, cap)
+                self.overflowed = (n, cap, longest)
             elif status != 0:
                 raise RuntimeError(f"dgs rasterizer: an earlier asynchronous call failed on the device: {_native.status_string(lib, status)} (status {status})")
         self.pending = keep
         if self.overflowed is not None:
-            n, cap = self.overflowed
+            n, cap, longest = self.overflowed
             self.overflowed = None
-            raise RuntimeError(f"dgs rasterizer: an earlier asynchronous render produced {n} instances but its binning buffer held {cap}: "
-                               f"that call's image is NaN.  The capacity is now {self.capacity}; run the step again")
+            raise RuntimeError(f"dgs rasterizer: an earlier asynchronous render outgrew what its plan provided -- {n} instances for a binning buffer "
+                               f"of {cap}, longest tile list {longest} -- that call's image is NaN.  The plan now holds capacity {self.capacity}, "
+                               f"form {self.form}, longest list {self.longest}; run the step again")
 
 
 class RasterBackend:

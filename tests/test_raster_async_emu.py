@@ -56,8 +56,10 @@ def test_planned_autograd_equals_synchronous_gradients():
 
 
 def test_stale_form_is_still_correct_and_refreshed():
-    """The plan's form comes from the PREVIOUS call's statistics: a sparse scene rendered with the dense scene's form (and the other
-    way round) gives the same bits; the call after it has the right form again."""
+    """The plan's form comes from the PREVIOUS call's statistics.  Scan and rank sort are valid for any scene: a sparse scene rendered
+    with the dense scene's form gives the same bits, and the call after it has the right form again.  The per-tile LDS sort is launched
+    ALONE, sized for 1.5 x the longest list the plan has seen (no radix sort, no fallback kernels in the sequence): a scene whose
+    lists outgrow that is a deferred failure like an instance overflow -- NaN, the next call raises, the one after renders."""
     res = 64
     be = RasterBackend(lib=emu_lib())
     dense, c2w, k = _scene(res, "init", 1)
@@ -69,10 +71,14 @@ def test_stale_form_is_still_correct_and_refreshed():
     assert plan.form == 2
     assert torch.equal(be.render_views(*sparse, res, res, c2w, k), ref_sparse)      # scan form on a sparse scene
     assert torch.equal(be.render_views(*sparse, res, res, c2w, k), ref_sparse)
-    assert plan.form == 3
-    assert torch.equal(be.render_views(*dense, res, res, c2w, k), ref_dense)        # LDS-sort hint on a dense scene (falls back on the device)
-    be.render_views(*dense, res, res, c2w, k)
-    assert plan.form == 2
+    assert plan.form == 3 and 0 < plan.longest < 4096
+    assert torch.equal(be.render_views(*sparse, res, res, c2w, k), ref_sparse)      # the LDS sort alone
+    img = be.render_views(*dense, res, res, c2w, k)                                 # lists of ~9,000 entries against LDS sized for the sparse scene's
+    assert torch.isnan(img).all()
+    with pytest.raises(RuntimeError, match="binning buffer"):
+        be.render_views(*dense, res, res, c2w, k)
+    assert plan.form == 2 and plan.longest > 4096                                   # the failed call's statistics arrived: dense again
+    assert torch.equal(be.render_views(*dense, res, res, c2w, k), ref_dense)
 
 
 def test_overflow_is_nan_and_raises_on_the_next_call(monkeypatch):
