@@ -243,6 +243,9 @@ def raster_roofline(dev, res, V, iters=10):
         for name, fn, nbytes, flops in (("forward", fwd, bytes_f, flop_f), ("forward_backward", fb, bytes_f + bytes_b, flop_f + flop_b)):
             for _ in range(3):
                 fn()
+                # the plan picks a call's ordering form from the statistics that have ARRIVED: let this regime's arrive before the timed
+                # calls (a host that runs 13 calls ahead would time the previous regime's form -- valid, but not this scene's)
+                torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
@@ -557,6 +560,8 @@ def main():
             variants[name] = {"ms_per_step": round(wall, 3), "host_enqueue_ms_per_step": round(host, 3), "gpu_ms_per_step": round(gpu, 3)}
 
     run_step = graph_step or step
+    if use_graph:
+        graphed(gb, t)          # the sampling loop above went through the same graph: its static tensors hold the loop's last inputs
     for _ in range(a.warmup):
         run_step()
     nl = MODEL_CFG["num_layers"]

@@ -114,10 +114,16 @@ typedef struct DgsDitAttentionArgs {
                                   Zero-filled ONCE by the caller (the kernel leaves the counters at zero); one per stream
                                   that launches concurrently.                                                          */
     size_t tail_ws_bytes;
+    int32_t tail_mode;         /* the L % 32 tail queries: 0 (default) inside the main kernel (key-split records + merge at its end);
+                                  1: this launch computes the full 32-query units only; 2: this launch computes ONLY the tail queries
+                                  (a small VALU kernel, one workgroup per (sample, head)) -- the pair 1 + 2 on two streams is what
+                                  dgs_dit_forward runs: the tail hides behind the main kernel instead of ending it (needs
+                                  dgs_dit_attention_tail_splittable(L, lpad); tail_ws is not used by either)                   */
 } DgsDitAttentionArgs;
 
 /* Bytes of DgsDitAttentionArgs.tail_ws for this shape (0 when L % 32 == 0). */
 size_t dgs_dit_attention_tail_bytes(int32_t B, int32_t heads, int32_t L);
+int32_t dgs_dit_attention_tail_splittable(int32_t L, int32_t lpad);
 
 typedef struct DgsDitAttentionBackwardArgs {
     int32_t B, heads, L, lpad;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 7   /* bumped with every change of a struct or prototype in the include directory (round 2 = 2, unversioned) */
+#define DGS_ABI_VERSION 8   /* bumped with every change of a struct or prototype in the include directory (round 2 = 2, unversioned) */
 #define DGS_TILE 16 /* cuda_rasterizer/config.h:14-15 */
 
 typedef void* dgs_stream_t; /* hipStream_t */

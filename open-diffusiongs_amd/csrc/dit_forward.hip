@@ -115,6 +115,26 @@ struct Prof {
 #define DGS_PROF(k, expr) do { prof.before(k); const int rc_ = (expr); prof.after(k); if (rc_ != DGS_OK) { fprintf(stderr, "[dgs] %s:%d: status %d\n", __FILE__, __LINE__, rc_); return rc_; } } while (0)
 
 namespace {
+// The second stream of the inference sequence: the L % 32 tail queries of every block's attention (the DiT's two learned tokens) run
+// there as a small launch of their own, forked behind the QKV GEMM and joined in front of the proj GEMM, so that they overlap the
+// main attention kernel instead of ending it (dit_attention.hip: attention_tail_kernel).  One side stream and two events per block
+// for the process, created on first use -- before any stream capture (the first forward of a shape is never captured: dgs_amd/graph.py
+// warms up); inside a capture the fork / join are edges of the graph.  DGS_ATTN_TAIL_STREAM=0: everything in the main kernel.
+struct TailStream {
+    hipStream_t side = nullptr;
+    hipEvent_t fork[64], join[64];
+    bool ok = false;
+    TailStream() {
+        const char* e = getenv("DGS_ATTN_TAIL_STREAM");
+        if (e && atoi(e) == 0) return;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return;
+        for (int i = 0; i < 64; ++i)
+            if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return;
+        ok = true;
+    }
+};
+TailStream& tail_stream() { static TailStream t; return t; }
+
 // DiT blocks [first, last) of the inference sequence on the residual stream ws.x (utils_transformer.py:271-290).
 int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last, int B, int lpad, int L, Prof& prof, dgs_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -122,6 +142,8 @@ int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last
     DgsDitAttentionArgs at{};
     at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = ws.qk; at.vt = ws.vt; at.out = ws.ao; at.scale = 0.125f; at.q_prescaled = 1;
     at.tail_ws = ws.attn_tail; at.tail_ws_bytes = ws.attn_tail_bytes;
+    TailStream& ts = tail_stream();
+    const bool split_tail = ts.ok && m->layers <= 64 && dgs_dit_attention_tail_splittable(L, lpad);
     for (int i = first; i < last; ++i) {
         const DgsDitLayerWeights& lw = m->layer[i];
         const float* mod = ws.mod + (size_t)i * 6 * W;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -134,7 +156,20 @@ int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last
         q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad; q.valid_rows = L;
         q.q_scale = at.scale * 1.44269504088896341f;       // queries leave the GEMM pre-scaled for the exp2-domain softmax
         DGS_PROF(2, dgs_dit_gemm(&q, stream));
-        DGS_PROF(1, dgs_dit_attention(&at, stream));
+        if (split_tail) {
+            // fork: the tail queries need this block's K / V of ALL tokens (the QKV GEMM above), nothing else
+            if (hipEventRecord(ts.fork[i], st) != hipSuccess || hipStreamWaitEvent(ts.side, ts.fork[i], 0) != hipSuccess) return DGS_ERR_DEVICE;
+            at.tail_mode = 2;
+            DGS_TRY(dgs_dit_attention(&at, ts.side));
+            if (hipEventRecord(ts.join[i], ts.side) != hipSuccess) return DGS_ERR_DEVICE;
+            at.tail_mode = 1;
+            DGS_PROF(1, dgs_dit_attention(&at, stream));
+            // join: the proj GEMM reads the attention output of every row
+            if (hipStreamWaitEvent(st, ts.join[i], 0) != hipSuccess) return DGS_ERR_DEVICE;
+        } else {
+            at.tail_mode = 0;
+            DGS_PROF(1, dgs_dit_attention(&at, stream));
+        }
         DgsDitGemmArgs pr{};
         pr.M = M; pr.N = W; pr.K = W; pr.A = ws.ao; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
         pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad; pr.valid_rows = L;

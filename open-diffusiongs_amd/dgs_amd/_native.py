@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # or an A/B side (tools/ab_build.sh).  Never a fallback: whatever is named must exist and pass the ABI check.
 LIB_PATH = os.environ.get("DGS_AMD_LIBRARY") or os.path.join(os.path.dirname(HERE), "lib", "libdgs_hip.so")
 
-ABI_VERSION = 7          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
+ABI_VERSION = 8          # == DGS_ABI_VERSION of include/dgs_raster.h; bump both whenever a struct or prototype changes
 DGS_ERR_BINNING_OVERFLOW = -7    # include/dgs_raster.h DgsStatus
 c_float_p = ctypes.POINTER(ctypes.c_float)
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
@@ -160,7 +160,7 @@ class DgsDitAttentionArgs(ctypes.Structure):
                 ("qk", ctypes.c_void_p), ("vt", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_float),
                 ("ld_qk", ctypes.c_int32), ("k_offset", ctypes.c_int32), ("vt_batch_stride", ctypes.c_int64),
                 ("lse2", ctypes.c_void_p), ("q_prescaled", ctypes.c_int32), ("tail_ws", ctypes.c_void_p),
-                ("tail_ws_bytes", ctypes.c_size_t)]
+                ("tail_ws_bytes", ctypes.c_size_t), ("tail_mode", ctypes.c_int32)]
 
 
 class DgsDitAttentionBackwardArgs(ctypes.Structure):
@@ -274,7 +274,7 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
-               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds", "dgs_debug_clock_probe",
+               "dgs_dit_attention_tail_bytes", "dgs_dit_attention_tail_splittable", "dgs_dit_run_blocks", "dgs_debug_poison_lds", "dgs_debug_clock_probe",
                "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes",
                "dgs_dit_workspace_bytes_for_tokens"]
 
@@ -295,6 +295,8 @@ def _declare_dit(L):
     L.dgs_dit_gemm_splitk_bytes.argtypes = [ctypes.c_int32] * 4
     L.dgs_dit_attention_tail_bytes.restype = ctypes.c_size_t
     L.dgs_dit_attention_tail_bytes.argtypes = [ctypes.c_int32] * 3
+    L.dgs_dit_attention_tail_splittable.restype = ctypes.c_int32
+    L.dgs_dit_attention_tail_splittable.argtypes = [ctypes.c_int32] * 2
     L.dgs_dit_lpad.restype = ctypes.c_int32
     L.dgs_dit_lpad.argtypes = [ctypes.c_int32]
     L.dgs_dit_workspace_bytes.restype = ctypes.c_size_t

@@ -87,20 +87,22 @@ class DitOps:
         self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))
         return (out, vt) if epilogue == _native.EPI_QKV else out
 
-    def attention(self, qk, vt, L, heads, qkv_layout=False, lse2=None, q_prescaled=False):
+    def attention(self, qk, vt, L, heads, qkv_layout=False, lse2=None, q_prescaled=False, tail_mode=0, out=None):
         """qk bf16 [B*lpad, 2*heads*64], vt bf16 [B, heads*64, lpad] -> bf16 [B*lpad, heads*64].
-        qkv_layout: `qk` is the training tensor [B*lpad, 3W] and `vt` its transposed copy [B, 3W, lpad]."""
+        qkv_layout: `qk` is the training tensor [B*lpad, 3W] and `vt` its transposed copy [B, 3W, lpad].
+        tail_mode (dgs_dit.h): 0 everything in one launch; 1 the full 32-query units only; 2 the L % 32 tail queries only (into `out`)."""
         B, _, lpad = vt.shape
         W = heads * 64
-        out = torch.zeros((B * lpad, W), dtype=torch.bfloat16, device=qk.device)
+        if out is None:
+            out = torch.zeros((B * lpad, W), dtype=torch.bfloat16, device=qk.device)
         a = DgsDitAttentionArgs()
         a.B, a.heads, a.L, a.lpad = B, heads, L, lpad
         a.qk, a.vt, a.out, a.scale = _p(qk), _p(vt), _p(out), 0.125
         if qkv_layout:
             a.ld_qk, a.k_offset, a.vt_batch_stride = 3 * W, W, 3 * W * lpad
             a.vt = ctypes.c_void_p(vt.data_ptr() + 2 * W * lpad * 2)
-        a.lse2, a.q_prescaled = _p(lse2), int(q_prescaled)
-        nb = int(self.lib.dgs_dit_attention_tail_bytes(B, heads, L))
+        a.lse2, a.q_prescaled, a.tail_mode = _p(lse2), int(q_prescaled), int(tail_mode)
+        nb = int(self.lib.dgs_dit_attention_tail_bytes(B, heads, L)) if tail_mode == 0 else 0
         if nb:      # caller-owned scratch of the L % 32 tail queries (zero-filled: holds the arrival counters)
             tail = torch.zeros(nb, dtype=torch.uint8, device=qk.device)
             a.tail_ws, a.tail_ws_bytes = _p(tail), nb

@@ -326,6 +326,11 @@ static inline hipError_t hipFree(void* p) { std::free(p); return 0; }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return 0; }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return 0; }
+#define hipEventDisableTiming 0x2
+#define hipStreamNonBlocking 0x1
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }

@@ -167,6 +167,43 @@ def test_attention_production_shapes(L, B, prescaled):
     assert worst < (3e-2 if prescaled else 4e-2)
 
 
+@pytest.mark.parametrize("L,B", [(4098, 1), (16386, 1), (258, 2), (1027, 1)])
+def test_attention_tail_as_its_own_launch(L, B):
+    """`tail_mode` 1 + 2 (what dgs_dit_forward runs on two streams: the L % 32 learned-token queries as a small launch of their own beside
+    the main kernel) against fp64 and against the one-launch form: main rows bit-identical, tail rows within the attention bars."""
+    heads = 16
+    lpad = (L + 127) // 128 * 128
+    g = torch.Generator(device=DEV).manual_seed(L + 1)
+    q, k, v = (torch.randn(B, heads, lpad, 64, generator=g, device=DEV) for _ in range(3))
+    q[0, 3, L - 1] *= 8.0
+    k[0, 3, 5] *= 8.0
+    c = 0.125 * 1.4426950408889634
+    qb, kb, vb = _bf(q * c), _bf(k), _bf(v)
+    qk = torch.cat([qb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64), kb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64)], 1).contiguous()
+    vt = vb.permute(0, 1, 3, 2).reshape(B, heads * 64, lpad).contiguous()
+    ops = _ops()
+    assert ops.lib.dgs_dit_attention_tail_splittable(L, lpad) == 1
+    one = ops.attention(qk, vt, L, heads, q_prescaled=True)
+    two = ops.attention(qk, vt, L, heads, q_prescaled=True, tail_mode=1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # the tail launch on another stream, as in the forward
+        ops.attention(qk, vt, L, heads, q_prescaled=True, tail_mode=2, out=two)
+    torch.cuda.current_stream().wait_stream(side)
+    nmain = L // 32 * 32
+    rows = lambda o: o.reshape(B, lpad, heads * 64)
+    assert torch.equal(rows(one)[:, :nmain], rows(two)[:, :nmain])
+    out = two.float().reshape(B, lpad, heads, 64).permute(0, 2, 1, 3)
+    worst = 0.0
+    for b in range(B):
+        for h in range(heads):
+            s = (qb[b, h, nmain:L].double() @ kb[b, h, :L].double().t()) * 0.6931471805599453
+            ref = s.softmax(-1) @ vb[b, h, :L].double()
+            worst = max(worst, float((out[b, h, nmain:L].double() - ref).abs().max()))
+    assert worst < 1.5e-2, worst
+    assert float((rows(one)[:, nmain:L].float() - rows(two)[:, nmain:L].float()).abs().max()) < 3e-2
+
+
 @pytest.mark.parametrize("kind", ["obj", "scene"])
 def test_forward_matches_reference_golden(kind):
     from dgs_amd.dit import DitEngine
