@@ -116,9 +116,11 @@ typedef struct DgsDitAttentionArgs {
     size_t tail_ws_bytes;
     int32_t tail_mode;         /* the L % 32 tail queries: 0 (default) inside the main kernel (key-split records + merge at its end);
                                   1: this launch computes the full 32-query units only; 2: this launch computes ONLY the tail queries
-                                  (a small VALU kernel, one workgroup per (sample, head)) -- the pair 1 + 2 on two streams is what
-                                  dgs_dit_forward runs: the tail hides behind the main kernel instead of ending it (needs
-                                  dgs_dit_attention_tail_splittable(L, lpad); tail_ws is not used by either)                   */
+                                  (a small VALU kernel, one workgroup per (sample, head)).  The pair 1 + 2 on two streams was meant
+                                  to hide the tail behind the main kernel; measured, it cannot (the main kernel's one round of
+                                  workgroups holds every CU's register file: DESIGN.md section 9d) -- dgs_dit_forward uses mode 0
+                                  unless DGS_ATTN_TAIL_STREAM=1.  Needs dgs_dit_attention_tail_splittable(L, lpad); tail_ws is not
+                                  used by modes 1 and 2                                                                          */
 } DgsDitAttentionArgs;
 
 /* Bytes of DgsDitAttentionArgs.tail_ws for this shape (0 when L % 32 == 0). */

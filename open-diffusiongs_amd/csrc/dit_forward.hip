@@ -115,18 +115,20 @@ struct Prof {
 #define DGS_PROF(k, expr) do { prof.before(k); const int rc_ = (expr); prof.after(k); if (rc_ != DGS_OK) { fprintf(stderr, "[dgs] %s:%d: status %d\n", __FILE__, __LINE__, rc_); return rc_; } } while (0)
 
 namespace {
-// The second stream of the inference sequence: the L % 32 tail queries of every block's attention (the DiT's two learned tokens) run
-// there as a small launch of their own, forked behind the QKV GEMM and joined in front of the proj GEMM, so that they overlap the
-// main attention kernel instead of ending it (dit_attention.hip: attention_tail_kernel).  One side stream and two events per block
-// for the process, created on first use -- before any stream capture (the first forward of a shape is never captured: dgs_amd/graph.py
-// warms up); inside a capture the fork / join are edges of the graph.  DGS_ATTN_TAIL_STREAM=0: everything in the main kernel.
+// MEASURED AND DROPPED (round 4, profiles/r04_attention_tail_stream_ab.txt) -- kept behind DGS_ATTN_TAIL_STREAM=1 with its tests: the
+// L % 32 tail queries of every block's attention (the DiT's two learned tokens) as a small launch of their own on a second stream,
+// forked behind the QKV GEMM and joined in front of the proj GEMM (dit_attention.hip: attention_tail_kernel), meant to overlap the main
+// attention kernel instead of ending it (9 of 80 us).  It cannot: the main kernel is ONE round of 256 workgroups whose eight waves hold
+// the whole register file of their CU, so nothing co-resides -- the 16 tail workgroups take 16 CUs first and the 16 main workgroups they
+// displace run as a second round: attention 79.5 -> 109-115 us, the step 6.12 -> 7.3-7.5 ms, eager or captured.  One side stream and two
+// events per block for the process, created on first use (never inside a capture: dgs_amd/graph.py warms up).
 struct TailStream {
     hipStream_t side = nullptr;
     hipEvent_t fork[64], join[64];
     bool ok = false;
     TailStream() {
         const char* e = getenv("DGS_ATTN_TAIL_STREAM");
-        if (e && atoi(e) == 0) return;
+        if (!e || atoi(e) == 0) return;                          // off unless asked for
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return;
         for (int i = 0; i < 64; ++i)
             if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return;

@@ -144,8 +144,10 @@ class SpacedDiffusion:
                 if i == 0:
                     model.graphed(input_batch, mt).check(wait=True)       # a deferred device-side failure of the replays surfaces here
                     render = render.clone()
-                    for gm in gaussians:          # GaussianModel containers over the graph's output tensors
-                        gm.set_data(gm._xyz.clone(), gm.get_features.clone(), gm._scaling.clone(), gm._rotation.clone(), gm._opacity.clone())
+                    # NEW containers over copies: the graph's own GaussianModel objects keep pointing at its output tensors
+                    import copy
+                    gaussians = [copy.copy(gm).set_data(gm._xyz.clone(), gm.get_features.clone(), gm._scaling.clone(), gm._rotation.clone(),
+                                                        gm._opacity.clone()) for gm in gaussians]
             else:
                 render, gaussians = model(input_batch, self.model_timesteps(t))
             pred = torch.empty_like(x) if (i == 0 or not keep_last_only) else None

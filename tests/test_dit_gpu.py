@@ -182,7 +182,7 @@ def test_attention_tail_as_its_own_launch(L, B):
     qk = torch.cat([qb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64), kb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64)], 1).contiguous()
     vt = vb.permute(0, 1, 3, 2).reshape(B, heads * 64, lpad).contiguous()
     ops = _ops()
-    assert ops.lib.dgs_dit_attention_tail_splittable(L, lpad) == 1
+    assert ops._ops.lib.dgs_dit_attention_tail_splittable(L, lpad) == 1
     one = ops.attention(qk, vt, L, heads, q_prescaled=True)
     two = ops.attention(qk, vt, L, heads, q_prescaled=True, tail_mode=1)
     side = torch.cuda.Stream()
