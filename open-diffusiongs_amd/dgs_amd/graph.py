@@ -36,7 +36,8 @@ class GraphedForward:
         torch.cuda.current_stream(dev).wait_stream(side)
         backend.check_async(wait=True)                 # the warm-up renders' statistics: capacity + ordering form of the capture
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread_local: other threads of the process (RCCL's watchdog polls its events) must not invalidate the capture
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.rendered, self.gaussians = model(self.static, self.t)
         B, V, _, H, W = self.static["image"].shape
         Vr = int(self.static["c2w"].shape[1])

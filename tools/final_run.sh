@@ -27,6 +27,9 @@ python tools/pmc_traffic.py > $out/${tag}_pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic.json $out/pmc_traffic.json
 cp gpurun_out/dit_pmc.txt $out/${tag}_dit_pmc.txt
 python tools/raster_det_ab.py > $out/${tag}_raster_deterministic_ab.txt 2>&1
+# the driver's multi-GPU launch line with the one GPU there is: RCCL process group of one rank, every collective issued
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 2 --force-dist --no-cpu-baseline > $out/${tag}_bench_torchrun_rccl_world1.json 2>> $out/${tag}_bench.err
+cut -c1-400 $out/${tag}_bench_torchrun_rccl_world1.json
 # second contract line, now with `traffic` (the PMC JSON above carries this tree's source hashes)
 cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
 python bench.py --no-extras --no-cpu-baseline > $out/${tag}_bench_after_pmc.json 2>> $out/${tag}_bench.err
