@@ -559,6 +559,35 @@ def main():
             wall, host, gpu = timed_loop(20, fn)
             variants[name] = {"ms_per_step": round(wall, 3), "host_enqueue_ms_per_step": round(host, 3), "gpu_ms_per_step": round(gpu, 3)}
 
+    families = None
+    if not a.no_extras and not a.dry_run_cpu and B == 1:
+        # every kernel family of the block on its own roofline (informational; two eager steps per family with HIP events around its
+        # launches, outside the timed region): MFMA for attention and the K-heavy GEMMs, HBM for LayerNorm; the gate-residual family
+        # (proj + fc2) moves the fp32 residual stream and is priced on both
+        nlay = MODEL_CFG["num_layers"]
+        Wd = MODEL_CFG["width"]
+        fam = {"attention": (nlay, 4.0 * L * L * Wd, None), "gemm_qkv": (nlay, 2.0 * L * 3 * Wd * Wd, 2 * L * Wd + 6 * Wd * Wd + 6 * L * Wd),
+               "gemm_fc1_gelu": (nlay, 2.0 * L * 4 * Wd * Wd, 2 * L * Wd + 8 * Wd * Wd + 8 * L * Wd),
+               "gemm_gate_residual": (2 * nlay, 2.0 * L * 2.5 * Wd * Wd, 5 * L * Wd + 5 * Wd * Wd + 8 * L * Wd),   # mean of proj (K = W) and fc2 (K = 4 W)
+               "layernorm": (2 * nlay, None, 6 * L * Wd)}
+        families = {}
+        for kind, (per, flops, nbytes) in fam.items():
+            us = []
+            for _ in range(2):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * per)]
+                for e in ev:
+                    e.record()
+                step(prof=(PROF_KINDS[kind], ev))
+                torch.cuda.synchronize()
+                us += [ev[2 * j].elapsed_time(ev[2 * j + 1]) * 1e3 for j in range(per)]
+            avg = float(np.mean(us))
+            rec = {"launches_per_step": per, "avg_launch_us": round(avg, 2)}
+            if flops:
+                rec.update({"tflops": round(flops / avg / 1e6, 1), "frac_of_bf16_mfma_peak": round(flops / (avg * 1e-6) / PEAK_BF16_MFMA, 4)})
+            if nbytes:
+                rec.update({"algorithmic_gbps": round(nbytes / avg / 1e3, 1), "frac_of_hbm_peak": round(nbytes / (avg * 1e-6) / PEAK_HBM, 4)})
+            families[kind] = rec
+
     run_step = graph_step or step
     if use_graph:
         graphed(gb, t)          # the sampling loop above went through the same graph: its static tensors hold the loop's last inputs
@@ -650,6 +679,8 @@ def main():
         }
         if variants:
             out["step_variants"] = variants
+        if families:
+            out["kernel_families"] = families
         if loop_ms is not None:
             out["sampling_loop_30_steps"] = {"ms_per_loop": round(loop_ms, 2), "renders_per_s": round(B * V * 30 / (loop_ms * 1e-3), 1),
                                              "note": "per GPU; informational, not part of value"}

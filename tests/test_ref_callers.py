@@ -89,6 +89,46 @@ def _sampler_case(device, lib, width, layers, res):
     assert len(g_ref) == len(g_mine) == B and float((g_ref[0].get_xyz - g_mine[0].get_xyz).abs().max()) <= 1e-3
 
 
+def _pipeline_case(device, lib, width, layers, res, half):
+    """The call convention of the reference's inference pipeline (pipline_obj.py:264-308), reproduced with its own sampler: `input_batch` an
+    EasyDict whose `image` holds ONLY the conditioning view (p_mean_variance rebuilds it as cat(image[:, :1], image_noisy) every step,
+    gaussian_diffusion.py:349), rays of all four views from its `TransformInput`, every tensor cast to the system dtype (half precision
+    in the shipped pipeline), the loop under `torch.autocast`, `clip_denoised=False`; consumed like the pipeline does
+    (`final_out['denoiser_output_dict']['pred_gaussians'][0]`, `['render_images'][0]`)."""
+    callers = ref_glue.load_callers()
+    refd = ref_glue.load_diffusion()
+    from oracle.ref_glue import _EasyDict as edict
+    m = _model(device, lib, width, layers, seed=8).eval()
+    base = _batch(1, 4, res, device, seed=3)
+    image_torch = base["image"][:, 0]                                   # [1, 3, H, W]: the preprocessed input image
+    sample_noise = torch.randn(1, 3, 3, res, res, generator=torch.Generator().manual_seed(2)).to(device)
+    rgbs_input = torch.cat((image_torch.unsqueeze(1), sample_noise), dim=1)
+    ray_o, ray_d = callers.TransformInput(rgbs_input, base["c2w"], base["fxfycxcy"])
+    dt = half if half is not None else torch.float32
+    input_batch = edict(image=rgbs_input[:, :1].to(dt), c2w=base["c2w"].to(dt), fxfycxcy=base["fxfycxcy"].to(dt), ray_o=ray_o.to(dt), ray_d=ray_d.to(dt))
+    input_batch["image_noisy"] = sample_noise.to(dt)
+    system = types.SimpleNamespace(diffusion_inference=refd.create_diffusion("30", predict_xstart=True), shape_model=m)
+    torch.manual_seed(4)
+    steps = 0
+    with torch.autocast(device_type=device.type, dtype=dt, enabled=half is not None):
+        for out in system.diffusion_inference.p_sample_loop_progressive(system.shape_model, sample_noise.shape, input_batch, clip_denoised=False,
+                                                                        progress=False, device=device):
+            final_out = out
+            steps += 1
+    assert steps == 30
+    gaussians = final_out["denoiser_output_dict"]["pred_gaussians"][0]
+    pred_images = final_out["denoiser_output_dict"]["render_images"][0]
+    assert pred_images.shape == (4, 3, res, res) and pred_images.dtype == torch.float32 and bool(torch.isfinite(pred_images).all())
+    assert gaussians.get_xyz.shape == (2 + 4 * res * res, 3) and bool(torch.isfinite(gaussians.get_xyz).all())
+    assert float(gaussians.get_opacity.min()) >= 0.0 and float(gaussians.get_scaling.max()) <= float(np.exp(-1.2)) + 1e-6   # to_gs clamp, denoiser.py:103-120
+    assert final_out["sample"].shape == sample_noise.shape and bool(torch.isfinite(final_out["sample"].float()).all())
+    # the render of the conditioning view of the final Gaussians through the product's OWN entry gives the pipeline's image back
+    with torch.no_grad():
+        again = m.gs_renderer(gaussians._xyz[None], gaussians.get_features[None], gaussians._scaling[None], gaussians._rotation[None],
+                              gaussians._opacity[None], res, res, C2W=base["c2w"].to(dt).float(), fxfycxcy=base["fxfycxcy"].to(dt).float())
+    assert float((again[0] - pred_images).abs().max()) <= 1e-5
+
+
 class _LossComputer:
     """LossComputer.forward's signature and return tuple (utils/losses.py:261-369) with the terms the product has on the device; the
     LPIPS / SSIM networks (out of scope, no weights offline) contribute zeros."""
@@ -169,6 +209,19 @@ def test_reference_sampler_over_the_product_emulated():
 def test_reference_system_forward_over_the_product_emulated():
     from emu_util import emu_lib
     _system_case(torch.device("cpu"), emu_lib(), 256, 1, 16)
+
+
+@needs_ref
+@pytest.mark.parametrize("half", [None, torch.bfloat16], ids=["fp32", "bf16_autocast"])
+def test_reference_pipeline_call_convention_emulated(half):
+    from emu_util import emu_lib
+    _pipeline_case(torch.device("cpu"), emu_lib(), 256, 1, 16, half)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_reference_pipeline_call_convention_gpu():
+    _pipeline_case(torch.device("cuda:0"), None, 1024, 24, 64, torch.float16)
 
 
 @needs_ref
