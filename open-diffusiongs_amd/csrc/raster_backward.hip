@@ -187,9 +187,10 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
         unsigned m16 = 0u;
         if (idx >= 0) {
             const uint32_t id = p.bn.point_list[rg.x + (uint32_t)idx];
-            const float2 xy = p.g.means2D[vo + id];
-            const float4 co = p.g.conic_opacity[vo + id];
-            float4 rc = p.g.rgb_cut[vo + id];
+            const BlendRecord* rec = p.g.blend + vo + id;      // one line per entry (raster_state.h)
+            const float4 co = rec->co;
+            float4 rc = rec->rc;
+            const float2 xy = rec->xy;
             m16 = cell_mask(xy, co, rc.w, tx0, ty0);
             if (colors_per_set) {
                 const float* c = p.colors_pre + 3 * ((size_t)s * p.P + id);

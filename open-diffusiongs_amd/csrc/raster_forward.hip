@@ -178,8 +178,10 @@ __device__ __forceinline__ bool preprocess_one(const FwdParams& p, int v, int id
     p.g.depths[gi] = tz;
     p.radii[gi] = irad;
     p.g.means2D[gi] = make_float2(px, py);
-    p.g.conic_opacity[gi] = make_float4(conx, cony, conz, op);
-    p.g.rgb_cut[gi] = make_float4(rgb[0], rgb[1], rgb[2], cut);
+    BlendRecord* rec = p.g.blend + gi;
+    rec->co = make_float4(conx, cony, conz, op);
+    rec->rc = make_float4(rgb[0], rgb[1], rgb[2], cut);
+    rec->xy = make_float2(px, py);
     p.g.clamped[gi] = (uint8_t)cbits;
     p.g.tiles_touched[gi] = (uint32_t)((y1 - y0) * (x1 - x0));
     p.g.keys[0][gi] = __float_as_uint(tz);
@@ -838,9 +840,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
         unsigned m16 = 0u;
         if (pos < rg.y && (!SCAN || (uint32_t)tid < ts.waiting)) {
             const uint32_t id = SCAN ? s_ring[(ts.head + (uint32_t)tid) & (kRing - 1u)] : p.bn.point_list[pos];
-            const float2 xy = p.g.means2D[vo + id];
-            const float4 co = p.g.conic_opacity[vo + id];
-            const float4 rc = p.g.rgb_cut[vo + id];
+            const BlendRecord* rec = p.g.blend + vo + id;      // one line per entry (raster_state.h)
+            const float4 co = rec->co;
+            const float4 rc = rec->rc;
+            const float2 xy = rec->xy;
             s_xy[tid] = xy; s_co[tid] = co; s_rgbc[tid] = rc;
             m16 = cell_mask(xy, co, rc.w, tx0, ty0);
         } else {
@@ -959,6 +962,12 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
 // and this is the shorter launch)
 __global__ __launch_bounds__(1024) void zero_words_kernel(uint32_t* dst, int n) {
     for (int i = threadIdx.x; i < n; i += 1024) dst[i] = 0u;
+}
+
+// dgs_raster_state_read("conic_opacity" | "rgb"): the parity tests' view of one field of the blend records
+__global__ void record_field_kernel(const BlendRecord* rec, float4* dst, size_t n, int field) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = field ? rec[i].rc : rec[i].co;
 }
 
 __global__ void mark_visible_kernel(int P, const float* means, const float* vm, uint8_t* present) {
@@ -1196,8 +1205,12 @@ int64_t dgs_raster_state_read(const char* name, int32_t P, int32_t W, int32_t H,
     const auto is = [&](const char* s) { return strcmp(name, s) == 0; };
     if (is("depths")) { src = g.depths; bytes = n * 4; }
     else if (is("means2D")) { src = g.means2D; bytes = n * 8; }
-    else if (is("conic_opacity")) { src = g.conic_opacity; bytes = n * 16; }
-    else if (is("rgb")) { src = g.rgb_cut; bytes = n * 16; }
+    else if (is("conic_opacity") || is("rgb")) {
+        bytes = n * 16;
+        if ((int64_t)bytes > dst_bytes) return DGS_ERR_INVALID_ARGUMENT;
+        if (n) hipLaunchKernelGGL(record_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g.blend, static_cast<float4*>(dst), n, is("rgb") ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? (int64_t)bytes : (int64_t)DGS_ERR_DEVICE;
+    }
     else if (is("tiles_touched")) { src = g.tiles_touched; bytes = n * 4; }
     else if (is("clamped")) { src = g.clamped; bytes = n; }
     else if (is("cov3D")) { src = g.cov3D; bytes = n * 24; }

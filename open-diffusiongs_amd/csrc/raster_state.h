@@ -2,8 +2,8 @@
 //
 // The reference keeps GeometryState / ImageState / BinningState (rasterizer_impl.h:29-65) inside three
 // caller-owned byte buffers; the contents are private to the library, so the layout here is our own
-// (data laid out for the MI355X pipeline: SoA arrays per (view, Gaussian), 16-byte records for the blend
-// kernel's LDS staging, per-tile ranges instead of 64-bit sort keys).
+// (data laid out for the MI355X pipeline: SoA arrays per (view, Gaussian) for the streaming kernels, one 64-byte
+// record per (view, Gaussian) for the blend kernels' gathers, per-tile ranges instead of 64-bit sort keys).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -33,11 +33,23 @@ struct Carver {
 
 inline int sort_blocks(int P) { return (P + kSortTile - 1) / kSortTile; }
 
+// Everything the blend kernels need of one (view, Gaussian), in ONE 64-byte line.  The per-tile lists are depth ordered, so consecutive
+// entries are unrelated Gaussians: every field read is its own memory request.  As three arrays (8 + 16 + 16 bytes) a staged entry cost
+// three 64-byte requests (measured, round 4: 198 bytes fetched per walked entry, blend_forward 537 MB per 4 views in the trained-like
+// regime -- 2.3 TB/s of a ~3.5 TB/s random-request ceiling, profiles/pmc_traffic.json `fetch_calibration.records`); as one aligned
+// record it is one.
+struct alignas(64) BlendRecord {
+    float4 co;                     // (conic.x, conic.y, conic.z, opacity)
+    float4 rc;                     // (r, g, b, alpha-skip threshold on `power`)
+    float2 xy;                     // pixel coordinates (also in means2D, which the binning kernels stream)
+    float2 unused;
+};
+static_assert(sizeof(BlendRecord) == 64, "one record, one line");
+
 struct GeomState {                 // arrays indexed [view * P + gaussian]
     float* depths;                 // p_view.z
     float2* means2D;               // pixel coordinates
-    float4* conic_opacity;         // (conic.x, conic.y, conic.z, opacity)
-    float4* rgb_cut;               // (r, g, b, alpha-skip threshold on `power`)
+    BlendRecord* blend;            // conic + opacity, colour + cut-off, pixel coordinates
     float* cov3D;                  // 6 per Gaussian
     uint8_t* clamped;              // bit c set: colour channel c was clamped at 0
     int32_t* internal_radii;
@@ -55,8 +67,7 @@ struct GeomState {                 // arrays indexed [view * P + gaussian]
         const size_t n = P * V;
         g.depths = c.take<float>(n);
         g.means2D = c.take<float2>(n);
-        g.conic_opacity = c.take<float4>(n);
-        g.rgb_cut = c.take<float4>(n);
+        g.blend = c.take<BlendRecord>(n);
         g.cov3D = c.take<float>(6 * n);
         g.clamped = c.take<uint8_t>(n);
         g.internal_radii = c.take<int32_t>(n);
