@@ -32,7 +32,7 @@
 namespace dgs {
 
 struct BwdParams {
-    int P, D, M, W, H, V, vps, gx, gy, T, raw_act, exact_exp;
+    int P, D, M, W, H, V, vps, gx, gy, T, raw_act, exact_exp, ablate;
     const float *bg, *means3D, *shs, *colors_pre, *opac, *scales, *rots, *cov_pre, *viewm, *projm, *campos, *tanfov;
     float tanfovx, tanfovy, scale_mod;
     const int* radii;
@@ -47,13 +47,11 @@ struct BwdParams {
     float4* slot_a;              // [slots]     {colour r, g, b, mean2D x}
     float4* slot_b;              // [slots]     {mean2D y, conic xx, conic xy, conic yy}
     float* slot_c;               // [slots]     opacity
-    float* op_view;              // [V*P]       per-view opacity sums (added over the views of a set, in view order, by preprocess_backward_kernel)
-    float* col_view;             // [V*P*3]     per-view colour sums when colours are per set (precomputed colours); else null
 };
 
 // Scratch of the deterministic backward, carved from ONE caller-owned buffer (dgs_raster_backward_scratch_bytes).
 struct BwdScratch {
-    uint32_t* slot_base; uint32_t* block_sums; unsigned long long* last_key; float4* slot_a; float4* slot_b; float* slot_c; float* op_view; float* col_view;
+    uint32_t* slot_base; uint32_t* block_sums; unsigned long long* last_key; float4* slot_a; float4* slot_b; float* slot_c;
     static BwdScratch carve(void* buf, size_t P, size_t V, size_t T, size_t slots, size_t* bytes) {
         Carver c(buf);
         BwdScratch s;
@@ -63,8 +61,6 @@ struct BwdScratch {
         s.slot_a = c.take<float4>(slots);
         s.slot_b = c.take<float4>(slots);
         s.slot_c = c.take<float>(slots);
-        s.op_view = c.take<float>(P * V);
-        s.col_view = c.take<float>(3 * P * V);
         if (bytes) *bytes = c.bytes();
         return s;
     }
@@ -109,6 +105,33 @@ __global__ __launch_bounds__(256) void touched_scan_kernel(const uint32_t* touch
     if (first <= n && n < first + 16) slot_base[n] = run;     // the end: first slot behind the last Gaussian (n % 16 elements of this thread counted)
 }
 
+// Row length of the per-batch accumulators in LDS, [value][entry]: 256 entries + 4, so that the flush below -- lane = (entry, value),
+// sixteen lanes an entry -- reads bank (4 z + e) mod 32: two lanes a bank at worst (256 would put the nine values of an entry in one).
+constexpr int kAccRow = 260;
+
+// Flush of the atomic form: the nine sums of a (tile, Gaussian) instance go into the Gaussian's 64-byte gradient record with ONE atomic
+// instruction, lane z of a 16-lane group adding value z.  The lanes of one instruction that fall into the same line travel to L2 as one
+// request: measured (tools/ubench/atomic_layout_bench.hip, 2.7 M instances = the trained-like regime, 4 views at 256^2) 134 us against
+// 1,178 us for nine instructions into four arrays with a lane per instance -- the form of rounds 1-4, whose cost inside the blend
+// kernel was 0.19 ms of 0.88 (ablation, profiles/r04_raster_backward_ablation.txt).  A wave flushes the 64 entries per 128 it staged itself
+// (it reads their ids), so no barrier separates the flush from the next batch's staging.  NPASS passes of four entries.
+template <int NPASS>
+__device__ __forceinline__ void flush_records(float (*acc)[kAccRow], const uint32_t* s_id, float* grad_acc, size_t vo, int first_entry, int lane) {
+    const int z = lane & 15, sub = lane >> 4;
+    if (z < 9) {
+#pragma unroll 4
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int e = first_entry + 4 * pass + sub;
+            const float val = acc[z][e];
+            if (val != 0.f) {
+                acc[z][e] = 0.f;
+                atomicAdd(grad_acc + 16 * (vo + s_id[e]) + z, val);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();      // the wave's next staging overwrites the ids its other lanes read here (no instruction on the GPU)
+}
+
 // grid V*T (workgroup b takes tile tile_order[b]), 256 threads = 4 wave64.  backward.cu:399-557.
 //
 // Lanes, pixels and lists as in the forward (blend_forward_kernel): wave g owns strip g, its four 16-lane rows own the strip's
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
     // order the four waves get there (fp32: the sum's last bit depends on that order).  Deterministic form: a copy per wave -- inside
     // a wave the adds happen in program order -- and the four copies are added in wave order when the batch is done.
     constexpr int NACC = DET ? 4 : 1;
-    __shared__ float s_acc[NACC][9][256];
+    __shared__ float s_acc[NACC][9][kAccRow];
     const uint32_t vt = p.im.tile_order[blockIdx.x];           // order_tiles_kernel: most replayed entries first
     const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T), s = v / p.vps;
     const int bx = tile % p.gx, by = tile / p.gx;
@@ -268,9 +291,10 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                         c9[6] = -0.5f * gdx * dy * dL_dG;
                         c9[7] = -0.5f * gdy * dy * dL_dG;
                         c9[8] = G * dL_dalpha;
+                        const bool reduce = !(kRasterAblate && (p.ablate & 16)), add = !(kRasterAblate && (p.ablate & 2));
 #pragma unroll
-                        for (int q = 0; q < 9; ++q) c9[q] = row_sum_to_lane15(take ? c9[q] : 0.f);
-                        if ((lane & 15) == 15 && ((takers >> (16 * row)) & 0xFFFFull) != 0ull) {
+                        for (int q = 0; q < 9; ++q) c9[q] = reduce ? row_sum_to_lane15(take ? c9[q] : 0.f) : (take ? c9[q] : 0.f);
+                        if (add && (lane & 15) == 15 && ((takers >> (16 * row)) & 0xFFFFull) != 0ull) {
 #pragma unroll
                             for (int q = 0; q < 9; ++q) lds_add(&s_acc[DET ? wave : 0][q][j], c9[q]);
                         }
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             Entry ea = load(word & 255u), eb;
             if constexpr (kRasterStats) st_entries += tot;
             uint32_t k = 0;
-            for (; __ballot(k < tot) != 0ull; k += 4) {
+            for (; __ballot(k < tot) != 0ull && !(kRasterAblate && (p.ablate & 4)); k += 4) {
                 const uint32_t word_next = lst[(k >> 2) + 1u];
                 eb = load((word >> 8) & 255u);  step(k, word & 255u, ea);
                 ea = load((word >> 16) & 255u); step(k + 1u, (word >> 8) & 255u, eb);
@@ -293,45 +317,34 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             if constexpr (kRasterStats) st_trips += k;
         }
         __syncthreads();
-        // entry `tid`: the tile's sums, one atomic per value
-        {
+        if constexpr (!DET) {
+            if (!(kRasterAblate && (p.ablate & 1))) flush_records<16>(s_acc[0], s_id, p.g.grad_acc, vo, 64 * wave, lane);
+        } else {
+            // entry `tid`: the tile's sums, stored into the slot of (Gaussian, this tile)
             float c9[9];
             bool any = false;
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
-                if constexpr (DET) c9[q] = ((s_acc[0][q][tid] + s_acc[1][q][tid]) + s_acc[2][q][tid]) + s_acc[3][q][tid];
-                else c9[q] = s_acc[0][q][tid];
+                c9[q] = ((s_acc[0][q][tid] + s_acc[1][q][tid]) + s_acc[2][q][tid]) + s_acc[3][q][tid];
                 any = any || c9[q] != 0.f;
             }
-            if constexpr (DET) {
-                // every replayed entry STORES its sums (zeros too) into the slot of (Gaussian, this tile): Gaussian-major, the tile's
-                // index inside the Gaussian's rectangle (the forward's tile_rect on the same state: the same rectangle)
-                if (idx >= 0) {
-                    if (any) {
+            // every replayed entry STORES its sums (zeros too): Gaussian-major, the tile's index inside the Gaussian's rectangle (the
+            // forward's tile_rect on the same state: the same rectangle)
+            if (idx >= 0) {
+                if (any) {
 #pragma unroll
-                        for (int w = 0; w < NACC; ++w)
+                    for (int w = 0; w < NACC; ++w)
 #pragma unroll
-                            for (int q = 0; q < 9; ++q) s_acc[w][q][tid] = 0.f;
-                    }
-                    const uint32_t id = s_id[tid];
-                    const size_t gv = vo + id;
-                    int x0, y0, x1, y1;
-                    tile_rect(s_xy[tid].x, s_xy[tid].y, p.radii[gv], p.gx, p.gy, &x0, &y0, &x1, &y1);
-                    const size_t slot = (size_t)p.slot_base[gv] + (size_t)((by - y0) * (x1 - x0) + (bx - x0));
-                    p.slot_a[slot] = make_float4(c9[0], c9[1], c9[2], c9[3]);
-                    p.slot_b[slot] = make_float4(c9[4], c9[5], c9[6], c9[7]);
-                    p.slot_c[slot] = c9[8];
+                        for (int q = 0; q < 9; ++q) s_acc[w][q][tid] = 0.f;
                 }
-            } else if (any) {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) s_acc[0][q][tid] = 0.f;
                 const uint32_t id = s_id[tid];
-                const size_t gv = vo + id, gs = (size_t)s * p.P + id;
-                float* dc = p.dL_dcolors + 3 * (colors_per_set ? gs : gv);
-                atomicAdd(dc, c9[0]); atomicAdd(dc + 1, c9[1]); atomicAdd(dc + 2, c9[2]);
-                atomicAdd(p.dL_dmean2D + 3 * gv, c9[3]); atomicAdd(p.dL_dmean2D + 3 * gv + 1, c9[4]);
-                atomicAdd(p.dL_dconic + 4 * gv, c9[5]); atomicAdd(p.dL_dconic + 4 * gv + 1, c9[6]); atomicAdd(p.dL_dconic + 4 * gv + 3, c9[7]);
-                atomicAdd(p.dL_dopacity + gs, c9[8]);
+                const size_t gv = vo + id;
+                int x0, y0, x1, y1;
+                tile_rect(s_xy[tid].x, s_xy[tid].y, p.radii[gv], p.gx, p.gy, &x0, &y0, &x1, &y1);
+                const size_t slot = (size_t)p.slot_base[gv] + (size_t)((by - y0) * (x1 - x0) + (bx - x0));
+                p.slot_a[slot] = make_float4(c9[0], c9[1], c9[2], c9[3]);
+                p.slot_b[slot] = make_float4(c9[4], c9[5], c9[6], c9[7]);
+                p.slot_c[slot] = c9[8];
             }
         }
     }
@@ -355,6 +368,261 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
         if (tid == 0)
             p.im.tile_stats[(size_t)p.V * p.T + vt] = make_uint4(s_stat[0].x + s_stat[1].x + s_stat[2].x + s_stat[3].x,
                                                                  s_stat[0].y + s_stat[1].y + s_stat[2].y + s_stat[3].y, 0u, (uint32_t)rounds);
+    }
+}
+
+__device__ __forceinline__ v2f sel2(bool a, bool b, v2f t, v2f f) { return v2f{a ? t.x : f.x, b ? t.y : f.y}; }
+
+// The same replay with TWO pixels per lane.  grid V*T (workgroup b takes tile tile_order[b]), 128 threads = 2 wave64.
+//
+// Why.  The walk of blend_backward_kernel is bound by VALU issue, not by memory or LDS: a full step is ~165 VALU instructions per
+// wave (ISA count; 2.35 M wave steps x 660 cycles on 1,024 SIMDs = 0.63 ms of the kernel's 0.80 ms in the trained-like regime, 4 views at
+// 256^2), 45 of them the cross-lane reduction of the nine sums, ~100 plain fp32 multiplies / adds / selects.  gfx950 issues fp32
+// multiplies, adds and FMAs on register PAIRS at the same cost (v_pk_mul_f32, v_pk_add_f32): a lane that owns two pixels does the
+// arithmetic of both with one instruction each, and the reduction (one add, then three DPP steps over 8 lanes instead of four over
+// 16) serves 16 pixels with 4 instructions per value instead of 5 per value.  Cells, lists and the per-(cell, entry) culling are
+// unchanged: a wave's eight 8-lane groups own eight 4 x 4 cells (wave w: strips 2w, 2w+1), lane q of a group the pixels
+// (q & 3, 2 (q >> 2)) and (q & 3, 2 (q >> 2) + 1) of its cell -- same x, so dx is shared; a step covers 128 (pixel, entry) pairs.
+// Per pixel the arithmetic is the reference's, in the reference's order (every operation on a pair is the scalar operation
+// on each half); the masks are applied to one factor (0 x finite) instead of to the nine products, which adds (+-)0 to a sum
+// where the other kernel adds +0.  The order in which a cell's 16 pixels are added differs from the other kernel's.
+// Batches of 256 entries are staged by 128 threads, two entries each (entry e of the batch by thread e & 127).
+template <bool FAST_EXP, bool DET>
+__global__ __launch_bounds__(128) void blend_backward_pair_kernel(BwdParams p) {
+    __shared__ uint32_t s_id[256];
+    __shared__ uint2 s_stat[kRasterStats ? 2 : 1];
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float4 s_rgbc[256];
+    __shared__ uint32_t s_max[2];
+    __shared__ uint4 s_cnt[16];                           // [cell] entries of the batch the cell keeps, per 64 entries of the batch
+    __shared__ uint8_t s_list[17][256];
+    constexpr int NACC = DET ? 2 : 1;                     // deterministic form: a copy per wave, added in wave order (see blend_backward_kernel)
+    __shared__ float s_acc[NACC][9][kAccRow];
+    const uint32_t vt = p.im.tile_order[blockIdx.x];
+    const int v = (int)(vt / (uint32_t)p.T), tile = (int)(vt % (uint32_t)p.T), s = v / p.vps;
+    const int bx = tile % p.gx, by = tile / p.gx;
+    const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 3, q = lane & 7;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cell = wave * 8 + grp;                      // cell_mask bit: 4 * strip + column
+    const int pxi = bx * kTile + 4 * (cell & 3) + (q & 3), pyi = by * kTile + 4 * (cell >> 2) + 2 * (q >> 2);
+    const bool in0 = pxi < p.W && pyi < p.H, in1 = pxi < p.W && pyi + 1 < p.H;
+    const float pfx = (float)pxi;
+    const v2f pfy = {(float)pyi, (float)(pyi + 1)};
+    const float tx0 = (float)(bx * kTile), ty0 = (float)(by * kTile);
+    const unsigned long long lanes_before = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const size_t HW = (size_t)p.H * p.W, pid0 = (size_t)p.W * pyi + pxi, pid1 = pid0 + (size_t)p.W;
+    const uint2 rg = p.im.ranges[vt];
+    const size_t vo = (size_t)v * p.P;
+
+    const v2f T_final = {in0 ? p.im.final_T[(size_t)v * HW + pid0] : 0.0f, in1 ? p.im.final_T[(size_t)v * HW + pid1] : 0.0f};
+    v2f T = T_final;
+    const uint32_t lc0 = in0 ? p.im.n_contrib[(size_t)v * HW + pid0] : 0u, lc1 = in1 ? p.im.n_contrib[(size_t)v * HW + pid1] : 0u;
+    v2f dpix[3];
+    {
+        const float* g = p.dL_dpix + (size_t)v * 3 * HW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dpix[c] = v2f{in0 ? g[c * HW + pid0] : 0.f, in1 ? g[c * HW + pid1] : 0.f};
+    }
+    v2f bg_dot = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bg_dot += p.bg[c] * dpix[c];
+    v2f accum_rec[3], last_color[3], last_alpha = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { accum_rec[c] = v2f{0.f, 0.f}; last_color[c] = v2f{0.f, 0.f}; }
+    const float ddelx_dx = (float)(0.5 * p.W), ddely_dy = (float)(0.5 * p.H);
+
+    uint32_t mc = max(lc0, lc1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
+    if (lane == 0) s_max[wave] = mc;
+#pragma unroll
+    for (int w = 0; w < NACC; ++w)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { s_acc[w][k][tid] = 0.f; s_acc[w][k][tid + 128] = 0.f; }
+    __syncthreads();
+    const uint32_t todo = max(s_max[0], s_max[1]);             // <= rg.y - rg.x
+    const int rounds = (int)((todo + 255u) / 256u);
+    const bool colors_per_set = p.colors_pre != nullptr;
+    uint32_t st_entries = 0, st_trips = 0;
+    for (int i = 0; i < rounds; ++i) {
+        // batch entry e (0..255) = 1-based list index contributor = todo - (i * 256 + e), staged by thread e & 127
+        unsigned m16[2] = {0u, 0u};
+        int idxs[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = h * 128 + tid;
+            const int idx = (int)todo - 1 - (i * 256 + e);
+            idxs[h] = idx;
+            if (idx >= 0) {
+                const uint32_t id = p.bn.point_list[rg.x + (uint32_t)idx];
+                const BlendRecord* rec = p.g.blend + vo + id;
+                const float4 co = rec->co;
+                float4 rc = rec->rc;
+                const float2 xy = rec->xy;
+                m16[h] = cell_mask(xy, co, rc.w, tx0, ty0);
+                if (colors_per_set) {
+                    const float* c = p.colors_pre + 3 * ((size_t)s * p.P + id);
+                    rc.x = c[0]; rc.y = c[1]; rc.z = c[2];
+                }
+                s_id[e] = id; s_xy[e] = xy; s_co[e] = co; s_rgbc[e] = rc;
+            } else {
+                s_id[e] = 0u; s_xy[e] = make_float2(0.f, 0.f); s_co[e] = make_float4(0.f, 0.f, 0.f, 0.f); s_rgbc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const unsigned long long keep = __ballot((m16[h] >> c) & 1u);
+                if (lane == 0) reinterpret_cast<uint32_t*>(&s_cnt[c])[2 * h + wave] = (uint32_t)__popcll(keep);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const unsigned long long keep = __ballot((m16[h] >> c) & 1u);
+                if ((m16[h] >> c) & 1u) {
+                    const uint4 cn = s_cnt[c];
+                    const int part = 2 * h + wave;                      // which 64 entries of the batch
+                    const uint32_t ahead = (part > 0 ? cn.x : 0u) + (part > 1 ? cn.y : 0u) + (part > 2 ? cn.z : 0u);
+                    s_list[c][ahead + (uint32_t)__popcll(keep & lanes_before)] = (uint8_t)(h * 128 + tid);
+                }
+            }
+        __syncthreads();
+        {
+            const uint4 cn = s_cnt[cell];
+            const uint32_t tot = cn.x + cn.y + cn.z + cn.w;
+            const uint32_t first = todo - (uint32_t)(i * 256);
+            struct Entry { float2 xy; float4 co; float4 rc; };
+            auto load = [&](uint32_t j) { return Entry{s_xy[j], s_co[j], s_rgbc[j]}; };
+            auto step = [&](uint32_t k, uint32_t j, const Entry& e) {
+                const float dx = e.xy.x - pfx;
+                const v2f dy = e.xy.y - pfy;
+                const v2f power = -0.5f * (e.co.x * dx * dx + e.co.z * dy * dy) - e.co.y * dx * dy;
+                const uint32_t back = first - j;                         // 1-based list index of the entry (backward.cu:463-468)
+                const bool near0 = k < tot && in0 && back <= lc0 && !(power.x > 0.0f) && !(power.x < e.rc.w);
+                const bool near1 = k < tot && in1 && back <= lc1 && !(power.y > 0.0f) && !(power.y < e.rc.w);
+                if (__ballot(near0 || near1) != 0ull) {
+                    const v2f G = {blend_exp<FAST_EXP>(near0 ? power.x : 0.0f), blend_exp<FAST_EXP>(near1 ? power.y : 0.0f)};
+                    v2f alpha = e.co.w * G;
+                    alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y);
+                    const bool take0 = near0 && !(alpha.x < 1.0f / 255.0f), take1 = near1 && !(alpha.y < 1.0f / 255.0f);
+                    const unsigned long long takers = __ballot(take0 || take1);
+                    if (takers != 0ull) {
+                        const v2f one_m = 1.f - alpha;
+                        v2f inv1ma = {0.f, 0.f}, Tn;
+                        if constexpr (FAST_EXP) { inv1ma = v2f{hw_rcp(one_m.x), hw_rcp(one_m.y)}; Tn = T * inv1ma; }
+                        else Tn = T / one_m;
+                        const v2f dch = sel2(take0, take1, alpha * Tn, v2f{0.f, 0.f});
+                        const v2f la1 = 1.f - last_alpha;
+                        v2f c9[9];
+                        v2f dLa = {0.f, 0.f};
+                        auto channel = [&](int ch, float col) {
+                            const v2f rec = last_alpha * last_color[ch] + la1 * accum_rec[ch];
+                            dLa += (col - rec) * dpix[ch];
+                            c9[ch] = dch * dpix[ch];
+                            accum_rec[ch] = sel2(take0, take1, rec, accum_rec[ch]);
+                            last_color[ch] = sel2(take0, take1, v2f{col, col}, last_color[ch]);
+                        };
+                        channel(0, e.rc.x); channel(1, e.rc.y); channel(2, e.rc.z);
+                        dLa *= Tn;
+                        if constexpr (FAST_EXP) dLa += (-T_final * inv1ma) * bg_dot;
+                        else dLa += (-T_final / one_m) * bg_dot;
+                        T = sel2(take0, take1, Tn, T);
+                        last_alpha = sel2(take0, take1, alpha, last_alpha);
+                        const v2f dLa_m = sel2(take0, take1, dLa, v2f{0.f, 0.f});
+                        const v2f dL_dG = e.co.w * dLa_m;
+                        const v2f gdx = G * dx, gdy = G * dy;
+                        const v2f dG_ddelx = -gdx * e.co.x - gdy * e.co.y;
+                        const v2f dG_ddely = -gdy * e.co.z - gdx * e.co.y;
+                        c9[3] = dL_dG * dG_ddelx * ddelx_dx;
+                        c9[4] = dL_dG * dG_ddely * ddely_dy;
+                        c9[5] = -0.5f * gdx * dx * dL_dG;
+                        c9[6] = -0.5f * gdx * dy * dL_dG;
+                        c9[7] = -0.5f * gdy * dy * dL_dG;
+                        c9[8] = G * dLa_m;
+                        const bool reduce = !(kRasterAblate && (p.ablate & 16)), add = !(kRasterAblate && (p.ablate & 2));
+                        float s9[9];
+#pragma unroll
+                        for (int z = 0; z < 9; ++z) s9[z] = reduce ? oct_sum_to_lane7(c9[z].x + c9[z].y) : c9[z].x + c9[z].y;
+                        if (add && q == 7 && ((takers >> (8 * grp)) & 0xFFull) != 0ull) {
+#pragma unroll
+                            for (int z = 0; z < 9; ++z) lds_add(&s_acc[DET ? wave : 0][z][j], s9[z]);
+                        }
+                    }
+                }
+            };
+            const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
+            uint32_t word = lst[0];
+            Entry ea = load(word & 255u), eb;
+            if constexpr (kRasterStats) st_entries += tot;
+            uint32_t k = 0;
+            for (; __ballot(k < tot) != 0ull && !(kRasterAblate && (p.ablate & 4)); k += 4) {
+                const uint32_t word_next = lst[(k >> 2) + 1u];
+                eb = load((word >> 8) & 255u);  step(k, word & 255u, ea);
+                ea = load((word >> 16) & 255u); step(k + 1u, (word >> 8) & 255u, eb);
+                eb = load(word >> 24);          step(k + 2u, (word >> 16) & 255u, ea);
+                ea = load(word_next & 255u);    step(k + 3u, word >> 24, eb);
+                word = word_next;
+            }
+            if constexpr (kRasterStats) st_trips += 2u * k;          // a trip issues 128 pixel slots: counted as two of the 64-slot trips
+        }
+        __syncthreads();
+        if constexpr (!DET) {
+            if (!(kRasterAblate && (p.ablate & 1))) {
+                flush_records<16>(s_acc[0], s_id, p.g.grad_acc, vo, 64 * wave, lane);            // the entries this wave staged: e = h * 128 + tid
+                flush_records<16>(s_acc[0], s_id, p.g.grad_acc, vo, 128 + 64 * wave, lane);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = h * 128 + tid;
+                float c9[9];
+                bool any = false;
+#pragma unroll
+                for (int z = 0; z < 9; ++z) {
+                    c9[z] = s_acc[0][z][e] + s_acc[1][z][e];
+                    any = any || c9[z] != 0.f;
+                }
+                if (idxs[h] >= 0) {
+                    if (any) {
+#pragma unroll
+                        for (int w = 0; w < NACC; ++w)
+#pragma unroll
+                            for (int z = 0; z < 9; ++z) s_acc[w][z][e] = 0.f;
+                    }
+                    const uint32_t id = s_id[e];
+                    const size_t gv = vo + id;
+                    int x0, y0, x1, y1;
+                    tile_rect(s_xy[e].x, s_xy[e].y, p.radii[gv], p.gx, p.gy, &x0, &y0, &x1, &y1);
+                    const size_t slot = (size_t)p.slot_base[gv] + (size_t)((by - y0) * (x1 - x0) + (bx - x0));
+                    p.slot_a[slot] = make_float4(c9[0], c9[1], c9[2], c9[3]);
+                    p.slot_b[slot] = make_float4(c9[4], c9[5], c9[6], c9[7]);
+                    p.slot_c[slot] = c9[8];
+                }
+            }
+        }
+    }
+    if constexpr (DET) {
+        if (tid == 0) {
+            unsigned long long key = 0ull;
+            if (todo > 0) {
+                const uint32_t id = p.bn.point_list[rg.x + todo - 1u];
+                key = ((unsigned long long)__float_as_uint(p.g.depths[vo + id]) << 32) | id;
+            }
+            p.last_key[vt] = key;
+        }
+    }
+    if constexpr (kRasterStats) {
+        uint32_t ent = q == 0 ? st_entries : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ent += (uint32_t)__shfl_xor((int)ent, o);
+        if (lane == 0) s_stat[wave] = make_uint2(ent, st_trips);
+        __syncthreads();
+        if (tid == 0)
+            p.im.tile_stats[(size_t)p.V * p.T + vt] = make_uint4(s_stat[0].x + s_stat[1].x, s_stat[0].y + s_stat[1].y, 0u, (uint32_t)rounds);
     }
 }
 
@@ -435,9 +703,9 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* work,
 }
 
 // Deterministic form: grid (ceil(P / 256), V), one thread per (view, Gaussian).  It adds the slots of the tiles that replayed the
-// Gaussian, in rectangle order (row-major), and writes the view's dL_dmean2D / dL_dconic / dL_dcolors rows and its opacity (and,
-// with per-set colours, colour) sums -- which preprocess_backward_kernel adds over the views of a set in view order.  Every output
-// element is written.  The tiles' keys sit in LDS (8 bytes per tile): a Gaussian of the random-init regime tests ~50 of them.
+// Gaussian, in rectangle order (row-major), and writes the nine sums as the (view, Gaussian)'s gradient record -- what the atomic form
+// accumulates with atomics; preprocess_backward_kernel reads either.  The tiles' keys sit in LDS (8 bytes per tile): a Gaussian of the
+// random-init regime tests ~50 of them.
 template <bool LDS_KEYS>
 __global__ __launch_bounds__(256) void gather_partials_kernel(BwdParams p) {
     DGS_DYNAMIC_LDS(smem);
@@ -469,11 +737,12 @@ __global__ __launch_bounds__(256) void gather_partials_kernel(BwdParams p) {
                 }
             }
     }
-    p.dL_dmean2D[3 * gi] = a[3]; p.dL_dmean2D[3 * gi + 1] = a[4]; p.dL_dmean2D[3 * gi + 2] = 0.f;
-    p.dL_dconic[4 * gi] = a[5]; p.dL_dconic[4 * gi + 1] = a[6]; p.dL_dconic[4 * gi + 2] = 0.f; p.dL_dconic[4 * gi + 3] = a[7];
-    if (p.colors_pre == nullptr) { p.dL_dcolors[3 * gi] = a[0]; p.dL_dcolors[3 * gi + 1] = a[1]; p.dL_dcolors[3 * gi + 2] = a[2]; }
-    else { p.col_view[3 * gi] = a[0]; p.col_view[3 * gi + 1] = a[1]; p.col_view[3 * gi + 2] = a[2]; }
-    p.op_view[gi] = a[8];
+    if (radius > 0) {      // the record of a culled Gaussian is never read
+        float4* rec = reinterpret_cast<float4*>(p.g.grad_acc + 16 * gi);
+        rec[0] = make_float4(a[0], a[1], a[2], a[3]);
+        rec[1] = make_float4(a[4], a[5], a[6], a[7]);
+        rec[2] = make_float4(a[8], 0.f, 0.f, 0.f);
+    }
 }
 
 // grid ceil(S*P / 256).  One thread per (set, Gaussian); loops over the views of the set.
@@ -488,23 +757,30 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
     const int nsh = p.shs ? 3 * p.M : 0;
     for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
     const int v0 = s * p.vps, v1 = min(p.V, v0 + p.vps);
-    if (p.op_view) {     // deterministic form: the per-set sums over the views of the set, in view order (gather_partials_kernel wrote the per-view terms)
-        float o = 0.f, c3[3] = {0.f, 0.f, 0.f};
-        for (int v = v0; v < v1; ++v) {
-            const size_t gi = (size_t)v * p.P + idx;
-            o += p.op_view[gi];
-            if (p.colors_pre) { c3[0] += p.col_view[3 * gi]; c3[1] += p.col_view[3 * gi + 1]; c3[2] += p.col_view[3 * gi + 2]; }
-        }
-        p.dL_dopacity[si] = o;
-        if (p.colors_pre) { p.dL_dcolors[3 * si] = c3[0]; p.dL_dcolors[3 * si + 1] = c3[1]; p.dL_dcolors[3 * si + 2] = c3[2]; }
-    }
+    // The blend kernel's nine sums per (view, Gaussian) arrive as one 64-byte record (GeomState::grad_acc: accumulated by atomics, or
+    // written by gather_partials_kernel); the per-view rows the reference returns (dL_dmeans2D, dL_dconic, dL_dcolors) are written from it
+    // here -- every element, nothing is pre-filled -- and the per-set sums (opacity; colours when they are per set) are added over the
+    // views of the set in view order.
+    float op_sum = 0.f, col_sum[3] = {0.f, 0.f, 0.f};
     for (int v = v0; v < v1; ++v) {
         const size_t gi = (size_t)v * p.P + idx;
-        if (!(p.radii[gi] > 0)) {                  // culled in this view: its dL_dcov3D row is zero (the buffer is not pre-filled)
+        if (!(p.radii[gi] > 0)) {                  // culled in this view: its rows are zero
 #pragma unroll
             for (int k = 0; k < 6; ++k) p.dL_dcov3D[6 * gi + k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p.dL_dmean2D[3 * gi + k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p.dL_dconic[4 * gi + k] = 0.f;
+            if (!p.colors_pre) { p.dL_dcolors[3 * gi] = 0.f; p.dL_dcolors[3 * gi + 1] = 0.f; p.dL_dcolors[3 * gi + 2] = 0.f; }
             continue;
         }
+        const float4* rec = reinterpret_cast<const float4*>(p.g.grad_acc + 16 * gi);
+        const float4 r0 = rec[0], r1 = rec[1];
+        op_sum += p.g.grad_acc[16 * gi + 8];
+        p.dL_dmean2D[3 * gi] = r0.w; p.dL_dmean2D[3 * gi + 1] = r1.x; p.dL_dmean2D[3 * gi + 2] = 0.f;
+        p.dL_dconic[4 * gi] = r1.y; p.dL_dconic[4 * gi + 1] = r1.z; p.dL_dconic[4 * gi + 2] = 0.f; p.dL_dconic[4 * gi + 3] = r1.w;
+        if (p.colors_pre) { col_sum[0] += r0.x; col_sum[1] += r0.y; col_sum[2] += r0.z; }
+        else { p.dL_dcolors[3 * gi] = r0.x; p.dL_dcolors[3 * gi + 1] = r0.y; p.dL_dcolors[3 * gi + 2] = r0.z; }
         const float* vm = p.viewm + 16 * v;
         const float* proj = p.projm + 16 * v;
         float tanx, tany;
@@ -535,7 +811,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
         const M3 cov = m3_mul(m3_mul(m3_t(Tm), m3_t(Vrk)), Tm);
         const float a = cov.c[0][0] + 0.3f, b = cov.c[0][1], c = cov.c[1][1] + 0.3f;
         const float denom = a * c - b * b;
-        const float dcx = p.dL_dconic[4 * gi], dcy = p.dL_dconic[4 * gi + 1], dcz = p.dL_dconic[4 * gi + 3];
+        const float dcx = r1.y, dcy = r1.z, dcz = r1.w;
         float dL_da = 0, dL_db = 0, dL_dc = 0;
         const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
         float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -578,14 +854,13 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
         const float m_w = 1.0f / (hw + 0.0000001f);
         const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
         const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
-        const float d2x = p.dL_dmean2D[3 * gi], d2y = p.dL_dmean2D[3 * gi + 1];
+        const float d2x = r0.w, d2y = r1.x;
         dmv[0] += (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
         dmv[1] += (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
         dmv[2] += (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
         if (p.shs) {
             const unsigned cb = p.g.clamped[gi];
-            const float dRGB[3] = {(cb & 1u) ? 0.f : p.dL_dcolors[3 * gi], (cb & 2u) ? 0.f : p.dL_dcolors[3 * gi + 1],
-                                   (cb & 4u) ? 0.f : p.dL_dcolors[3 * gi + 2]};
+            const float dRGB[3] = {(cb & 1u) ? 0.f : r0.x, (cb & 2u) ? 0.f : r0.y, (cb & 4u) ? 0.f : r0.z};
             const float* cam = p.campos + 3 * v;
             sh_backward(p.D, p.shs + 3 * (size_t)p.M * si, mx - cam[0], my - cam[1], mz - cam[2], dRGB, dsh, dmv);
         }
@@ -594,10 +869,12 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
     p.dL_dmeans3D[3 * si] = dmean[0]; p.dL_dmeans3D[3 * si + 1] = dmean[1]; p.dL_dmeans3D[3 * si + 2] = dmean[2];
     if (p.dL_dsh)
         for (int k = 0; k < nsh; ++k) p.dL_dsh[(size_t)nsh * si + k] = dsh[k];
+    if (p.colors_pre) { p.dL_dcolors[3 * si] = col_sum[0]; p.dL_dcolors[3 * si + 1] = col_sum[1]; p.dL_dcolors[3 * si + 2] = col_sum[2]; }
     if (p.raw_act) {   // d sigmoid, gs_core.py:334
         const float op = 1.0f / (1.0f + det_expf(-p.opac[si]));
-        p.dL_dopacity[si] = p.dL_dopacity[si] * (op * (1.0f - op));
+        op_sum = op_sum * (op * (1.0f - op));
     }
+    p.dL_dopacity[si] = op_sum;
     if (!p.cov_pre && p.dL_dscales && p.dL_drots) {
         // ---- computeCov3D backward, backward.cu:278-341, on the view-summed dL/dSigma ----
         float sx = p.scales[3 * si], sy = p.scales[3 * si + 1], sz = p.scales[3 * si + 2];
@@ -653,6 +930,31 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
     }
 }
 
+// Which walk.  Two pixels per lane halves the VALU work of a step but also the number of waves (a tile is two waves instead of four):
+// measured (profiles/r04_raster_backward_walks.txt, forward + backward per call) 4 views at 256^2 -- 1,024 workgroups, two waves per
+// SIMD -- 1.194 ms against 1.144 (trained-like) and 1.080 against 0.970 (random init); 16 views at 256^2 3.299 against 3.429; 4 views
+// at 512^2 3.093 against 3.202.  So: the two-pixel walk from 3,072 workgroups on (every CU then holds its six), the one-pixel walk
+// below.  The deterministic form takes the two-pixel walk always (its LDS holds a copy of the accumulators per wave: two instead of
+// four).  DGS_RASTER_BWD_WALK=1 | 2 forces one (A/B runs).
+template <bool DET>
+static bool pair_walk(int workgroups) {
+    static const int forced = [] { const char* e = getenv("DGS_RASTER_BWD_WALK"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2) return forced == 2;
+    return DET || workgroups >= 3072;
+}
+
+template <bool DET>
+static void launch_blend_backward(const BwdParams& p, int V, hipStream_t st) {
+    const dim3 grid((unsigned)(V * p.T));
+    if (pair_walk<DET>(V * p.T)) {
+        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_pair_kernel<false, DET>), grid, dim3(128), 0, st, p);
+        else hipLaunchKernelGGL((blend_backward_pair_kernel<true, DET>), grid, dim3(128), 0, st, p);
+    } else {
+        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_kernel<false, DET>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((blend_backward_kernel<true, DET>), grid, dim3(256), 0, st, p);
+    }
+}
+
 }  // namespace dgs
 
 using namespace dgs;
@@ -682,6 +984,7 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
     p.scales = a->scales; p.rots = a->rotations; p.cov_pre = a->cov3D_precomp; p.viewm = a->viewmatrix; p.projm = a->projmatrix;
     p.campos = a->campos; p.tanfov = a->tanfov; p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.scale_mod = a->scale_modifier;
     p.radii = a->radii; p.dL_dpix = a->dL_dpix;
+    if constexpr (kRasterAblate) { static const int ab = [] { const char* e = getenv("DGS_RASTER_BWD_ABLATE"); return e ? atoi(e) : 0; }(); p.ablate = ab; }
     p.g = GeomState::carve(const_cast<void*>(a->geom_buffer), (size_t)P, (size_t)V, nullptr);
     p.im = ImageState::carve(const_cast<void*>(a->img_buffer), (size_t)W, (size_t)H, (size_t)V, nullptr);
     p.bn = BinningState::carve(const_cast<void*>(a->binning_buffer), (size_t)(a->num_rendered < 1 ? 1 : a->num_rendered), nullptr);
@@ -689,7 +992,7 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
     p.dL_dopacity = a->dL_dopacity; p.dL_dmeans3D = a->dL_dmeans3D; p.dL_dsh = a->dL_dsh; p.dL_dscales = a->dL_dscales;
     p.dL_drots = a->dL_drotations;
 
-    const size_t nv = (size_t)V * P, ns = (size_t)S * P, ncol = (a->colors_precomp ? ns : nv) * 3;
+    const size_t nv = (size_t)V * P, ns = (size_t)S * P;
     const bool det = a->scratch != nullptr;
     if (det) {
         // ---- deterministic form: slots instead of atomics, nothing to fill ----
@@ -698,13 +1001,11 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
         const BwdScratch sc = BwdScratch::carve(a->scratch, (size_t)P, (size_t)V, (size_t)p.T, slots, &need);
         if (a->scratch_bytes < need) return DGS_ERR_ALLOC;
         p.slot_base = sc.slot_base; p.last_key = sc.last_key; p.slot_a = sc.slot_a; p.slot_b = sc.slot_b; p.slot_c = sc.slot_c;
-        p.op_view = sc.op_view; p.col_view = sc.col_view;
         const unsigned nb = (unsigned)((nv + 4095) / 4096);
         hipLaunchKernelGGL(touched_block_sums_kernel, dim3(nb), dim3(256), 0, st, p.g.tiles_touched, nv, sc.block_sums);
         hipLaunchKernelGGL(touched_scan_kernel, dim3(nb), dim3(256), 0, st, p.g.tiles_touched, nv, sc.block_sums, sc.slot_base);
         hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_work, V * p.T, p.im.tile_order);
-        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_kernel<false, true>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((blend_backward_kernel<true, true>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
+        launch_blend_backward<true>(p, V, st);
         if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
         const dim3 gridPV((unsigned)((P + 255) / 256), (unsigned)V);
         if (p.T <= 4096) hipLaunchKernelGGL((gather_partials_kernel<true>), gridPV, dim3(256), (size_t)p.T * 8, st, p);
@@ -713,22 +1014,11 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
         if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
         return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
     }
-    // The four tensors the blend kernel accumulates into start from zero (the reference's torch::zeros, rasterize_points.cu:148-156);
-    // everything else is written in full by preprocess_backward_kernel.  A caller that lays the four out back to back
-    // (dgs_amd/raster.py does) gets ONE fill instead of four.
-    if (p.dL_dconic == p.dL_dmean2D + nv * 3 && p.dL_dcolors == p.dL_dconic + nv * 4 && p.dL_dopacity == p.dL_dcolors + ncol) {
-        hipMemsetAsync(p.dL_dmean2D, 0, (nv * 7 + ncol + ns) * sizeof(float), st);
-    } else {
-        hipMemsetAsync(p.dL_dmean2D, 0, nv * 3 * sizeof(float), st);
-        hipMemsetAsync(p.dL_dconic, 0, nv * 4 * sizeof(float), st);
-        hipMemsetAsync(p.dL_dcolors, 0, ncol * sizeof(float), st);
-        hipMemsetAsync(p.dL_dopacity, 0, ns * sizeof(float), st);
-    }
+    // The gradient records the blend kernel adds into start from zero (the reference's torch::zeros of its four accumulators,
+    // rasterize_points.cu:148-156); the tensors of the interface are written in full by preprocess_backward_kernel.
+    if (hipMemsetAsync(p.g.grad_acc, 0, nv * 16 * sizeof(float), st) != hipSuccess) return DGS_ERR_DEVICE;
     if (a->num_rendered != 0) hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_work, V * p.T, p.im.tile_order);
-    if (a->num_rendered != 0) {
-        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_kernel<false, false>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((blend_backward_kernel<true, false>), dim3((unsigned)(V * p.T)), dim3(256), 0, st, p);
-    }
+    if (a->num_rendered != 0) launch_blend_backward<false>(p, V, st);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;

@@ -17,6 +17,14 @@ constexpr bool kRasterStats = true;
 constexpr bool kRasterStats = false;
 #endif
 
+// Ablation switches of the backward blend kernels, tools' library only (DGS_RASTER_BWD_ABLATE, a bit set; results are WRONG by design):
+// 1 no global atomics / slot stores, 2 no LDS adds, 4 no walk at all, 16 no cross-lane reduction.  What a part costs = time with - time without.
+#if defined(DGS_INSTRUMENT)
+constexpr bool kRasterAblate = true;
+#else
+constexpr bool kRasterAblate = false;
+#endif
+
 // auxiliary.h:46-56 (getRect): the tile rectangle [x0, x1) x [y0, y1) of a Gaussian from its pixel position and radius
 __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int* x0, int* y0, int* x1, int* y1) {
     const float r = (float)radius;
@@ -106,6 +114,23 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
     return v;
 #endif
 }
+
+// Sum over each 8-lane group of a wave; the total of a group is valid in its lane 7 only.
+__device__ __forceinline__ float oct_sum_to_lane7(float v) {
+#ifdef HIPEMU
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+#else
+    v += dpp_mov<0x111>(v);   // row_shr:1
+    v += dpp_mov<0x112>(v);   // row_shr:2
+    v += dpp_mov<0x114>(v);   // row_shr:4 (lanes 8..11 of a row pick up the other group's lanes 4..7: never lane 7 or 15)
+    return v;
+#endif
+}
+
+// two fp32 values per lane: arithmetic on them is ONE packed instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, gfx90a+)
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // fp32 add into LDS, no return value (ds_add_f32).
 __device__ __forceinline__ void lds_add(float* addr, float v) {

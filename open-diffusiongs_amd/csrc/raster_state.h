@@ -61,6 +61,8 @@ struct GeomState {                 // arrays indexed [view * P + gaussian]
     uint32_t* radix_base;          // [V][256]
     float* act_scale;              // [V*P*3] activated scale  (raw_activations only; else unused)
     float* act_rot;                // [V*P*4] normalised quaternion
+    float* grad_acc;               // [V*P*16] backward only: the nine sums of the blend backward per (view, Gaussian) in ONE 64-byte line
+                                   //          {colour r g b, mean2D x y, conic xx xy yy, opacity, 7 unused} (raster_backward.hip)
     static GeomState carve(void* buf, size_t P, size_t V, size_t* bytes) {
         Carver c(buf);
         GeomState g;
@@ -78,6 +80,7 @@ struct GeomState {                 // arrays indexed [view * P + gaussian]
         g.radix_base = c.take<uint32_t>(V * 256);
         g.act_scale = c.take<float>(3 * n);
         g.act_rot = c.take<float>(4 * n);
+        g.grad_acc = c.take<float>(16 * n);
         if (bytes) *bytes = c.bytes();
         return g;
     }

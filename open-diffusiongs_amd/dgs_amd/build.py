@@ -21,7 +21,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE,
 STRICT_FP = ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 # DiT attention: fmaxf on MFMA outputs must not be preceded by canonicalising v_max (cdna_hip_programming.md appendix B);
 # masked scores use -inf, so infinities stay honoured.
-FLAGS = {"raster_forward.hip": STRICT_FP, "raster_backward.hip": STRICT_FP, "sampler.hip": STRICT_FP, "loss.hip": STRICT_FP, "dit_attention.hip": ["-fno-honor-nans", "-fno-slp-vectorize"], "dit_attention_backward.hip": ["-fno-slp-vectorize"]}
+# raster_backward.hip: the SLP vectorizer pairs loads of neighbouring struct fields of the staged entry and leaves it in scratch memory
+# (blend_backward_pair_kernel: 3 dwords stored and reloaded per step); the two-pixel arithmetic is written on explicit float pairs
+FLAGS = {"raster_forward.hip": STRICT_FP, "raster_backward.hip": STRICT_FP + ["-fno-slp-vectorize"], "sampler.hip": STRICT_FP, "loss.hip": STRICT_FP, "dit_attention.hip": ["-fno-honor-nans", "-fno-slp-vectorize"], "dit_attention_backward.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

@@ -18,6 +18,7 @@ def backward_form(request):
     be = emu_backend()
     old = be.deterministic
     be.deterministic = request.param == "deterministic"
+    be.last_backward_deterministic = None
     yield request.param
     assert be.last_backward_deterministic in (None, request.param == "deterministic")
     be.deterministic = old
@@ -88,3 +89,18 @@ def test_batched_autograd_matches_dropin_binding_with_torch_activations():
     for a, r_, name in zip(leaves, ref_leaves, ("xyz", "features", "scaling", "rotation", "opacity")):
         scale = float(r_.grad.abs().max())
         assert float((a.grad - r_.grad).abs().max()) <= 1e-3 * scale + 1e-9, name
+
+
+@pytest.mark.parametrize("walk", [1, 2])
+def test_both_walks_forced(walk, backward_form):
+    """The library picks the walk of the blend backward by grid size (raster_backward.hip `pair_walk`: one pixel per lane below 3,072
+    workgroups, two from there on; the deterministic form always two) -- the small scenes above only ever reach one of them per form.
+    DGS_RASTER_BWD_WALK forces either; it is read once per process, hence the child."""
+    import os, subprocess, sys
+    if backward_form != "atomic":
+        pytest.skip("the child runs both forms itself")
+    env = dict(os.environ, DGS_RASTER_BWD_WALK=str(walk))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "matches_oracle or long_lists or precomputed"], env=env, capture_output=True, text=True, timeout=1200,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -147,3 +147,15 @@ def test_dropin_binding_autograd_vs_batched_renderer_256():
         num = float((a.grad - b.grad).double().norm())
         den = float(b.grad.double().norm())
         assert num <= 2e-3 * den + 1e-12, (name, num, den)
+
+
+@pytest.mark.parametrize("walk", [1, 2])
+def test_both_walks_forced(walk):
+    """Both walks of the blend backward (one / two pixels per lane; the library picks by grid size, raster_backward.hip `pair_walk`),
+    forced by DGS_RASTER_BWD_WALK in a child process, on the parity cases of this file that finish in seconds."""
+    import os, subprocess, sys
+    env = dict(os.environ, DGS_RASTER_BWD_WALK=str(walk))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "small_scenes or diffusiongs_shaped or bit_reproducible or precomputed_colors"], env=env, capture_output=True,
+                       text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
