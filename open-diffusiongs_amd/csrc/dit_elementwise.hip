@@ -87,40 +87,46 @@ __global__ __launch_bounds__(256) void rowlinear_kernel(RowLinParams p) {
     }
     __syncthreads();
     // kRowLinFeatures output features per workgroup, a wave takes every fourth: the staging of x (and its SiLU) above is paid once
-    // per 32 features instead of once per 4, and two features' weight rows are in flight per wave (the adaLN GEMV of all 24 blocks
-    // streams 310 MB of weights once per forward: 3.0 TB/s with 4 features per workgroup)
+    // per 32 features instead of once per 4.  The adaLN GEMV of all 24 blocks streams 310 MB of weights once per forward, so what
+    // counts is bytes in flight: NF features' weight rows are requested per wave before the first is used (two: 3.6 TB/s; eight,
+    // with one or two input rows: see DESIGN.md section 8).  Per feature the sum runs over k in the same order whatever NF is.
+    constexpr int NF = MR <= 2 ? 8 : 2;
     const int n_end = min(p.N, ((int)blockIdx.x + 1) * kRowLinFeatures);
-    for (int n = blockIdx.x * kRowLinFeatures + wave; n < n_end; n += 8) {
-        const int n2 = n + 4;                                  // the wave's second feature of this pass (if it exists)
-        const bool two = n2 < n_end;
-        float acc[2][MR];
+    for (int n = blockIdx.x * kRowLinFeatures + wave; n < n_end; n += 4 * NF) {
+        float acc[NF][MR];
+        const bf16_t* wr[NF];
 #pragma unroll
-        for (int m = 0; m < MR; ++m) { acc[0][m] = 0.f; acc[1][m] = 0.f; }
-        const bf16_t* wr0 = p.W + (size_t)n * p.K;
-        const bf16_t* wr1 = p.W + (size_t)(two ? n2 : n) * p.K;
+        for (int f = 0; f < NF; ++f) {
+            wr[f] = p.W + (size_t)(n + 4 * f < n_end ? n + 4 * f : n) * p.K;      // a feature past the end re-reads the first (result dropped)
+#pragma unroll
+            for (int m = 0; m < MR; ++m) acc[f][m] = 0.f;
+        }
         for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
-            const uint4 w0 = *reinterpret_cast<const uint4*>(wr0 + k0);
-            const uint4 w1 = *reinterpret_cast<const uint4*>(wr1 + k0);
-            const float wf[2][8] = {{bf2f(w0.x & 0xffffu), bf2f(w0.x >> 16), bf2f(w0.y & 0xffffu), bf2f(w0.y >> 16),
-                                     bf2f(w0.z & 0xffffu), bf2f(w0.z >> 16), bf2f(w0.w & 0xffffu), bf2f(w0.w >> 16)},
-                                    {bf2f(w1.x & 0xffffu), bf2f(w1.x >> 16), bf2f(w1.y & 0xffffu), bf2f(w1.y >> 16),
-                                     bf2f(w1.z & 0xffffu), bf2f(w1.z >> 16), bf2f(w1.w & 0xffffu), bf2f(w1.w >> 16)}};
+            uint4 w[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) w[f] = *reinterpret_cast<const uint4*>(wr[f] + k0);
+            float4 xa[MR], xb[MR];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                const float4 xa = *reinterpret_cast<const float4*>(xs + m * p.K + k0);
-                const float4 xb = *reinterpret_cast<const float4*>(xs + m * p.K + k0 + 4);
+                xa[m] = *reinterpret_cast<const float4*>(xs + m * p.K + k0);
+                xb[m] = *reinterpret_cast<const float4*>(xs + m * p.K + k0 + 4);
+            }
 #pragma unroll
-                for (int f = 0; f < 2; ++f)
-                    acc[f][m] += wf[f][0] * xa.x + wf[f][1] * xa.y + wf[f][2] * xa.z + wf[f][3] * xa.w + wf[f][4] * xb.x + wf[f][5] * xb.y + wf[f][6] * xb.z + wf[f][7] * xb.w;
+            for (int f = 0; f < NF; ++f) {
+                const float wf[8] = {bf2f(w[f].x & 0xffffu), bf2f(w[f].x >> 16), bf2f(w[f].y & 0xffffu), bf2f(w[f].y >> 16),
+                                     bf2f(w[f].z & 0xffffu), bf2f(w[f].z >> 16), bf2f(w[f].w & 0xffffu), bf2f(w[f].w >> 16)};
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+                    acc[f][m] += wf[0] * xa[m].x + wf[1] * xa[m].y + wf[2] * xa[m].z + wf[3] * xa[m].w + wf[4] * xb[m].x + wf[5] * xb[m].y + wf[6] * xb[m].z + wf[7] * xb[m].w;
             }
         }
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const int nf = f ? n2 : n;
+        for (int f = 0; f < NF; ++f) {
+            const int nf = n + 4 * f;
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 float v = wave_sum(acc[f][m]);
-                if (lane == 0 && m < p.M && (f == 0 || two)) {
+                if (lane == 0 && m < p.M && nf < n_end) {
                     if (p.bias) v += p.bias[nf];
                     if (p.silu_out) v = silu(v);
                     p.out[(size_t)m * p.N + nf] = v;
