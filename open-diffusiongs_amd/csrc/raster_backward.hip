@@ -946,12 +946,14 @@ static bool pair_walk(int workgroups) {
 template <bool DET>
 static void launch_blend_backward(const BwdParams& p, int V, hipStream_t st) {
     const dim3 grid((unsigned)(V * p.T));
+    size_t pad = 0;                // tools' library: DGS_RASTER_BWD_LDS_PAD = bytes of unused LDS per workgroup (fewer workgroups per CU)
+    if constexpr (kRasterAblate) { static const int e = [] { const char* v = getenv("DGS_RASTER_BWD_LDS_PAD"); return v ? atoi(v) : 0; }(); pad = (size_t)e; }
     if (pair_walk<DET>(V * p.T)) {
-        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_pair_kernel<false, DET>), grid, dim3(128), 0, st, p);
-        else hipLaunchKernelGGL((blend_backward_pair_kernel<true, DET>), grid, dim3(128), 0, st, p);
+        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_pair_kernel<false, DET>), grid, dim3(128), pad, st, p);
+        else hipLaunchKernelGGL((blend_backward_pair_kernel<true, DET>), grid, dim3(128), pad, st, p);
     } else {
-        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_kernel<false, DET>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((blend_backward_kernel<true, DET>), grid, dim3(256), 0, st, p);
+        if (p.exact_exp) hipLaunchKernelGGL((blend_backward_kernel<false, DET>), grid, dim3(256), pad, st, p);
+        else hipLaunchKernelGGL((blend_backward_kernel<true, DET>), grid, dim3(256), pad, st, p);
     }
 }
 

@@ -1145,11 +1145,15 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
                            : (1 << kFormRankSort) | (1 << kFormScan) | (1 << kFormBitonic);
     }
 
+    // tools' library: DGS_RASTER_FWD_LDS_PAD = bytes of unused LDS per blend workgroup (fewer of them per CU: is the walk bound by
+    // throughput or by the number of waves?  raster_common.h kRasterAblate)
+    size_t blend_pad = 0;
+    if constexpr (kRasterAblate) { static const int pad = [] { const char* e = getenv("DGS_RASTER_FWD_LDS_PAD"); return e ? atoi(e) : 0; }(); blend_pad = (size_t)pad; }
     if ((forms & ((1 << kFormRankSort) | (1 << kFormScan))) && !radix_done) radix_sort();
     if (forms & (1 << kFormScan)) {
         hipLaunchKernelGGL(rank_rects_kernel, gridP, dim3(256), 0, st, p);
-        if (p.exact_exp) hipLaunchKernelGGL((blend_forward_kernel<true, false>), dim3(VT), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((blend_forward_kernel<true, true>), dim3(VT), dim3(256), 0, st, p);
+        if (p.exact_exp) hipLaunchKernelGGL((blend_forward_kernel<true, false>), dim3(VT), dim3(256), blend_pad, st, p);
+        else hipLaunchKernelGGL((blend_forward_kernel<true, true>), dim3(VT), dim3(256), blend_pad, st, p);
     }
     if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) {
         if (lds_tiles) hipLaunchKernelGGL((emit_instances_kernel<true>), gridP, dim3(256), (size_t)p.T * 8, st, p);
@@ -1165,8 +1169,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(VT), dim3(256), lds, st, p);
     }
     if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) {
-        if (p.exact_exp) hipLaunchKernelGGL((blend_forward_kernel<false, false>), dim3(VT), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((blend_forward_kernel<false, true>), dim3(VT), dim3(256), 0, st, p);
+        if (p.exact_exp) hipLaunchKernelGGL((blend_forward_kernel<false, false>), dim3(VT), dim3(256), blend_pad, st, p);
+        else hipLaunchKernelGGL((blend_forward_kernel<false, true>), dim3(VT), dim3(256), blend_pad, st, p);
     }
     return check(st, a->debug);
 }
