@@ -139,10 +139,10 @@ typedef struct DgsRasterBackwardArgs {
     const void* geom_buffer;
     const void* binning_buffer;
     const void* img_buffer;
-    /* gradient outputs: the callee zero-fills what it accumulates into and WRITES every other element (the caller need not
-     * pre-fill anything; the reference's torch::zeros, rasterize_points.cu:148-156).  dL_dmeans2D, dL_dconic, dL_dcolors and
-     * dL_dopacity laid out back to back in that order are zeroed with one fill.
-     * With V > 1 gradients of the views of one set are SUMMED into that set's slot.   */
+    /* gradient outputs: every element is WRITTEN by the call (the caller need not pre-fill anything; the reference's torch::zeros,
+     * rasterize_points.cu:148-156).  What the blend backward accumulates lives in the geometry buffer (a 64-byte record per
+     * (view, Gaussian), zero-filled by the call); the per-view tensors below are written from it.
+     * With V > 1 gradients of the views of one set are SUMMED into that set's slot, in view order.   */
     float* dL_dmeans2D;   /* [V,P,3]  (per view, like the reference's per-call tensor)   */
     float* dL_dconic;     /* [V,P,4]  scratch ([P,2,2] in the reference), never returned to Python */
     float* dL_dcolors;    /* SH given: [V,P,3] per-view scratch (consumed by the SH backward); colours precomputed: [S,P,3],
@@ -154,11 +154,12 @@ typedef struct DgsRasterBackwardArgs {
     float* dL_dscales;    /* [S,P,3]  or NULL */
     float* dL_drotations; /* [S,P,4]  or NULL */
     int32_t exact_exp;    /* as DgsRasterForwardArgs.exact_exp: must equal the forward's */
-    /* Deterministic form (the product's default; dgs_amd/raster.py): `scratch` = dgs_raster_backward_scratch_bytes(...) bytes of device
+    /* Deterministic form (opt-in: dgs_amd/raster.py `deterministic`): `scratch` = dgs_raster_backward_scratch_bytes(...) bytes of device
      * memory (contents irrelevant, nothing is read before it is written).  Every (tile, Gaussian) instance then has a slot of its
      * own, a tile STORES its sums there and a gather adds a Gaussian's slots in a fixed order: no floating-point atomic anywhere,
      * the same bits on every run.  NULL: the sums of a Gaussian's tiles meet in fp32 atomics (the reference's way, backward.cu:
-     * 10 atomicAdd per pair; here one per tile and value) -- run-to-run differences of the order of 1e-7 relative.            */
+     * 10 atomicAdd per pair; here one instruction per (tile, Gaussian) into the record) -- run-to-run differences of the order of
+     * 1e-7 relative.                                                                                                            */
     void* scratch;
     size_t scratch_bytes;
 } DgsRasterBackwardArgs;

@@ -6,14 +6,16 @@
 //   reference (CUDA)                                         this file
 //   -------------------------------------------------------  ---------------------------------------------------------
 //   renderCUDA backward  backward.cu:399-557                 blend_backward_kernel: same back-to-front replay per 16x16
-//     9-10 global atomicAdd per contributing (pixel,           tile; the nine per-Gaussian sums are reduced across the 64
-//     Gaussian) pair                                           lanes of a wave (DPP adds), across the tile's four waves in
-//                                                              LDS, and leave as ONE atomic per value per (tile, Gaussian)
-//                                                              instead of <= 256; 16x4 strips the Gaussian's ellipse cannot
-//                                                              reach are skipped on a scalar bit test; the replay starts at
-//                                                              the tile's deepest contributor
-//                                                            DETERMINISTIC form (DgsRasterBackwardArgs.scratch, the product's
-//                                                              default): no atomic at all.  A (tile, Gaussian) instance has a slot
+//     9-10 global atomicAdd per contributing (pixel,           tile on the forward's 4 x 4 cells and per-cell lists; the nine
+//     Gaussian) pair                                           per-Gaussian sums are reduced across a cell's 16 lanes (DPP
+//                                                              adds), across the tile's cells in LDS, and leave as ONE atomic
+//                                                              INSTRUCTION per (tile, Gaussian) into the Gaussian's 64-byte
+//                                                              gradient record (lane z adds value z: one L2 request) instead
+//                                                              of <= 256 x 9; the replay starts at the tile's deepest
+//                                                              contributor.  blend_backward_pair_kernel: the same with two
+//                                                              pixels per lane (packed fp32), for grids of >= 3,072 tiles
+//                                                            DETERMINISTIC form (DgsRasterBackwardArgs.scratch, opt-in):
+//                                                              no atomic at all.  A (tile, Gaussian) instance has a slot
 //                                                              of its own, Gaussian-major -- slot = (exclusive scan of
 //                                                              tiles_touched)[Gaussian] + index of the tile in the Gaussian's
 //                                                              rectangle --, the tile STORES its nine sums there, and
