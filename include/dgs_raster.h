@@ -198,7 +198,9 @@ int dgs_rays_from_c2w(int32_t n, const float* c2w, const float* fxfycxcy, int32_
 /* Introspection for the parity tests: copies a named array of the forward state out of the
  * opaque buffers into `dst` (device pointer, `dst_bytes` capacity).  Names: "depths", "means2D",
  * "conic_opacity", "rgb", "tiles_touched", "clamped", "cov3D", "ranges", "n_contrib", "final_T",
- * "point_list", "list_len", "tile_work", "tile_scanned" (and "tile_stats", "tile_stats_bwd": zero in the product library).  Returns the number of bytes written or a negative DgsStatus.            */
+ * "point_list", "list_len", "tile_work", "tile_scanned" (and "tile_stats", "tile_stats_bwd": zero in the product library).
+ * "cov3D" is kept only by a forward with `debug` set (nothing on the product path reads it: the backward recomputes it).
+ * Returns the number of bytes written or a negative DgsStatus.            */
 int64_t dgs_raster_state_read(const char* name, int32_t P, int32_t width, int32_t height, int32_t V,
                               int64_t num_rendered, const void* geom_buffer, const void* binning_buffer,
                               const void* img_buffer, void* dst, int64_t dst_bytes, dgs_stream_t stream);

@@ -759,6 +759,14 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
     const int nsh = p.shs ? 3 * p.M : 0;
     for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
     const int v0 = s * p.vps, v1 = min(p.V, v0 + p.vps);
+    // the 3D covariance does not depend on the view: once per Gaussian, from the inputs (the forward's instruction sequence, raster_common.h)
+    float c6[6];
+    if (p.cov_pre) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = p.cov_pre[6 * si + k];
+    } else {
+        cov3d_from_scale_rot(p.scales + 3 * si, p.rots + 4 * si, p.raw_act != 0, p.scale_mod, c6);
+    }
     // The blend kernel's nine sums per (view, Gaussian) arrive as one 64-byte record (GeomState::grad_acc: accumulated by atomics, or
     // written by gather_partials_kernel); the per-view rows the reference returns (dL_dmeans2D, dL_dconic, dL_dcolors) are written from it
     // here -- every element, nothing is pre-filled -- and the per-set sums (opacity; colours when they are per set) are added over the
@@ -789,14 +797,6 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
         if (p.tanfov) { tanx = p.tanfov[2 * v]; tany = p.tanfov[2 * v + 1]; } else { tanx = p.tanfovx; tany = p.tanfovy; }
         const float focal_y = p.H / (2.0f * tany), focal_x = p.W / (2.0f * tanx);
         // ---- computeCov2DCUDA, backward.cu:144-274 ----
-        float c6[6];
-        if (p.cov_pre) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) c6[k] = p.cov_pre[6 * si + k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) c6[k] = p.g.cov3D[6 * gi + k];
-        }
         float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
         float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
         const float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];

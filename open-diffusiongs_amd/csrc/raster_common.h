@@ -62,6 +62,30 @@ __device__ __forceinline__ M3 m3_t(const M3& A) {
 }
 
 
+// computeCov3D, forward.cu:118-152, with the activations of gs_core.py:330-334 fused when `raw_act` (exp of the scales, F.normalize of
+// the quaternion).  Called by the forward's preprocess and -- once per (set, Gaussian), the covariance does not depend on the view -- by
+// preprocess_backward_kernel: the same instruction sequence (the files are built without contraction), so the backward sees the
+// forward's bits without a 24-byte copy per (view, Gaussian) going through memory.
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* scales3, const float* rot4, bool raw_act, float scale_mod, float* c6) {
+    float sx = scales3[0], sy = scales3[1], sz = scales3[2];
+    float qr = rot4[0], qx = rot4[1], qy = rot4[2], qz = rot4[3];
+    if (raw_act) {
+        sx = det_expf(sx); sy = det_expf(sy); sz = det_expf(sz);
+        const float nrm = fmaxf(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
+        qr = qr / nrm; qx = qx / nrm; qy = qy / nrm; qz = qz / nrm;
+    }
+    M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    S.c[0][0] = scale_mod * sx; S.c[1][1] = scale_mod * sy; S.c[2][2] = scale_mod * sz;
+    const float r = qr, x = qx, y = qy, z = qz;
+    const M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                         2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                         2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    const M3 Mm = m3_mul(S, R);
+    const M3 Sig = m3_mul(m3_t(Mm), Mm);
+    c6[0] = Sig.c[0][0]; c6[1] = Sig.c[0][1]; c6[2] = Sig.c[0][2];
+    c6[3] = Sig.c[1][1]; c6[4] = Sig.c[1][2]; c6[5] = Sig.c[2][2];
+}
+
 // Which of a tile's sixteen 4 x 4 pixel cells can a Gaussian touch at all?
 // A (pixel, Gaussian) pair contributes only if cut <= power <= 0 with power = -0.5 (A dx^2 + C dy^2) - B dx dy, i.e. inside
 // the ellipse A dx^2 + 2 B dx dy + C dy^2 <= -2 cut, whose bounding box has half extents sqrt(q C / det), sqrt(q A / det).

@@ -33,6 +33,7 @@ struct FwdParams {
                              // bitmap sort, 2 per-tile scan, 3 instance list + per-tile bitonic sort in LDS
     int bitonic_cap;         // longest tile list the bitonic form is launched for (LDS entries), 0: form not available
     int exact_exp;           // blend exponential: 0 hardware v_exp_f32 (default), 1 det_expf (bit-identical floats with the oracle)
+    int debug;               // DgsRasterForwardArgs.debug: also keeps the per-view cov3D copy in the state (inspection)
     int* radii;
     float* out_color;
     GeomState g;
@@ -112,27 +113,13 @@ __device__ __forceinline__ bool preprocess_one(const FwdParams& p, int v, int id
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = p.cov_pre[6 * si + k];
     } else {
-        float sx = p.scales[3 * si], sy = p.scales[3 * si + 1], sz = p.scales[3 * si + 2];
-        float qr = p.rots[4 * si], qx = p.rots[4 * si + 1], qy = p.rots[4 * si + 2], qz = p.rots[4 * si + 3];
-        if (p.raw_act) {   // gs_core.py:330-334 fused: exp / F.normalize
-            sx = det_expf(sx); sy = det_expf(sy); sz = det_expf(sz);
-            const float nrm = fmaxf(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
-            qr = qr / nrm; qx = qx / nrm; qy = qy / nrm; qz = qz / nrm;
-            p.g.act_scale[3 * gi] = sx; p.g.act_scale[3 * gi + 1] = sy; p.g.act_scale[3 * gi + 2] = sz;
-            p.g.act_rot[4 * gi] = qr; p.g.act_rot[4 * gi + 1] = qx; p.g.act_rot[4 * gi + 2] = qy; p.g.act_rot[4 * gi + 3] = qz;
-        }
-        M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
-        S.c[0][0] = p.scale_mod * sx; S.c[1][1] = p.scale_mod * sy; S.c[2][2] = p.scale_mod * sz;
-        const float r = qr, x = qx, y = qy, z = qz;
-        const M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-                             2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-                             2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
-        const M3 Mm = m3_mul(S, R);
-        const M3 Sig = m3_mul(m3_t(Mm), Mm);
-        c6[0] = Sig.c[0][0]; c6[1] = Sig.c[0][1]; c6[2] = Sig.c[0][2];
-        c6[3] = Sig.c[1][1]; c6[4] = Sig.c[1][2]; c6[5] = Sig.c[2][2];
+        cov3d_from_scale_rot(p.scales + 3 * si, p.rots + 4 * si, p.raw_act != 0, p.scale_mod, c6);
+        // the state copy is for inspection only (dgs_raster_state_read "cov3D": the parity tests, which run with `debug`); the backward
+        // recomputes the covariance once per Gaussian
+        if (p.debug) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p.g.cov3D[6 * gi + k] = c6[k];
+            for (int k = 0; k < 6; ++k) p.g.cov3D[6 * gi + k] = c6[k];
+        }
     }
     // ---- computeCov2D (forward.cu:74-113) ----
     const float limx = 1.3f * tanx, limy = 1.3f * tany;
@@ -1044,6 +1031,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     p.campos = a->campos; p.tanfov = a->tanfov; p.tanfovx = a->tanfovx; p.tanfovy = a->tanfovy; p.scale_mod = a->scale_modifier;
     p.prefiltered = a->prefiltered; p.raw_act = a->raw_activations; p.radii = a->radii; p.out_color = a->out_color;
     p.exact_exp = a->exact_exp ? 1 : 0;
+    p.debug = a->debug ? 1 : 0;
 
     size_t gbytes, ibytes;
     GeomState::carve(nullptr, (size_t)P, (size_t)V, &gbytes);

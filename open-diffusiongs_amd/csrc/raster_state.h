@@ -50,7 +50,7 @@ struct GeomState {                 // arrays indexed [view * P + gaussian]
     float* depths;                 // p_view.z
     float2* means2D;               // pixel coordinates
     BlendRecord* blend;            // conic + opacity, colour + cut-off, pixel coordinates
-    float* cov3D;                  // 6 per Gaussian
+    float* cov3D;                  // 6 per Gaussian: written only by a `debug` forward (inspection); nothing reads it
     uint8_t* clamped;              // bit c set: colour channel c was clamped at 0
     int32_t* internal_radii;
     uint32_t* tiles_touched;
@@ -59,8 +59,6 @@ struct GeomState {                 // arrays indexed [view * P + gaussian]
     uint32_t* rank_of;             // position of the Gaussian in its view's depth order
     uint32_t* radix_hist;          // [V][blocks][256]
     uint32_t* radix_base;          // [V][256]
-    float* act_scale;              // [V*P*3] activated scale  (raw_activations only; else unused)
-    float* act_rot;                // [V*P*4] normalised quaternion
     float* grad_acc;               // [V*P*16] backward only: the nine sums of the blend backward per (view, Gaussian) in ONE 64-byte line
                                    //          {colour r g b, mean2D x y, conic xx xy yy, opacity, 7 unused} (raster_backward.hip)
     static GeomState carve(void* buf, size_t P, size_t V, size_t* bytes) {
@@ -78,8 +76,6 @@ struct GeomState {                 // arrays indexed [view * P + gaussian]
         g.rank_of = c.take<uint32_t>(n);
         g.radix_hist = c.take<uint32_t>(V * (size_t)sort_blocks((int)P) * 256);
         g.radix_base = c.take<uint32_t>(V * 256);
-        g.act_scale = c.take<float>(3 * n);
-        g.act_rot = c.take<float>(4 * n);
         g.grad_acc = c.take<float>(16 * n);
         if (bytes) *bytes = c.bytes();
         return g;
