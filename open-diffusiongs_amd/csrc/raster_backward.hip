@@ -748,6 +748,10 @@ __global__ __launch_bounds__(256) void gather_partials_kernel(BwdParams p) {
 }
 
 // grid ceil(S*P / 256).  One thread per (set, Gaussian); loops over the views of the set.
+// MAXM: SH coefficients the per-thread gradient array is sized for.  DiffusionGS trains degree 0 (one coefficient: `gaussians_sh_degree 0`,
+// denoiser.py:96): with the 48-float array of degree 3 the kernel needs 213 registers -- two waves per SIMD on a kernel that is a chain
+// of memory round trips; sized for what the call has it runs at twice the occupancy.
+template <int MAXM>
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, int S) {
     const size_t si = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (si >= (size_t)S * p.P) return;
@@ -755,9 +759,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
     const float mx = p.means3D[3 * si], my = p.means3D[3 * si + 1], mz = p.means3D[3 * si + 2];
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov_sum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float dsh[48];
+    float dsh[3 * MAXM];
     const int nsh = p.shs ? 3 * p.M : 0;
-    for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3 * MAXM; ++k) dsh[k] = 0.f;
     const int v0 = s * p.vps, v1 = min(p.V, v0 + p.vps);
     // the 3D covariance does not depend on the view: once per Gaussian, from the inputs (the forward's instruction sequence, raster_common.h)
     float c6[6];
@@ -864,13 +869,16 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(BwdParams p, i
             const unsigned cb = p.g.clamped[gi];
             const float dRGB[3] = {(cb & 1u) ? 0.f : r0.x, (cb & 2u) ? 0.f : r0.y, (cb & 4u) ? 0.f : r0.z};
             const float* cam = p.campos + 3 * v;
-            sh_backward(p.D, p.shs + 3 * (size_t)p.M * si, mx - cam[0], my - cam[1], mz - cam[2], dRGB, dsh, dmv);
+            sh_backward(MAXM == 1 ? 0 : p.D, p.shs + 3 * (size_t)p.M * si, mx - cam[0], my - cam[1], mz - cam[2], dRGB, dsh, dmv);
         }
         dmean[0] += dmv[0]; dmean[1] += dmv[1]; dmean[2] += dmv[2];
     }
     p.dL_dmeans3D[3 * si] = dmean[0]; p.dL_dmeans3D[3 * si + 1] = dmean[1]; p.dL_dmeans3D[3 * si + 2] = dmean[2];
-    if (p.dL_dsh)
-        for (int k = 0; k < nsh; ++k) p.dL_dsh[(size_t)nsh * si + k] = dsh[k];
+    if (p.dL_dsh) {
+#pragma unroll
+        for (int k = 0; k < 3 * MAXM; ++k)
+            if (k < nsh) p.dL_dsh[(size_t)nsh * si + k] = dsh[k];
+    }
     if (p.colors_pre) { p.dL_dcolors[3 * si] = col_sum[0]; p.dL_dcolors[3 * si + 1] = col_sum[1]; p.dL_dcolors[3 * si + 2] = col_sum[2]; }
     if (p.raw_act) {   // d sigmoid, gs_core.py:334
         const float op = 1.0f / (1.0f + det_expf(-p.opac[si]));
@@ -959,6 +967,13 @@ static void launch_blend_backward(const BwdParams& p, int V, hipStream_t st) {
     }
 }
 
+static void launch_preprocess_backward(const BwdParams& p, int S, size_t ns, hipStream_t st) {
+    const dim3 grid((unsigned)((ns + 255) / 256));
+    // one coefficient (degree 0, or precomputed colours: no SH at all) / up to 16
+    if (!p.shs || (p.M == 1 && p.D == 0)) hipLaunchKernelGGL(preprocess_backward_kernel<1>, grid, dim3(256), 0, st, p, S);
+    else hipLaunchKernelGGL(preprocess_backward_kernel<16>, grid, dim3(256), 0, st, p, S);
+}
+
 }  // namespace dgs
 
 using namespace dgs;
@@ -1014,7 +1029,7 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
         const dim3 gridPV((unsigned)((P + 255) / 256), (unsigned)V);
         if (p.T <= 4096) hipLaunchKernelGGL((gather_partials_kernel<true>), gridPV, dim3(256), (size_t)p.T * 8, st, p);
         else hipLaunchKernelGGL((gather_partials_kernel<false>), gridPV, dim3(256), 0, st, p);
-        hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
+        launch_preprocess_backward(p, S, ns, st);
         if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
         return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
     }
@@ -1024,7 +1039,7 @@ extern "C" int dgs_raster_backward(const DgsRasterBackwardArgs* a, dgs_stream_t 
     if (a->num_rendered != 0) hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_work, V * p.T, p.im.tile_order);
     if (a->num_rendered != 0) launch_blend_backward<false>(p, V, st);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, p, S);
+    launch_preprocess_backward(p, S, ns, st);
     if (a->debug && hipStreamSynchronize(st) != hipSuccess) return DGS_ERR_DEVICE;
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }
