@@ -427,14 +427,16 @@ __global__ __launch_bounds__(256) void emit_instances_kernel(FwdParams p) {
         __syncthreads();
         for (int i = threadIdx.x; i < p.T; i += 256) {
             const uint32_t c = lcnt[i];
-            if (c) { lbase[i] = atomicAdd(&cursor[i], c); lcnt[i] = 0; }
+            // the tile's first slot rides along with the cursor's round trip (as a load of its own in the loop below it was one more
+            // dependent trip per instance: the kernel is a chain of them, 0.82 of its wave cycles parked -- profiles/r04_raster_sq_pmc.txt)
+            if (c) { lbase[i] = ranges[i].x + atomicAdd(&cursor[i], c); lcnt[i] = 0; }
         }
         __syncthreads();
         if (vis)
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x) {
                     const int t = y * p.gx + x;
-                    const uint32_t slot = ranges[t].x + lbase[t] + atomicAdd(&lcnt[t], 1u);
+                    const uint32_t slot = lbase[t] + atomicAdd(&lcnt[t], 1u);
                     if (wide) p.bn.inst_key[slot] = key; else p.bn.inst_rank[slot] = rank;
                 }
     } else if (vis) {
