@@ -595,11 +595,25 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
     const uint64_t* src = p.bn.inst_key + rg.x;
+    // The tile's keys, ONCE, into registers: thread t holds keys t, t + NT, ... (at most KPT = the launch's LDS capacity / NT; all
+    // loads in flight together).  The three passes below (range, histogram, scatter) each used to walk `src` with the next load
+    // behind the use of the previous one -- ~12 dependent L2 round trips per pass for a 3,000-entry list, 0.67 of the kernel's wave
+    // cycles parked (profiles/r04_raster_sq_pmc.txt).
+    constexpr int KPT = NT == 256 ? 32 : 16;                   // 8,192 / 256 (tile_bitonic_kernel<256> is launched up to that capacity), 16,384 / 1,024
+    uint64_t kreg[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)u * NT;
+        kreg[u] = i < n ? src[i] : ~0ull;
+    }
     // 1. range of the depth bits
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    for (uint32_t i = tid; i < n; i += NT) {
-        const uint32_t d = (uint32_t)(src[i] >> 32);
-        lo = min(lo, d); hi = max(hi, d);
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        if ((uint32_t)tid + (uint32_t)u * NT < n) {
+            const uint32_t d = (uint32_t)(kreg[u] >> 32);
+            lo = min(lo, d); hi = max(hi, d);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
@@ -614,7 +628,9 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
     const float scale = (float)B / ((float)(hi - lo) + 1.0f);
     auto bucket = [&](uint32_t d) { return min((uint32_t)((float)(d - lo) * scale), B - 1u); };
     // 2. histogram
-    for (uint32_t i = tid; i < n; i += NT) atomicAdd(&cnt[bucket((uint32_t)(src[i] >> 32))], 1u);
+#pragma unroll
+    for (int u = 0; u < KPT; ++u)
+        if ((uint32_t)tid + (uint32_t)u * NT < n) atomicAdd(&cnt[bucket((uint32_t)(kreg[u] >> 32))], 1u);
     __syncthreads();
     // 3. exclusive scan of the counts (kBuckets / NT consecutive buckets per thread; buckets >= B are empty) and the largest bucket
     const uint32_t per = kBuckets / NT;
@@ -630,10 +646,9 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
 #pragma unroll
     for (int w = 0; w < NWV; ++w) big = max(big, s_red[2][w]);
     // 4. scatter into the buckets (cnt[] keeps the bucket starts, cur[] are the cursors)
-    for (uint32_t i = tid; i < n; i += NT) {
-        const uint64_t k = src[i];
-        keys[atomicAdd(&cur[bucket((uint32_t)(k >> 32))], 1u)] = k;
-    }
+#pragma unroll
+    for (int u = 0; u < KPT; ++u)
+        if ((uint32_t)tid + (uint32_t)u * NT < n) keys[atomicAdd(&cur[bucket((uint32_t)(kreg[u] >> 32))], 1u)] = kreg[u];
     __syncthreads();
     if (big <= (uint32_t)kBucketLimit) {
         // 5. one thread per bucket: insertion sort on the full keys (cur[b] is now the bucket's end)
