@@ -530,10 +530,11 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(FwdParams p, int wwords)
 // tile's list, no global sort at all, and the keys' order IS the reference's (tile, depth bits, Gaussian index):
 //   1. min / max of the tile's depth bits;  2. histogram over B ~ n / 4 buckets under the monotone map
 //   b = floor((bits - min) * B / (max - min + 1)) (LDS atomics);  3. exclusive scan -> bucket starts;  4. keys scattered into
-//   their buckets in LDS (arrival order inside a bucket is arbitrary);  5. every bucket -- ~4 keys -- finished by ONE thread
-//   with an insertion sort on the full 64-bit keys.  The map is monotone, so bucket order + in-bucket order is the total order;
-//   the keys of a tile are distinct, so the result does not depend on the order atomics happened to arrive in.
-// A tile whose depths pile up (a bucket above kBucketLimit keys: insertion sort is quadratic) takes the bitonic network over
+//   their buckets in LDS (arrival order inside a bucket is arbitrary);  5. every KEY finds its place inside its bucket -- ~4 keys --
+//   by counting the bucket's smaller keys (full 64-bit compare) and leaves for the tile's list from there.  The map is monotone, so
+//   bucket order + in-bucket order is the total order; the keys of a tile are distinct, so the result does not depend on the order
+//   atomics happened to arrive in.
+// A tile whose depths pile up (a bucket above kBucketLimit keys: the counting is quadratic) takes the bitonic network over
 // the whole list instead -- O(n log^2 n), data-independent.  (The network alone was measured first: 0.34 ms per 4 views at
 // 256^2 and 3.7 ms at 512^2, where 8 k-key tiles need 91 LDS round trips each.)
 constexpr int kBuckets = 2048, kBucketLimit = 40;
@@ -651,17 +652,21 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
         if ((uint32_t)tid + (uint32_t)u * NT < n) keys[atomicAdd(&cur[bucket((uint32_t)(kreg[u] >> 32))], 1u)] = kreg[u];
     __syncthreads();
     if (big <= (uint32_t)kBucketLimit) {
-        // 5. one thread per bucket: insertion sort on the full keys (cur[b] is now the bucket's end)
-        for (uint32_t b = tid; b < B; b += NT) {
+        // 5. one thread per KEY: its place inside its bucket is the number of smaller keys there (keys are distinct), and the tile's
+        //    list leaves from here.  (One thread per BUCKET running an insertion sort left the workgroup waiting for the thread with the
+        //    largest bucket -- a chain of ~s^2 / 2 dependent LDS round trips for s keys, s up to 19 in the trained-like regime -- and
+        //    needed one more pass to write the list out.)  cur[b] is the bucket's end by now.
+        for (uint32_t i = tid; i < n; i += NT) {
+            const uint64_t k = keys[i];
+            const uint32_t b = bucket((uint32_t)(k >> 32));
             const uint32_t s0 = cnt[b], e0 = cur[b];
-            for (uint32_t i = s0 + 1; i < e0; ++i) {
-                const uint64_t x = keys[i];
-                uint32_t j = i;
-                while (j > s0 && keys[j - 1] > x) { keys[j] = keys[j - 1]; --j; }
-                keys[j] = x;
-            }
+            uint32_t below = 0;
+            for (uint32_t j = s0; j < e0; ++j) below += keys[j] < k ? 1u : 0u;
+            p.bn.point_list[rg.x + s0 + below] = (uint32_t)k;
         }
-    } else {
+        return;
+    }
+    {
         uint32_t m = 8 * NT;
         while (m < n) m <<= 1;                                 // <= bitonic_cap (the host sized the LDS for it)
         for (uint32_t i = n + tid; i < m; i += NT) keys[i] = ~0ull;
