@@ -156,16 +156,6 @@ __device__ __forceinline__ float oct_sum_to_lane7(float v) {
 // two fp32 values per lane: arithmetic on them is ONE packed instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, gfx90a+)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Workgroup barrier that orders LDS traffic only: vector-memory loads stay in flight across it (__syncthreads() drains them).
-__device__ __forceinline__ void lds_barrier() {
-#ifdef HIPEMU
-    __syncthreads();
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#endif
-}
-
 // fp32 add into LDS, no return value (ds_add_f32).
 __device__ __forceinline__ void lds_add(float* addr, float v) {
 #ifdef HIPEMU

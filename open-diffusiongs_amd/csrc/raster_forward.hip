@@ -810,7 +810,6 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     __shared__ uint4 s_cnt[16];                           // [cell] entries of the batch the cell keeps, per staging wave
     __shared__ uint8_t s_list[17][256];                   // [cell] their batch indices, front to back (+ one row: the walk reads a group ahead)
     __shared__ uint32_t s_walk[4];
-    __shared__ uint32_t s_live[4];
     __shared__ uint2 s_stat[kRasterStats ? 4 : 1];
     __shared__ uint32_t s_ring[SCAN ? kRing : 1];         // scan form: list entries found, not yet staged
     __shared__ uint32_t s_scan[4];
@@ -838,38 +837,8 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
     uint32_t st_entries = 0, st_trips = 0, st_batches = 0;      // tile_stats (measurement): per lane its cell's entries, per wave its loop trips
-    // List form: the records of batch i + 1 are requested BEFORE batch i is compacted and walked and are held in registers meanwhile
-    // (the gather is a memory round trip per batch, ~12 batches a tile in the trained-like regime; the kernel's waves were parked for
-    // 0.45 of their cycles, profiles/r04_raster_sq_pmc.txt).  Hence barriers that order LDS only inside the loop: __syncthreads()
-    // would wait for the loads in flight.  A slot without an entry holds a finite record: the walk reads ahead of its lists (stale
-    // indices), and the product-default arithmetic multiplies a masked-out lane's colour by a zero weight instead of selecting --
-    // 0 * NaN from LDS left by an earlier kernel would poison the pixel.
-    // The requests carry no branch and no select on their results (a zero record selected at the request made hipcc wait for the
-    // loads there): a position behind the list's end is clamped to its last entry, and whether the slot holds an entry is decided
-    // when the record is stored to LDS.  The index of an entry is requested one batch ahead of its record (the record's address
-    // depends on it).
-    struct Staged { float2 xy; float4 co; float4 rc; };
-    auto entry_at = [&](int i) { return p.bn.point_list[min(rg.x + (uint32_t)i * 256u + (uint32_t)tid, rg.y - 1u)]; };   // rounds > 0: rg.y > rg.x
-    auto record_of = [&](uint32_t id, Staged& st) {
-        const BlendRecord* rec = p.g.blend + vo + id;              // one line per entry (raster_state.h)
-        st.co = rec->co; st.rc = rec->rc; st.xy = rec->xy;
-    };
-    Staged nxt;
-    uint32_t id_nxt = 0;
-    if (!SCAN && rounds > 0) {
-        const uint32_t id0 = entry_at(0);
-        id_nxt = entry_at(1);
-        record_of(id0, nxt);
-    }
     for (int i = 0; i < rounds; ++i) {
-        if (SCAN) {
-            if (__syncthreads_count(done) == 256) break;
-        } else {
-            const bool live = __ballot(!done) != 0ull;
-            if (lane == 0) s_live[wave] = live ? 1u : 0u;
-            lds_barrier();                                         // also: every wave is done walking the previous batch
-            if ((s_live[0] | s_live[1] | s_live[2] | s_live[3]) == 0u) break;
-        }
+        if (__syncthreads_count(done) == 256) break;
         if constexpr (kRasterStats) ++st_batches;
         const uint32_t pos = rg.x + (uint32_t)i * 256u + (uint32_t)tid;
         const uint32_t need = min(256u, rg.y - rg.x - (uint32_t)i * 256u);
@@ -878,23 +847,18 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
                 scan_more(p, ts, s_ring, s_scan, rects, order, p.bn.point_list + rg.x, rg.y - rg.x, (uint32_t)bx, (uint32_t)by, lane, wave, lanes_before);
         }
         unsigned m16 = 0u;
-        if (!SCAN) {
-            const bool has = pos < rg.y;
-            const float2 xy = has ? nxt.xy : make_float2(0.f, 0.f);
-            const float4 co = has ? nxt.co : make_float4(0.f, 0.f, 0.f, 0.f), rc = has ? nxt.rc : make_float4(0.f, 0.f, 0.f, 0.f);
-            s_xy[tid] = xy; s_co[tid] = co; s_rgbc[tid] = rc;
-            if (has) m16 = cell_mask(xy, co, rc.w, tx0, ty0);
-            record_of(id_nxt, nxt);                                // batch i + 1: in flight across the compaction and the walk below
-            id_nxt = entry_at(i + 2);
-        } else if (pos < rg.y && (uint32_t)tid < ts.waiting) {
-            const uint32_t id = s_ring[(ts.head + (uint32_t)tid) & (kRing - 1u)];
-            const BlendRecord* rec = p.g.blend + vo + id;
+        if (pos < rg.y && (!SCAN || (uint32_t)tid < ts.waiting)) {
+            const uint32_t id = SCAN ? s_ring[(ts.head + (uint32_t)tid) & (kRing - 1u)] : p.bn.point_list[pos];
+            const BlendRecord* rec = p.g.blend + vo + id;      // one line per entry (raster_state.h)
             const float4 co = rec->co;
             const float4 rc = rec->rc;
             const float2 xy = rec->xy;
             s_xy[tid] = xy; s_co[tid] = co; s_rgbc[tid] = rc;
             m16 = cell_mask(xy, co, rc.w, tx0, ty0);
         } else {
+            // a slot without an entry holds a finite record: the walk reads ahead of its lists (stale indices), and the product-default
+            // arithmetic multiplies a masked-out lane's colour by a zero weight instead of selecting -- 0 * NaN from LDS left by an
+            // earlier kernel would poison the pixel
             s_xy[tid] = make_float2(0.f, 0.f); s_co[tid] = make_float4(0.f, 0.f, 0.f, 0.f); s_rgbc[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         unsigned long long keeps[16];
@@ -903,7 +867,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
             keeps[c] = __ballot((m16 >> c) & 1u);
             if (lane == 0) reinterpret_cast<uint32_t*>(&s_cnt[c])[wave] = (uint32_t)__popcll(keeps[c]);
         }
-        if (SCAN) __syncthreads(); else lds_barrier();
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             if ((m16 >> c) & 1u) {
@@ -912,7 +876,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
                 s_list[c][ahead + (uint32_t)__popcll(keeps[c] & lanes_before)] = (uint8_t)tid;
             }
         }
-        if (SCAN) __syncthreads(); else lds_barrier();
+        __syncthreads();
         if (SCAN) { const uint32_t took = min(need, ts.waiting); ts.head += took; ts.waiting -= took; }
         const uint32_t base = (uint32_t)i * 256u;
         const unsigned long long alive = __ballot(!done);
