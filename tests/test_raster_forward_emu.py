@@ -51,6 +51,16 @@ def test_many_instances_per_tile_and_ties():
     assert_forward_parity(emu_backend(), sc, cams, H, W, CPU)
 
 
+def test_ties_inside_a_bucket_below_the_network_limit():
+    """30 identical depth keys land in ONE bucket of the per-tile LDS sort and stay below its limit (40: above it the tile takes the
+    bitonic network, which the test above exercises with 100): the place of a key inside its bucket comes from counting the
+    bucket's smaller 64-bit keys, so equal depth bits are ordered by Gaussian index like the reference's stable sort."""
+    H, W = 48, 48
+    sc, cams = small_scene(3000, W, H, seed=11, log_scale=-1.2)
+    sc["xyz"][300:330] = sc["xyz"][300]
+    assert_forward_parity(emu_backend(), sc, cams, H, W, CPU)
+
+
 def clustered_scene(P, n_front, res):
     """n_front faint Gaussians stacked on the first tile, nearest to the camera, the rest tiny and elsewhere: the first tile's
     list is a fraction of P but its entries are the first depth ranks (the scan form's window is sized from the average

@@ -107,6 +107,10 @@ def test_many_instances_ties_and_windows():
     P = 16128 * 32 + 5000
     sc, cams = small_scene(P, 32, 32, seed=12, log_scale=-6.0, spread=0.8)
     assert_forward_parity(_backend(), sc, cams, 32, 32, _dev())
+    # 30 equal depth keys: one bucket of the per-tile LDS sort, below the limit at which the tile takes the bitonic network
+    sc, cams = small_scene(3000, W, H, seed=11, log_scale=-1.2)
+    sc["xyz"][300:330] = sc["xyz"][300]
+    assert_forward_parity(_backend(), sc, cams, H, W, _dev())
 
 
 def test_two_sets_precomputed_colors():
