@@ -95,10 +95,15 @@ typedef struct DgsRasterForwardArgs {
     int64_t binning_capacity;
     int32_t* num_rendered_dev;   /* device int32[4], written by the call in both modes when not NULL: [0] = num_rendered (low 32 bits),
                                     [1] = status (DgsStatus), [2] = longest tile list, [3] = 0                               */
-    int32_t* num_rendered_host;  /* PINNED host int32[4] or NULL: the same four words, copied behind the call (an asynchronous D2H copy on the
-                                    stream: valid once the stream has passed it -- record an event behind the call)                 */
+    int32_t* num_rendered_host;  /* DEVICE-ACCESSIBLE host int32[4] or NULL: the same four words, STORED BY A KERNEL of the call through this
+                                    pointer (no memcpy: a copy node in a captured sequence proved unreliable on ROCm 7.2) -- so it must be
+                                    page-locked memory that is mapped into the device's address space at this very address and coherent
+                                    (hipHostMalloc with hipHostMallocMapped | hipHostMallocCoherent, or torch's pin_memory=True); plain
+                                    pageable or un-mapped page-locked memory faults.  Valid once the stream has passed the call --
+                                    record an event behind it                                                                        */
     int64_t longest_hint;        /* async mode, IN: the longest tile list the caller expects (a previous call of this shape), 0 =
-                                    unknown.  Sizes the LDS of the per-tile sort; a longer list only changes the form that runs   */
+                                    unknown.  Sizes the LDS of the per-tile sort (form 3 named: that kernel is launched alone); a
+                                    longer list is sorted in LDS-sized chunks merged by rank -- slower, never an error             */
     /* ---- result ---- */
     int64_t num_rendered;        /* host, OUT (sync mode); -1 in async mode             */
     int64_t longest_list;        /* host, OUT (sync mode); -1 in async mode             */

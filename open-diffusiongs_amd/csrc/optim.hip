@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void adamw_refresh_kernel(const DgsAdamWTensor
     }
     const DgsAdamWTensor t = tab[lo];
     const int local = bid - t.first_tile;
+    // A non-finite gradient norm (an overflowed loss, a NaN from upstream): the whole update is skipped on every rank alike (the norm
+    // is the all-reduced one) -- parameters, both moments and the engine's copies stay as they are -- which is what the reference's
+    // 16-mixed training does with such a step (torch.cuda.amp.GradScaler.step skips the optimizer when it found inf / NaN).
+    if (h.grad_sumsq != nullptr && (__float_as_uint(h.grad_sumsq[0]) & 0x7f800000u) == 0x7f800000u) return;   // exponent all ones: inf / NaN
     const float gc = clip_coef(h);                                 // 1 without a clip: g * 1.0f is g
     if (t.copy_t == nullptr) {
         // ---- flat tile: elements [local * 4096, +4096) ----

@@ -32,6 +32,8 @@ struct FwdParams {
     int bin_mode;            // binning form: 0 chosen from the instance statistics (binning_form), else forced: 1 instance list + rank
                              // bitmap sort, 2 per-tile scan, 3 instance list + per-tile bitonic sort in LDS
     int bitonic_cap;         // longest tile list the bitonic form is launched for (LDS entries), 0: form not available
+    int bitonic_any;         // 1: the bitonic form was launched ALONE (async call with a forced form): it takes lists of any length --
+                             // those beyond its LDS in sorted chunks merged by rank (tile_bitonic_kernel), never another form
     int exact_exp;           // blend exponential: 0 hardware v_exp_f32 (default), 1 det_expf (bit-identical floats with the oracle)
     int debug;               // DgsRasterForwardArgs.debug: also keeps the per-view cov3D copy in the state (inspection)
     int* radii;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys
 // order of the per-tile kernels (deal_tiles, by list length).
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2* ranges, uint32_t* cursor, int n,
                                                          int32_t* totals, long long capacity, uint32_t* order, int gx, int gy,
-                                                         int32_t* stats_dev, int32_t* stats_host, int list_cap) {
+                                                         int32_t* stats_dev, int32_t* stats_host) {
     __shared__ uint32_t scratch[20];
     __shared__ uint32_t smax;
     __shared__ uint32_t s_class[1024];
@@ -357,9 +359,6 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2
         totals[0] = (int32_t)carry;
         totals[2] = (int32_t)smax;
         if (capacity >= 0 && (long long)carry > capacity) totals[1] = DGS_ERR_BINNING_OVERFLOW;
-        // async call that launched the per-tile LDS sort ALONE (its caller named the longest list it expects): a longer list has no
-        // kernel to go to -- the same deferred failure as an instance overflow (NaN image, raised by the next call, which sizes for it)
-        if (list_cap > 0 && smax > (uint32_t)list_cap) totals[1] = DGS_ERR_BINNING_OVERFLOW;
         // the caller's copies of the four words (DgsRasterForwardArgs.num_rendered_dev / num_rendered_host), written by this kernel:
         // the host copy is a store into pinned, device-visible host memory -- no memcpy node in a captured call
         const int32_t st1 = totals[1];
@@ -376,8 +375,8 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2
 // bitonic: sparse scenes whose longest tile list fits the LDS the kernel was launched with; rank sort: the rest.
 enum { kFormRankSort = 1, kFormScan = 2, kFormBitonic = 3 };
 __host__ __device__ __forceinline__ int binning_form_of(int bin_mode, int bitonic_cap, long long num_rendered, long long longest,
-                                                        long long T, long long P, long long V) {
-    const bool fits = bitonic_cap > 0 && longest <= bitonic_cap;
+                                                        long long T, long long P, long long V, bool any_len = false) {
+    const bool fits = bitonic_cap > 0 && (any_len || longest <= bitonic_cap);
     if (bin_mode == kFormScan || bin_mode == kFormRankSort) return bin_mode;
     if (bin_mode == kFormBitonic) return fits ? kFormBitonic : kFormRankSort;
     if (num_rendered * 10 >= T * P * V) return kFormScan;
@@ -388,7 +387,8 @@ __host__ __device__ __forceinline__ bool scan_form_possible(int gx, int gy, long
     return gx <= 255 && gy <= 255 && T * P <= (1ll << 31);
 }
 __device__ __forceinline__ int binning_form(const FwdParams& p) {
-    return binning_form_of(p.bin_mode, p.bitonic_cap, (long long)(uint32_t)p.im.totals[0], (long long)(uint32_t)p.im.totals[2], p.T, p.P, p.V);
+    return binning_form_of(p.bin_mode, p.bitonic_cap, (long long)(uint32_t)p.im.totals[0], (long long)(uint32_t)p.im.totals[2], p.T, p.P, p.V,
+                           p.bitonic_any != 0);
 }
 __device__ __forceinline__ bool binning_is_scan(const FwdParams& p) { return binning_form(p) == kFormScan; }
 
@@ -596,11 +596,53 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
     const uint64_t* src = p.bn.inst_key + rg.x;
+    constexpr int KPT = NT == 256 ? 32 : 16;                   // 8,192 / 256 (tile_bitonic_kernel<256> is launched up to that capacity), 16,384 / 1,024
+    {
+        // A list longer than this launch's LDS (only when the form was launched alone -- `bitonic_any` -- for a caller that expected
+        // shorter lists; any other launch sends such a tile to the rank sort): chunks of C keys are sorted in LDS and written back
+        // in place, then every key's place in the tile's list is its place in its own chunk + the number of smaller keys in each other
+        // chunk (binary search; the keys of a tile are distinct).  O(n (n / C) log C): the rare path of a plan that went stale -- the
+        // reference pays a full radix sort of all instances for every call (rasterizer_impl.cu:303).
+        const uint32_t C = min((uint32_t)p.bitonic_cap, (uint32_t)(KPT * NT));
+        if (n > C) {
+            uint64_t* sorted = p.bn.inst_key + rg.x;
+            const uint32_t nchunks = (n + C - 1) / C;
+            for (uint32_t c = 0; c < nchunks; ++c) {
+                const uint32_t len = min(C, n - c * C);
+                uint32_t m = 8 * NT;
+                while (m < len) m <<= 1;
+                for (uint32_t i = tid; i < m; i += NT) keys[i] = i < len ? sorted[c * C + i] : ~0ull;
+                __syncthreads();
+                bitonic_sort_lds<NT>(keys, m, tid);
+                __syncthreads();
+                for (uint32_t i = tid; i < len; i += NT) sorted[c * C + i] = keys[i];
+                __syncthreads();
+            }
+            __threadfence_block();                             // one workgroup: its own global writes are visible behind the barrier
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += NT) {
+                const uint64_t k = sorted[i];
+                const uint32_t mine = i / C;
+                uint32_t place = i - mine * C;
+                for (uint32_t c = 0; c < nchunks; ++c) {
+                    if (c == mine) continue;
+                    const uint64_t* ch = sorted + c * C;
+                    uint32_t lo = 0, hi = min(C, n - c * C);   // first index with ch[index] > k == number of smaller keys (distinct)
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (ch[mid] < k) lo = mid + 1; else hi = mid;
+                    }
+                    place += lo;
+                }
+                p.bn.point_list[rg.x + place] = (uint32_t)k;
+            }
+            return;
+        }
+    }
     // The tile's keys, ONCE, into registers: thread t holds keys t, t + NT, ... (at most KPT = the launch's LDS capacity / NT; all
     // loads in flight together).  The three passes below (range, histogram, scatter) each used to walk `src` with the next load
     // behind the use of the previous one -- ~12 dependent L2 round trips per pass for a 3,000-entry list, 0.67 of the kernel's wave
     // cycles parked (profiles/r04_raster_sq_pmc.txt).
-    constexpr int KPT = NT == 256 ? 32 : 16;                   // 8,192 / 256 (tile_bitonic_kernel<256> is launched up to that capacity), 16,384 / 1,024
     uint64_t kreg[KPT];
 #pragma unroll
     for (int u = 0; u < KPT; ++u) {
@@ -1095,15 +1137,15 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     p.bin_mode = a->binning_form;
     if (p.bin_mode < 0 || p.bin_mode > 3 || (p.bin_mode == 0 && !can_scan) || (p.bin_mode == kFormScan && !can_scan)) p.bin_mode = can_scan ? 0 : kFormBitonic;
     // async + the LDS sort named + the longest list the caller expects: that kernel alone (no radix sort, no rank-sort fallback in
-    // the launch sequence); its LDS is sized for 1.5 x the expectation
+    // the launch sequence); its LDS is sized for 1.5 x the expectation, and a list that outgrows it is sorted in LDS-sized chunks merged
+    // by rank (tile_bitonic_kernel's long-list path: slower, never wrong)
     int bitonic_only_cap = 0;
     if (async && p.bin_mode == kFormBitonic && a->longest_hint > 0) {
         bitonic_only_cap = 2048;
         while (bitonic_only_cap < a->longest_hint + a->longest_hint / 2 && bitonic_only_cap < kBitonicMax) bitonic_only_cap <<= 1;
     }
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, p.im.ranges, p.im.tile_cursor, VT, p.im.totals,
-                       async ? (long long)a->binning_capacity : -1LL, p.im.tile_order, p.gx, p.gy, a->num_rendered_dev, a->num_rendered_host,
-                       bitonic_only_cap);
+                       async ? (long long)a->binning_capacity : -1LL, p.im.tile_order, p.gx, p.gy, a->num_rendered_dev, a->num_rendered_host);
     rc = check(st, a->debug);
     if (rc) return rc;
 
@@ -1148,9 +1190,10 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         // the device when a list does not fit (both are launched).  All forms produce the same lists bit for bit.
         a->num_rendered = -1;
         a->longest_list = -1;
-        // LDS the per-tile sort is launched with: for the longest list the caller expects (+ 50 %) -- then it is launched alone and a
-        // longer list is a deferred failure (scan_tiles_kernel) --, else the maximum with the rank sort beside it as the device's fallback
+        // LDS the per-tile sort is launched with: for the longest list the caller expects (+ 50 %) -- then it is launched alone and
+        // takes a longer list through its chunked path --, else the maximum with the rank sort beside it as the device's fallback
         p.bitonic_cap = bitonic_only_cap ? bitonic_only_cap : kBitonicMax;
+        p.bitonic_any = bitonic_only_cap ? 1 : 0;
         forms = p.bin_mode ? (1 << p.bin_mode) | (p.bin_mode == kFormBitonic && !bitonic_only_cap ? 1 << kFormRankSort : 0)
                            : (1 << kFormRankSort) | (1 << kFormScan) | (1 << kFormBitonic);
     }

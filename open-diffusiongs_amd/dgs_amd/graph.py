@@ -17,6 +17,8 @@ _INPUT_KEYS = ("image", "ray_o", "ray_d", "c2w", "fxfycxcy")
 
 
 class GraphedForward:
+    MAX_RASTER_CALLS = 8          # pinned statistics rows handed to the rasterizer calls of one captured step
+
     def __init__(self, model, input_batch, timesteps, warmup=2):
         dev = input_batch["image"].device
         if dev.type != "cuda":
@@ -25,7 +27,15 @@ class GraphedForward:
         self.static = {k: input_batch[k].detach().clone() for k in _INPUT_KEYS}
         self.t = timesteps.detach().clone()
         self.key = self.shape_key(input_batch, timesteps)
-        backend = model.gs_renderer.backend()
+        self._backend = model.gs_renderer.backend()
+        self.replays = self.recaptures = self.healed = 0
+        self._capture(warmup)
+
+    def _capture(self, warmup):
+        """Warm-up + capture.  The rasterizer calls of the captured step report into pinned rows of THIS graph (allocated here, outside
+        the capture), and the backend tells which plans they ran from (`_watch`): a plan at risk -- binning capacity below the worst
+        case of its shape (dgs_amd/raster.py `_AsyncPlan`) -- makes every replay a verified one."""
+        dev, model, backend = self.t.device, self.model, self._backend
         # warm-up on a side stream: the first render of a shape synchronises (it learns the binning capacity), workspaces are
         # allocated, per-kernel attributes are set -- none of which may happen inside the capture
         side = torch.cuda.Stream(dev)
@@ -35,50 +45,71 @@ class GraphedForward:
                 model(self.static, self.t)
         torch.cuda.current_stream(dev).wait_stream(side)
         backend.check_async(wait=True)                 # the warm-up renders' statistics: capacity + ordering form of the capture
+        self._rows = torch.zeros(self.MAX_RASTER_CALLS, 4, dtype=torch.int32).pin_memory()
+        backend.begin_capture_log(self._rows)
         self.graph = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (RCCL's watchdog polls its events) must not invalidate the capture
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.rendered, self.gaussians = model(self.static, self.t)
-        B, V, _, H, W = self.static["image"].shape
-        Vr = int(self.static["c2w"].shape[1])
-        self._plan = backend.plan_for(model.cfg.n_gaussians + V * H * W, W, H, B * Vr, Vr, dev)
-        self._stats = getattr(self._plan, "graph_stats", None)     # pinned int32[4], rewritten by every replay
+        try:
+            # thread_local: other threads of the process (RCCL's watchdog polls its events) must not invalidate the capture
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.rendered, self.gaussians = model(self.static, self.t)
+        finally:
+            self._watch = backend.end_capture_log()    # [(plan, pinned row, capacity, (P, W, H, V))] of the captured rasterizer calls
+        if not self._watch:
+            raise RuntimeError("GraphedForward: the captured step made no planned rasterizer call -- nothing to verify replays against")
+        self._verify = any(plan.at_risk(cap) for plan, _row, cap, _shape in self._watch)
         self._event = None
-        self._backend = backend
-        self.replays = 0
 
     @staticmethod
     def shape_key(input_batch, timesteps):
         return tuple((k, tuple(input_batch[k].shape), input_batch[k].dtype) for k in _INPUT_KEYS) + (tuple(timesteps.shape), timesteps.dtype)
 
-    def check(self, wait=True):
-        """Raise if the latest replay failed on the device (wait=True: block until it has finished)."""
-        self._check_previous(wait=wait)
+    def _failed(self):
+        """The latest replay's statistics rows (valid once its event has passed): raises for a device-side failure other than an
+        outgrown buffer, returns True if a call outgrew its buffer (after telling the plans what the scene needs)."""
+        from . import _native
+        over = False
+        for plan, row, cap, shape in self._watch:
+            n, status, longest = int(row[0]) & 0xFFFFFFFF, int(row[1]), int(row[2]) & 0xFFFFFFFF
+            if status == _native.DGS_ERR_BINNING_OVERFLOW:
+                plan.note(self._backend.lib, n, longest, *shape)
+                over = True
+            elif status != 0:
+                raise RuntimeError(f"GraphedForward: a replay failed on the device ({_native.status_string(self._backend.lib, status)})")
+        return over
 
-    def _check_previous(self, wait=False):
-        """The previous replay's instance statistics (in pinned memory once its event has passed): a scene that outgrew the captured
-        binning capacity rendered NaN -- raise, as the eager path does on its next call."""
-        if self._event is None or self._stats is None:
+    def check(self, wait=True):
+        """Unverified graphs (no plan at risk: their buffers hold the worst case, a replay cannot outgrow them): raise if the latest
+        replay reported any other device-side failure.  Verified graphs have nothing pending -- `replay` looked already."""
+        if self._event is None:
             return
         if wait:
             self._event.synchronize()
         elif not self._event.query():
             return
         self._event = None
-        n, status = int(self._stats[0]) & 0xFFFFFFFF, int(self._stats[1])
-        if status != 0:
-            from . import _native
-            raise RuntimeError(f"GraphedForward: the previous replay failed on the device ({_native.status_string(self._backend.lib, status)}; "
-                               f"{n} instances, captured capacity {self._plan.capacity}): its image is NaN.  Drop this graph "
-                               f"(DGSDenoiser.drop_graphs()) and run the step eagerly once to re-learn the capacity")
+        if self._failed():
+            raise RuntimeError("GraphedForward: a replay outgrew a binning buffer that was sized for the worst case of its shape")
 
     def replay(self):
-        self._check_previous()
-        self.graph.replay()
-        self._event = torch.cuda.Event()
-        self._event.record()
-        self.replays += 1
-        return self.rendered, self.gaussians
+        """One step.  With a plan at risk the host waits for the replay and looks at what its rasterizer calls reported; a scene
+        that outgrew the captured capacity is healed here -- the graph is captured again with buffers sized for it (the warm-up
+        of the capture renders the scene eagerly, which raises the plan's capacity) and replayed -- so the tensors this returns
+        are always a complete render, as the reference's are (it resizes on every call: rasterize_points.cu:27-33)."""
+        for _ in range(4):
+            self.graph.replay()
+            self.replays += 1
+            self._event = torch.cuda.Event()
+            self._event.record()
+            if not self._verify:
+                return self.rendered, self.gaussians
+            self._event.synchronize()
+            self._event = None
+            if not self._failed():
+                return self.rendered, self.gaussians
+            self.healed += 1
+            self.recaptures += 1
+            self._capture(warmup=1)
+        raise RuntimeError("GraphedForward: a step kept outgrowing its binning buffers")
 
     def __call__(self, input_batch, timesteps):
         for k, dst in self.static.items():

@@ -34,25 +34,48 @@ def _prep(t, device):
 class _AsyncPlan:
     """What the backend knows about the calls of ONE shape (P, W, H, V, views per set, device): the instance statistics the device
     reported for the calls so far.  They size the next call's binning buffer and pick its ordering form, so that the call itself
-    reads nothing back (the reference blocks on `num_rendered` in every forward, rasterizer_impl.cu:281).
+    reads nothing back (the reference blocks on `num_rendered` in every forward, rasterizer_impl.cu:281, and can therefore never
+    fail on an instance count: rasterize_points.cu:27-33,76-78 resize by callback).  The same guarantee here, without the block:
 
-    capacity  2 x the most instances any call of this shape produced (the buffer is torch memory: a cached block after the first
-              call); a call that needs more flags DGS_ERR_BINNING_OVERFLOW on the device and renders NaN -- it cannot tell the host
-              in time -- and the NEXT call of the shape raises, with the capacity already raised.
+    capacity  max(2 x the most instances any call of this shape produced,  min(worst case, budget)) -- the worst case is V x T x P
+              (every Gaussian in every tile); forward-only renders (`Renderer.forward`) may spend `budget_bytes` on the buffer
+              (torch memory: a cached block after the first call; only the part a scene fills is ever touched), which at the
+              object model's 256^2 shape IS the worst case (3.2 GB of 288): such a plan cannot overflow and never waits.
+    at risk   a plan whose capacity is below the worst case.  Its calls are VERIFIED: the host waits for the four statistics words
+              (stored by the call's second kernel, long before the blend) and, if the scene outgrew the buffer, renders it again
+              with a buffer sized for it -- on the same stream, into the same outputs, before anything else was enqueued.  What a
+              caller sees is the reference's behaviour: a correct image, always; what it pays is the host's run-ahead at that
+              point (the device does not idle: the rest of the render is already enqueued).  A call that is being CAPTURED cannot
+              wait: the graph's owner verifies each replay instead (dgs_amd/graph.py).
     form      dgs_raster_binning_form() of the latest statistics that have arrived (any form is correct for any scene -- the lists
-              are bit-identical -- a stale one only costs time).
-    Statistics travel device -> pinned host words behind each call; `poll` looks at the ones whose copy has finished."""
+              are bit-identical -- a stale one only costs time); `longest` = the longest tile list seen (sizes the LDS sort's LDS;
+              a longer list takes that kernel's chunked path).
+    Statistics travel device -> pinned host words behind each call; `poll` looks at the ones that have arrived."""
 
     MARGIN = 2.0
     SLOTS = 64                     # pinned host words for the statistics of that many calls in flight
+    BUDGET_BYTES = int(float(os.environ.get("DGS_RASTER_PLAN_GIB", "4")) * 2 ** 30)   # forward-only plans: floor of the binning buffer
 
-    def __init__(self):
+    def __init__(self, worst=0, bytes_per_instance=12):
         self.capacity, self.form, self.longest, self.seen_max = 0, 0, 0, 0
+        self.worst = int(worst)    # V x T x P: no scene of this shape has more instances
+        self.bytes_per_instance = int(bytes_per_instance)
         self.pending = []          # (event or None, host int32[4], capacity the call ran with)
-        self.overflowed = None     # (instances, capacity) of a call that did not fit, until it has been reported
-        self.calls = {"sync": 0, "async": 0}
+        self.overflowed = None     # (instances, capacity) of an UNVERIFIED call that did not fit (a capture without an owner), until reported
+        self.calls = {"sync": 0, "async": 0, "healed": 0}
         self.host = None           # pinned int32[SLOTS + 1, 4]: allocated ONCE, outside any stream capture (a pinned allocation is not a
-        self.slot = 0              # stream operation: inside a capture it invalidates the capture); row SLOTS belongs to a captured graph
+        self.slot = 0              # stream operation: inside a capture it invalidates the capture); row SLOTS: captures without an owner
+
+    def capacity_for(self, forward_only):
+        """Instances the next call's binning buffer holds.  Forward-only callers get the budget's floor on top of the history; a call
+        whose state feeds a backward does not (the deterministic backward's scratch is 36 bytes per SLOT)."""
+        cap = self.capacity
+        if forward_only and cap > 0 and self.worst > 0:
+            cap = max(cap, min(self.worst, self.BUDGET_BYTES // self.bytes_per_instance))
+        return min(cap, self.worst) if self.worst > 0 else cap
+
+    def at_risk(self, capacity):
+        return self.worst <= 0 or capacity < self.worst
 
     def host_words(self, for_graph):
         if self.host is None:
@@ -69,7 +92,7 @@ class _AsyncPlan:
 
     def note(self, lib, n, longest, P, W, H, V):
         self.seen_max = max(self.seen_max, int(n))
-        self.longest = int(longest)
+        self.longest = max(self.longest, int(longest))
         self.capacity = max(self.capacity, int(self.MARGIN * self.seen_max) + 1024)
         self.form = int(lib.dgs_raster_binning_form(0, int(n), int(longest), P, W, H, V))
 
@@ -93,9 +116,9 @@ class _AsyncPlan:
         if self.overflowed is not None:
             n, cap, longest = self.overflowed
             self.overflowed = None
-            raise RuntimeError(f"dgs rasterizer: an earlier asynchronous render outgrew what its plan provided -- {n} instances for a binning buffer "
-                               f"of {cap}, longest tile list {longest} -- that call's image is NaN.  The plan now holds capacity {self.capacity}, "
-                               f"form {self.form}, longest list {self.longest}; run the step again")
+            raise RuntimeError(f"dgs rasterizer: an earlier UNVERIFIED asynchronous render (a call captured into a graph that nobody "
+                               f"verifies: use dgs_amd.graph.GraphedForward) outgrew its binning buffer -- {n} instances for {cap}, longest "
+                               f"tile list {longest} -- that call's image is NaN.  The plan now holds capacity {self.capacity}, form {self.form}")
 
 
 class RasterBackend:
@@ -111,6 +134,8 @@ class RasterBackend:
         self.deterministic = os.environ.get("DGS_RASTER_DETERMINISTIC", "0") not in ("", "0")
         self.deterministic_budget = int(float(os.environ.get("DGS_RASTER_DETERMINISTIC_GIB", "64")) * 2 ** 30)
         self.last_backward_deterministic = None
+        self.last_async_stats = None     # device int32[4] of the latest NON-planned asynchronous call (a caller with its own capacity)
+        self._capture_log, self._capture_rows = [], []
 
     # -- helpers ---------------------------------------------------------------------------
     @staticmethod
@@ -145,7 +170,13 @@ class RasterBackend:
         return num_rendered, color[0], radii[0], geom, binning, img
 
     def plan_for(self, P, W, H, V, views_per_set, device):
-        return self._plans.setdefault((int(P), int(W), int(H), int(V), int(views_per_set), str(device)), _AsyncPlan())
+        key = (int(P), int(W), int(H), int(V), int(views_per_set), str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            tiles = ((int(W) + 15) // 16) * ((int(H) + 15) // 16)
+            per = max(1, int(self.lib.dgs_raster_binning_bytes(1 << 20)) >> 20)
+            plan = self._plans[key] = _AsyncPlan(worst=int(V) * tiles * int(P), bytes_per_instance=per)
+        return plan
 
     def check_async(self, wait=True):
         """Look at the statistics of every asynchronous call so far (wait=True: block until their copies have arrived) and raise if
@@ -156,12 +187,14 @@ class RasterBackend:
 
     def forward_views(self, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                       viewmatrix, projmatrix, campos, tanfov, tanfovx, tanfovy, image_height, image_width, sh, degree,
-                      prefiltered, debug, views_per_set=1, raw_activations=False, binning_capacity=0, planned=False):
+                      prefiltered, debug, views_per_set=1, raw_activations=False, binning_capacity=0, planned=False, forward_only=False):
         """Batched entry: means3D [S,P,3] (other per-Gaussian inputs [S,P,...]); viewmatrix/projmatrix [V,4,4];
         campos [V,3]; tanfov optional [V,2] tensor.  Returns (num_rendered, color[V,3,H,W], radii[V,P], geom, binning, img).
         planned=True (the product's render path: Renderer.forward): no host synchronisation -- the binning capacity and the ordering
         form come from the `_AsyncPlan` of this shape; the FIRST call of a shape runs the synchronous form to learn them.  The
-        returned `num_rendered` is then the capacity the binning buffer was carved with (what the backward takes)."""
+        returned `num_rendered` is then the capacity the binning buffer was carved with (what the backward takes); a scene that
+        outgrows the plan is rendered again before the call returns (`_AsyncPlan`), never reported as NaN.  forward_only=True: no
+        backward will take this call's state, so the buffer may be sized for the worst case within the plan's budget."""
         device = means3D.device
         S, P = int(means3D.shape[0]), int(means3D.shape[1])
         V = int(viewmatrix.shape[0])
@@ -199,47 +232,85 @@ class RasterBackend:
         a.exact_exp = int(self.exact_exp)
         plan = self.plan_for(P, W, H, V, views_per_set, device) if planned else None
         capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        if plan is not None:
-            if not capturing:
-                plan.poll(self.lib, P, W, H, V)
-            binning_capacity = plan.capacity          # 0 before the first call of the shape: the synchronous form, which reports N
-            if binning_capacity > 0 and a.binning_form == 0:
-                a.binning_form, a.longest_hint = plan.form, plan.longest
-            if capturing and binning_capacity <= 0:
-                raise RuntimeError("dgs rasterizer: the first render of a shape synchronises (it learns the binning capacity); run the step "
-                                   "once before capturing it in a graph")
-        a.binning_capacity = int(binning_capacity)
-        ndev = host = None
-        if binning_capacity > 0:
-            if plan is not None and device.type == "cuda":
-                # statistics -> pinned host words, copied by the library behind the call (a plain asynchronous D2H copy on the stream: a
-                # memcpy node when the call is being captured); looked at by a later call's poll()
-                host = plan.host_words(for_graph=capturing)
-                a.num_rendered_host = ctypes.c_void_p(host.data_ptr())
-            else:
-                ndev = torch.empty(4, dtype=torch.int32, device=device)
-                a.num_rendered_dev = ctypes.c_void_p(ndev.data_ptr())
-        rc = self.lib.dgs_raster_forward(ctypes.byref(a), self._stream(device))
-        self._check(rc)
-        if plan is not None:
+        forced_form = a.binning_form
+        if plan is not None and not capturing:
+            plan.poll(self.lib, P, W, H, V)
+        for _attempt in range(4):
+            if plan is not None:
+                binning_capacity = plan.capacity_for(forward_only)   # 0 before the first call of the shape: the synchronous form, which reports N
+                if binning_capacity > 0 and forced_form == 0:
+                    a.binning_form, a.longest_hint = plan.form, plan.longest
+                if capturing and binning_capacity <= 0:
+                    raise RuntimeError("dgs rasterizer: the first render of a shape synchronises (it learns the binning capacity); run the step "
+                                       "once before capturing it in a graph")
+            a.binning_capacity = int(binning_capacity)
+            ndev = host = None
             if binning_capacity > 0:
-                plan.calls["async"] += 1
-                if host is not None:
-                    if capturing:
-                        plan.graph_stats = host       # rewritten by every replay: the graph's owner polls it (dgs_amd/graph.py)
-                    else:
-                        ev = torch.cuda.Event()
-                        ev.record(torch.cuda.current_stream(device))
-                        plan.pending.append((ev, host, int(binning_capacity)))
+                if plan is not None and device.type == "cuda":
+                    # statistics -> pinned host words, stored by the call's scan kernel (device-mapped pinned memory: no copy node in a
+                    # captured call); looked at below (a plan at risk), by a later call's poll(), or by the owner of the graph
+                    host = self._capture_row() if capturing else None
+                    if host is None:
+                        host = plan.host_words(for_graph=capturing)
+                    a.num_rendered_host = ctypes.c_void_p(host.data_ptr())
                 else:
-                    plan.pending.append((None, ndev.clone(), int(binning_capacity)))
+                    ndev = torch.empty(4, dtype=torch.int32, device=device)
+                    a.num_rendered_dev = ctypes.c_void_p(ndev.data_ptr())
+            rc = self.lib.dgs_raster_forward(ctypes.byref(a), self._stream(device))
+            self._check(rc)
+            if binning_capacity <= 0:                 # synchronous form: the statistics are in the argument block
+                if plan is not None:
+                    plan.calls["sync"] += 1
+                    plan.note(self.lib, int(a.num_rendered), int(a.longest_list), P, W, H, V)
+                    if device.type == "cuda":
+                        plan.host_words(for_graph=True)   # the pinned words exist before anybody captures a call of this shape
+                return int(a.num_rendered), out_color, radii, holder["geom"], holder["binning"], holder["img"]
+            if plan is None:                          # a caller with a capacity of its own: the four words are its business
+                self.last_async_stats = ndev
                 return int(binning_capacity), out_color, radii, holder["geom"], holder["binning"], holder["img"]
-            plan.calls["sync"] += 1
-            plan.note(self.lib, int(a.num_rendered), int(a.longest_list), P, W, H, V)
-            if device.type == "cuda":
-                plan.host_words(for_graph=True)       # the pinned words exist before anybody captures a call of this shape
-        num_rendered = int(a.num_rendered) if binning_capacity <= 0 else ndev
-        return num_rendered, out_color, radii, holder["geom"], holder["binning"], holder["img"]
+            plan.calls["async"] += 1
+            if capturing:
+                # rewritten by every replay; the graph's owner (dgs_amd/graph.py) verifies each replay of a plan at risk
+                plan.graph_stats = host
+                self._capture_log.append((plan, host, int(binning_capacity), (P, W, H, V)))
+                break
+            if host is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+            else:
+                ev, host = None, ndev
+            if not plan.at_risk(binning_capacity):
+                plan.pending.append((ev, host if ev is not None else ndev.clone(), int(binning_capacity)))
+                break
+            # a plan at risk: verify before anything else is enqueued (class docstring).  The words are stored by the call's second
+            # kernel; the wait ends long before the blend does.
+            if ev is not None:
+                ev.synchronize()
+            n, status, longest = int(host[0]) & 0xFFFFFFFF, int(host[1]), int(host[2]) & 0xFFFFFFFF
+            plan.note(self.lib, n, longest, P, W, H, V)
+            if status == 0:
+                break
+            if status != _native.DGS_ERR_BINNING_OVERFLOW:
+                raise RuntimeError(f"dgs rasterizer: {_native.status_string(self.lib, status)} (status {status})")
+            plan.calls["healed"] += 1                 # the buffer was too small: again, now sized for this scene (same stream, same outputs)
+        else:
+            raise RuntimeError("dgs rasterizer: a render kept outgrowing its binning buffer")
+        return int(binning_capacity), out_color, radii, holder["geom"], holder["binning"], holder["img"]
+
+    # -- captured calls: the owner of a graph hands out the pinned rows its calls report into and learns which plans they used ----
+    def begin_capture_log(self, rows=None):
+        """Called by the owner of a graph before it captures: `rows` = pinned int32[k, 4] allocated outside the capture (one row per
+        rasterizer call of the captured sequence; without it the plan's shared row is used).  `end_capture_log()` returns
+        [(plan, row, capacity, (P, W, H, V))] of the calls captured since."""
+        self._capture_log = []
+        self._capture_rows = list(rows) if rows is not None else []
+
+    def end_capture_log(self):
+        log, self._capture_log, self._capture_rows = self._capture_log, [], []
+        return log
+
+    def _capture_row(self):
+        return self._capture_rows.pop(0) if self._capture_rows else None
 
     # -- _C.rasterize_gaussians_backward ----------------------------------------------------
     def rasterize_gaussians_backward(self, background, means3D, radii, colors, scales, rotations, scale_modifier,
@@ -359,7 +430,7 @@ class RasterBackend:
         degree = int(round(M ** 0.5)) - 1
         out = self.forward_views(bg, xyz, None, opacity.reshape(B, -1), scaling, rotation, 1.0, None, view, proj, campos,
                                  tanfov, 0.0, 0.0, height, width, features, degree, False, False, views_per_set=V,
-                                 raw_activations=True, planned=True)
+                                 raw_activations=True, planned=True, forward_only=True)
         return out[1].reshape(B, V, 3, int(height), int(width))
 
     # -- _C.mark_visible ------------------------------------------------------------------

@@ -168,6 +168,40 @@ def test_sumsq_and_clip_match_clip_grad_norm_on_the_emulator():
         fopt.step(max_grad_norm=0.5)
 
 
+def test_a_non_finite_gradient_norm_skips_the_whole_update():
+    """What GradScaler.step does for the reference's 16-mixed training when a step produced inf / NaN: no parameter, no moment, no
+    engine copy changes (the norm is the all-reduced one, so every rank skips alike); the next finite step updates as usual."""
+    from emu_util import emu_lib
+    lib = emu_lib()
+    dev = torch.device("cpu")
+    m = dn.DGSDenoiser(CFG, device=dev, lib=lib)
+    m.reset_parameters(seed=5)
+    eng = m.engine()
+    fg = eng._train_state()["fg"]
+    views = eng.grad_views()
+    for n, p in m.named_parameters():
+        p.grad = views[n].reshape(p.shape)
+    fopt = FusedAdamW(m, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+    fg.flat.copy_(torch.randn(fg.flat.shape, generator=torch.Generator().manual_seed(2)))
+    fopt.step(grad_sumsq=torch.tensor([4.0]), max_grad_norm=0.5)            # one finite step: the moments exist
+    before = [p.detach().clone() for p in m.parameters()]
+    moments = (fopt.exp_avg.clone(), fopt.exp_avg_sq.clone())
+    dst = eng.weight_destinations()
+    copies = {n: tuple(None if c is None else c.clone() for c in pair) for n, pair in dst.items()}
+    fg.flat.fill_(float("nan"))
+    for bad in (float("nan"), float("inf")):
+        fopt.step(grad_sumsq=torch.tensor([bad]), max_grad_norm=0.5)
+        for p, b in zip(m.parameters(), before):
+            assert torch.equal(p.detach(), b)
+        assert torch.equal(fopt.exp_avg, moments[0]) and torch.equal(fopt.exp_avg_sq, moments[1])
+    for n, pair in eng.weight_destinations().items():
+        for now, was in zip(pair, copies[n]):
+            assert (now is None and was is None) or torch.equal(now, was), n
+    fg.flat.copy_(torch.randn(fg.flat.shape, generator=torch.Generator().manual_seed(3)))
+    fopt.step(grad_sumsq=torch.tensor([4.0]), max_grad_norm=0.5)
+    assert all(torch.isfinite(p).all() for p in m.parameters()) and not torch.equal(next(iter(m.parameters())).detach(), before[0])
+
+
 @pytest.mark.gpu
 def test_fused_adamw_matches_torch_on_gpu_at_the_shipped_width():
     worst = _check(*_case(torch.device("cuda:0"), None, dict(width=1024, in_channels=9, patch_size=8, num_layers=2)))

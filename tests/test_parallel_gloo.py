@@ -321,3 +321,77 @@ def test_broadcast_and_global_norm_clip_two_ranks():
     assert abs(np.sqrt((g * g).sum()) - 1e-3 * norm / (norm + 1e-6)) <= 1e-8
     step = (end.astype(np.float64) - start)
     np.testing.assert_allclose(step, -g, atol=1.2e-7)                    # SGD(lr = 1): the step IS the clipped gradient (to the fp32 rounding of p - g, p <= 1)
+
+
+def _overflow_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "..", "open-diffusiongs_amd"), os.path.join(here, "..")):
+        sys.path.insert(0, os.path.abspath(p))
+    from dgs_amd import denoiser as dn
+    from dgs_amd.optim import FusedAdamW
+    from dgs_amd.parallel import init_distributed
+    from dgs_amd.raster import RasterBackend, _AsyncPlan
+    from dgs_amd.train import DataParallelTrainer
+    from dit_util import synth_inputs
+    from emu_util import emu_lib
+    from oracle import dit_oracle as D
+    init_distributed(backend="gloo")
+    _AsyncPlan.MARGIN = 1.3                                     # the buffer holds little more than the plan has seen (an optimizer step moves the scene a bit)
+    cfg = D.Cfg(width=256, num_layers=1)
+    res = 64                                                    # 16 tiles per view: the near cameras give 2.2 x the far cameras' instances
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(cfg, 2, 2, res, seed=9)
+    sl = slice(rank, rank + 1)
+    batch = dict(image=images[sl], ray_o=ray_o[sl], ray_d=ray_d[sl], c2w=c2w[sl], fxfycxcy=k[sl])
+    far = c2w[sl].clone()
+    far[..., :3, 3] *= 3.0                                      # cameras three times as far: fewer tiles per Gaussian
+    target = torch.rand(2, 2, 3, res, res, generator=torch.Generator().manual_seed(3))[sl]
+    runs = {}
+    for mode in ("jump", "reference"):
+        m = dn.DGSDenoiser(dict(width=256, in_channels=9, patch_size=8, num_layers=1), device="cpu", lib=emu_lib())
+        m.reset_parameters(seed=1)
+        be = m.gs_renderer._backend = RasterBackend(lib=emu_lib())
+        with DataParallelTrainer(m, FusedAdamW(m, lr=1e-2, betas=(0.9, 0.99), weight_decay=0.0), bucket_bytes=1 << 20, max_grad_norm=0.5) as tr:
+            if mode == "jump":
+                tr.step(batch, t[sl], target, render_c2w=far)        # both ranks: the plan learns the far cameras' scene
+            else:                                                    # same first step, then a backend that has seen nothing: every
+                tr.step(batch, t[sl], target, render_c2w=far)        # render of step 2 runs the synchronous form (exact buffers)
+                be = m.gs_renderer._backend = RasterBackend(lib=emu_lib())
+            # step 2: rank 0 renders from the near cameras (far more instances than its plan provides), rank 1 stays far
+            loss = tr.step(batch, t[sl], target, render_c2w=None if rank == 0 else far)
+            plan = next(iter(be._plans.values()))
+            runs[mode] = (float(loss), float(tr.last_grad_sumsq), dict(plan.calls),
+                          torch.cat([q.detach().reshape(-1) for q in m.parameters()]).numpy())
+    out.put((rank, runs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_outgrows_its_raster_plan_and_the_ranks_stay_in_step():
+    """Rank 0's render outgrows the binning buffer its plan provides while rank 1's does not: rank 0 repeats the render inside its
+    forward (dgs_amd/raster.py `_AsyncPlan`: a plan at risk verifies its calls), nothing non-finite reaches the loss, the gradient
+    all-reduce and the clip see the same collectives on both ranks, and both replicas end with the parameters of the run in which
+    every render used the synchronous form."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    r0, r1 = res[0][1], res[1][1]
+    assert r0["jump"][2]["healed"] == 1 and r1["jump"][2]["healed"] == 0, (r0["jump"][2], r1["jump"][2])
+    assert r0["reference"][2]["healed"] == 0 and r0["reference"][2]["async"] == 0
+    for r in (r0, r1):
+        assert np.isfinite(r["jump"][0]) and np.isfinite(r["jump"][1]) and np.isfinite(r["jump"][3]).all()
+        assert r["jump"][0] == r["reference"][0] and r["jump"][1] == r["reference"][1]       # same loss, same (all-reduced) norm
+        np.testing.assert_array_equal(r["jump"][3], r["reference"][3])                      # same parameters
+    np.testing.assert_array_equal(r0["jump"][3], r1["jump"][3])                             # replicas identical
+    assert r0["jump"][1] == r1["jump"][1]
