@@ -116,11 +116,12 @@ typedef struct DgsDitAttentionArgs {
     size_t tail_ws_bytes;
     int32_t tail_mode;         /* the L % 32 tail queries: 0 (default) inside the main kernel (key-split records + merge at its end);
                                   1: this launch computes the full 32-query units only; 2: this launch computes ONLY the tail queries
-                                  (a small VALU kernel, one workgroup per (sample, head)).  The pair 1 + 2 on two streams was meant
-                                  to hide the tail behind the main kernel; measured, it cannot (the main kernel's one round of
-                                  workgroups holds every CU's register file: DESIGN.md section 9d) -- dgs_dit_forward uses mode 0
-                                  unless DGS_ATTN_TAIL_STREAM=1.  Needs dgs_dit_attention_tail_splittable(L, lpad); tail_ws is not
-                                  used by modes 1 and 2                                                                          */
+                                  (a small VALU kernel, one workgroup per (sample, head)).  dgs_dit_forward always uses mode 0: the
+                                  pair 1 + 2 on two streams cannot hide the tail (rounds 4 and 5 measured both orders:
+                                  profiles/r04_attention_tail_stream_ab.txt, profiles/r05_tail_chain_ab.txt); the modes stay as an
+                                  operator-level option (a caller with idle CUs) and as what the tools' build of the launch sequence
+                                  selects with DGS_TAIL_CHAIN.  Needs dgs_dit_attention_tail_splittable(L, lpad); tail_ws is not used
+                                  by modes 1 and 2                                                                               */
 } DgsDitAttentionArgs;
 
 /* Bytes of DgsDitAttentionArgs.tail_ws for this shape (0 when L % 32 == 0). */

@@ -162,6 +162,16 @@ __device__ __forceinline__ void raw_barrier() {
     __syncthreads();
 #endif
 }
+// workgroup barrier that orders LDS accesses only: the wave's LDS operations have completed, its vector-memory queue is left alone
+__device__ __forceinline__ void lds_barrier() {
+#ifndef HIPEMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 // fence for hipcc's instruction scheduler: what is written before it issues before it
 __device__ __forceinline__ void sched_fence() {
 #ifndef HIPEMU
@@ -175,6 +185,11 @@ __device__ __forceinline__ void sched_fence() {
 constexpr bool kInstrumented = true;
 #else
 constexpr bool kInstrumented = false;
+#endif
+// Launch-sequence experiments that were built, measured and did not win (each names its profiles/ file) are compiled into the tools'
+// library and the CPU emulation build (whose tests keep them correct), never into the product library.
+#if defined(DGS_INSTRUMENT) || defined(HIPEMU)
+#define DGS_EXPERIMENTS 1
 #endif
 // shader-clock / constant 100 MHz stamps of the debug modes (0 on the emulator)
 __device__ __forceinline__ long long cycle_stamp() {

@@ -124,6 +124,7 @@ template <int I, int N, class F> __device__ __forceinline__ void sliced_for(F&& 
 }
 
 __device__ long long dgs_gemm_dbg[16];   // DGS_GEMM_DBG: cycle stamps of workgroup 0, wave 0 (loop total, wait + barrier share)
+__device__ unsigned dgs_gemm_tl[1024][4]; // DGS_GEMM_DBG: per workgroup {start, loop start, loop end, end} on the constant 100 MHz clock (low 32 bits)
 
 // NW = 4 ("quad"): the same ring and schedule with 4 waves as 2 x 2, a wave owning 128 x 128 (4 x 4 accumulators = 256
 // registers, which hipcc keeps in AGPRs: MFMA reads and writes them there, nothing else touches them before the epilogue).
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         (void)t;
     };
     const long long dbg_t0 = dbg == 1 ? cycle_stamp() : 0;
+    const long long dbg_w1 = dbg == 1 ? wall_stamp() : 0;
     auto k_loop = [&](auto dbg_tag) {
         for (int t = 0; t < nk - NS; t += NS)                      // unrolled by the ring depth: slots are literals
             sliced_for<0, NS>([&](auto sc) { iteration(t + decltype(sc)::value, sc, std::true_type{}, SIC<0>{}, SIC<0>{}, dbg_tag); });
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         k_loop(std::false_type{});
     }
     const long long dbg_t1 = dbg == 1 ? cycle_stamp() : 0;
+    const long long dbg_w2 = dbg == 1 ? wall_stamp() : 0;
     if (epi_staged<EPI>(p)) {          // the ring is idle now (everybody passed the last barrier): a private LDS patch per wave
         char* patch = lds + wave * epi_strip_bytes(2);
 #pragma unroll
@@ -421,6 +424,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     }
     if constexpr (kInstrumented) if (dbg == 1) {
         wait_vmcnt<0>();
+        if (tid == 0 && bid < 1024) {
+            dgs_gemm_tl[bid][0] = (unsigned)dbg_w0; dgs_gemm_tl[bid][1] = (unsigned)dbg_w1; dgs_gemm_tl[bid][2] = (unsigned)dbg_w2;
+            dgs_gemm_tl[bid][3] = (unsigned)wall_stamp();
+        }
         if (tid == 0) {
             atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[6]), (unsigned long long)(cycle_stamp() - dbg_k0));
             atomicMax(reinterpret_cast<unsigned long long*>(&dgs_gemm_dbg[7]), (unsigned long long)dbg_wait);
@@ -495,6 +502,28 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
         long long h[12];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(dgs_gemm_dbg), sizeof(h));
+        {
+            // the launch's timeline: per phase min / mean / max over the tile workgroups, in us from the first workgroup's start
+            static unsigned tl[1024][4];
+            (void)hipMemcpyFromSymbol(tl, HIP_SYMBOL(dgs_gemm_tl), sizeof(tl));
+            const int n = p.ntiles < 1024 ? p.ntiles : 1024;
+            unsigned t0 = 0xffffffffu;
+            for (int i = 0; i < n; ++i) t0 = tl[i][0] < t0 ? tl[i][0] : t0;
+            double acc[4] = {0, 0, 0, 0}, mn[4] = {1e9, 1e9, 1e9, 1e9}, mx[4] = {0, 0, 0, 0};
+            const int nt = p.nfull_items < n ? p.nfull_items : n;
+            for (int i = 0; i < nt; ++i)
+                for (int k = 0; k < 4; ++k) { const double v = (tl[i][k] - t0) / 100.0; acc[k] += v; mn[k] = v < mn[k] ? v : mn[k]; mx[k] = v > mx[k] ? v : mx[k]; }
+            fprintf(stderr, "[gemm timeline] %d tile workgroups (of %d), us since the first start: start %.2f/%.2f/%.2f  loop start %.2f/%.2f/%.2f  loop end %.2f/%.2f/%.2f  end %.2f/%.2f/%.2f (min/mean/max)\n",
+                    nt, n, mn[0], acc[0] / nt, mx[0], mn[1], acc[1] / nt, mx[1], mn[2], acc[2] / nt, mx[2], mn[3], acc[3] / nt, mx[3]);
+            double xe[8] = {0}, xl[8] = {0}; int xn[8] = {0};
+            for (int i = 0; i < nt; ++i) { xe[i & 7] += (tl[i][3] - t0) / 100.0; xl[i & 7] += (tl[i][2] - tl[i][1]) / 100.0; ++xn[i & 7]; }
+            fprintf(stderr, "[gemm timeline] by block id %% 8 (XCD): mean loop us / mean end us:");
+            for (int x = 0; x < 8; ++x) fprintf(stderr, " %.2f/%.2f", xn[x] ? xl[x] / xn[x] : 0.0, xn[x] ? xe[x] / xn[x] : 0.0);
+            double se = 0, s2 = 0;      // workgroups with a side job (the first ntail) against the rest: time to the loop
+            int c1 = 0, c2 = 0;
+            for (int i = 0; i < nt; ++i) { if (p.tail_wgs == 0 && i < p.ntail) { se += (tl[i][1] - tl[i][0]) / 100.0; ++c1; } else { s2 += (tl[i][1] - tl[i][0]) / 100.0; ++c2; } }
+            fprintf(stderr, "\n[gemm timeline] prologue us: %d workgroups with a side job %.2f, %d without %.2f\n", c1, c1 ? se / c1 : 0.0, c2, c2 ? s2 / c2 : 0.0);
+        }
         fprintf(stderr, "[gemm dbg] M=%d N=%d K=%d BN=%d: prologue %lld, loop %lld cycles (%lld per slab), vmcnt wait %lld, barrier %lld, epilogue %lld | slowest wg %lld cycles, max vmcnt wait %lld per slab, workgroup 0: %lld cycles in %.2f us = %.0f MHz\n", p.M,
                 p.N, p.K, BN, h[4], h[0], h[0] / h[3], h[1] / h[3], h[2] / h[3], h[5], h[6], h[7] / h[3], h[10], h[11] / 100.0, h[10] / (h[11] / 100.0));
     }

@@ -12,10 +12,14 @@ NAMES = {"means2D": "dL_dmeans2D", "colors": "dL_dcolors", "opacity": "dL_dopaci
          "cov3D": "dL_dcov3D", "sh": "dL_dsh", "scales": "dL_dscales", "rotations": "dL_drotations"}
 
 
+OBSERVED = []          # (what, max |got - ref| / max |ref|) of every comparison: tools/raster_grad_error.py reads it
+
+
 def close(got, ref, rtol=2e-4, what=""):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     scale = max(float(np.abs(ref).max()), 1e-12)
     err = float(np.abs(got - ref).max())
+    OBSERVED.append((what, err / scale))
     assert err <= rtol * scale + 1e-9, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 

@@ -139,7 +139,7 @@ def test_eager_forward_recovers_from_an_instance_jump(monkeypatch):
     m = _model(seed=3)
     res = 128
     batch, t = synth.make_batch(1, res, V=4, device=DEV, seed=2, with_t=True)
-    far = _far(batch, 3.0)
+    far = _far(batch, 5.0)
     with torch.no_grad():
         want_far, want_near = _fresh_reference(m, far, t), _fresh_reference(m, batch, t)
         m.gs_renderer._backend = be = RasterBackend()
@@ -169,7 +169,7 @@ def test_graph_overflow_recovers(monkeypatch):
     m = _model(seed=3)
     res = 128
     batch, t = synth.make_batch(1, res, V=4, device=DEV, seed=2, with_t=True)
-    far = _far(batch, 3.0)
+    far = _far(batch, 5.0)
     with torch.no_grad():
         want_far, want_near = _fresh_reference(m, far, t), _fresh_reference(m, batch, t)
         m.gs_renderer._backend = RasterBackend()             # a backend of its own: fresh plans
@@ -196,7 +196,7 @@ def test_graph_with_the_worst_case_buffer_never_waits():
     m = _model(seed=3)
     res = 128
     batch, t = synth.make_batch(1, res, V=4, device=DEV, seed=2, with_t=True)
-    far = _far(batch, 3.0)
+    far = _far(batch, 5.0)
     with torch.no_grad():
         want_near = _fresh_reference(m, batch, t)
         m.gs_renderer._backend = RasterBackend()

@@ -243,3 +243,44 @@ def test_engine_copies_follow_the_optimizer_in_a_trainer_step(kind):
                 assert torch.equal(copy_t, copy.t()), (kind, n)
             moved += int(not torch.equal(p.detach(), before[n]))
         assert moved > 0.9 * len(before), (kind, moved)
+
+
+@pytest.mark.gpu
+def test_two_trainer_runs_from_the_same_state_are_bit_identical():
+    """The training step is bit-reproducible by default: DataParallelTrainer selects the rasterizer backward without floating-point
+    atomics (dgs_raster.h `scratch`), the DiT backward has none, the norm / clip / AdamW launches sum in a fixed order.  Three steps at
+    256^2 (L = 4098, two samples, 4 rendered views each, clip + FusedAdamW), twice from the same seed: identical losses, identical
+    gradient norms, every parameter identical bit for bit.  With deterministic=False the atomic form runs and says so."""
+    import numpy as np
+    from dgs_amd import cameras, synth
+    from dgs_amd.train import DataParallelTrainer
+    dev = torch.device("cuda:0")
+    res, B, RV = 256, 2, 4
+    batch, t = synth.make_batch(B, res, V=4, device=dev, seed=5, with_t=True)
+    rc2w = torch.tensor(np.stack([cameras.ring_cameras(RV, phase_deg=5.0 + 7 * b) for b in range(B)])).to(dev)
+    rk = torch.tensor(cameras.default_fxfycxcy(res)).expand(B, RV, 4).contiguous().to(dev)
+    target = torch.rand(B, RV, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    runs = []
+    for _ in range(2):
+        m = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=4), device=dev)
+        m.reset_parameters(seed=2)
+        m = m.to(dev)
+        m.train()
+        with DataParallelTrainer(m, FusedAdamW(m, lr=1e-4, betas=(0.9, 0.99), weight_decay=0.05), max_grad_norm=0.5) as tr:
+            assert tr.deterministic and m.gs_renderer.backend().deterministic
+            log = []
+            for _ in range(3):
+                loss = tr.step(batch, t, target, rc2w, rk)
+                log.append((float(loss), float(tr.last_grad_sumsq)))
+            assert m.gs_renderer.backend().last_backward_deterministic
+        runs.append((log, {n: p.detach().clone() for n, p in m.named_parameters()}))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    bad = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[1][1][n])]
+    assert not bad, (len(bad), bad[:6])
+    m = dn.DGSDenoiser(dict(width=1024, in_channels=9, patch_size=8, num_layers=4), device=dev)
+    m.reset_parameters(seed=2)
+    m = m.to(dev)
+    m.train()
+    with DataParallelTrainer(m, FusedAdamW(m, lr=1e-4), deterministic=False) as tr:
+        tr.step(batch, t, target, rc2w, rk)
+        assert m.gs_renderer.backend().last_backward_deterministic is False

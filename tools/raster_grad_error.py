@@ -1,0 +1,32 @@
+"""What the rasterizer backward achieves against the oracle's fp64-accumulated sums (SURVEY section 8c asks for 1e-4 of each tensor's
+max), per gradient tensor, with the product's blend exponential (hardware v_exp_f32) and with the oracle's own (`exact_exp`):
+256^2 trained-like (2 views) and random-init (1 view), 512^2 trained-like (1 view); atomic and deterministic backward.
+    python tools/raster_grad_error.py  > gpurun_out/raster_grad_error.txt"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "open-diffusiongs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+
+import raster_bwd_util as U
+from dgs_amd import synth
+from dgs_amd.raster import RasterBackend
+
+DEV = torch.device("cuda:0")
+for res, regime, views in ((256, "trained", 2), (256, "init", 1), (512, "trained", 1)):
+    sc = synth.gaussian_scene(res, regime=regime, seed=0)
+    cams, _, _ = synth.render_cameras(res, 4, phase_deg=10)
+    for exact in (False, True):
+        for det in (False, True):
+            be = RasterBackend()
+            be.deterministic = det
+            U.OBSERVED.clear()
+            U.assert_backward_parity(be, sc, cams[:views], res, res, DEV, exact=exact, rtol=1.0)
+            worst = {}
+            for what, e in U.OBSERVED:
+                k = what.split(" view")[0]
+                worst[k] = max(worst.get(k, 0.0), e)
+            print(f"{res}^2 {regime:8s} {views} view(s)  exp {'oracle' if exact else 'v_exp_f32'}  backward {'deterministic' if det else 'atomic':13s}  "
+                  f"max over tensors {max(worst.values()):.2e}   " + "  ".join(f"{k} {v:.1e}" for k, v in worst.items()), flush=True)
