@@ -388,12 +388,23 @@ def train_bench(a, dev, rank, world, steps, warmup, scene=None):
     log = tr.reducer.launch_log
     tr.close()
     micro = min(B, getattr(model, "MAX_DIFFERENTIABLE_BATCH", 4))
-    head = {} if scene is None else {
+    mem = None
+    if not DRY["on"]:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        mem = {"peak_allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "reserved": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1),
+               "free": round(free_b / 2 ** 30, 1), "total": round(total_b / 2 ** 30, 1)}
+    rb = getattr(model.gs_renderer, "backend", None)
+    raster_note = None
+    if rb is not None:
+        be = rb()
+        raster_note = {"deterministic_backward": bool(getattr(be, "last_backward_deterministic", False)),
+                       "plans": [{"capacity": pl.capacity, "seen_max": pl.seen_max, "calls": dict(pl.calls)} for pl in be._plans.values()][-3:]}
+    head = {"gpu_memory_gib": mem, "raster": raster_note} if scene is None else {
         "workload": "scene-512 training step (BASELINE.json configs[4]: train_scene_stage2.sh, diffusionGS_scene_512.yaml): DGSDenoiserScene, "
                     "%d samples / GPU as micro-batches of %d inside one optimizer step, %d input + %d rendered views at %d^2, L=%d, P=%d" %
                     (B, micro, V, RV, res, L, 2 + V * res * res),
         "micro_batch": micro, "resolution": res, "tokens": L, "dit_tflop_per_sample_fwd": round(dit_flops(L) / 1e12, 2),
-        "gpu_memory_gib": {"peak_allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1) if not DRY["on"] else None}}
+        "gpu_memory_gib": mem, "raster": raster_note}
     return {**head, "ms_per_step": round(ms, 2), "samples_per_s": round(B * world / (ms * 1e-3), 2), "batch_per_gpu": B, "rendered_views": RV,
             "steps": steps, "warmup": warmup, "loss": round(float(loss), 6), "recompute": recompute, "optimizer": a.optimizer,
             "dit_tflops_per_gpu": round(flops / (ms * 1e-3) / 1e12, 1), "frac_of_bf16_peak": round(flops / (ms * 1e-3) / PEAK_BF16_MFMA, 4),
@@ -475,7 +486,16 @@ def main():
         if a.dry_run_cpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)   # RCCL
+            os.environ.setdefault("NCCL_DEBUG", "VERSION")    # RCCL prints its version line into stderr when its communicator comes up: the
+            dist.init_process_group("nccl", device_id=dev)   # run's own evidence that the collectives below went through RCCL
+        # every rank adds one: the number of ranks that really took part in THIS process group, said before anything is timed
+        seen = torch.ones(1, dtype=torch.float32, device=dev if not a.dry_run_cpu else "cpu")
+        dist.all_reduce(seen)
+        if not a.dry_run_cpu:
+            torch.cuda.synchronize()
+        print(f"[bench] rank {rank}: process group up, backend {dist.get_backend()}, world_size {dist.get_world_size()}, ranks_seen {int(seen.item())}"
+              f"{'' if int(seen.item()) == a.gpus else '  != --gpus ' + str(a.gpus)}", file=sys.stderr, flush=True)
+        assert int(seen.item()) == world, f"all-reduce over the process group counted {int(seen.item())} ranks, WORLD_SIZE={world}"
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dry_note = {"dry_run": "CPU emulator + gloo + tiny model: exercises launch / timing / reduction plumbing, NOT a measurement"} if a.dry_run_cpu else {}
 

@@ -301,6 +301,103 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pass as ONE kernel (4 launches per sort instead of 12: the three-kernel pass is 6.8 + 6.5 + 20.2 us plus two launch
+// boundaries at 256^2 x 4 views, profiles/r04_bench_kernel_stats.txt).  A workgroup counts its tile's digits, PUBLISHES the 256
+// counts (agent-scope stores: performed at the memory side, visible to every XCD without a fence) and adds one to the view's arrival
+// counter; once all NB workgroups of the view have arrived it reads all NB x 256 counts (agent-scope loads) -- thread d sums digit
+// d over the blocks in front of its own and over all of them -- scans the digit totals, and scatters as radix_scatter_kernel does.
+// The wait is a spin on one word by one lane (s_sleep between polls) and needs the view's workgroups to be resident together:
+// dispatch is in block order and a view's workgroups only wait for each other, so whatever fits the chip of the views in front has
+// either finished or can finish; the host still takes the three-kernel pass when NB x V exceeds what the chip holds at once
+// (training calls with dozens of views) and on the CPU emulation build (workgroups run one after the other there).  The spin is
+// bounded: a view that does not assemble in ~1 s leaves DGS_ERR_DEVICE in the call's status word instead of hanging the GPU.
+// Keys and values stay in registers between the count and the scatter (one read of the tile instead of two).
+// ------------------------------------------------------------------------------------------------
+#ifndef HIPEMU
+__global__ __launch_bounds__(256) void radix_pass_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                                                        uint32_t* rank_of, uint32_t* hist, uint32_t* arrived, int32_t* status, int P, int NB,
+                                                        int shift) {
+    __shared__ uint32_t wcount[4][256];
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t scratch[8];
+    __shared__ int s_ok;
+    const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const size_t vo = (size_t)v * P;
+    uint32_t key[kSortItems], val[kSortItems];
+    running[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int i = b * kSortTile + r * 256 + tid;
+        const bool valid = i < P;
+        key[r] = valid ? keys_in[vo + i] : 0xFFFFFFFFu;
+        val[r] = valid ? (vals_in ? vals_in[vo + i] : (uint32_t)i) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+        if (b * kSortTile + r * 256 + tid < P) atomicAdd(&running[(key[r] >> shift) & 255u], 1u);
+    __syncthreads();
+    uint32_t* const hv = hist + (size_t)v * NB * 256;
+    __hip_atomic_store(hv + (size_t)b * 256 + tid, running[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's count stores have been performed
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(arrived + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+            if (__hip_atomic_load(arrived + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)NB) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!ok) status[1] = DGS_ERR_DEVICE;
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    // thread d: digit d's count in the blocks in front of this one, and in all of them
+    uint32_t before = 0, total = 0;
+    for (int j0 = 0; j0 < NB; j0 += 16) {                        // sixteen loads per round trip
+        uint32_t c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = j0 + u < NB ? __hip_atomic_load(hv + (size_t)(j0 + u) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { total += c[u]; if (j0 + u < b) before += c[u]; }
+    }
+    uint32_t all;
+    const uint32_t ex = block_exclusive_scan<256>(total, scratch, &all);
+    __syncthreads();
+    running[tid] = ex + before;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
+        __syncthreads();
+        const bool valid = b * kSortTile + r * 256 + tid < P;
+        const uint32_t dig = (key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long m = __ballot((dig >> bit) & 1u);
+            peers &= ((dig >> bit) & 1u) ? m : ~m;
+        }
+        const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+        if (valid && rank_in_wave == 0) wcount[wave][dig] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[dig] + rank_in_wave;
+            for (int w = 0; w < wave; ++w) pos += wcount[w][dig];
+            keys_out[vo + pos] = key[r];
+            vals_out[vo + pos] = val[r];
+            if (rank_of) rank_of[vo + val[r]] = pos;
+        }
+        __syncthreads();
+        running[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
+    }
+}
+#endif
+
 // Exclusive scan of the V*T tile counts -> [start,end) ranges into the packed instance list (one workgroup), and the launch
 // order of the per-tile kernels (deal_tiles, by list length).
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2* ranges, uint32_t* cursor, int n,
@@ -1122,8 +1219,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
     if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
-    // tile_count and totals are neighbours in the image state (ImageState::carve): one fill
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, (int)(reinterpret_cast<uint32_t*>(p.im.totals + 4) - p.im.tile_count));
+    // tile_count, totals and the radix sort's arrival counters are neighbours in the image state (ImageState::carve): one fill
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, (int)(p.im.radix_sync + 4 * kRadixSyncViews - p.im.tile_count));
     const dim3 gridP((P + 255) / 256, V);
     const bool lds_tiles = p.T <= 4096;
     if (lds_tiles) hipLaunchKernelGGL((preprocess_kernel<true>), gridP, dim3(256), (size_t)p.T * 4, st, p);
@@ -1157,6 +1254,22 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     bool radix_done = false;
     auto radix_sort = [&]() {
         const int NB = sort_blocks(P);
+#ifndef HIPEMU
+        // one kernel per pass while all of a call's sort workgroups fit the chip together (radix_pass_kernel); DGS_RASTER_RADIX3=1: the
+        // three-kernel pass (measurement aid)
+        static const int ncu = [] { int n = 0, d = 0; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+        static const bool three = getenv("DGS_RASTER_RADIX3") && atoi(getenv("DGS_RASTER_RADIX3")) != 0;
+        if (!three && ncu > 0 && (long long)NB * V <= 4ll * ncu && V <= kRadixSyncViews) {
+            for (int pass = 0; pass < 4; ++pass) {
+                const int in = pass & 1, out = in ^ 1;
+                hipLaunchKernelGGL(radix_pass_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], pass == 0 ? (const uint32_t*)nullptr : p.g.vals[in], p.g.keys[out],
+                                   p.g.vals[out], pass == 3 ? p.g.rank_of : (uint32_t*)nullptr, p.g.radix_hist, p.im.radix_sync + pass * kRadixSyncViews, p.im.totals, P, NB,
+                                   8 * pass);
+            }
+            radix_done = true;
+            return;
+        }
+#endif
         for (int pass = 0; pass < 4; ++pass) {
             const int in = pass & 1, out = in ^ 1;
             hipLaunchKernelGGL(radix_hist_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], p.g.radix_hist, P, NB, 8 * pass);

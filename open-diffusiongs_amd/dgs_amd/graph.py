@@ -16,6 +16,21 @@ import torch
 _INPUT_KEYS = ("image", "ray_o", "ray_d", "c2w", "fxfycxcy")
 
 
+_ROW_POOL = []          # page-locked int32[4] rows, allocated in chunks and NEVER freed (a graph may still store into its rows while it is
+                        # being collected; freeing page-locked memory is a device-wide synchronisation)
+
+
+def _pinned_rows(n):
+    """n page-locked statistics rows for one capture, from a process-wide pool."""
+    while len(_ROW_POOL) < n:
+        chunk = torch.zeros(64, 4, dtype=torch.int32).pin_memory()
+        _ROW_POOL.extend(chunk[i] for i in range(64))
+    rows, _ROW_POOL[:] = _ROW_POOL[:n], _ROW_POOL[n:]
+    for r in rows:
+        r.zero_()
+    return rows
+
+
 class GraphedForward:
     MAX_RASTER_CALLS = 8          # pinned statistics rows handed to the rasterizer calls of one captured step
 
@@ -45,19 +60,34 @@ class GraphedForward:
                 model(self.static, self.t)
         torch.cuda.current_stream(dev).wait_stream(side)
         backend.check_async(wait=True)                 # the warm-up renders' statistics: capacity + ordering form of the capture
-        self._rows = torch.zeros(self.MAX_RASTER_CALLS, 4, dtype=torch.int32).pin_memory()
+        if getattr(self, "_rows", None):
+            _ROW_POOL.extend(self._rows)               # a re-capture: the graph that stored into them is replaced below
+        self._rows = _pinned_rows(self.MAX_RASTER_CALLS)
         backend.begin_capture_log(self._rows)
         self.graph = torch.cuda.CUDAGraph()
+        # No cyclic garbage collection while the stream is capturing: a finalizer that frees page-locked memory or destroys a graph of
+        # an object that died earlier is not a capturable operation (seen as a bare abort() in the GPU suite when graph tests ran behind
+        # tests that leave trainers and backends for the collector).  torch.cuda.graph() collects once on entry; this keeps it at that.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             # thread_local: other threads of the process (RCCL's watchdog polls its events) must not invalidate the capture
             with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.rendered, self.gaussians = model(self.static, self.t)
         finally:
+            if gc_was_on:
+                gc.enable()
             self._watch = backend.end_capture_log()    # [(plan, pinned row, capacity, (P, W, H, V))] of the captured rasterizer calls
         if not self._watch:
             raise RuntimeError("GraphedForward: the captured step made no planned rasterizer call -- nothing to verify replays against")
         self._verify = any(plan.at_risk(cap) for plan, _row, cap, _shape in self._watch)
         self._event = None
+
+    def __del__(self):
+        rows = getattr(self, "_rows", None)
+        if rows and _ROW_POOL is not None:
+            _ROW_POOL.extend(rows)                     # back to the pool (never freed)
 
     @staticmethod
     def shape_key(input_batch, timesteps):

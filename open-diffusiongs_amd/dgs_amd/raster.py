@@ -90,10 +90,20 @@ class _AsyncPlan:
         self.slot = (self.slot + 1) % self.SLOTS
         return w
 
+    @staticmethod
+    def _grid(n):
+        """n rounded up to a grid of eight steps per power of two.  A training run's instance count creeps by a few thousand every
+        step; a capacity that followed it exactly asked the allocator for a slightly LARGER multi-gigabyte buffer every step -- no cached
+        block ever fits, each step pays a fresh hipMalloc (1.2 s per step with the 45 GB scratch of the deterministic backward,
+        profiles/r05_train_det_alloc.txt) and the freed blocks pile up in the cache."""
+        n = max(int(n), 1024)
+        step = max(1 << (n.bit_length() - 1), 8) >> 3
+        return -(-n // step) * step
+
     def note(self, lib, n, longest, P, W, H, V):
         self.seen_max = max(self.seen_max, int(n))
         self.longest = max(self.longest, int(longest))
-        self.capacity = max(self.capacity, int(self.MARGIN * self.seen_max) + 1024)
+        self.capacity = max(self.capacity, self._grid(self.MARGIN * self.seen_max + 1024))
         self.form = int(lib.dgs_raster_binning_form(0, int(n), int(longest), P, W, H, V))
 
     def poll(self, lib, P, W, H, V, wait=False):

@@ -32,20 +32,24 @@ class DataParallelTrainer:
         """deterministic (default on; DGS_RASTER_DETERMINISTIC=0 or False turns it off): the rasterizer backward without floating-point
         atomics (dgs_raster.h `scratch`), which makes the WHOLE step bit-reproducible -- the DiT backward, the bucketed all-reduce
         order, the norm and the AdamW launch already are -- for +0.10 of 1.07 ms of rasterizer backward at 4 views of 256^2
-        (profiles/r04_raster_deterministic_ab.txt), ~0.1 % of the step.  Two runs from the same state then hold identical parameters,
+        (profiles/r04_raster_deterministic_ab.txt), ~0.1 % of the step, in trained-like scenes, and +1.6 % of the step (90.9 -> 92.4 ms,
+        profiles/r05_train_det_alloc.txt) in the densest case the bench has: 4 x 10 views of random-init Gaussians, 634 M instances,
+        45 GB of scratch (36 bytes per instance slot; past `backend.deterministic_budget` = 64 GiB the atomic form runs and
+        `backend.last_backward_deterministic` says so).  Two runs from the same state then hold identical parameters,
         and so do the ranks of a data-parallel job after every step (tests/test_optim.py, tests/test_parallel_gloo.py).
         max_grad_norm: global-norm gradient clip (Lightning `gradient_clip_val`; the reference trains with 0.5,
         configs/diffusionGS_rel.yaml:76-77) -- the norm's partial sums are taken bucket by bucket behind each bucket's all-reduce and
         the scale is applied inside the optimizer launch (FusedAdamW) or as one in-place scale of the flat buffer (any other optimizer).
         broadcast_from: the rank whose parameters every rank starts from (DDP's init-time broadcast); None skips it."""
         self.model, self.opt = model, optimizer
+        import os
         if deterministic is None:
-            import os
             deterministic = os.environ.get("DGS_RASTER_DETERMINISTIC", "1") not in ("", "0")
         self.deterministic = bool(deterministic)
         renderer = getattr(model, "gs_renderer", None)
         self._raster_backend = renderer.backend() if renderer is not None and hasattr(renderer, "backend") else None
         self._raster_was_deterministic = getattr(self._raster_backend, "deterministic", None)
+        self._raster_was_budget = getattr(self._raster_backend, "deterministic_budget", None)
         if self._raster_backend is not None:
             self._raster_backend.deterministic = self.deterministic
         self.accumulate = int(accumulate_grad_batches)
@@ -85,6 +89,7 @@ class DataParallelTrainer:
                     p.grad = p.grad.clone()
             if self._raster_backend is not None and self._raster_was_deterministic is not None:
                 self._raster_backend.deterministic = self._raster_was_deterministic
+                self._raster_backend.deterministic_budget = self._raster_was_budget
 
     def __enter__(self):
         return self

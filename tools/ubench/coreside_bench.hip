@@ -23,6 +23,17 @@ __global__ __launch_bounds__(256, 8) void bg_gemv_kernel(const uint4* __restrict
     if (lane == 0) out[wave] = s;
 }
 
+// An RCCL-shaped neighbour: `wgs` workgroups of 512 threads copy `n16` 16-byte words in a grid-stride loop (a ring all-reduce step on one
+// rank is a few dozen such workgroups streaming its buckets between HBM and the xGMI links for the whole backward).
+__global__ __launch_bounds__(512) void bg_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 512) dst[i] = src[i];
+}
+
+extern "C" int coreside_copy(const void* src, void* dst, size_t bytes, int wgs, void* stream) {
+    hipLaunchKernelGGL(bg_copy_kernel, dim3(wgs), dim3(512), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(src), static_cast<uint4*>(dst), bytes / 16);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int coreside_bg(const void* w, const void* a, float* out, int wgs, int chunks, size_t wave_stride_uint4, void* stream) {
     hipLaunchKernelGGL(bg_gemv_kernel, dim3(wgs), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(w), static_cast<const uint4*>(a), out, chunks,
                        wave_stride_uint4);
