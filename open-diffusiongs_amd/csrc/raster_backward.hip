@@ -324,11 +324,12 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
         } else {
             // entry `tid`: the tile's sums, stored into the slot of (Gaussian, this tile)
             float c9[9];
-            bool any = false;
-#pragma unroll
+            bool any = false;                                      // any of the four per-wave copies non-zero: from the COPIES, not from their
+#pragma unroll                                                     // sum (partials that cancel exactly would otherwise stay behind for the next batch)
             for (int q = 0; q < 9; ++q) {
-                c9[q] = ((s_acc[0][q][tid] + s_acc[1][q][tid]) + s_acc[2][q][tid]) + s_acc[3][q][tid];
-                any = any || c9[q] != 0.f;
+                const float a0 = s_acc[0][q][tid], a1 = s_acc[1][q][tid], a2 = s_acc[2][q][tid], a3 = s_acc[3][q][tid];
+                c9[q] = ((a0 + a1) + a2) + a3;
+                any = any || a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f;
             }
             // every replayed entry STORES its sums (zeros too): Gaussian-major, the tile's index inside the Gaussian's rectangle (the
             // forward's tile_rect on the same state: the same rectangle)
@@ -585,8 +586,9 @@ __global__ __launch_bounds__(128) void blend_backward_pair_kernel(BwdParams p) {
                 bool any = false;
 #pragma unroll
                 for (int z = 0; z < 9; ++z) {
-                    c9[z] = s_acc[0][z][e] + s_acc[1][z][e];
-                    any = any || c9[z] != 0.f;
+                    const float a0 = s_acc[0][z][e], a1 = s_acc[1][z][e];
+                    c9[z] = a0 + a1;
+                    any = any || a0 != 0.f || a1 != 0.f;           // the copies, not their sum (see blend_backward_kernel)
                 }
                 if (idxs[h] >= 0) {
                     if (any) {

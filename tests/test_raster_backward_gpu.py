@@ -50,15 +50,21 @@ def test_full_size_256_vs_oracle(regime, views):
     assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV)
 
 
-@pytest.mark.parametrize("regime,views", [("trained", 2), ("init", 1)])
-def test_full_size_256_product_default_exp(regime, views):
-    """The same with the product's blend exponential (hardware v_exp_f32, `exact_exp` = 0): 2e-3 of each tensor's max."""
+@pytest.mark.parametrize("regime,views,rtol", [("trained", 2, 4e-3), ("init", 1, 1e-5)])
+def test_full_size_256_product_default_exp(regime, views, rtol):
+    """The same with the product's blend exponential (hardware v_exp_f32, `exact_exp` = 0).  Bars = 2-3 x what tools/raster_grad_error.py
+    measures against the oracle's fp64 sums (profiles/r05_raster_grad_error.txt): 1.8e-3 of a tensor's max in the trained-like scene
+    (dL/dscale; 1.3e-3 dL/dopacity) and 3.4e-6 in the random-init scene -- against 6.6e-6 / 4.7e-6 with the oracle's own exponential,
+    which is what summation order leaves.  The trained-like figure is not rounding noise accumulating: v_exp_f32's last-place error puts a
+    few (pixel, Gaussian) pairs on the other side of the 1/255 alpha cut-off (forward.cu:336 / backward.cu:478), and such a pair moves its
+    Gaussian's gradient by the pair's whole contribution; thin, nearly transparent Gaussians -- the trained-like scene -- have many
+    pairs near the cut-off.  SURVEY 8c's 1e-4 holds for the oracle-exp build (`exact_exp` = 1, 7e-6); DESIGN.md section 2 states both."""
     sc = synth.gaussian_scene(256, regime=regime, seed=0)
     cams, _, _ = synth.render_cameras(256, 4, phase_deg=10)
-    assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV, exact=False, rtol=2e-3)
+    assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV, exact=False, rtol=rtol)
 
 
-@pytest.mark.parametrize("exact,rtol", [(True, 2e-4), (False, 2e-3)], ids=["exact_exp", "product_default"])
+@pytest.mark.parametrize("exact,rtol", [(True, 2e-4), (False, 2e-4)], ids=["exact_exp", "product_default"])
 def test_full_size_512_vs_oracle(exact, rtol):
     """BASELINE configs[4] (512^2, P = 1,048,578 Gaussians, 1,024 tiles, trained-like regime: N ~ 7 M instances, the list forms of
     the binning incl. the 1,024-thread per-tile sort): every gradient of one view against the oracle's fp64-accumulated sums
