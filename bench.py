@@ -135,18 +135,27 @@ def cpu_baseline(model, batch, t, res, V, hip_gaussians, hip_render):
     cores = os.cpu_count() or 1
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     cpu = {k: v[:1].cpu() for k, v in batch.items()}
-    # The DiT leg (97 % of the baseline's time) on ALL host cores and on 64 threads (beyond that torch's CPU GEMMs at
-    # L = 4098 mostly add oversubscription): both are measured and stated, `value` / `cores` are the faster of the two.
-    dit_runs = {}
+    # The DiT leg is 97 % of the baseline's time.  SURVEY.md 8d asks for all host cores; beyond ~64 threads torch's CPU GEMMs at L = 4098
+    # mostly add oversubscription (256 threads: 89 s against 12.7 s with 64 on the round-5 box).  To keep the leg inside its ~30 s budget
+    # both thread counts are timed on a TWO-block probe of the same sample (the 24 blocks are identical work), the full 24 blocks run once
+    # with the faster count; `value` / `cores` are that run, the probe times of both counts are stated.
+    probe_cfg = D.Cfg(num_layers=2)
+    probe = {}
     for n_thr in sorted({cores, min(cores, 64)}, reverse=True):
         torch.set_num_threads(n_thr)
         RO.set_threads(n_thr)                      # torch and the oracle share one OpenMP runtime: keep its pool at the torch size for the DiT leg
         t0 = time.perf_counter()
         with torch.no_grad():
-            g, _ = D.image_to_gaussians(sd, D.Cfg(), cpu["image"], cpu["ray_o"], cpu["ray_d"], t[:1].cpu())
-        dit_runs[n_thr] = time.perf_counter() - t0
-    dit_threads = min(dit_runs, key=dit_runs.get)
-    t_dit = dit_runs[dit_threads]
+            D.image_to_gaussians(sd, probe_cfg, cpu["image"], cpu["ray_o"], cpu["ray_d"], t[:1].cpu())
+        probe[n_thr] = time.perf_counter() - t0
+    dit_threads = min(probe, key=probe.get)
+    torch.set_num_threads(dit_threads)
+    RO.set_threads(dit_threads)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        g, _ = D.image_to_gaussians(sd, D.Cfg(), cpu["image"], cpu["ray_o"], cpu["ray_d"], t[:1].cpu())
+    t_dit = time.perf_counter() - t0
+    dit_runs = probe
     view, proj, campos, tanfov = D.camera_matrices(cpu["c2w"][0], cpu["fxfycxcy"][0], res, res)
     act = lambda gm: dict(xyz=gm["xyz"][0].numpy(), shs=gm["features"][0].numpy(),
                           op=torch.sigmoid(gm["opacity"][0]).numpy(), sc=torch.exp(gm["scaling"][0]).numpy(),
@@ -172,7 +181,7 @@ def cpu_baseline(model, batch, t, res, V, hip_gaussians, hip_render):
                 sample=f"1 sample of the same step: DiT forward at L=4098, all 24 blocks ({t_dit:.1f} s, torch-CPU fp32 oracle, "
                        f"{dit_threads} threads) + {V} oracle rasterizations at {res}^2 ({t_raster:.2f} s, C++ oracle, OpenMP over "
                        f"Gaussians / tiles, {raster_threads} threads); `cores` = the threads of the faster DiT leg (97 % of the time); "
-                       f"DiT leg by thread count: " + ", ".join(f"{k} threads {v:.1f} s" for k, v in sorted(dit_runs.items())) + f"; host has {cores} cores"), float(psnr)
+                       f"two-block probe of the DiT leg by thread count: " + ", ".join(f"{k} threads {v:.1f} s" for k, v in sorted(dit_runs.items())) + f"; host has {cores} cores"), float(psnr)
 
 
 PEAK_FP32_VALU = 157.3e12   # same guide, "Peak FP32 (vector)"

@@ -85,6 +85,8 @@ __device__ __forceinline__ int pi16(int r) { return (r & ~12) | ((r & 4) << 1) |
 // one key tile of the tail queries, by one wave; rec = this tile's records [r][TAIL_REC]
 // `lds_k` != nullptr: the tile's K / V^T images and the tail queries' rows are in LDS (same layout as the ring tiles; foff = the
 // lane's fragment offsets of the main loop); otherwise the fragments are gathered from global memory.
+// REC_LDS: `rec` is in LDS (the workgroup merges its waves' records before anything leaves for memory: plain stores)
+template <bool REC_LDS = false>
 __device__ __forceinline__ void tail_tile(const AttnParams& p, int t, int r, const bf16_t* Qg, const bf16_t* Kg, const bf16_t* Vg, float* rec, int lane,
                                           const char* lds_k = nullptr, const char* lds_v = nullptr, const char* lds_q = nullptr, const int* foff = nullptr) {
     const int l31 = lane & 31, half = lane >> 5;
@@ -147,11 +149,20 @@ __device__ __forceinline__ void tail_tile(const AttnParams& p, int t, int r, con
     }
     if (l31 < r) {                             // lane owns query l31: d = db * 32 + 8 (rr >> 2) + 4 half + (rr & 3)
         float* q = rec + l31 * TAIL_REC;       // [max, sum, -, -, O[64]]: four consecutive d per accumulator group = one 16-byte store
-        if (half == 0) st_agent2(q, mx, la[0]);
+        if constexpr (REC_LDS) {
+            if (half == 0) { q[0] = mx; q[1] = la[0]; }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            st_agent4(q + 4 + 8 * g + 4 * half, o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]);
-            st_agent4(q + 4 + 32 + 8 * g + 4 * half, o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]);
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(q + 4 + 8 * g + 4 * half) = make_float4(o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]);
+                *reinterpret_cast<float4*>(q + 4 + 32 + 8 * g + 4 * half) = make_float4(o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]);
+            }
+        } else {
+            if (half == 0) st_agent2(q, mx, la[0]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                st_agent4(q + 4 + 8 * g + 4 * half, o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]);
+                st_agent4(q + 4 + 32 + 8 * g + 4 * half, o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]);
+            }
         }
     }
 }
@@ -580,19 +591,42 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
                 outv[4 * db + g].y = pack_bf2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
             }
     }
-    // ---- tail queries: wave w takes key tile qblk + nqb * w (K / V^T are L2-resident by now).  Its record stores are
-    //      issued BEFORE the output stores so that the counted wait below covers exactly them. ----
+    // ---- tail queries: wave w takes key tile qblk + nqb * w (K / V^T are L2-resident by now) and leaves its record {max, sum, O[64]} per
+    //      tail query in LDS (the ring is idle); the first r * 64 threads fold the workgroup's records into ONE (round 5: the last
+    //      workgroup of the head then merges nqb records instead of one per key tile -- 16 instead of 65 at L = 4,098: its record loads,
+    //      folds and combine were 9.7 k cycles at the very end of the kernel, profiles/r03_attn_tail_merge_stamps.txt).  The record's
+    //      stores are issued BEFORE the output stores so that the counted wait below covers exactly them. ----
     const int bh = b * p.heads + head;
     if (tail_r) {
         if (tail_age < 0) stage_tail();                 // a single-tile sequence: no iteration with a wait came by
         wait_vmcnt<0>();                                // every wave's pieces of the staged tiles have landed ...
         raw_barrier();                                  // ... and are visible to the wave that reads them
-        bool staged = wave < TAIL_LDS_TILES;
-        for (int tt = qblk + p.nqb * wave; tt < ntiles; tt += p.nqb * NW) {
-            float* const rec = p.tail_ws + ((size_t)bh * ntiles + tt) * tail_r * TAIL_REC;
-            if (staged) tail_tile(p, tt, tail_r, Qg, Kg, Vg, rec, lane, tail_lds + (2 * wave) * KV_TILE_BYTES, tail_lds + (2 * wave + 1) * KV_TILE_BYTES, tail_q, foff);
-            else tail_tile(p, tt, tail_r, Qg, Kg, Vg, rec, lane);
-            staged = false;
+        float* const wrec = reinterpret_cast<float*>(lds) + (size_t)wave * tail_r * TAIL_REC;     // this wave's records: [r][TAIL_REC] in the idle ring
+        const int tt = qblk + p.nqb * wave;             // ntiles <= nqb * NW: at most one tile per wave
+        if (tt < ntiles) {
+            if (wave < TAIL_LDS_TILES) tail_tile<true>(p, tt, tail_r, Qg, Kg, Vg, wrec, lane, tail_lds + (2 * wave) * KV_TILE_BYTES, tail_lds + (2 * wave + 1) * KV_TILE_BYTES, tail_q, foff);
+            else tail_tile<true>(p, tt, tail_r, Qg, Kg, Vg, wrec, lane);
+        } else if (lane < tail_r) {                     // no tile: an empty record (weight exp2(-3e38 - M) = 0 in the fold)
+            wrec[lane * TAIL_REC] = -3.0e38f; wrec[lane * TAIL_REC + 1] = 0.0f;
+        }
+        lds_barrier();
+        for (int item = tid; item < tail_r * 64; item += 64 * NW) {       // item = (tail query, d): fold the NW records in wave order
+            const int qq = item >> 6, d = item & 63;
+            const float* rw = reinterpret_cast<const float*>(lds) + qq * TAIL_REC;
+            float M = rw[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, rw[w * tail_r * TAIL_REC]);
+            float l = 0.0f, o = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float* rr = rw + w * tail_r * TAIL_REC;
+                const float wgt = fast_exp2(rr[0] - M);
+                l += wgt * rr[1];
+                o += (rr[1] > 0.0f ? wgt * rr[4 + d] : 0.0f);          // an empty record's O is not initialised
+            }
+            float* const rec = p.tail_ws + ((size_t)bh * p.nqb + qblk) * tail_r * TAIL_REC + qq * TAIL_REC;
+            st_agent(rec + 4 + d, o);
+            if (d == 0) st_agent2(rec, M, l);
         }
     }
     MAIN_STAMP(7);
@@ -626,7 +660,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     wait_lgkmcnt0();
     raw_barrier();
     MAIN_STAMP(5);
-    if (*flag) tail_merge(p, bh, ntiles, tail_r, lds);
+    if (*flag) tail_merge(p, bh, p.nqb, tail_r, lds);        // one record per workgroup of the head
     MAIN_STAMP(6);
 }
 

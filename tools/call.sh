@@ -5,6 +5,5 @@ out=$R/gpurun_out/call
 mkdir -p $out
 cd $R
 export PYTHONPATH=$R/open-diffusiongs_amd:$R
-timeout 300 python tools/rccl_neighbour_cost.py > $out/rccl_neighbour.txt 2>&1; grep -v amdgpu $out/rccl_neighbour.txt
-( time timeout 1700 python -m pytest tests -m gpu -q > $out/pytest_gpu_full.txt 2>&1 ) 2>&1 | grep real
-grep -v "^  File\|^$" $out/pytest_gpu_full.txt | tail -12 | cut -c1-300
+timeout 600 python -m pytest tests/test_dit_gpu.py -m gpu -x -q -k "attention" 2>&1 | tail -3
+timeout 600 python tools/attn_ab.py open-diffusiongs_amd/lib/libdgs_hip_base.so > $out/attn_ab.txt 2>&1; grep -v amdgpu $out/attn_ab.txt | tail -12
