@@ -275,6 +275,7 @@ __device__ void tail_merge(const AttnParams& p, int bh, int nrec, int r, char* l
 // consumes it) followed by the row max of S'(t+1) (17 ops).
 constexpr int RING = 4;
 __device__ long long dgs_attn_dbg[4096 + 64];   // DGS_ATTN_DBG & 4: loop cycles (s_memtime) per wave of the first 512 workgroups; & 8: phases of wg 0
+__device__ unsigned dgs_attn_tl[512][8];   // DGS_ATTN_DBG & 16: per-workgroup phase stamps (100 MHz clock, low 32 bits)
 
 
 
@@ -309,7 +310,10 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int dbg = kInstrumented ? p.dbg : 0;         // debug switches exist in the instrumented library only (dit_common.h)
-#define MAIN_STAMP(i) if ((dbg & 8) && blockIdx.x == 0 && tid == 0) dgs_attn_dbg[4096 + 16 + (i)] = cycle_stamp()
+    // DGS_ATTN_DBG & 16: every workgroup's {start, loop end, tail tile + fold done, output stores issued, arrived, end} on the constant
+    // 100 MHz clock (dgs_attn_tl: the launch's timeline, like the GEMMs' profiles/r05_gemm_timeline.txt)
+#define MAIN_STAMP(i) do { if ((dbg & 8) && blockIdx.x == 0 && tid == 0) dgs_attn_dbg[4096 + 16 + (i)] = cycle_stamp(); \
+                           if ((dbg & 16) && tid == 0 && blockIdx.x < 512) dgs_attn_tl[blockIdx.x][(i)] = (unsigned)wall_stamp(); } while (0)
     MAIN_STAMP(0);
     // ---- block -> (sample, head, query block) ----
     int id = blockIdx.x;
@@ -882,6 +886,24 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     }
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(p.nmain), dim3(512), lds_bytes, st, p);
 #ifdef DGS_INSTRUMENT
+    if (dbg & 16) {
+        static unsigned tl[512][8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(tl, HIP_SYMBOL(dgs_attn_tl), sizeof(tl));
+        const int n = p.nmain < 512 ? p.nmain : 512;
+        unsigned t0 = 0xffffffffu;
+        for (int i = 0; i < n; ++i) t0 = tl[i][0] < t0 ? tl[i][0] : t0;
+        // stamps: 0 start, 3 loop end, 7 tail tile + fold, 4 output stores issued, 5 arrived (records drained, counter), 6 end (merge if last)
+        const int order[6] = {0, 3, 7, 4, 5, 6};
+        const char* names[6] = {"start", "loop end", "tail tile + fold", "stores issued", "arrived", "end"};
+        fprintf(stderr, "[attn timeline] L=%d, %d workgroups, us since the first start (min/mean/max):", a->L, n);
+        for (int k = 0; k < 6; ++k) {
+            double mn = 1e9, mx = 0, sum = 0;
+            for (int i = 0; i < n; ++i) { const double v = (tl[i][order[k]] - t0) / 100.0; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; }
+            fprintf(stderr, "  %s %.2f/%.2f/%.2f", names[k], mn, sum / n, mx);
+        }
+        fprintf(stderr, "\n");
+    }
     if (dbg & 4) {
         static long long host[4096 + 64];
         (void)hipStreamSynchronize(st);

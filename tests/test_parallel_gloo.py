@@ -358,6 +358,7 @@ def _overflow_worker(rank, world, port, out):
             else:                                                    # same first step, then a backend that has seen nothing: every
                 tr.step(batch, t[sl], target, render_c2w=far)        # render of step 2 runs the synchronous form (exact buffers)
                 be = m.gs_renderer._backend = RasterBackend(lib=emu_lib())
+                be.deterministic = tr.deterministic              # the trainer selected the atomic-free backward on the backend it found
             # step 2: rank 0 renders from the near cameras (far more instances than its plan provides), rank 1 stays far
             loss = tr.step(batch, t[sl], target, render_c2w=None if rank == 0 else far)
             plan = next(iter(be._plans.values()))

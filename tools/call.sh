@@ -5,5 +5,5 @@ out=$R/gpurun_out/call
 mkdir -p $out
 cd $R
 export PYTHONPATH=$R/open-diffusiongs_amd:$R
-timeout 600 python -m pytest tests/test_dit_gpu.py -m gpu -x -q -k "attention" 2>&1 | tail -3
-timeout 600 python tools/attn_ab.py open-diffusiongs_amd/lib/libdgs_hip_base.so > $out/attn_ab.txt 2>&1; grep -v amdgpu $out/attn_ab.txt | tail -12
+DGS_AMD_LIBRARY=$R/open-diffusiongs_amd/lib/libdgs_hip_instr.so DGS_ATTN_DBG=28 timeout 200 python tools/attn_timeline.py > $out/attn_timeline.txt 2>&1
+grep -v amdgpu $out/attn_timeline.txt | cut -c1-400

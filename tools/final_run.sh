@@ -2,7 +2,7 @@
 # The round's measurement artefacts in one GPU call (from the repo root on the GPU box): everything lands under gpurun_out/final/.
 #   tools/final_run.sh [tag]        then copy gpurun_out/final/* into profiles/ (names carry the tag)
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/final
 mkdir -p $out
@@ -21,6 +21,7 @@ prof() {   # name, command...
 }
 prof bench python $R/bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --graph 0
 prof train_step python $R/bench.py --mode train --steps 3 --warmup 1
+prof train_scene512 python $R/bench.py --mode train-scene --steps 1 --warmup 1
 prof raster256_trained python $R/tools/raster_microbench.py --res 256 --regime trained
 prof raster256_init python $R/tools/raster_microbench.py --res 256 --regime init
 python tools/pmc_traffic.py > $out/${tag}_pmc_traffic.log 2>&1
