@@ -317,6 +317,28 @@ def scene_512(dev, steps=5):
                           "frac": round(4.0 * L * L * 1024 / (attn_ms * 1e-3) / PEAK_BF16_MFMA, 4)}}
 
 
+def batch_sweep(dev, model, res, V, batches=(2, 4), steps=8):
+    """Informational: the same sampling step with more than one sample per GPU (the reference samples one object at a time,
+    pipline_obj.py; a serving deployment would batch).  renders/s = B x V / step time; eager steps, events on the stream."""
+    import torch
+    from dgs_amd import synth
+    out = {}
+    for B in batches:
+        batch, t = synth.make_batch(B, res, V=V, device=dev, seed=7, with_t=True)
+        with torch.no_grad():
+            for _ in range(2):
+                model(batch, t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                model(batch, t)
+            e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        out[f"batch_{B}"] = {"ms_per_step": round(ms, 3), "renders_per_s": round(B * V / (ms * 1e-3), 1)}
+    return out
+
+
 def train_bench(a, dev, rank, world, steps, warmup, scene=None):
     """BASELINE configs[3] (train_obj_stage1.sh, diffusionGS_rel.yaml): per GPU B samples x 4 input views at 256^2, `--train-views`
     rendered views; one `DataParallelTrainer.step` = DiT forward (activations saved) + rasterization + MSE + rasterizer backward +
@@ -775,6 +797,8 @@ def main():
         try:
             stage("extras: raster roofline")
             rr = raster_roofline(dev, res, V) if rank == 0 else None
+            stage("extras: batch sweep")
+            sweep = batch_sweep(dev, model, res, V) if rank == 0 and not DRY["on"] else None
             stage("extras: scene 512")
             s512 = scene_512(dev) if rank == 0 else None
             del model, eng
@@ -794,6 +818,7 @@ def main():
             emit_and_leave(f"{type(e).__name__}: {e}")
         if rank == 0:
             out["raster"] = rr
+            out["batch_sweep"] = sweep
             out["scene_512"] = s512
             out["train_step"] = tb
             out["train_step_scene_512"] = tb512

@@ -94,13 +94,14 @@ typedef struct DgsRasterForwardArgs {
      * The backward of such a call takes binning_capacity as its `num_rendered`.                                              */
     int64_t binning_capacity;
     int32_t* num_rendered_dev;   /* device int32[4], written by the call in both modes when not NULL: [0] = num_rendered (low 32 bits),
-                                    [1] = status (DgsStatus), [2] = longest tile list, [3] = 0                               */
+                                    [1] = status (DgsStatus), [2] = longest tile list, [3] = 1 (written last: "the other three are valid") */
     int32_t* num_rendered_host;  /* DEVICE-ACCESSIBLE host int32[4] or NULL: the same four words, STORED BY A KERNEL of the call through this
                                     pointer (no memcpy: a copy node in a captured sequence proved unreliable on ROCm 7.2) -- so it must be
                                     page-locked memory that is mapped into the device's address space at this very address and coherent
                                     (hipHostMalloc with hipHostMallocMapped | hipHostMallocCoherent, or torch's pin_memory=True); plain
-                                    pageable or un-mapped page-locked memory faults.  Valid once the stream has passed the call --
-                                    record an event behind it                                                                        */
+                                    pageable or un-mapped page-locked memory faults.  Valid once word [3] reads non-zero (clear it
+                                    before the call; the kernel writes it last, behind a system-scope fence -- the call's second kernel,
+                                    long before its blend), or once the stream has passed the call                                    */
     int64_t longest_hint;        /* async mode, IN: the longest tile list the caller expects (a previous call of this shape), 0 =
                                     unknown.  Sizes the LDS of the per-tile sort (form 3 named: that kernel is launched alone); a
                                     longer list is sorted in LDS-sized chunks merged by rank -- slower, never an error             */

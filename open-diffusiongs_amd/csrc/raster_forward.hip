@@ -459,8 +459,14 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(uint32_t* count, uint2
         // the caller's copies of the four words (DgsRasterForwardArgs.num_rendered_dev / num_rendered_host), written by this kernel:
         // the host copy is a store into pinned, device-visible host memory -- no memcpy node in a captured call
         const int32_t st1 = totals[1];
-        if (stats_dev) { stats_dev[0] = (int32_t)carry; stats_dev[1] = st1; stats_dev[2] = (int32_t)smax; stats_dev[3] = 0; }
-        if (stats_host) { stats_host[0] = (int32_t)carry; stats_host[1] = st1; stats_host[2] = (int32_t)smax; stats_host[3] = 0; }
+        // word [3] = 1 is written LAST, behind a system-scope fence: a host that polls it (dgs_amd/raster.py: a plan at risk) reads the
+        // other three as soon as it turns non-zero -- long before the call's blend kernels have run
+        if (stats_dev) { stats_dev[0] = (int32_t)carry; stats_dev[1] = st1; stats_dev[2] = (int32_t)smax; stats_dev[3] = 1; }
+        if (stats_host) {
+            stats_host[0] = (int32_t)carry; stats_host[1] = st1; stats_host[2] = (int32_t)smax;
+            __threadfence_system();
+            *reinterpret_cast<volatile int32_t*>(stats_host + 3) = 1;
+        }
     }
     deal_tiles(count, n, smax, order, s_class, scratch);
 }

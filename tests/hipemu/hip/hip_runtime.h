@@ -249,6 +249,7 @@ static inline int __syncthreads_and(int p) { return hipemu::block_reduce(p, 2); 
 static inline int __syncthreads_or(int p) { return hipemu::block_reduce(p, 3); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() {}
 static inline int __lane_id() { return hipemu::ctx().cur->lane; }
 
 template <class T> static inline T __shfl(T v, int src, int = 64) { return hipemu::shfl(v, src); }
