@@ -18,22 +18,17 @@ namespace dgs {
 // row itself, so the kernel is ONE memory round trip.  (As run-time tests of p.weight / p.shift inside the output loop the
 // compiler emitted, per 1 KiB of the row, branch -> load -> s_waitcnt vmcnt(0) -> store: four more dependent round trips behind the
 // reductions, ~2 of the kernel's 6.9 us at the DiT shape.)  Same arithmetic in the same order as before: outputs are bit-identical.
-template <int VPL, bool WEIGHT, bool MOD, bool F32OUT, int RPW = 1>   // float4 vectors per lane: width = 256 * VPL; RPW rows per wave
+template <int VPL, bool WEIGHT, bool MOD, bool F32OUT>   // float4 vectors per lane: width = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y;                                  // the sample: grid.y (no per-row division in front of the operand loads)
-    // RPW = 2 (the block LayerNorms at width 1024): a wave takes two neighbouring rows of one sample -- half the waves for the same
-    // bytes, both rows' loads in flight together, the per-column operands (shift / scale / weight) loaded once for the pair.  The
-    // arithmetic per row is unchanged: outputs are bit-identical with RPW = 1 (tools/ln_ab.py).
-    const int local = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW, row = b * p.rows_per_batch + local;
+    const int local = blockIdx.x * 4 + (threadIdx.x >> 6), row = b * p.rows_per_batch + local;
     if (local >= p.rows_per_batch || row >= p.rows) return;
-    const bool two = RPW == 2 && local + 1 < p.rows_per_batch && row + 1 < p.rows;
     const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)row * p.width);
-    float4 v[RPW][VPL], w[WEIGHT ? VPL : 1], sh[MOD ? VPL : 1], sc[MOD ? VPL : 1];
+    float4 v[VPL], w[WEIGHT ? VPL : 1], sh[MOD ? VPL : 1], sc[MOD ? VPL : 1];
+    float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) v[r][i] = xr[(r == 0 || two ? (size_t)r * (p.width / 4) : 0) + i * 64 + lane];
+    for (int i = 0; i < VPL; ++i) v[i] = xr[i * 64 + lane];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c4 = i * 64 + lane;   // float4 index inside the row
@@ -45,32 +40,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
     }
     sched_fence();                      // every load is issued before the first use of the row (hipcc otherwise sinks half of them)
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        if (r == 1 && !two) break;
-        float sum = 0.f;
+    for (int i = 0; i < VPL; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(sum) / (float)p.width;
+    float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) sum += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
-        const float mean = wave_sum(sum) / (float)p.width;
-        float sq = 0.f;
+    for (int i = 0; i < VPL; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.width + p.eps);
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            v[r][i].x -= mean; v[r][i].y -= mean; v[r][i].z -= mean; v[r][i].w -= mean;
-            sq += (v[r][i].x * v[r][i].x + v[r][i].y * v[r][i].y) + (v[r][i].z * v[r][i].z + v[r][i].w * v[r][i].w);
+    for (int i = 0; i < VPL; ++i) {
+        const int c4 = i * 64 + lane;
+        float4 y = make_float4(v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd);
+        if constexpr (WEIGHT) { y.x *= w[i].x; y.y *= w[i].y; y.z *= w[i].z; y.w *= w[i].w; }
+        if constexpr (MOD) {
+            y.x = y.x * (1.0f + sc[i].x) + sh[i].x; y.y = y.y * (1.0f + sc[i].y) + sh[i].y;
+            y.z = y.z * (1.0f + sc[i].z) + sh[i].z; y.w = y.w * (1.0f + sc[i].w) + sh[i].w;
         }
-        const float rstd = rsqrtf(wave_sum(sq) / (float)p.width + p.eps);
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c4 = i * 64 + lane;
-            float4 y = make_float4(v[r][i].x * rstd, v[r][i].y * rstd, v[r][i].z * rstd, v[r][i].w * rstd);
-            if constexpr (WEIGHT) { y.x *= w[i].x; y.y *= w[i].y; y.z *= w[i].z; y.w *= w[i].w; }
-            if constexpr (MOD) {
-                y.x = y.x * (1.0f + sc[i].x) + sh[i].x; y.y = y.y * (1.0f + sc[i].y) + sh[i].y;
-                y.z = y.z * (1.0f + sc[i].z) + sh[i].z; y.w = y.w * (1.0f + sc[i].w) + sh[i].w;
-            }
-            if constexpr (F32OUT) reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)(row + r) * p.width)[c4] = y;
-            else reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)(row + r) * p.width)[c4] =
-                     make_uint2(pack_bf2(y.x, y.y), pack_bf2(y.z, y.w));
-        }
+        if constexpr (F32OUT) reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)row * p.width)[c4] = y;
+        else reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)row * p.width)[c4] =
+                 make_uint2(pack_bf2(y.x, y.y), pack_bf2(y.z, y.w));
     }
 }
 
@@ -277,13 +267,6 @@ int launch_layernorm(const DgsDitLayerNormArgs* a, hipStream_t st) {
     p.out_f32 = a->out_f32; p.eps = a->eps; p.x = a->x; p.weight = a->weight; p.shift = a->shift; p.scale = a->scale; p.out = a->out;
     const dim3 grid((p.rows_per_batch + 3) / 4, (a->rows + p.rows_per_batch - 1) / p.rows_per_batch), block(256);
     const bool w = a->weight != nullptr, m = a->shift != nullptr, f = a->out_f32 != 0;
-    if (a->width == 1024 && m && !w && !f) {          // the DiT blocks' LN + modulate: two rows per wave (layernorm_kernel RPW)
-        static const bool one = getenv("DGS_LN_RPW") && atoi(getenv("DGS_LN_RPW")) == 1;      // measurement aid
-        if (!one) {
-            hipLaunchKernelGGL((layernorm_kernel<4, false, true, false, 2>), dim3((p.rows_per_batch + 7) / 8, grid.y), block, 0, st, p);
-            return launch_ok();
-        }
-    }
 #define DGS_LN_CASE(V)                                                                                                                   \
     case V:                                                                                                                              \
         if (w) { if (m) { if (f) hipLaunchKernelGGL((layernorm_kernel<V, true, true, true>), grid, block, 0, st, p);                     \
