@@ -198,3 +198,17 @@ def test_dropin_binding_matches_oracle():
     assert np.array_equal(vis.cpu().numpy(), mark_visible(sc["xyz"], cam["viewmatrix"], cam["projmatrix"]))
     with pytest.raises(Exception):
         rast(means3D=t(sc["xyz"]), means2D=means2D, opacities=t(sc["opacities"]))
+
+
+def test_three_kernel_radix_pass_forced(request):
+    """The depth radix sort runs one kernel per pass while a call's sort workgroups fit the chip together (radix_pass_kernel) and the
+    three-kernel pass otherwise (training calls with dozens of views): DGS_RASTER_RADIX3=1 forces the latter on the cases of this file
+    that finish in seconds, in a child process (the switch is read once per process)."""
+    import os, subprocess, sys
+    if request.node.callspec.params.get("binning_form") != "auto":
+        pytest.skip("one run is enough: the child process runs the forms that use the depth sort itself")
+    env = dict(os.environ, DGS_RASTER_RADIX3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(small_scenes or diffusiongs_shaped) and (scan or sort)"], env=env, capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

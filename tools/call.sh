@@ -5,5 +5,8 @@ out=$R/gpurun_out/call
 mkdir -p $out
 cd $R
 export PYTHONPATH=$R/open-diffusiongs_amd:$R
-timeout 300 python tools/ln_ab.py open-diffusiongs_amd/lib/libdgs_hip_base.so > $out/ln_ab.txt 2>&1; grep -v amdgpu $out/ln_ab.txt | cut -c1-200
-for i in 1 2; do for r in 1 2; do DGS_LN_RPW=$r timeout 300 python bench.py --no-extras --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('rpw $r:', d['ms_per_step'], d['kernel_families']['layernorm'])"; done; done
+INSTR=$R/open-diffusiongs_amd/lib/libdgs_hip_instr.so
+DGS_AMD_LIBRARY=$INSTR DGS_GEMM_DBG=1 GEMM_CASES=fc2,proj timeout 300 python tools/gemm_check.py 4 > $out/gemm_dbg_256x128.txt 2>&1
+grep "gemm dbg\|timeline\] 1\|us  " $out/gemm_dbg_256x128.txt | cut -c1-330
+GEMM_CASES=fc2,proj timeout 200 python tools/gemm_check.py 0,4 2>&1 | grep -v amdgpu
+timeout 600 python -m pytest tests/test_raster_forward_gpu.py -m gpu -x -q -k "three_kernel" 2>&1 | tail -2
