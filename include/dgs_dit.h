@@ -114,14 +114,13 @@ typedef struct DgsDitAttentionArgs {
                                   Zero-filled ONCE by the caller (the kernel leaves the counters at zero); one per stream
                                   that launches concurrently.                                                          */
     size_t tail_ws_bytes;
-    int32_t tail_mode;         /* the L % 32 tail queries: 0 (default) inside the main kernel (key-split records + merge at its end);
-                                  1: this launch computes the full 32-query units only; 2: this launch computes ONLY the tail queries
-                                  (a small VALU kernel, one workgroup per (sample, head)).  dgs_dit_forward always uses mode 0: the
-                                  pair 1 + 2 on two streams cannot hide the tail (rounds 4 and 5 measured both orders:
-                                  profiles/r04_attention_tail_stream_ab.txt, profiles/r05_tail_chain_ab.txt); the modes stay as an
-                                  operator-level option (a caller with idle CUs) and as what the tools' build of the launch sequence
-                                  selects with DGS_TAIL_CHAIN.  Needs dgs_dit_attention_tail_splittable(L, lpad); tail_ws is not used
-                                  by modes 1 and 2                                                                               */
+    int32_t tail_mode;         /* 0.  (The L % 32 tail queries run inside the main kernel: key-split records + a merge at its end.)
+                                  1 / 2 exist in the EXPERIMENTS build only (the tools' library built with -DDGS_INSTRUMENT and the CPU
+                                  emulator): 1 = this launch computes the full 32-query units only, 2 = ONLY the tail queries (a small
+                                  VALU kernel, one workgroup per (sample, head)) -- the pair on two streams cannot hide the tail
+                                  (profiles/r04_attention_tail_stream_ab.txt, profiles/r05_tail_chain_ab.txt), so the product library
+                                  does not carry it: there any value but 0 is DGS_ERR_INVALID_ARGUMENT and
+                                  dgs_dit_attention_tail_splittable() is 0                                                       */
 } DgsDitAttentionArgs;
 
 /* Bytes of DgsDitAttentionArgs.tail_ws for this shape (0 when L % 32 == 0). */

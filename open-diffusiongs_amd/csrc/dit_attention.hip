@@ -668,6 +668,9 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     MAIN_STAMP(6);
 }
 
+// EXPERIMENTS BUILD ONLY (tools' library -DDGS_INSTRUMENT, CPU emulator): it lost twice on the GPU (profiles/r04_attention_tail_stream_ab.txt,
+// profiles/r05_tail_chain_ab.txt) and is not compiled into the product library, whose dgs_dit_attention rejects tail_mode 1 / 2.
+#ifdef DGS_EXPERIMENTS
 // ---- the L % 32 tail queries as a launch of their own (DgsDitAttentionArgs.tail_mode = 2) -------------------------------------------
 // Inside the main kernel the two learned-token queries cost ~9 of 80 us at L = 4098: their partial records have to be merged when
 // the LAST workgroup of a head is done (records performed at the memory side -> arrival counter -> record loads: a chain at the very
@@ -806,6 +809,7 @@ __global__ __launch_bounds__(512) void attention_tail_kernel(AttnParams p) {
 }
 
 constexpr int kTailKernelMaxLds = 144 * 1024;
+#endif  // DGS_EXPERIMENTS
 
 }  // namespace dgs
 
@@ -822,8 +826,13 @@ extern "C" size_t dgs_dit_attention_tail_bytes(int32_t B, int32_t heads, int32_t
 
 /* Whether the L % 32 tail queries of this shape can run as a launch of their own (tail_mode 1 + 2). */
 extern "C" int32_t dgs_dit_attention_tail_splittable(int32_t L, int32_t lpad) {
+#ifdef DGS_EXPERIMENTS
     const int R = L % 32, Lp = (L + 7) & ~7;
     return R >= 1 && R <= 4 && L >= 256 && lpad % 8 == 0 && R * Lp * (int)sizeof(float) <= kTailKernelMaxLds;
+#else
+    (void)L; (void)lpad;
+    return 0;                                  // the product library has no tail launch
+#endif
 }
 
 extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream) {
@@ -837,6 +846,9 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     p.lse2 = a->lse2;
     const int tail_mode = a->tail_mode;        // 0: the tail queries inside the main kernel; 1: main kernel only; 2: the tail launch only
     if (tail_mode < 0 || tail_mode > 2) return DGS_ERR_INVALID_ARGUMENT;
+#ifndef DGS_EXPERIMENTS
+    if (tail_mode != 0) return DGS_ERR_INVALID_ARGUMENT;          // modes 1 / 2: the experiments build only (dgs_dit.h)
+#endif
     p.nfull = a->L / 32;                       // full 32-query wave units; the L % 32 rest goes to the tail workgroups
     p.nqb = p.nfull ? (p.nfull + NW - 1) / NW : 1;        // L < 32: one workgroup per head, tail path only
     p.nmain = a->B * a->heads * p.nqb;
@@ -855,6 +867,7 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     p.qk = a->qk; p.vt = a->vt; p.out = a->out; p.q_prescaled = a->q_prescaled;
     p.scale_log2e = a->scale * 1.44269504088896341f;
     hipStream_t st = static_cast<hipStream_t>(stream);
+#ifdef DGS_EXPERIMENTS
     if (tail_mode == 2) {
         const int R = a->L % 32, Lp = (a->L + 7) & ~7;
         const int tail_lds = R * Lp * (int)sizeof(float);
@@ -874,6 +887,7 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
         }
         return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
     }
+#endif
     // 64 KiB of rings; DGS_ATTN_LDS_PAD (bytes) adds unused LDS to cap the workgroups per CU (measurement aid)
     static const int lds_pad = getenv("DGS_ATTN_LDS_PAD") ? atoi(getenv("DGS_ATTN_LDS_PAD")) : 0;
     // + the staged tail tiles and the tail queries' tile when L % 32 != 0: 64 + 80 + 8 = 152 KiB (one workgroup per CU either way)

@@ -90,7 +90,8 @@ class DitOps:
     def attention(self, qk, vt, L, heads, qkv_layout=False, lse2=None, q_prescaled=False, tail_mode=0, out=None):
         """qk bf16 [B*lpad, 2*heads*64], vt bf16 [B, heads*64, lpad] -> bf16 [B*lpad, heads*64].
         qkv_layout: `qk` is the training tensor [B*lpad, 3W] and `vt` its transposed copy [B, 3W, lpad].
-        tail_mode (dgs_dit.h): 0 everything in one launch; 1 the full 32-query units only; 2 the L % 32 tail queries only (into `out`)."""
+        tail_mode (dgs_dit.h): 0 everything in one launch; 1 the full 32-query units only; 2 the L % 32 tail queries only (into `out`) --
+        1 / 2 in the experiments build of the library only (the product library rejects them)."""
         B, _, lpad = vt.shape
         W = heads * 64
         if out is None:

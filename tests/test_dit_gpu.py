@@ -45,6 +45,18 @@ def _ops():
     return _Poisoned(DitOps())
 
 
+def _experiments_ops():
+    """DitOps on the tools' build of the same sources (lib/libdgs_hip_instr.so, -DDGS_INSTRUMENT: built by __graft_entry__.build()): the
+    experiments that lost on the GPU are compiled into it and not into the product library."""
+    import os
+    from dgs_amd import _native
+    from dgs_amd.dit import DitOps
+    path = os.path.join(os.path.dirname(_native.LIB_PATH), "libdgs_hip_instr.so")
+    if not os.path.exists(path):
+        pytest.skip("the tools' build of the library is missing (DGS_INSTRUMENT=1 python -m dgs_amd.build)")
+    return _Poisoned(DitOps(lib=_native.open_library(path)))
+
+
 def _bf(t):
     return t.to(torch.bfloat16)
 
@@ -169,8 +181,9 @@ def test_attention_production_shapes(L, B, prescaled):
 
 @pytest.mark.parametrize("L,B", [(4098, 1), (16386, 1), (258, 2), (1027, 1)])
 def test_attention_tail_as_its_own_launch(L, B):
-    """`tail_mode` 1 + 2 (what dgs_dit_forward runs on two streams: the L % 32 learned-token queries as a small launch of their own beside
-    the main kernel) against fp64 and against the one-launch form: main rows bit-identical, tail rows within the attention bars."""
+    """`tail_mode` 1 + 2 (the L % 32 learned-token queries as a small launch of their own beside the main kernel: an experiment that lost,
+    kept in the tools' build of the library) against fp64 and against the one-launch form: main rows bit-identical, tail rows within
+    the attention bars.  The product library does not carry the launch and says so."""
     heads = 16
     lpad = (L + 127) // 128 * 128
     g = torch.Generator(device=DEV).manual_seed(L + 1)
@@ -181,7 +194,11 @@ def test_attention_tail_as_its_own_launch(L, B):
     qb, kb, vb = _bf(q * c), _bf(k), _bf(v)
     qk = torch.cat([qb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64), kb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64)], 1).contiguous()
     vt = vb.permute(0, 1, 3, 2).reshape(B, heads * 64, lpad).contiguous()
-    ops = _ops()
+    product = _ops()
+    assert product._ops.lib.dgs_dit_attention_tail_splittable(L, lpad) == 0
+    with pytest.raises(RuntimeError, match="status"):
+        product.attention(qk, vt, L, heads, q_prescaled=True, tail_mode=1)
+    ops = _experiments_ops()
     assert ops._ops.lib.dgs_dit_attention_tail_splittable(L, lpad) == 1
     one = ops.attention(qk, vt, L, heads, q_prescaled=True)
     two = ops.attention(qk, vt, L, heads, q_prescaled=True, tail_mode=1)
