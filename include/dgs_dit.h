@@ -114,18 +114,14 @@ typedef struct DgsDitAttentionArgs {
                                   Zero-filled ONCE by the caller (the kernel leaves the counters at zero); one per stream
                                   that launches concurrently.                                                          */
     size_t tail_ws_bytes;
-    int32_t tail_mode;         /* 0.  (The L % 32 tail queries run inside the main kernel: key-split records + a merge at its end.)
-                                  1 / 2 exist in the EXPERIMENTS build only (the tools' library built with -DDGS_INSTRUMENT and the CPU
-                                  emulator): 1 = this launch computes the full 32-query units only, 2 = ONLY the tail queries (a small
-                                  VALU kernel, one workgroup per (sample, head)) -- the pair on two streams cannot hide the tail
-                                  (profiles/r04_attention_tail_stream_ab.txt, profiles/r05_tail_chain_ab.txt), so the product library
-                                  does not carry it: there any value but 0 is DGS_ERR_INVALID_ARGUMENT and
-                                  dgs_dit_attention_tail_splittable() is 0                                                       */
+    int32_t tail_mode;         /* reserved: 0 (anything else is DGS_ERR_INVALID_ARGUMENT).  The L % 32 tail queries run inside the main
+                                  kernel: key-split records + a merge at its end.  (Rounds 4-5 ran them as a launch of their own behind
+                                  this field; it lost twice -- profiles/r04_attention_tail_stream_ab.txt, profiles/r05_tail_chain_ab.txt --
+                                  and lives on as tools/next/tail_chain_experiment.patch.)                                          */
 } DgsDitAttentionArgs;
 
 /* Bytes of DgsDitAttentionArgs.tail_ws for this shape (0 when L % 32 == 0). */
 size_t dgs_dit_attention_tail_bytes(int32_t B, int32_t heads, int32_t L);
-int32_t dgs_dit_attention_tail_splittable(int32_t L, int32_t lpad);
 
 typedef struct DgsDitAttentionBackwardArgs {
     int32_t B, heads, L, lpad;
@@ -254,7 +250,7 @@ typedef struct DgsDitForwardArgs {
     float* tokens;             /* optional [B,L,W] f32: tokens after the last block, reference order  */
     /* optional measurement hook (bench.py roofline): hipEvent_t handles recorded on `stream` immediately before
      * and after every launch of ONE kernel class -- 1: attention, 2: QKV GEMM, 3: gate+residual GEMMs (proj, fc2),
-     * 4: fc1 GEMM (+GELU), 5: LayerNorm+modulate.  prof_events holds 2 * prof_capacity handles, used in launch
+     * 4: fc1 GEMM (+GELU), 5: LayerNorm+modulate, 6: the proj GEMM alone, 7: the fc2 GEMM alone.  prof_events holds 2 * prof_capacity handles, used in launch
      * order (before, after); *prof_count (host) receives the number of launches recorded.  NULL -> off.           */
     void** prof_events;
     int32_t prof_kind;

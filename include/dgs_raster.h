@@ -114,11 +114,15 @@ typedef struct DgsRasterForwardArgs {
                                     3 instance list + per-tile sort in LDS (falls back to 1 when a list does not fit): that form
                                     only is launched -- what an async caller passes from dgs_raster_binning_form() of the
                                     previous call's statistics.  All forms produce the reference's lists bit for bit.  */
-    int32_t exact_exp;           /* exponential of a (pixel, Gaussian) pair in the blend loop.  0 (default): the hardware's
-                                    v_exp_f32 -- what the reference's `exp()` compiles to under its fast-math build; 1: a fixed
-                                    IEEE sequence the CPU oracle restates (oracle exp_mode 1), every float of the result
-                                    bit-identical with the oracle.  Integer artefacts that do not depend on alpha (radii, tile
-                                    lists, ranges, sort order) are identical in both; pass the same value to the backward.  */
+    int32_t exact_exp;           /* exponential of a (pixel, Gaussian) pair in the blend loop (the reference: CUDA's <= 2 ulp expf,
+                                    forward.cu:332-358 / backward.cu:463-532; its build passes no fast-math flag).  0 (default):
+                                    v_exp_f32 with the rounding error of its argument compensated (<= 1.3 ulp measured), and the
+                                    oracle's sequence for a pair whose alpha falls within 1e-6 of the 1/255 cut-off, so both put
+                                    every pair on the same side of it (csrc/dgs_device.h blend_exp; gradients within 1e-5 of the
+                                    oracle's); 1: a fixed IEEE sequence the CPU oracle restates (oracle exp_mode 1), every float
+                                    of the result bit-identical with the oracle.  Integer artefacts that do not depend on alpha
+                                    (radii, tile lists, ranges, sort order) are identical in both; pass the same value to the
+                                    backward.  */
 } DgsRasterForwardArgs;
 
 typedef struct DgsRasterBackwardArgs {

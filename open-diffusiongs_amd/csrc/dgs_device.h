@@ -85,15 +85,61 @@ __device__ __forceinline__ float hw_rcp(float x) {
 #endif
 }
 
-// exp(power) of a (pixel, Gaussian) pair inside the blend loops (-5.6 < power <= 0 for every pair that passes the cut-off).
-// FAST (the product default): v_mul + v_exp_f32 -- what the reference's CUDA `exp()` under fast math is on its hardware, two VALU
-//   instead of fourteen in the innermost loop of both blend kernels; integer artefacts that do not depend on alpha (radii, tile
-//   lists, ranges, sort order) are unaffected, colours move by a few fp32 ulp.
+// min(0.99, x) of the blend loops (forward.cu:340 / backward.cu:476: CUDA's min returns the number when one operand is NaN, and so
+// does v_min_f32): ONE v_min_f32.  fminf() compiles to v_max_f32 x, x (quieting a signalling NaN) + v_min_f32 -- a VALU per step.
+__device__ __forceinline__ float alpha_clamp(float x) {
+#ifdef HIPEMU
+    return fminf(0.99f, x);
+#else
+    float r;
+    asm("v_min_f32 %0, 0x3f7d70a4, %1" : "=v"(r) : "v"(x));
+    return r;
+#endif
+}
+
+// Mask of the wave's lanes whose predicate holds, straight from the compare (HIP's __ballot(int) takes the predicate as an integer:
+// v_cndmask + v_cmp_ne per call in the blend loops).
+__device__ __forceinline__ unsigned long long wave_ballot(bool pred) {
+#ifdef HIPEMU
+    return __ballot(pred ? 1 : 0);
+#else
+    return __builtin_amdgcn_ballot_w64(pred);
+#endif
+}
+
+// exp(power) of a (pixel, Gaussian) pair inside the blend loops (-5.6 < power <= 0 for every pair that passes the cut-off); `opacity`
+// is the factor the caller multiplies it with to get alpha.  The reference calls `exp(power)` of a plain nvcc build (its setup.py
+// passes no --use_fast_math): CUDA's <= 2 ulp expf (forward.cu:332-358, backward.cu:463-532).
+// FAST (the product default): the hardware's 2^x with the rounding error of its ARGUMENT compensated.  t = fl(power * log2e) is off by
+//   up to |t| * 2^-24 (3-6 ulp of the result near power = -5.5, which is where the 1/255 cut-off sits); e = fma(power, L2E_HI, -t) +
+//   power * L2E_LO is that error to first order, and exp = 2^t * (1 + e ln 2): mul, 2 fma, v_exp_f32, mul, fma -- six VALU instead of the
+//   oracle sequence's fourteen; measured on the device over 2^24 points of (-8, 0]: max 1.26 ulp against 7.63 for the bare
+//   v_exp_f32(power * log2e) and 1.01 for the oracle's sequence (tools/ubench/exp_ulp_bench.hip, profiles/r06_exp_ulp.txt).
+//   A pair whose alpha lands within 1e-6 (relative) of the 1/255 cut-off -- closer than the two exponentials may differ -- is evaluated
+//   with det_expf_core, so the product and the oracle (hence the strict build of the reference) put every pair on the SAME side of the
+//   cut-off; a pair on the other side would move its Gaussian's gradient by the pair's whole contribution (round 5 measured 1.8e-3 of
+//   a gradient tensor's max from such pairs with the bare v_exp_f32; 5e-6 with this form, profiles/r06_raster_grad_error.txt).  The
+//   branch is wave-uniform, out of line, and taken about once per 10^5 wave steps.  Forward and backward call this one function with the same operands, so they agree on
+//   which pairs were blended.
 // exact: det_expf_core, the fixed IEEE sequence the oracle restates (exp_mode 1): every float bit-identical with the oracle.
 template <bool FAST>
-__device__ __forceinline__ float blend_exp(float power) {
-    if constexpr (FAST) return hw_exp2(power * 1.44269504088896341f);
-    else return det_expf_core(power);
+__device__ __forceinline__ float blend_exp(float power, float opacity) {
+    if constexpr (FAST) {
+        const float kL2eHi = 1.44269504088896341f;                                      // fl(log2 e)
+        const float kL2eLo = (float)(1.44269504088896341 - (double)1.44269504088896341f);   // log2 e - fl(log2 e) = 1.9259630e-8
+        const float t = power * kL2eHi;
+        float e = __builtin_fmaf(power, kL2eHi, -t);
+        e = __builtin_fmaf(power, kL2eLo, e);
+        const float ex = hw_exp2(t);
+        float G = __builtin_fmaf(ex, e * 0.693147180559945309f, ex);
+        const float kBand = 1e-6f;
+        const float kCut = 1.0f / 255.0f;
+        const bool edge = __builtin_fabsf(opacity * G - kCut) < kCut * kBand;
+        if (__builtin_expect(wave_ballot(edge) != 0ull, 0)) G = edge ? det_expf_core(power) : G;
+        return G;
+    } else {
+        return det_expf_core(power);
+    }
 }
 
 // Exclusive scan of one value per thread over a block of `NT` threads (NT multiple of 64, <= 1024).

@@ -668,149 +668,6 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(AttnParams p) {
     MAIN_STAMP(6);
 }
 
-// EXPERIMENTS BUILD ONLY (tools' library -DDGS_INSTRUMENT, CPU emulator): it lost twice on the GPU (profiles/r04_attention_tail_stream_ab.txt,
-// profiles/r05_tail_chain_ab.txt) and is not compiled into the product library, whose dgs_dit_attention rejects tail_mode 1 / 2.
-#ifdef DGS_EXPERIMENTS
-// ---- the L % 32 tail queries as a launch of their own (DgsDitAttentionArgs.tail_mode = 2) -------------------------------------------
-// Inside the main kernel the two learned-token queries cost ~9 of 80 us at L = 4098: their partial records have to be merged when
-// the LAST workgroup of a head is done (records performed at the memory side -> arrival counter -> record loads: a chain at the very
-// end of a one-round grid).  As a separate small launch on a second stream (csrc/dit_forward.hip forks it behind
-// the QKV GEMM and joins it in front of the proj GEMM) the same work -- R x L scores, a softmax, R x 64 outputs per head: 1 MFLOP,
-// 1 MiB of K / V^T per head out of L2 -- hides behind the main kernel, which then has no tail path at all.
-// One workgroup per (sample, head), 512 threads, plain VALU (a wave's MFMA tile would be 2 / 32 full):
-//   pass 1  thread = key: s[r][key] = q_r . k_key (v_dot2, the queries in registers), scores to LDS, block max
-//   pass 2  p = exp2(s - max) in place, block sum
-//   pass 3  thread = (key slice, d): O[r][d] += p[r][key] V^T[d][key] over its slice (16-byte loads along the token-contiguous V^T row,
-//           p broadcast from LDS), the eight slices meet in LDS
-// fp32 probabilities (the main path rounds P to bf16 for its second MFMA): the tail rows come out a little more exact than before.
-template <int R>
-__global__ __launch_bounds__(512) void attention_tail_kernel(AttnParams p) {
-    DGS_DYNAMIC_LDS(lds);
-    float* const sc = reinterpret_cast<float*>(lds);           // [R][Lp] scores / probabilities, Lp = L rounded up to 8
-    __shared__ float s_red[8][R];                              // per-wave max / sum
-    __shared__ float s_o[8][R][64];
-    const int Lp = (p.L + 7) & ~7;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x, head = bh % p.heads, b = bh / p.heads;
-    const size_t row0 = (size_t)b * p.lpad;
-    const bf16_t* Qg = p.qk + row0 * p.ld_qk + head * 64;
-    const bf16_t* Kg = Qg + p.k_offset;
-    const bf16_t* Vg = p.vt + (size_t)b * p.vt_batch_stride + (size_t)head * 64 * p.lpad;
-    const int q0 = p.nfull * 32;
-    uint4 qf[R][8];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            uint4 raw = *reinterpret_cast<const uint4*>(Qg + (size_t)(q0 + r) * p.ld_qk + c * 8);
-            if (!p.q_prescaled) {
-                raw.x = scale_bf2(raw.x, p.scale_log2e); raw.y = scale_bf2(raw.y, p.scale_log2e);
-                raw.z = scale_bf2(raw.z, p.scale_log2e); raw.w = scale_bf2(raw.w, p.scale_log2e);
-            }
-            qf[r][c] = raw;
-        }
-    // ---- pass 1: scores (log2 domain: the queries carry scale * log2 e) ----
-    float mx[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) mx[r] = -3.0e38f;
-    for (int key = tid; key < Lp; key += 512) {
-        float s[R];
-        if (key < p.L) {
-            uint4 kf[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) kf[c] = *reinterpret_cast<const uint4*>(Kg + (size_t)key * p.ld_qk + c * 8);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc += dot8_bf16(qf[r][c], kf[c]);
-                s[r] = acc;
-                mx[r] = fmaxf(mx[r], acc);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) s[r] = -3.0e38f;       // padding keys of the last group of 8: probability 0
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) sc[r * Lp + key] = s[r];
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float w = wave_max(mx[r]);
-        if (lane == 0) s_red[wave][r] = w;
-    }
-    __syncthreads();
-    float M[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        M[r] = s_red[0][r];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) M[r] = fmaxf(M[r], s_red[w][r]);
-    }
-    __syncthreads();
-    // ---- pass 2: probabilities in place, row sums ----
-    float ls[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) ls[r] = 0.0f;
-    for (int key = tid; key < Lp; key += 512) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float pr = fast_exp2(sc[r * Lp + key] - M[r]);
-            sc[r * Lp + key] = pr;
-            ls[r] += pr;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float w = wave_sum(ls[r]);
-        if (lane == 0) s_red[wave][r] = w;
-    }
-    __syncthreads();
-    float l[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        l[r] = s_red[0][r];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) l[r] += s_red[w][r];          // fixed order
-    }
-    // ---- pass 3: O = P V, thread = (key slice `wave`, feature d = lane) ----
-    const int groups = Lp / 8;                                    // 8 keys = one 16-byte piece of a V^T row
-    const int per = (groups + 7) / 8, g0 = wave * per, g1 = min(groups, g0 + per);
-    const bf16_t* vrow = Vg + (size_t)lane * p.lpad;
-    float o[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) o[r] = 0.0f;
-    for (int g = g0; g < g1; ++g) {
-        const uint4 v8 = *reinterpret_cast<const uint4*>(vrow + (size_t)g * 8);     // keys 8 g .. 8 g + 7 (beyond L: padding columns, p = 0)
-        const float v[8] = {bf2f(v8.x & 0xffffu), bf2f(v8.x >> 16), bf2f(v8.y & 0xffffu), bf2f(v8.y >> 16),
-                            bf2f(v8.z & 0xffffu), bf2f(v8.z >> 16), bf2f(v8.w & 0xffffu), bf2f(v8.w >> 16)};
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float4 pa = *reinterpret_cast<const float4*>(sc + r * Lp + g * 8), pb = *reinterpret_cast<const float4*>(sc + r * Lp + g * 8 + 4);
-            // a padding column of V^T may hold anything finite (the padding contract): its probability is exactly 0
-            o[r] += pa.x * v[0] + pa.y * v[1] + pa.z * v[2] + pa.w * v[3] + pb.x * v[4] + pb.y * v[5] + pb.z * v[6] + pb.w * v[7];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) s_o[wave][r][lane] = o[r];
-    __syncthreads();
-    if (tid < R * 64) {
-        const int r = tid >> 6, d = tid & 63;
-        float acc = s_o[0][r][d];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) acc += s_o[w][r][d];          // slice order
-        float lr = l[0], Mr = M[0];
-#pragma unroll
-        for (int q = 1; q < R; ++q) if (q == r) { lr = l[q]; Mr = M[q]; }
-        const int qrow = q0 + r;
-        p.out[((size_t)b * p.lpad + qrow) * (size_t)(p.heads * 64) + head * 64 + d] = (bf16_t)f2bf_fast(acc / lr);
-        if (d == 0 && p.lse2) p.lse2[((size_t)b * p.heads + head) * p.lpad + qrow] = Mr + log2f(lr);
-    }
-}
-
-constexpr int kTailKernelMaxLds = 144 * 1024;
-#endif  // DGS_EXPERIMENTS
-
 }  // namespace dgs
 
 using namespace dgs;
@@ -824,17 +681,6 @@ extern "C" size_t dgs_dit_attention_tail_bytes(int32_t B, int32_t heads, int32_t
     return tail_counter_bytes(B, heads) + (size_t)B * heads * ntiles * r * TAIL_REC * sizeof(float);
 }
 
-/* Whether the L % 32 tail queries of this shape can run as a launch of their own (tail_mode 1 + 2). */
-extern "C" int32_t dgs_dit_attention_tail_splittable(int32_t L, int32_t lpad) {
-#ifdef DGS_EXPERIMENTS
-    const int R = L % 32, Lp = (L + 7) & ~7;
-    return R >= 1 && R <= 4 && L >= 256 && lpad % 8 == 0 && R * Lp * (int)sizeof(float) <= kTailKernelMaxLds;
-#else
-    (void)L; (void)lpad;
-    return 0;                                  // the product library has no tail launch
-#endif
-}
-
 extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream) {
     if (!a || a->B <= 0 || a->heads <= 0 || a->L <= 0 || a->lpad < a->L || a->lpad % 128 || !a->qk || !a->vt || !a->out)
         return DGS_ERR_INVALID_ARGUMENT;
@@ -844,17 +690,13 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     p.k_offset = a->k_offset > 0 ? a->k_offset : a->heads * 64;
     p.vt_batch_stride = a->vt_batch_stride > 0 ? a->vt_batch_stride : (long long)a->heads * 64 * a->lpad;
     p.lse2 = a->lse2;
-    const int tail_mode = a->tail_mode;        // 0: the tail queries inside the main kernel; 1: main kernel only; 2: the tail launch only
-    if (tail_mode < 0 || tail_mode > 2) return DGS_ERR_INVALID_ARGUMENT;
-#ifndef DGS_EXPERIMENTS
-    if (tail_mode != 0) return DGS_ERR_INVALID_ARGUMENT;          // modes 1 / 2: the experiments build only (dgs_dit.h)
-#endif
+    if (a->tail_mode != 0) return DGS_ERR_INVALID_ARGUMENT;        // reserved (dgs_dit.h): the tail queries run inside the main kernel
     p.nfull = a->L / 32;                       // full 32-query wave units; the L % 32 rest goes to the tail workgroups
     p.nqb = p.nfull ? (p.nfull + NW - 1) / NW : 1;        // L < 32: one workgroup per head, tail path only
     p.nmain = a->B * a->heads * p.nqb;
     static const int dbg = kInstrumented && getenv("DGS_ATTN_DBG") ? atoi(getenv("DGS_ATTN_DBG")) : 0;     // instrumented library only
     p.dbg = dbg;
-    const int r = tail_mode == 0 ? a->L % 32 : 0;      // tail queries of the MAIN kernel
+    const int r = a->L % 32;                           // tail queries: split over the key tiles behind the main loop
     p.tail_r = r;
     p.tail_ws = nullptr; p.tail_cnt = nullptr;
     if (r) {
@@ -867,27 +709,6 @@ extern "C" int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stre
     p.qk = a->qk; p.vt = a->vt; p.out = a->out; p.q_prescaled = a->q_prescaled;
     p.scale_log2e = a->scale * 1.44269504088896341f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#ifdef DGS_EXPERIMENTS
-    if (tail_mode == 2) {
-        const int R = a->L % 32, Lp = (a->L + 7) & ~7;
-        const int tail_lds = R * Lp * (int)sizeof(float);
-        if (R < 1 || R > 4 || p.nfull < 1 || tail_lds > kTailKernelMaxLds || a->lpad % 8) return DGS_ERR_INVALID_ARGUMENT;
-        static const bool attr_ok =
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_tail_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kTailKernelMaxLds) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_tail_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kTailKernelMaxLds) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_tail_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kTailKernelMaxLds) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_tail_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kTailKernelMaxLds) == hipSuccess;
-        if (!attr_ok) return DGS_ERR_DEVICE;
-        const dim3 grid(a->B * a->heads), block(512);
-        switch (R) {
-            case 1: hipLaunchKernelGGL(attention_tail_kernel<1>, grid, block, tail_lds, st, p); break;
-            case 2: hipLaunchKernelGGL(attention_tail_kernel<2>, grid, block, tail_lds, st, p); break;
-            case 3: hipLaunchKernelGGL(attention_tail_kernel<3>, grid, block, tail_lds, st, p); break;
-            default: hipLaunchKernelGGL(attention_tail_kernel<4>, grid, block, tail_lds, st, p); break;
-        }
-        return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
-    }
-#endif
     // 64 KiB of rings; DGS_ATTN_LDS_PAD (bytes) adds unused LDS to cap the workgroups per CU (measurement aid)
     static const int lds_pad = getenv("DGS_ATTN_LDS_PAD") ? atoi(getenv("DGS_ATTN_LDS_PAD")) : 0;
     // + the staged tail tiles and the tail queries' tile when L % 32 != 0: 64 + 80 + 8 = 152 KiB (one workgroup per CU either way)

@@ -186,11 +186,6 @@ constexpr bool kInstrumented = true;
 #else
 constexpr bool kInstrumented = false;
 #endif
-// Launch-sequence experiments that were built, measured and did not win (each names its profiles/ file) are compiled into the tools'
-// library and the CPU emulation build (whose tests keep them correct), never into the product library.
-#if defined(DGS_INSTRUMENT) || defined(HIPEMU)
-#define DGS_EXPERIMENTS 1
-#endif
 // shader-clock / constant 100 MHz stamps of the debug modes (0 on the emulator)
 __device__ __forceinline__ long long cycle_stamp() {
 #ifndef HIPEMU

@@ -108,36 +108,14 @@ namespace {
 // bench.py's roofline hook: HIP events around every launch of one kernel class, on the launch stream.
 struct Prof {
     void** ev; int kind, cap, n; hipStream_t st;
-    void before(int k) { if (ev && k == kind && n < cap) hipEventRecord(static_cast<hipEvent_t>(ev[2 * n]), st); }
-    void after(int k) { if (ev && k == kind && n < cap) { hipEventRecord(static_cast<hipEvent_t>(ev[2 * n + 1]), st); ++n; } }
+    bool hit(int k) const { return ev && n < cap && (k == kind || (kind == 3 && (k == 6 || k == 7))); }      // 3 = both gated-residual GEMMs (6 proj, 7 fc2)
+    void before(int k) { if (hit(k)) hipEventRecord(static_cast<hipEvent_t>(ev[2 * n]), st); }
+    void after(int k) { if (hit(k)) { hipEventRecord(static_cast<hipEvent_t>(ev[2 * n + 1]), st); ++n; } }
 };
 }  // namespace
 #define DGS_PROF(k, expr) do { prof.before(k); const int rc_ = (expr); prof.after(k); if (rc_ != DGS_OK) { fprintf(stderr, "[dgs] %s:%d: status %d\n", __FILE__, __LINE__, rc_); return rc_; } } while (0)
 
 namespace {
-#ifdef DGS_EXPERIMENTS
-// EXPERIMENT (tools' library / emulator build, DGS_TAIL_CHAIN=1|2; measured and not shipped: profiles/r05_tail_chain_ab.txt).
-// The learned-token rows as a chain of their own on a second stream (dit_tail_rows.hip has the why and the measurements).  One side
-// stream and two events per block per host thread, created on first use (never inside a capture: dgs_amd/graph.py warms up).
-//   main:  LN1  QKV ........ wait(join i) attention(full units) record(fork i)  proj  LN2  fc1  fc2            (4,096-row tiles only)
-//   side:  ............ QKV'(i) record(join i) ........ wait(fork i) attention(tail queries) proj' LN2+fc1' fc2' LN1+QKV'(i+1) ...
-// Data that crosses: the tail rows' q / k / V^T (side -> main attention: join), the attention kernel's reads of them and the
-// 4,096 rows' K / V^T (main -> side: fork).  x, h and the attention output of the tail rows are touched by the side chain only.
-// DGS_TAIL_CHAIN=0 (or a shape the chain does not take): the rows stay side jobs inside the main kernels, as before.
-struct TailChain {
-    hipStream_t side = nullptr;
-    hipEvent_t fork[64], join[64], begin, end;
-    bool ok = false;
-    TailChain() {
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return;
-        for (int i = 0; i < 64; ++i)
-            if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return;
-        if (hipEventCreateWithFlags(&begin, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&end, hipEventDisableTiming) != hipSuccess) return;
-        ok = true;
-    }
-};
-TailChain& tail_chain() { static thread_local TailChain t; return t; }
-#endif
 
 // DiT blocks [first, last) of the inference sequence on the residual stream ws.x (utils_transformer.py:271-290).
 int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last, int B, int lpad, int L, Prof& prof, dgs_stream_t stream) {
@@ -147,36 +125,7 @@ int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last
     at.B = B; at.heads = m->heads; at.L = L; at.lpad = lpad; at.qk = ws.qk; at.vt = ws.vt; at.out = ws.ao; at.scale = 0.125f; at.q_prescaled = 1;
     at.tail_ws = ws.attn_tail; at.tail_ws_bytes = ws.attn_tail_bytes;
     const float q_scale = at.scale * 1.44269504088896341f;         // queries leave the GEMM pre-scaled for the exp2-domain softmax
-#ifdef DGS_EXPERIMENTS
-    // the rows behind the last full 256-row tile: the chain takes them when they are the learned tokens (<= 4 rows, behind >= 1 full tile)
-    const int R = L % 256;
-    const char* chain_env = getenv("DGS_TAIL_CHAIN");            // read per call: tests compare the forms in one process
-    const int chain_mode = chain_env ? atoi(chain_env) : 0;        // 0 (default): off;  1: every operator of the rows;  2: the tail QUERIES stay in the main attention kernel
-    const bool chain = chain_mode > 0 && last > first && m->layers <= 64 && R >= 1 && R <= 4 && L > 256 && W <= 1024 &&
-                       dgs_dit_attention_tail_splittable(L, lpad) && tail_chain().ok;
-    const bool attn_in_main = chain && chain_mode == 2;
-    TailChain* const tcp = chain ? &tail_chain() : nullptr;
-    hipStream_t sd = chain ? tcp->side : nullptr;
-    auto side_qkv = [&](int i) {                                   // LN1 + QKV of block i for the tail rows
-        const float* mod = ws.mod + (size_t)i * 6 * W;
-        TailRowsParams t{};
-        t.B = B; t.R = R; t.lpad = lpad; t.row0 = L - R; t.N = 3 * W; t.K = W; t.ldw = W; t.ldo = 2 * W; t.epilogue = DGS_EPI_QKV;
-        t.mod_stride = nmod; t.eps = 1e-6f; t.q_scale = q_scale; t.x = ws.x; t.shift = mod; t.scale = mod + W;
-        t.W = m->layer[i].qkv_w; t.bias = m->layer[i].qkv_b; t.out = ws.qk; t.vt = ws.vt;
-        return launch_tail_rows(t, sd);
-    };
-    if (chain) {
-        TailChain& tc = *tcp;
-        // fork: the residual stream of the tail rows is what the kernels in front of this call left on the main stream
-        if (hipEventRecord(tc.begin, st) != hipSuccess || hipStreamWaitEvent(sd, tc.begin, 0) != hipSuccess) return DGS_ERR_DEVICE;
-        DGS_TRY(side_qkv(first));
-        if (hipEventRecord(tc.join[first], sd) != hipSuccess) return DGS_ERR_DEVICE;
-    }
-    const int main_rows = chain ? L - R : L;                       // what the main kernels see as a sample's live rows
-#else
-    constexpr bool chain = false;
-    const int main_rows = L;
-#endif
+    const int main_rows = L;                                       // a sample's live rows (padding rows behind them are never computed)
     for (int i = first; i < last; ++i) {
         const DgsDitLayerWeights& lw = m->layer[i];
         const float* mod = ws.mod + (size_t)i * 6 * W;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -189,43 +138,11 @@ int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last
         q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad; q.valid_rows = main_rows;
         q.q_scale = q_scale;
         DGS_PROF(2, dgs_dit_gemm(&q, stream));
-#ifdef DGS_EXPERIMENTS
-        if (chain) {
-            TailChain& tc = *tcp;
-            // join: the attention kernel reads the tail rows' k / V^T like every other key
-            if (hipStreamWaitEvent(st, tc.join[i], 0) != hipSuccess) return DGS_ERR_DEVICE;
-            at.tail_mode = attn_in_main ? 0 : 1;                   // the full 32-query units
-            DGS_PROF(1, dgs_dit_attention(&at, stream));
-            if (hipEventRecord(tc.fork[i], st) != hipSuccess || hipStreamWaitEvent(sd, tc.fork[i], 0) != hipSuccess) return DGS_ERR_DEVICE;
-            // ---- the side chain of this block (behind the main attention: that kernel's eight waves hold their CU's whole register
-            //      file, nothing runs beside it; everything below runs beside proj / LN2 / fc1 / fc2 / LN1 / QKV of the main stream) ----
-            at.tail_mode = 2;                                      // the L % 32 tail queries, all keys
-            if (!attn_in_main) DGS_TRY(dgs_dit_attention(&at, sd));
-            TailRowsParams t{};
-            t.B = B; t.R = R; t.lpad = lpad; t.row0 = L - R; t.mod_stride = nmod; t.gate_stride = nmod; t.eps = 1e-6f; t.q_scale = 1.0f;
-            t.N = W; t.K = W; t.A = ws.ao; t.lda = W; t.W = lw.proj_w; t.ldw = W; t.bias = lw.proj_b; t.epilogue = DGS_EPI_GATE_RESIDUAL;
-            t.out = ws.x; t.ldo = W; t.gate = mod + 2 * W;
-            DGS_TRY(launch_tail_rows(t, sd));
-            t.A = nullptr; t.x = ws.x; t.shift = mod + 3 * W; t.scale = mod + 4 * W;
-            t.N = 4 * W; t.K = W; t.W = lw.fc1_w; t.ldw = W; t.bias = lw.fc1_b; t.epilogue = DGS_EPI_GELU_BF16; t.out = ws.h; t.ldo = 4 * W; t.gate = nullptr;
-            DGS_TRY(launch_tail_rows(t, sd));
-            t.x = nullptr; t.shift = t.scale = nullptr; t.A = ws.h; t.lda = 4 * W;
-            t.N = W; t.K = 4 * W; t.W = lw.fc2_w; t.ldw = 4 * W; t.bias = lw.fc2_b; t.epilogue = DGS_EPI_GATE_RESIDUAL; t.out = ws.x; t.ldo = W; t.gate = mod + 5 * W;
-            DGS_TRY(launch_tail_rows(t, sd));
-            if (i + 1 < last) {
-                DGS_TRY(side_qkv(i + 1));
-                if (hipEventRecord(tc.join[i + 1], sd) != hipSuccess) return DGS_ERR_DEVICE;
-            } else if (hipEventRecord(tc.end, sd) != hipSuccess) return DGS_ERR_DEVICE;
-        } else
-#endif
-        {
-            at.tail_mode = 0;
-            DGS_PROF(1, dgs_dit_attention(&at, stream));
-        }
+        DGS_PROF(1, dgs_dit_attention(&at, stream));
         DgsDitGemmArgs pr{};
         pr.M = M; pr.N = W; pr.K = W; pr.A = ws.ao; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
         pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad; pr.valid_rows = main_rows;
-        DGS_PROF(3, dgs_dit_gemm(&pr, stream));
+        DGS_PROF(6, dgs_dit_gemm(&pr, stream));
         l1.shift = mod + 3 * W; l1.scale = mod + 4 * W;
         DGS_PROF(5, launch_layernorm(&l1, st));
         DgsDitGemmArgs f1{};
@@ -236,12 +153,8 @@ int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last
         f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = ws.h; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
         f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.out = ws.x; f2.ldo = W; f2.gate = mod + 5 * W; f2.gate_stride = nmod; f2.rows_per_batch = lpad; f2.valid_rows = main_rows;
         // (fused split-K for this 64-tile GEMM was built and measured: 66 -> 86 us, see DgsDitGemmArgs.splitk_ws / DESIGN.md section 9)
-        DGS_PROF(3, dgs_dit_gemm(&f2, stream));
+        DGS_PROF(7, dgs_dit_gemm(&f2, stream));
     }
-#ifdef DGS_EXPERIMENTS
-    // join: whatever follows on the main stream (the heads, the token gather) reads the tail rows of the residual stream
-    if (chain && hipStreamWaitEvent(st, tcp->end, 0) != hipSuccess) return DGS_ERR_DEVICE;
-#endif
     return DGS_OK;
 }
 }  // namespace

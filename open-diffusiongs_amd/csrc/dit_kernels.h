@@ -33,21 +33,6 @@ struct GsParams {
     float *xyz, *features, *scaling, *rotation, *opacity, *aligned;
 };
 
-// the learned-token rows as kernels of their own (dit_tail_rows.hip)
-struct TailRowsParams {
-    int B, R, lpad, row0, N, K, lda, ldw, ldo, epilogue, mod_stride, gate_stride, cols_per_wave;
-    float eps, q_scale;
-    const float* x;          // LN form: residual stream [B * lpad, K] (fp32): A = bf16(LayerNorm(x rows) * (1 + scale) + shift); else NULL
-    const float *shift, *scale;
-    const bf16_t* A;         // plain form: bf16 rows [B * lpad, lda]
-    const bf16_t* W;         // [N, ldw]
-    const float* bias;
-    void* out;               // QKV: [M, ldo] q | k (bf16);  GELU: [M, ldo] bf16;  gated residual: [M, ldo] fp32, updated in place
-    bf16_t* vt;              // QKV: V^T [B][N / 3][lpad]
-    const float* gate;       // gated residual: [B, gate_stride]
-};
-int launch_tail_rows(const TailRowsParams& p, hipStream_t st);
-
 int launch_layernorm(const DgsDitLayerNormArgs* a, hipStream_t st);
 int launch_rowlinear(const DgsDitRowLinearArgs* a, hipStream_t st);
 int launch_timestep(const int64_t* t, float* emb, int B, hipStream_t st);

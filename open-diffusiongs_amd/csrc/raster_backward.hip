@@ -256,12 +256,13 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
                 // used to drop the pair)
                 const float dx = e.xy.x - pfx, dy = e.xy.y - pfy;
                 const float power = -0.5f * (e.co.x * dx * dx + e.co.z * dy * dy) - e.co.y * dx * dy;
-                const bool near = k < tot && inside && first - j <= last_contributor && !(power > 0.0f) && !(power < e.rc.w);
-                if (__ballot(near) != 0ull) {
-                    const float G = blend_exp<FAST_EXP>(near ? power : 0.0f);
-                    const float alpha = fminf(0.99f, e.co.w * G);
-                    const bool take = near && !(alpha < 1.0f / 255.0f);
-                    const unsigned long long takers = __ballot(take);
+                // (bitwise &: plain compares; && would branch under a saved exec mask)
+                const bool near = (k < tot) & inside & (first - j <= last_contributor) & !(power > 0.0f) & !(power < e.rc.w);
+                if (wave_ballot(near) != 0ull) {
+                    const float G = blend_exp<FAST_EXP>(near ? power : 0.0f, e.co.w);
+                    const float alpha = alpha_clamp(e.co.w * G);
+                    const bool take = near & !(alpha < 1.0f / 255.0f);
+                    const unsigned long long takers = wave_ballot(take);
                     if (takers != 0ull) {                               // wave-uniform: somebody in this strip touches its Gaussian
                         // product default: one v_rcp_f32 serves both divisions by (1 - alpha) (the exact mode keeps the reference's two
                         // correctly rounded divisions, backward.cu:478,506: ~10 VALU each)
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BwdParams p) {
             Entry ea = load(word & 255u), eb;
             if constexpr (kRasterStats) st_entries += tot;
             uint32_t k = 0;
-            for (; __ballot(k < tot) != 0ull && !(kRasterAblate && (p.ablate & 4)); k += 4) {
+            for (; wave_ballot(k < tot) != 0ull && !(kRasterAblate && (p.ablate & 4)); k += 4) {
                 const uint32_t word_next = lst[(k >> 2) + 1u];
                 eb = load((word >> 8) & 255u);  step(k, word & 255u, ea);
                 ea = load((word >> 16) & 255u); step(k + 1u, (word >> 8) & 255u, eb);
@@ -505,14 +506,14 @@ __global__ __launch_bounds__(128) void blend_backward_pair_kernel(BwdParams p) {
                 const v2f dy = e.xy.y - pfy;
                 const v2f power = -0.5f * (e.co.x * dx * dx + e.co.z * dy * dy) - e.co.y * dx * dy;
                 const uint32_t back = first - j;                         // 1-based list index of the entry (backward.cu:463-468)
-                const bool near0 = k < tot && in0 && back <= lc0 && !(power.x > 0.0f) && !(power.x < e.rc.w);
-                const bool near1 = k < tot && in1 && back <= lc1 && !(power.y > 0.0f) && !(power.y < e.rc.w);
-                if (__ballot(near0 || near1) != 0ull) {
-                    const v2f G = {blend_exp<FAST_EXP>(near0 ? power.x : 0.0f), blend_exp<FAST_EXP>(near1 ? power.y : 0.0f)};
+                const bool near0 = (k < tot) & in0 & (back <= lc0) & !(power.x > 0.0f) & !(power.x < e.rc.w);
+                const bool near1 = (k < tot) & in1 & (back <= lc1) & !(power.y > 0.0f) & !(power.y < e.rc.w);
+                if (wave_ballot(near0 | near1) != 0ull) {
+                    const v2f G = {blend_exp<FAST_EXP>(near0 ? power.x : 0.0f, e.co.w), blend_exp<FAST_EXP>(near1 ? power.y : 0.0f, e.co.w)};
                     v2f alpha = e.co.w * G;
-                    alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y);
-                    const bool take0 = near0 && !(alpha.x < 1.0f / 255.0f), take1 = near1 && !(alpha.y < 1.0f / 255.0f);
-                    const unsigned long long takers = __ballot(take0 || take1);
+                    alpha.x = alpha_clamp(alpha.x); alpha.y = alpha_clamp(alpha.y);
+                    const bool take0 = near0 & !(alpha.x < 1.0f / 255.0f), take1 = near1 & !(alpha.y < 1.0f / 255.0f);
+                    const unsigned long long takers = wave_ballot(take0 | take1);
                     if (takers != 0ull) {
                         const v2f one_m = 1.f - alpha;
                         v2f inv1ma = {0.f, 0.f}, Tn;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(128) void blend_backward_pair_kernel(BwdParams p) {
             Entry ea = load(word & 255u), eb;
             if constexpr (kRasterStats) st_entries += tot;
             uint32_t k = 0;
-            for (; __ballot(k < tot) != 0ull && !(kRasterAblate && (p.ablate & 4)); k += 4) {
+            for (; wave_ballot(k < tot) != 0ull && !(kRasterAblate && (p.ablate & 4)); k += 4) {
                 const uint32_t word_next = lst[(k >> 2) + 1u];
                 eb = load((word >> 8) & 255u);  step(k, word & 255u, ea);
                 ea = load((word >> 16) & 255u); step(k + 1u, (word >> 8) & 255u, eb);

@@ -307,17 +307,24 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys
 // counts (agent-scope stores: performed at the memory side, visible to every XCD without a fence) and adds one to the view's arrival
 // counter; once all NB workgroups of the view have arrived it reads all NB x 256 counts (agent-scope loads) -- thread d sums digit
 // d over the blocks in front of its own and over all of them -- scans the digit totals, and scatters as radix_scatter_kernel does.
-// The wait is a spin on one word by one lane (s_sleep between polls) and needs the view's workgroups to be resident together:
-// dispatch is in block order and a view's workgroups only wait for each other, so whatever fits the chip of the views in front has
-// either finished or can finish; the host still takes the three-kernel pass when NB x V exceeds what the chip holds at once
-// (training calls with dozens of views) and on the CPU emulation build (workgroups run one after the other there).  The spin is
-// bounded: a view that does not assemble in ~1 s leaves DGS_ERR_DEVICE in the call's status word instead of hanging the GPU.
+// The wait is a spin on one word by one lane (s_sleep between polls) and needs the view's workgroups to be resident together.
+// Dispatch is in block order and a view's workgroups only wait for each other, so whatever fits the chip of the views in front has
+// either finished or can finish; the host takes the one-kernel pass only when NB x V fits what the occupancy query says the chip
+// holds of THIS kernel at once (else the three-kernel pass: training calls with dozens of views; and always on the CPU emulation
+// build, whose workgroups run one after the other).  The occupancy query knows nothing of another stream's or another process's
+// kernels holding CUs (an RCCL ring beside the next micro-batch's forward; two ranks on one device), so the spin is bounded by
+// the wall clock -- 20 ms of the constant 100 MHz counter -- and a view that did not assemble is NOT an error: the workgroup that
+// gives up records the pass in the view's rescue word and leaves WITHOUT scattering (the pass's input buffer is intact: a pass only
+// writes its output buffer), the later passes of that view return at once, and radix_rescue_kernel -- one workgroup per view
+// behind the four passes, which returns at once for a view that needs nothing -- finishes the view's sort from the failed pass on.
+// The call produces the same bits either way (tests/test_raster_forward_gpu.py::test_radix_rescue_*: a fault injected per pass, and
+// the render beside a second stream's kernel that holds 64 CUs).
 // Keys and values stay in registers between the count and the scatter (one read of the tile instead of two).
 // ------------------------------------------------------------------------------------------------
 #ifndef HIPEMU
 __global__ __launch_bounds__(256) void radix_pass_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                                                        uint32_t* rank_of, uint32_t* hist, uint32_t* arrived, int32_t* status, int P, int NB,
-                                                        int shift) {
+                                                        uint32_t* rank_of, uint32_t* hist, uint32_t* arrived, uint32_t* rescue, int P, int NB,
+                                                        int shift, int fault) {
     __shared__ uint32_t wcount[4][256];
     __shared__ uint32_t running[256];
     __shared__ uint32_t scratch[8];
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const uint32_t* keys_in
     const int lane = tid & 63, wave = tid >> 6;
     const size_t vo = (size_t)v * P;
     uint32_t key[kSortItems], val[kSortItems];
+    if (__hip_atomic_load(rescue + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;      // an earlier pass of this view did not assemble
     running[tid] = 0;
     __syncthreads();
 #pragma unroll
@@ -346,11 +354,14 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const uint32_t* keys_in
     if (tid == 0) {
         __hip_atomic_fetch_add(arrived + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 0;
-        for (int spin = 0; spin < (1 << 22); ++spin) {
+        const long long t0 = (long long)wall_clock64();                      // constant 100 MHz
+        // (fault injection, tests only: every other workgroup of the view gives up at once in pass `fault` -- the others scatter)
+        for (int spin = 0; !(fault == (shift >> 3) && (b & 1)); ++spin) {
             if (__hip_atomic_load(arrived + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)NB) { ok = 1; break; }
+            if ((spin & 63) == 63 && (long long)wall_clock64() - t0 > 2000000ll) break;          // 20 ms
             __builtin_amdgcn_s_sleep(4);
         }
-        if (!ok) status[1] = DGS_ERR_DEVICE;
+        if (!ok) __hip_atomic_fetch_max(rescue + v, (uint32_t)(shift >> 3) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_ok = ok;
     }
     __syncthreads();
@@ -394,6 +405,72 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const uint32_t* keys_in
         }
         __syncthreads();
         running[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
+    }
+}
+
+// One workgroup of 1,024 threads per view: passes [first failed, 3] of the view's LSD sort (see radix_pass_kernel), or nothing.
+// The same stable pass -- digit histogram, exclusive scan, ballot ranks inside a wave, waves chained through LDS counters -- with the
+// whole view as one tile: ~1 ms per pass at P = 262,146, paid only by a call whose one-kernel pass could not assemble.
+__global__ __launch_bounds__(1024) void radix_rescue_kernel(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t* rank_of,
+                                                           const uint32_t* rescue, int P) {
+    __shared__ uint32_t wcount[16][256];
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t scratch[20];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t first = __hip_atomic_load(rescue + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (first == 0u) return;
+    const size_t vo = (size_t)v * P;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int pass = (int)first - 1; pass < 4; ++pass) {
+        const uint32_t* kin = (pass & 1 ? keys1 : keys0) + vo;
+        const uint32_t* vin = (pass & 1 ? vals1 : vals0) + vo;
+        uint32_t* kout = (pass & 1 ? keys0 : keys1) + vo;
+        uint32_t* vout = (pass & 1 ? vals0 : vals1) + vo;
+        const int shift = 8 * pass;
+        if (tid < 256) running[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < P; i += 1024) atomicAdd(&running[(kin[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        uint32_t all = 0;
+        const uint32_t ex = block_exclusive_scan<1024>(tid < 256 ? running[tid] : 0u, scratch, &all);     // threads 0..255: digits in front of theirs
+        __syncthreads();
+        if (tid < 256) running[tid] = ex;
+        __syncthreads();
+        for (int i0 = 0; i0 < P; i0 += 1024) {
+            for (int w = tid; w < 16 * 256; w += 1024) (&wcount[0][0])[w] = 0;
+            __syncthreads();
+            const int i = i0 + tid;
+            const bool valid = i < P;
+            const uint32_t key = valid ? kin[i] : 0xFFFFFFFFu;
+            const uint32_t val = valid ? (pass == 0 ? (uint32_t)i : vin[i]) : 0u;
+            const uint32_t dig = (key >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long m = __ballot((dig >> bit) & 1u);
+                peers &= ((dig >> bit) & 1u) ? m : ~m;
+            }
+            const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+            if (valid && rank_in_wave == 0) wcount[wave][dig] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            if (valid) {
+                uint32_t pos = running[dig] + rank_in_wave;
+                for (int w = 0; w < wave; ++w) pos += wcount[w][dig];
+                kout[pos] = key;
+                vout[pos] = val;
+                if (pass == 3) rank_of[vo + val] = pos;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t add = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) add += wcount[w][tid];
+                running[tid] += add;
+            }
+            __syncthreads();
+        }
+        __threadfence();                                        // the next pass of this workgroup reads what every thread of it scattered
+        __syncthreads();
     }
 }
 #endif
@@ -1028,6 +1105,9 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
         if (alive != 0ull) {                                    // a wave whose 64 pixels are all finished only keeps the barriers
             const uint4 cn = s_cnt[cell];
             const uint32_t tot = (((alive >> (16 * row)) & 0xFFFFull) != 0ull) ? cn.x + cn.y + cn.z + cn.w : 0u;
+            // a lane's OWN list length: 0 once its pixel is finished, so "still walking" is the index compare the step makes anyway
+            // (a `done` flag tested per step is a VGPR 0/1 and costs three VALU per step to test and keep)
+            uint32_t tot_l = done ? 0u : tot;
             // software pipeline: the cell's indices arrive four at a time (one 32-bit word, the next word a group ahead), the
             // entry itself one step ahead, in two register sets that take turns -- the loop is unrolled by the word, so there is
             // no copy between steps and every shift is a literal (the rotating form spent 13 of its ~45 VALU per step on moves)
@@ -1037,14 +1117,15 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
             auto step = [&](uint32_t k, uint32_t j, const Entry& e) {
                 const float dx = e.xy.x - pfx, dy = e.xy.y - pfy;
                 const float power = -0.5f * (e.co.x * dx * dx + e.co.z * dy * dy) - e.co.y * dx * dy;
-                const bool pass = k < tot && !done && !(power > 0.0f) && !(power < e.rc.w);  // alpha < 1/255 guaranteed below the cut (preprocess_one)
-                if (__ballot(pass) != 0ull) {
-                    const float alpha = fminf(0.99f, e.co.w * blend_exp<FAST_EXP>(pass ? power : 0.0f));
+                // (bitwise &: the operands are three compares; && would make the second and third a branch under a saved exec mask)
+                const bool pass = (k < tot_l) & !(power > 0.0f) & !(power < e.rc.w);  // alpha < 1/255 guaranteed below the cut (preprocess_one)
+                if (wave_ballot(pass) != 0ull) {
+                    const float alpha = alpha_clamp(e.co.w * blend_exp<FAST_EXP>(pass ? power : 0.0f, e.co.w));
                     const float test_T = T * (1 - alpha);
-                    const bool contributes = pass && !(alpha < 1.0f / 255.0f);
-                    const bool finishes = contributes && test_T < 0.0001f;
-                    const bool blends = contributes && !finishes;
-                    done = done || finishes;
+                    const bool contributes = pass & !(alpha < 1.0f / 255.0f);
+                    const bool finishes = contributes & (test_T < 0.0001f);
+                    const bool blends = contributes & !finishes;
+                    tot_l = finishes ? 0u : tot_l;
                     if constexpr (FAST_EXP) {
                         // product default: one weight, three fused multiply-adds (5 VALU for 12; the exact mode keeps the
                         // reference's (c alpha) T products and separate adds, forward.cu:352-353, for bit-identity with the oracle)
@@ -1065,7 +1146,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
             Entry ea = load(word & 255u), eb;
             if constexpr (kRasterStats) st_entries += tot;
             uint32_t k = 0;
-            for (; __ballot(k < tot) != 0ull; k += 4) {
+            for (; wave_ballot(k < tot_l) != 0ull; k += 4) {
                 const uint32_t word_next = lst[(k >> 2) + 1u];
                 eb = load((word >> 8) & 255u);  step(k, word & 255u, ea);
                 ea = load((word >> 16) & 255u); step(k + 1u, (word >> 8) & 255u, eb);
@@ -1073,6 +1154,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
                 ea = load(word_next & 255u);    step(k + 3u, word >> 24, eb);
                 word = word_next;
             }
+            done = done | (tot_l != tot);                       // finished in this batch (tot >= 1 then), or before it
             if constexpr (kRasterStats) st_trips += k;
         }
     }
@@ -1226,7 +1308,7 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
                             kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
     if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
     // tile_count, totals and the radix sort's arrival counters are neighbours in the image state (ImageState::carve): one fill
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, (int)(p.im.radix_sync + 4 * kRadixSyncViews - p.im.tile_count));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, (int)(p.im.radix_sync + 5 * kRadixSyncViews - p.im.tile_count));
     const dim3 gridP((P + 255) / 256, V);
     const bool lds_tiles = p.T <= 4096;
     if (lds_tiles) hipLaunchKernelGGL((preprocess_kernel<true>), gridP, dim3(256), (size_t)p.T * 4, st, p);
@@ -1265,13 +1347,19 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         // three-kernel pass (measurement aid)
         static const int ncu = [] { int n = 0, d = 0; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
         static const bool three = getenv("DGS_RASTER_RADIX3") && atoi(getenv("DGS_RASTER_RADIX3")) != 0;
-        if (!three && ncu > 0 && (long long)NB * V <= 4ll * ncu && V <= kRadixSyncViews) {
+        // workgroups of radix_pass_kernel one CU holds at once, from the kernel's own registers and LDS (not a guessed constant)
+        static const int per_cu = [] { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, radix_pass_kernel, 256, 0) == hipSuccess ? n : 0; }();
+        // DGS_RASTER_RADIX_FAULT=<pass 0..3> (tests): half of every view's workgroups give up in that pass; radix_rescue_kernel finishes the sort
+        static const int fault = getenv("DGS_RASTER_RADIX_FAULT") ? atoi(getenv("DGS_RASTER_RADIX_FAULT")) : -1;
+        if (!three && ncu > 0 && per_cu > 0 && (long long)NB * V <= (long long)per_cu * ncu && V <= kRadixSyncViews) {
+            uint32_t* const rescue = p.im.radix_sync + 4 * kRadixSyncViews;
             for (int pass = 0; pass < 4; ++pass) {
                 const int in = pass & 1, out = in ^ 1;
                 hipLaunchKernelGGL(radix_pass_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], pass == 0 ? (const uint32_t*)nullptr : p.g.vals[in], p.g.keys[out],
-                                   p.g.vals[out], pass == 3 ? p.g.rank_of : (uint32_t*)nullptr, p.g.radix_hist, p.im.radix_sync + pass * kRadixSyncViews, p.im.totals, P, NB,
-                                   8 * pass);
+                                   p.g.vals[out], pass == 3 ? p.g.rank_of : (uint32_t*)nullptr, p.g.radix_hist, p.im.radix_sync + pass * kRadixSyncViews, rescue, P, NB,
+                                   8 * pass, fault);
             }
+            hipLaunchKernelGGL(radix_rescue_kernel, dim3(V), dim3(1024), 0, st, p.g.keys[0], p.g.keys[1], p.g.vals[0], p.g.vals[1], p.g.rank_of, rescue, P);
             radix_done = true;
             return;
         }

@@ -90,7 +90,8 @@ struct ImageState {
     uint32_t* tile_cursor;         // [V*T]   scatter cursors
     uint2* ranges;                 // [V*T]   [start,end) into the packed instance list
     int32_t* totals;               // [4]     {num_rendered, status, longest tile list, -}
-    uint32_t* radix_sync;          // [4][kRadixSyncViews] arrival counters of the one-kernel radix passes (raster_forward.hip radix_pass_kernel)
+    uint32_t* radix_sync;          // [5][kRadixSyncViews]: rows 0-3 arrival counters of the one-kernel radix passes (raster_forward.hip radix_pass_kernel);
+                                   //          row 4: per view, 1 + the first pass that did not assemble (0: none) -- radix_rescue_kernel finishes that view's sort
     uint32_t* tile_order;          // [V*T]   launch order of the per-tile kernels (workgroup b works on tile tile_order[b])
     uint32_t* tile_work;           // [V*T]   list entries the forward blend walked before the tile was finished
     uint32_t* tile_scanned;        // [V*T]   depth ranks the forward blend tested for the tile (scan form; else 0)
@@ -105,7 +106,7 @@ struct ImageState {
         s.n_contrib = c.take<uint32_t>(V * W * H);
         s.tile_count = c.take<uint32_t>(V * T);
         s.totals = c.take<int32_t>(4);             // directly behind tile_count: the forward zeroes both with one fill
-        s.radix_sync = c.take<uint32_t>(4 * kRadixSyncViews);      // ... and these
+        s.radix_sync = c.take<uint32_t>(5 * kRadixSyncViews);      // ... and these
         s.tile_cursor = c.take<uint32_t>(V * T);
         s.ranges = c.take<uint2>(V * T);
         s.tile_order = c.take<uint32_t>(V * T);

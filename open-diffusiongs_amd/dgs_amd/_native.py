@@ -274,7 +274,7 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_rowlinear_backward", "dgs_dit_gate_mul", "dgs_dit_saved_bytes", "dgs_dit_backward_workspace_bytes",
                "dgs_dit_forward_train", "dgs_dit_backward", "dgs_dit_layernorm", "dgs_dit_rowlinear", "dgs_dit_lpad",
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
-               "dgs_dit_attention_tail_bytes", "dgs_dit_attention_tail_splittable", "dgs_dit_run_blocks", "dgs_debug_poison_lds", "dgs_debug_clock_probe",
+               "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds", "dgs_debug_clock_probe",
                "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes",
                "dgs_dit_workspace_bytes_for_tokens"]
 
@@ -295,8 +295,6 @@ def _declare_dit(L):
     L.dgs_dit_gemm_splitk_bytes.argtypes = [ctypes.c_int32] * 4
     L.dgs_dit_attention_tail_bytes.restype = ctypes.c_size_t
     L.dgs_dit_attention_tail_bytes.argtypes = [ctypes.c_int32] * 3
-    L.dgs_dit_attention_tail_splittable.restype = ctypes.c_int32
-    L.dgs_dit_attention_tail_splittable.argtypes = [ctypes.c_int32] * 2
     L.dgs_dit_lpad.restype = ctypes.c_int32
     L.dgs_dit_lpad.argtypes = [ctypes.c_int32]
     L.dgs_dit_workspace_bytes.restype = ctypes.c_size_t

@@ -90,8 +90,7 @@ class DitOps:
     def attention(self, qk, vt, L, heads, qkv_layout=False, lse2=None, q_prescaled=False, tail_mode=0, out=None):
         """qk bf16 [B*lpad, 2*heads*64], vt bf16 [B, heads*64, lpad] -> bf16 [B*lpad, heads*64].
         qkv_layout: `qk` is the training tensor [B*lpad, 3W] and `vt` its transposed copy [B, 3W, lpad].
-        tail_mode (dgs_dit.h): 0 everything in one launch; 1 the full 32-query units only; 2 the L % 32 tail queries only (into `out`) --
-        1 / 2 in the experiments build of the library only (the product library rejects them)."""
+        tail_mode: reserved field of dgs_dit.h (0; the library rejects anything else)."""
         B, _, lpad = vt.shape
         W = heads * 64
         if out is None:
@@ -103,7 +102,7 @@ class DitOps:
             a.ld_qk, a.k_offset, a.vt_batch_stride = 3 * W, W, 3 * W * lpad
             a.vt = ctypes.c_void_p(vt.data_ptr() + 2 * W * lpad * 2)
         a.lse2, a.q_prescaled, a.tail_mode = _p(lse2), int(q_prescaled), int(tail_mode)
-        nb = int(self.lib.dgs_dit_attention_tail_bytes(B, heads, L)) if tail_mode == 0 else 0
+        nb = int(self.lib.dgs_dit_attention_tail_bytes(B, heads, L))
         if nb:      # caller-owned scratch of the L % 32 tail queries (zero-filled: holds the arrival counters)
             tail = torch.zeros(nb, dtype=torch.uint8, device=qk.device)
             a.tail_ws, a.tail_ws_bytes = _p(tail), nb

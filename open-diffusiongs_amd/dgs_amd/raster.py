@@ -136,7 +136,7 @@ class RasterBackend:
     def __init__(self, lib=None, exact_exp=None):
         self.lib = lib if lib is not None else _native.lib()
         self._plans = {}             # (P, W, H, V, views_per_set, device) -> _AsyncPlan
-        # exponential of the blend loops (dgs_raster.h `exact_exp`): False = the hardware's v_exp_f32 (product default), True = the
+        # exponential of the blend loops (dgs_raster.h `exact_exp`): False = compensated v_exp_f32 + cut-off guard band (product default, <= 1.3 ulp), True = the
         # fixed IEEE sequence the CPU oracle restates (floats bit-identical with the oracle: what the bit-exact parity tests select)
         self.exact_exp = bool(int(os.environ.get("DGS_RASTER_EXACT_EXP", "0") or 0)) if exact_exp is None else bool(exact_exp)
         # backward without floating-point atomics (dgs_raster.h `scratch`; DGS_RASTER_DETERMINISTIC=1 or `backend.deterministic = True`):

@@ -26,9 +26,9 @@ def close(got, ref, rtol=2e-4, what=""):
 def assert_backward_parity(backend, sc, cams, H, W, device, sh_degree=0, bg=(1.0, 1.0, 1.0), seed=0, colors_precomp=None,
                            cov3D_precomp=None, exact=True, rtol=2e-4):
     """One Gaussian set rendered into len(cams) views in ONE batched call; oracle: per view, gradients summed over views.
-    exact=True: the oracle's own exponential in the blend loops (the 2e-4 bar then measures summation order only);
-    exact=False / None: the product default (hardware v_exp_f32) -- a pair whose alpha sits within an ulp of the 1/255 cut-off
-    may then be counted by one side only, which moves that Gaussian's gradient by its whole contribution: pass rtol=2e-3."""
+    exact=True: the oracle's own exponential in the blend loops (every float bit-identical with the oracle; the bar measures summation
+    order only); exact=False / None: the product default (compensated v_exp_f32 + the cut-off guard band, csrc/dgs_device.h): the same
+    bar holds (profiles/r06_raster_grad_error.txt)."""
     with exp_mode(backend, exact):
         return _assert_backward_parity(backend, sc, cams, H, W, device, sh_degree, bg, seed, colors_precomp, cov3D_precomp, rtol)
 

@@ -112,39 +112,6 @@ def test_attention(ops, L, prescaled):
     assert torch.allclose(lse2[:, :, :L], torch.logsumexp(s, -1) * 1.4426950408889634, atol=5e-2, rtol=5e-3)
 
 
-@pytest.mark.parametrize("L,prescaled", [(258, True), (290, False), (515, True), (260, True)])
-def test_attention_tail_as_its_own_launch(ops, L, prescaled):
-    """dgs_dit.h `tail_mode`: the full 32-query units in the main kernel (1) + the L % 32 tail queries in the small VALU kernel (2) --
-    what dgs_dit_forward runs on two streams -- give the main rows of the one-launch form bit for bit and tail rows within the same
-    bars against the fp32 softmax; 1 .. 4 tail queries (258: the DiT's two learned tokens)."""
-    g = torch.Generator().manual_seed(5)
-    B, heads = 2, 2
-    lpad = (L + 127) // 128 * 128
-    assert ops.lib.dgs_dit_attention_tail_splittable(L, lpad) == 1 and ops.lib.dgs_dit_attention_tail_splittable(256, 256) == 0
-    assert ops.lib.dgs_dit_attention_tail_splittable(263, 384) == 0 and ops.lib.dgs_dit_attention_tail_splittable(130, 256) == 0
-    q, k, v = (torch.randn(B, heads, lpad, 64, generator=g) for _ in range(3))
-    q[1, 1, L - 1] *= 6.0                     # a spiky TAIL row
-    k[0, 0, 70] *= 6.0
-    c = 0.125 * 1.4426950408889634
-    qb, kb, vb = (_bf(q * c) if prescaled else _bf(q)), _bf(k), _bf(v)
-    qk = torch.cat([qb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64), kb.permute(0, 2, 1, 3).reshape(B * lpad, heads * 64)], 1).contiguous()
-    vt = vb.permute(0, 1, 3, 2).reshape(B, heads * 64, lpad).contiguous()
-    lse_a, lse_b = torch.zeros(B, heads, lpad), torch.zeros(B, heads, lpad)
-    one = ops.attention(qk, vt, L, heads, lse2=lse_a, q_prescaled=prescaled)
-    two = ops.attention(qk, vt, L, heads, lse2=lse_b, q_prescaled=prescaled, tail_mode=1)
-    nmain = L // 32 * 32
-    rows = lambda o: o.reshape(B, lpad, heads * 64)
-    assert float(rows(two)[:, nmain:L].float().abs().max()) == 0.0                     # the main launch leaves the tail rows alone
-    ops.attention(qk, vt, L, heads, lse2=lse_b, q_prescaled=prescaled, tail_mode=2, out=two)
-    assert torch.equal(rows(one)[:, :nmain], rows(two)[:, :nmain]) and torch.equal(lse_a[:, :, :nmain], lse_b[:, :, :nmain])
-    out = two.float().reshape(B, lpad, heads, 64).permute(0, 2, 1, 3)
-    s = (qb.float()[:, :, :L] @ kb.float()[:, :, :L].transpose(-1, -2)) * (0.6931471805599453 if prescaled else 0.125)
-    ref = s.softmax(-1) @ vb.float()[:, :, :L]
-    assert torch.allclose(out[:, :, nmain:L], ref[:, :, nmain:], atol=1e-2, rtol=1e-2)
-    assert torch.allclose(lse_b[:, :, nmain:L], (torch.logsumexp(s, -1) * 1.4426950408889634)[:, :, nmain:], atol=5e-2, rtol=5e-3)
-    assert float((rows(one)[:, nmain:L].float() - rows(two)[:, nmain:L].float()).abs().max()) < 3e-2
-
-
 def test_layernorm_modulate(ops):
     g = torch.Generator().manual_seed(4)
     rows, Wd = 24, 1024

@@ -31,10 +31,11 @@ def test_backward_matches_oracle(deg, seed, H, W, views):
 
 
 def test_backward_product_default_arithmetic():
-    """`exact_exp` = 0 (what the product runs): hardware exponential, one reciprocal for both divisions by (1 - alpha) -- the same
-    gradients to 2e-3 of each tensor's max (on the emulator the `hardware` forms are libm's: this checks the mode's plumbing)."""
+    """`exact_exp` = 0 (what the product runs): compensated hardware exponential + the cut-off guard band, one reciprocal for both
+    divisions by (1 - alpha) -- the same gradients at the exact mode's bar, 2e-4 of each tensor's max (on the emulator v_exp_f32 and
+    v_rcp_f32 are libm's exp2f and a division: this checks the mode's plumbing and the guard band's logic; the GPU suite measures)."""
     sc, cams = small_scene(200, 48, 48, seed=5, sh_degree=1, n_views=2)
-    assert_backward_parity(emu_backend(), sc, cams, 48, 48, DEV, sh_degree=1, exact=False, rtol=2e-3)
+    assert_backward_parity(emu_backend(), sc, cams, 48, 48, DEV, sh_degree=1, exact=False, rtol=2e-4)
 
 
 def test_backward_precomputed_inputs():

@@ -50,15 +50,14 @@ def test_full_size_256_vs_oracle(regime, views):
     assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV)
 
 
-@pytest.mark.parametrize("regime,views,rtol", [("trained", 2, 4e-3), ("init", 1, 1e-5)])
+@pytest.mark.parametrize("regime,views,rtol", [("trained", 2, 2e-4), ("init", 1, 2e-4)])
 def test_full_size_256_product_default_exp(regime, views, rtol):
-    """The same with the product's blend exponential (hardware v_exp_f32, `exact_exp` = 0).  Bars = 2-3 x what tools/raster_grad_error.py
-    measures against the oracle's fp64 sums (profiles/r05_raster_grad_error.txt): 1.8e-3 of a tensor's max in the trained-like scene
-    (dL/dscale; 1.3e-3 dL/dopacity) and 3.4e-6 in the random-init scene -- against 6.6e-6 / 4.7e-6 with the oracle's own exponential,
-    which is what summation order leaves.  The trained-like figure is not rounding noise accumulating: v_exp_f32's last-place error puts a
-    few (pixel, Gaussian) pairs on the other side of the 1/255 alpha cut-off (forward.cu:336 / backward.cu:478), and such a pair moves its
-    Gaussian's gradient by the pair's whole contribution; thin, nearly transparent Gaussians -- the trained-like scene -- have many
-    pairs near the cut-off.  SURVEY 8c's 1e-4 holds for the oracle-exp build (`exact_exp` = 1, 7e-6); DESIGN.md section 2 states both."""
+    """The same with the product's blend exponential (`exact_exp` = 0: v_exp_f32 with its argument's rounding error compensated,
+    <= 1.3 ulp measured on the device, and det_expf for a pair whose alpha falls within 1e-6 of the 1/255 cut-off: csrc/dgs_device.h
+    `blend_exp`) at the SAME bar as the oracle-exponential build: SURVEY 8c's 1e-4 holds with room -- tools/raster_grad_error.py measures
+    <= 5.3e-6 of a tensor's max in both scenes (profiles/r06_raster_grad_error.txt).  The reference's `exp(power)` (forward.cu:332-358,
+    backward.cu:463-532) is CUDA's <= 2 ulp expf -- its setup.py passes no fast-math flag -- and round 5's bare v_exp_f32(power * log2e)
+    (7.6 ulp at the cut-off) sat at 1.8e-3 here: pairs on the other side of the cut-off."""
     sc = synth.gaussian_scene(256, regime=regime, seed=0)
     cams, _, _ = synth.render_cameras(256, 4, phase_deg=10)
     assert_backward_parity(_backend(), sc, cams[:views], 256, 256, DEV, exact=False, rtol=rtol)

@@ -212,3 +212,72 @@ def test_three_kernel_radix_pass_forced(request):
                         "-k", "(small_scenes or diffusiongs_shaped) and (scan or sort)"], env=env, capture_output=True, text=True, timeout=1500,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("fault_pass", [0, 1, 2, 3])
+def test_radix_rescue_fault_injected(request, fault_pass):
+    """radix_pass_kernel waits inside the launch for all of a view's workgroups; a view that does not assemble (another stream's or
+    another process's kernels holding CUs) is finished by radix_rescue_kernel from the pass that failed -- never an error, never a
+    wrong order.  DGS_RASTER_RADIX_FAULT=<pass> makes every other workgroup of every view give up in that pass (the others scatter,
+    as they would in a real time-out); the parity cases that use the depth sort must still match the oracle bit for bit.  Child
+    process: the switch is read once per process."""
+    import os, subprocess, sys
+    if request.node.callspec.params.get("binning_form") != "auto":
+        pytest.skip("one run is enough: the child process runs the forms that use the depth sort itself")
+    env = dict(os.environ, DGS_RASTER_RADIX_FAULT=str(fault_pass))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "diffusiongs_shaped and (scan or sort)"], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _coreside_library():
+    """tools/ubench/coreside_bench.hip (an RCCL-shaped neighbour: `wgs` workgroups of 512 threads streaming a copy), built in place
+    if the snapshot does not carry it (hipcc is part of the image)."""
+    import ctypes, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tools", "ubench", "libcoreside.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so,
+                               os.path.join(root, "tools", "ubench", "coreside_bench.hip")])
+    lib = ctypes.CDLL(so)
+    lib.coreside_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    return lib
+
+
+def test_planned_render_beside_a_neighbour_stream(request):
+    """The multi-GPU training case on one GPU: the planned (no host synchronisation) render of 4 views at 256^2 -- one-kernel radix
+    passes, whose workgroups wait for each other inside the launch -- while a second stream runs an RCCL-shaped kernel (64 workgroups
+    of 512 threads streaming 1 GiB, tools/ubench/coreside_bench.hip) for the whole time.  Fifty renders in both regimes: every
+    image and every contributor count identical, bit for bit, to the render on an idle GPU (which the tests above pin to the oracle)."""
+    if request.node.callspec.params.get("binning_form") != "auto":
+        pytest.skip("one run is enough")
+    dev = _dev()
+    bg = _coreside_library()
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
+    for regime in ("init", "trained"):
+        be = _backend()
+        sc = synth.gaussian_scene(256, regime=regime, seed=0)
+        cams, _, _ = synth.render_cameras(256, 4, phase_deg=10)
+        xyz, shs, sca, rot, op = (t(sc[k]) for k in ("xyz", "shs", "scales", "rotations", "opacities"))
+        vm = t(np.stack([c["viewmatrix"] for c in cams])); pm = t(np.stack([c["projmatrix"] for c in cams]))
+        cp = t(np.stack([c["campos"] for c in cams])); bgc = t(np.ones(3, np.float32))
+
+        def run(cap):
+            return be.forward_views(bgc, xyz[None], None, op, sca, rot, 1.0, None, vm, pm, cp, None, cams[0]["tanfovx"], cams[0]["tanfovy"],
+                                    256, 256, shs, 0, False, False, views_per_set=4, binning_capacity=cap)
+
+        n = run(0)[0]
+        quiet = run(int(n * 1.2))
+        torch.cuda.synchronize()
+        want_img, want_radii = quiet[1].clone(), quiet[2].clone()
+        for it in range(50):
+            if it % 5 == 0:                                        # ~1 ms of copy per launch at 64 workgroups: keep the side stream busy
+                for _ in range(8):
+                    assert bg.coreside_copy(src.data_ptr(), dst.data_ptr(), 1 << 30, 64, side.cuda_stream) == 0
+            got = run(int(n * 1.2))
+            assert torch.equal(got[1], want_img) and torch.equal(got[2], want_radii), (regime, it)
+        torch.cuda.synchronize()

@@ -1,5 +1,6 @@
 """What the rasterizer backward achieves against the oracle's fp64-accumulated sums (SURVEY section 8c asks for 1e-4 of each tensor's
-max), per gradient tensor, with the product's blend exponential (hardware v_exp_f32) and with the oracle's own (`exact_exp`):
+max), per gradient tensor, with the product's blend exponential (printed as `v_exp_f32`: the compensated hardware exponential + the
+cut-off guard band of csrc/dgs_device.h `blend_exp`) and with the oracle's own (`exact_exp`):
 256^2 trained-like (2 views) and random-init (1 view), 512^2 trained-like (1 view); atomic and deterministic backward.
     python tools/raster_grad_error.py  > gpurun_out/raster_grad_error.txt"""
 import os
