@@ -388,6 +388,8 @@ def train_bench(a, dev, rank, world, steps, warmup, scene=None):
     _sync()
     if not DRY["on"]:
         tr.reducer.timing = {}                      # events around finish(): GPU time the compute stream waits for collectives
+    rbe = model.gs_renderer.backend() if hasattr(getattr(model, "gs_renderer", None), "backend") else None
+    wait0 = getattr(rbe, "verify_wait_s", 0.0)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.step(batch, t, target, rc2w, rk)
@@ -397,6 +399,29 @@ def train_bench(a, dev, rank, world, steps, warmup, scene=None):
     if DIST["on"]:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    verify_wait_ms = (getattr(rbe, "verify_wait_s", 0.0) - wait0) / steps * 1e3
+    # one more step, untimed, with an event behind every block_done callback of the backward: when the callback ran on the host against
+    # when the device got there -- is the host at least a block ahead when the callbacks launch the buckets' collectives?
+    lead = None
+    if not DRY["on"]:
+        tr.lead_probe = []
+        _sync()
+        h0 = time.perf_counter()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tr.step(batch, t, target, rc2w, rk)
+        _sync()
+        probe, tr.lead_probe = tr.lead_probe, None
+        if len(probe) >= 3:
+            dev_ms = [e0.elapsed_time(ev) for _, _, ev in probe]
+            host_ms = [(th - h0) * 1e3 for _, th, _ in probe]
+            leads = sorted(d - h for d, h in zip(dev_ms, host_ms))
+            gaps = sorted(b - a2 for a2, b in zip(dev_ms[:-1], dev_ms[1:]))
+            blk = gaps[len(gaps) // 2]
+            lead = {"callbacks": len(probe), "device_behind_host_ms": {"min": round(leads[0], 2), "median": round(leads[len(leads) // 2], 2), "max": round(leads[-1], 2)},
+                    "block_backward_ms_median": round(blk, 3), "blocks_ahead_min": round(leads[0] / blk, 1) if blk > 0 else None,
+                    "collectives_in_callbacks": bool(tr.reducer.active),
+                    "note": "per block_done callback of one untimed step: device completion time of the block's kernels minus the host time of the callback"}
     rank_ms = [t_local / steps * 1e3]
     ranks_seen = 1
     if DIST["on"]:
@@ -443,6 +468,11 @@ def train_bench(a, dev, rank, world, steps, warmup, scene=None):
             "gradient_clip_val": a.clip if a.clip > 0 else None,
             "grad_norm_before_clip": round(float(tr.last_grad_sumsq.sqrt()), 6) if tr.last_grad_sumsq is not None else None,
             "host_enqueue_ms_per_step": round((t_enq - t0) / steps * 1e3, 2),
+            # ... of which the host spent waiting for the device inside the rasterizer's verified calls (plans at risk: every training render;
+            # dgs_amd/raster.py) -- the rest is enqueue work proper
+            "host_verify_wait_ms_per_step": round(verify_wait_ms, 2),
+            "host_enqueue_work_ms_per_step": round((t_enq - t0) / steps * 1e3 - verify_wait_ms, 2),
+            "host_lead_in_backward": lead,
             "per_rank_ms": {"min": round(min(rank_ms), 2), "max": round(max(rank_ms), 2)}, "ranks_seen": ranks_seen,
             "parameter_broadcast_bytes": int(tr.broadcast_bytes),
             "allreduce": {"world": world, "collectives_issued": bool(tr.reducer.active), "buckets": len(tr.reducer.bounds), "exchange": a.grad_exchange,

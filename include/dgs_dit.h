@@ -134,7 +134,14 @@ typedef struct DgsDitAttentionBackwardArgs {
     float* D;                  /* [B, heads, lpad] scratch: -rowsum(dO o O) (the initial value of the dP accumulators) */
     uint16_t* dqkv;            /* out bf16 [B*lpad, 3W]: dq | dk | dv                                              */
     float scale;
+    uint16_t* dqkvT;           /* optional out bf16 [B, 3W, lpad]: the same gradients token-contiguous (what the qkv weight-gradient
+                                  GEMM reads; padding tokens are not written: the caller's buffer holds zeros there) or NULL   */
+    float* bias_part;          /* optional out [B * dgs_dit_attention_backward_slots(L)][3W]: per-workgroup column sums of dqkv over
+                                  the workgroup's valid tokens (slot = sample * slots + block) -- the qkv bias gradient's partial
+                                  rows, to be added in slot order -- or NULL                                                   */
 } DgsDitAttentionBackwardArgs;
+/* 256-token blocks (+ single tail tokens) per sample the backward's workgroups own: rows per sample of `bias_part`. */
+int32_t dgs_dit_attention_backward_slots(int32_t L);
 
 typedef struct DgsDitLayerNormArgs {
     int32_t rows, width;       /* width == 1024 (one wave per row, 16 elements per lane) or any multiple of 64 <= 2048 */

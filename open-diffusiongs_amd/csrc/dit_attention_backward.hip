@@ -41,6 +41,12 @@ struct AttnBwdParams {
     int ld_d;
     float scale, scale_log2e;
     int nmain, ntail;                          // 256-row blocks walked by the MFMA workgroups; tokens behind them (tail roles) or 0
+    // optional by-products the training backward used to take from two more kernels (transpose_kernel, colsum_wide_kernel): the
+    // gradients once more token-contiguous -- the accumulators ARE feature-major with the token in the lane, so the copy is a plain
+    // coalesced store -- and their per-workgroup column sums (the qkv bias gradient's partial rows, summed in slot order by col_reduce)
+    bf16_t *dqT, *dkT, *dvT;                   // [B, *, lpad] (offset to the dq / dk / dv feature blocks of a [B, 3W, lpad] tensor) or nullptr
+    float* bias_part;                          // [B * (nmain + ntail)][bias_stride] or nullptr: slot b * (nmain + ntail) + block, columns as in dqkv
+    int bias_stride;
     int dbg;                                   // instrumented library only (DGS_ATTN_DBG & 16: phase stamps of the dK/dV loop)
 };
 __device__ long long dgs_attn_bwd_dbg[2 * 8 * 8];       // [wave 0 | wave 5][tiles 20..27][tile top, scores done, products done, published, barrier]
@@ -136,7 +142,8 @@ __device__ __forceinline__ void axpy8(float (&acc)[8], float a, uint4 x) {
     acc[4] += a * bf2f(x.z & 0xffffu); acc[5] += a * bf2f(x.z >> 16); acc[6] += a * bf2f(x.w & 0xffffu); acc[7] += a * bf2f(x.w >> 16);
 }
 // sum of acc over the workgroup's 64 row slots (lanes of equal chunk, then the waves in order) -> out[64] (bf16, times c), tid < 64
-__device__ __forceinline__ void tail_reduce_store(float (&acc)[8], float* red, float c, bf16_t* out) {
+__device__ __forceinline__ void tail_reduce_store(float (&acc)[8], float* red, float c, bf16_t* out, bf16_t* outT = nullptr, int ldT = 0,
+                                                  float* bias = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -152,6 +159,8 @@ __device__ __forceinline__ void tail_reduce_store(float (&acc)[8], float* red, f
 #pragma unroll
         for (int w = 0; w < BNW; ++w) v += red[w * 64 + tid];
         out[tid] = (bf16_t)f2bf(c * v);
+        if (outT) outT[(size_t)tid * ldT] = (bf16_t)f2bf(c * v);         // the token's column of the transposed copy
+        if (bias) bias[tid] = c * v;                                       // a one-token workgroup: its partial row is the row itself
     }
     __syncthreads();
 }
@@ -209,7 +218,9 @@ __device__ __forceinline__ void tail_query_role(const AttnBwdParams& p, int blk,
             }
         });
     bf16_t* dq_head = p.dq + row0 * p.ld_d + head * 64;
-    tail_reduce_store(acc, red, p.scale, dq_head + (size_t)tq * p.ld_d);
+    tail_reduce_store(acc, red, p.scale, dq_head + (size_t)tq * p.ld_d,
+                      p.dqT ? p.dqT + (size_t)b * p.t_batch_stride_qkv + (size_t)head * 64 * p.lpad + tq : nullptr, p.lpad,
+                      p.bias_part ? p.bias_part + ((size_t)b * (p.nmain + p.ntail) + blk) * p.bias_stride + head * 64 : nullptr);
     if (blk == p.nmain) tail_zero_rows(p, dq_head);
 }
 
@@ -246,9 +257,48 @@ __device__ __forceinline__ void tail_key_role(const AttnBwdParams& p, int blk, i
         });
     bf16_t* dk_head = p.dk + row0 * p.ld_d + head * 64;
     bf16_t* dv_head = p.dv + row0 * p.ld_d + head * 64;
-    tail_reduce_store(ak, red, p.scale, dk_head + (size_t)tk * p.ld_d);
-    tail_reduce_store(av, red, 1.f, dv_head + (size_t)tk * p.ld_d);
+    const size_t tcol = (size_t)b * p.t_batch_stride_qkv + (size_t)head * 64 * p.lpad + tk;
+    float* const brow = p.bias_part ? p.bias_part + ((size_t)b * (p.nmain + p.ntail) + blk) * p.bias_stride + head * 64 : nullptr;
+    const int W = p.heads * 64;
+    tail_reduce_store(ak, red, p.scale, dk_head + (size_t)tk * p.ld_d, p.dkT ? p.dkT + tcol : nullptr, p.lpad, brow ? brow + W : nullptr);
+    tail_reduce_store(av, red, 1.f, dv_head + (size_t)tk * p.ld_d, p.dvT ? p.dvT + tcol : nullptr, p.lpad, brow ? brow + 2 * W : nullptr);
     if (blk == p.nmain) { tail_zero_rows(p, dk_head); tail_zero_rows(p, dv_head); }
+}
+
+// By-products of an MFMA workgroup's 256 tokens x 64 features (two accumulators of 32 features: register r of `lo` / `hi` is feature
+// 8 (r >> 2) + 4 half + (r & 3) (+ 32), the lane's l31 is the token): the token-contiguous copy and the column sums over the workgroup's
+// tokens.  Both through ONE fp32 image of the block in LDS, [feature][token] (65 KiB of the ring nobody reads any more): the accumulator
+// registers are written as they lie (a register = 32 consecutive tokens of one feature: conflict-free), then 32 lanes take a feature's 256
+// tokens eight apiece -- 16-byte stores of 8 bf16, 512 contiguous bytes per feature -- and their sum is the feature's partial.  (First
+// form of this round: one 2-byte store per register and an xor-shuffle tree per register -- 640 ds_bpermute per wave in the dK / dV
+// kernel; it cost the two kernels +75 us per block and the launches it replaced had cost 67: profiles/r06_attn_bwd_byproducts_ab.txt.)
+// Every thread of the workgroup calls it; invalid tokens (>= L: padding rows of the last block, waves without a live token) enter as zeros.
+constexpr int BYP_LD = 256 + 4;                // floats per feature row of the image (16-byte aligned rows, reads of 8 lanes span all banks)
+__device__ __forceinline__ void block_byproducts(const f32x16& lo, const f32x16& hi, float c, bool token_ok, bf16_t* rowT /* feature 0, the block's token 0 */,
+                                                 int lpad, int tokens_here /* lpad - the block's first token: the last block may reach past lpad */,
+                                                 float* bias /* 64 floats or nullptr */, float* img, int wave, int l31, int half) {
+    const int tok = wave * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = 8 * (r >> 2) + 4 * half + (r & 3);
+        img[f * BYP_LD + tok] = token_ok ? c * lo[r] : 0.f;
+        img[(32 + f) * BYP_LD + tok] = token_ok ? c * hi[r] : 0.f;
+    }
+    __syncthreads();
+    const int ch = threadIdx.x & 31;                               // tokens 8 ch .. 8 ch + 7
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int f = 16 * pass + (threadIdx.x >> 5);
+        const float4 v0 = *reinterpret_cast<const float4*>(img + f * BYP_LD + 8 * ch), v1 = *reinterpret_cast<const float4*>(img + f * BYP_LD + 8 * ch + 4);
+        if (rowT && 8 * ch < tokens_here) *reinterpret_cast<uint4*>(rowT + (size_t)f * lpad + 8 * ch) = make_uint4(pack_bf2(v0.x, v0.y), pack_bf2(v0.z, v0.w), pack_bf2(v1.x, v1.y), pack_bf2(v1.z, v1.w));
+        if (bias) {
+            float sum = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) sum += __shfl_xor(sum, d);
+            if (ch == 0) bias[f] = sum;
+        }
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -390,14 +440,20 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(AttnBwdParams 
     const int nplain = p.L / BT;                          // tiles without keys >= L
     for (int t = 0; t < nplain; ++t) tile(t, BoolTag<false>{});
     if (nplain < ntiles) tile(nplain, BoolTag<true>{});
-    if (!wave_live) return;
-    bf16_t* orow = p.dq + (row0 + q) * p.ld_d + head * 64;
+    if (wave_live) {
+        bf16_t* orow = p.dq + (row0 + q) * p.ld_d + head * 64;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float c = p.scale;
-        *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = make_uint2(pack_bf2(c * dq0[4 * g], c * dq0[4 * g + 1]), pack_bf2(c * dq0[4 * g + 2], c * dq0[4 * g + 3]));
-        *reinterpret_cast<uint2*>(orow + 32 + 8 * g + 4 * half) = make_uint2(pack_bf2(c * dq1[4 * g], c * dq1[4 * g + 1]), pack_bf2(c * dq1[4 * g + 2], c * dq1[4 * g + 3]));
+        for (int g = 0; g < 4; ++g) {
+            const float c = p.scale;
+            *reinterpret_cast<uint2*>(orow + 8 * g + 4 * half) = make_uint2(pack_bf2(c * dq0[4 * g], c * dq0[4 * g + 1]), pack_bf2(c * dq0[4 * g + 2], c * dq0[4 * g + 3]));
+            *reinterpret_cast<uint2*>(orow + 32 + 8 * g + 4 * half) = make_uint2(pack_bf2(c * dq1[4 * g], c * dq1[4 * g + 1]), pack_bf2(c * dq1[4 * g + 2], c * dq1[4 * g + 3]));
+        }
     }
+    if (p.dqT || p.bias_part)                                       // (uniform; the last tile's barrier is behind every wave: the ring is free)
+        block_byproducts(dq0, dq1, p.scale, wave_live && q_raw < p.L,
+                         p.dqT ? p.dqT + (size_t)b * p.t_batch_stride_qkv + (size_t)head * 64 * p.lpad + qblk * BQ : nullptr, p.lpad, p.lpad - qblk * BQ,
+                         p.bias_part ? p.bias_part + ((size_t)b * (p.nmain + p.ntail) + qblk) * p.bias_stride + head * 64 : nullptr,
+                         reinterpret_cast<float*>(lds), wave, l31, half);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -573,29 +629,44 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(AttnBwdParams
     const int nplain = p.L / BT;                          // tiles without queries >= L
     for (int t = 0; t < nplain; ++t) tile(t, BoolTag<false>{});
     if (nplain < ntiles) tile(nplain, BoolTag<true>{});
-    if (!wave_live) return;
     // lane = key: a key >= L only ever polluted its own dK / dV rows -- they are padding rows and receive exact zeros;
     // dK carries the `scale` the loop left out
     const float ck = p.scale;
-    bf16_t* krow = p.dk + (row0 + key) * p.ld_d + head * 64;
-    bf16_t* vrow = p.dv + (row0 + key) * p.ld_d + head * 64;
-    const uint2 zero2 = make_uint2(0u, 0u);
+    if (wave_live) {
+        bf16_t* krow = p.dk + (row0 + key) * p.ld_d + head * 64;
+        bf16_t* vrow = p.dv + (row0 + key) * p.ld_d + head * 64;
+        const uint2 zero2 = make_uint2(0u, 0u);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint2 k0 = make_uint2(pack_bf2(ck * dk0[4 * g], ck * dk0[4 * g + 1]), pack_bf2(ck * dk0[4 * g + 2], ck * dk0[4 * g + 3]));
-        const uint2 k1 = make_uint2(pack_bf2(ck * dk1[4 * g], ck * dk1[4 * g + 1]), pack_bf2(ck * dk1[4 * g + 2], ck * dk1[4 * g + 3]));
-        const uint2 v0 = make_uint2(pack_bf2(dv0[4 * g], dv0[4 * g + 1]), pack_bf2(dv0[4 * g + 2], dv0[4 * g + 3]));
-        const uint2 v1 = make_uint2(pack_bf2(dv1[4 * g], dv1[4 * g + 1]), pack_bf2(dv1[4 * g + 2], dv1[4 * g + 3]));
-        *reinterpret_cast<uint2*>(krow + 8 * g + 4 * half) = key_ok ? k0 : zero2;
-        *reinterpret_cast<uint2*>(krow + 32 + 8 * g + 4 * half) = key_ok ? k1 : zero2;
-        *reinterpret_cast<uint2*>(vrow + 8 * g + 4 * half) = key_ok ? v0 : zero2;
-        *reinterpret_cast<uint2*>(vrow + 32 + 8 * g + 4 * half) = key_ok ? v1 : zero2;
+        for (int g = 0; g < 4; ++g) {
+            const uint2 k0 = make_uint2(pack_bf2(ck * dk0[4 * g], ck * dk0[4 * g + 1]), pack_bf2(ck * dk0[4 * g + 2], ck * dk0[4 * g + 3]));
+            const uint2 k1 = make_uint2(pack_bf2(ck * dk1[4 * g], ck * dk1[4 * g + 1]), pack_bf2(ck * dk1[4 * g + 2], ck * dk1[4 * g + 3]));
+            const uint2 v0 = make_uint2(pack_bf2(dv0[4 * g], dv0[4 * g + 1]), pack_bf2(dv0[4 * g + 2], dv0[4 * g + 3]));
+            const uint2 v1 = make_uint2(pack_bf2(dv1[4 * g], dv1[4 * g + 1]), pack_bf2(dv1[4 * g + 2], dv1[4 * g + 3]));
+            *reinterpret_cast<uint2*>(krow + 8 * g + 4 * half) = key_ok ? k0 : zero2;
+            *reinterpret_cast<uint2*>(krow + 32 + 8 * g + 4 * half) = key_ok ? k1 : zero2;
+            *reinterpret_cast<uint2*>(vrow + 8 * g + 4 * half) = key_ok ? v0 : zero2;
+            *reinterpret_cast<uint2*>(vrow + 32 + 8 * g + 4 * half) = key_ok ? v1 : zero2;
+        }
+    }
+    if (p.dkT || p.bias_part) {                                     // (uniform; the ring is free behind the last tile's barrier)
+        const size_t tcol = (size_t)b * p.t_batch_stride_qkv + (size_t)head * 64 * p.lpad + kblk * BQ;
+        float* const brow = p.bias_part ? p.bias_part + ((size_t)b * (p.nmain + p.ntail) + kblk) * p.bias_stride + head * 64 : nullptr;
+        const int W = p.heads * 64;
+        block_byproducts(dk0, dk1, ck, wave_live && key_ok, p.dkT ? p.dkT + tcol : nullptr, p.lpad, p.lpad - kblk * BQ, brow ? brow + W : nullptr, reinterpret_cast<float*>(lds), wave, l31, half);
+        block_byproducts(dv0, dv1, 1.f, wave_live && key_ok, p.dvT ? p.dvT + tcol : nullptr, p.lpad, p.lpad - kblk * BQ, brow ? brow + 2 * W : nullptr, reinterpret_cast<float*>(lds), wave, l31, half);
     }
 }
 
 }  // namespace dgs
 
 using namespace dgs;
+
+extern "C" int32_t dgs_dit_attention_backward_slots(int32_t L) {
+    if (L <= 0) return 0;
+    const int full = L / BQ, rest = L % BQ;
+    const bool tail = full >= 1 && rest >= 1 && rest <= BWD_TAIL_MAX;
+    return tail ? full + rest : (L + BQ - 1) / BQ;
+}
 
 extern "C" int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, dgs_stream_t stream) {
     if (!a || a->B <= 0 || a->heads <= 0 || a->L <= 0 || a->lpad < a->L || a->lpad % 128) return DGS_ERR_INVALID_ARGUMENT;
@@ -608,6 +679,8 @@ extern "C" int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, 
     p.qT = a->qkvT; p.kT = a->qkvT + (size_t)W * a->lpad;
     p.o = a->o; p.dO = a->dO; p.dOT = a->dOT; p.lse2 = a->lse2; p.D = a->D;
     p.dq = a->dqkv; p.dk = a->dqkv + W; p.dv = a->dqkv + 2 * W;
+    p.dqT = a->dqkvT; p.dkT = a->dqkvT ? a->dqkvT + (size_t)W * a->lpad : nullptr; p.dvT = a->dqkvT ? a->dqkvT + (size_t)2 * W * a->lpad : nullptr;
+    p.bias_part = a->bias_part; p.bias_stride = 3 * W;
     p.scale = a->scale; p.scale_log2e = a->scale * 1.44269504088896341f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int full = a->L / BQ, rest = a->L % BQ;

@@ -409,9 +409,17 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
         DgsDitAttentionBackwardArgs ab{};
         ab.B = B; ab.heads = m->heads; ab.L = L; ab.lpad = lpad; ab.qkv = k.qkv; ab.qkvT = k.qkvT; ab.o = k.a; ab.dO = ws.da; ab.dOT = ws.daT;
         ab.lse2 = k.lse2; ab.D = ws.D; ab.dqkv = ws.dqkv; ab.scale = 0.125f;
+        // the token-contiguous copy the qkv weight gradient reads and the bias gradient's partial rows leave the attention backward's
+        // own epilogues (rounds 3-5: a transpose and a column-sum kernel behind it, 37 + 23 us per block at 4 samples); the padding
+        // tokens of dqkvT are never written: zero since the workspace was allocated
+        // (DGS_ATTN_BWD_BYPRODUCTS=0, measurement aid: the two kernels again -- profiles/r06_attn_bwd_byproducts_ab.txt)
+        static const bool byproducts = !(getenv("DGS_ATTN_BWD_BYPRODUCTS") && atoi(getenv("DGS_ATTN_BWD_BYPRODUCTS")) == 0);
+        if (byproducts) { ab.dqkvT = ws.dqkvT; ab.bias_part = ws.qkvb_part; }
         DGS_TRY(dgs_dit_attention_backward(&ab, stream));
-        DGS_TRY(launch_colsum(ws.dqkv, 3 * W, M, 3 * W, ws.qkvb_part, st));
-        DGS_TRY(launch_transpose(ws.dqkv, 3 * W, ws.dqkvT, B, lpad, 3 * W, st));
+        if (!byproducts) {
+            DGS_TRY(launch_colsum(ws.dqkv, 3 * W, M, 3 * W, ws.qkvb_part, st));
+            DGS_TRY(launch_transpose(ws.dqkv, 3 * W, ws.dqkvT, B, lpad, 3 * W, st));
+        }
         DGS_TRY(launch_transpose(k.h1, W, ws.actT, B, lpad, W, st));
         DGS_TRY(wgrad(ws.dqkvT, 3 * W, ws.actT, W, lg.qkv_w, B, lpad, ws, stream));
         DGS_TRY(dgrad(ws.dqkv, 3 * W, lt.qkv_wT, W, ws.dh, M, lpad, L, DGS_EPI_BF16, nullptr, nullptr, stream));
@@ -430,7 +438,7 @@ extern "C" int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, co
                 {ws.gate_part[0] + W, lg.fc2_b, B * gate_slots, 2 * W, W, 1, 0},
                 {ws.gate_part[1] + W, lg.proj_b, B * gate_slots, 2 * W, W, 1, 0},
                 {ws.fc1b_part, lg.fc1_b, bias_slots, 4 * W, 4 * W, 1, 0},
-                {ws.qkvb_part, lg.qkv_b, colsum_slots(M, 3 * W, 3 * W), 3 * W, 3 * W, 1, 0}};
+                {ws.qkvb_part, lg.qkv_b, byproducts ? B * dgs_dit_attention_backward_slots(L) : colsum_slots(M, 3 * W, 3 * W), 3 * W, 3 * W, 1, 0}};
             DGS_TRY(launch_col_reduce(jobs, 8, st));
         }
         DGS_TRY(ada_backward(6 * W * i, 6 * W, lg.ada_w, lg.ada_b));       // the block's six modulation gradients are complete

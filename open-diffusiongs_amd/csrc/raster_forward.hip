@@ -1144,7 +1144,6 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
             const uint32_t* lst = reinterpret_cast<const uint32_t*>(s_list[cell]);
             uint32_t word = lst[0];
             Entry ea = load(word & 255u), eb;
-            if constexpr (kRasterStats) st_entries += tot;
             uint32_t k = 0;
             for (; wave_ballot(k < tot_l) != 0ull; k += 4) {
                 const uint32_t word_next = lst[(k >> 2) + 1u];
@@ -1155,7 +1154,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(FwdParams p) {
                 word = word_next;
             }
             done = done | (tot_l != tot);                       // finished in this batch (tot >= 1 then), or before it
-            if constexpr (kRasterStats) st_trips += k;
+            if constexpr (kRasterStats) { st_entries += min(tot, k); st_trips += k; }    // the walk leaves a batch once the wave's 64 pixels are finished
         }
     }
     if (inside) {

@@ -167,7 +167,7 @@ class DgsDitAttentionBackwardArgs(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("heads", ctypes.c_int32), ("L", ctypes.c_int32), ("lpad", ctypes.c_int32),
                 ("qkv", ctypes.c_void_p), ("qkvT", ctypes.c_void_p), ("o", ctypes.c_void_p), ("dO", ctypes.c_void_p),
                 ("dOT", ctypes.c_void_p), ("lse2", ctypes.c_void_p), ("D", ctypes.c_void_p), ("dqkv", ctypes.c_void_p),
-                ("scale", ctypes.c_float)]
+                ("scale", ctypes.c_float), ("dqkvT", ctypes.c_void_p), ("bias_part", ctypes.c_void_p)]
 
 
 class DgsDitLayerNormArgs(ctypes.Structure):
@@ -276,10 +276,12 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
                "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds", "dgs_debug_clock_probe",
                "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes",
-               "dgs_dit_workspace_bytes_for_tokens"]
+               "dgs_dit_workspace_bytes_for_tokens", "dgs_dit_attention_backward_slots"]
 
 
 def _declare_dit(L):
+    L.dgs_dit_attention_backward_slots.restype = ctypes.c_int32
+    L.dgs_dit_attention_backward_slots.argtypes = [ctypes.c_int32]
     for name, argt in (("dgs_dit_gemm", DgsDitGemmArgs), ("dgs_dit_attention", DgsDitAttentionArgs),
                        ("dgs_dit_attention_backward", DgsDitAttentionBackwardArgs),
                        ("dgs_dit_layernorm_backward", DgsDitLayerNormBackwardArgs),

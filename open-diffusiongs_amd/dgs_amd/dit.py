@@ -109,8 +109,9 @@ class DitOps:
         self._check(self.lib.dgs_dit_attention(ctypes.byref(a), _stream(qk.device)))
         return out
 
-    def attention_backward(self, qkv, qkvT, o, dO, dOT, lse2, L, heads):
-        """-> dqkv bf16 [B*lpad, 3W] (dq | dk | dv)."""
+    def attention_backward(self, qkv, qkvT, o, dO, dOT, lse2, L, heads, byproducts=False):
+        """-> dqkv bf16 [B*lpad, 3W] (dq | dk | dv).  byproducts=True: -> (dqkv, dqkvT bf16 [B, 3W, lpad] -- padding tokens left zero --,
+        bias_part f32 [B * slots, 3W]: per-workgroup column sums over valid tokens; dgs_dit.h)."""
         B, _, lpad = qkvT.shape
         dqkv = torch.zeros_like(qkv)
         D = torch.zeros_like(lse2)
@@ -118,8 +119,13 @@ class DitOps:
         a.B, a.heads, a.L, a.lpad = B, heads, L, lpad
         a.qkv, a.qkvT, a.o, a.dO, a.dOT, a.lse2, a.D, a.dqkv = (_p(t) for t in (qkv, qkvT, o, dO, dOT, lse2, D, dqkv))
         a.scale = 0.125
+        dqkvT = part = None
+        if byproducts:
+            dqkvT = torch.zeros_like(qkvT)
+            part = torch.full((B * int(self.lib.dgs_dit_attention_backward_slots(L)), 3 * heads * 64), float("nan"), dtype=torch.float32, device=qkv.device)
+            a.dqkvT, a.bias_part = _p(dqkvT), _p(part)
         self._check(self.lib.dgs_dit_attention_backward(ctypes.byref(a), _stream(qkv.device)))
-        return dqkv
+        return (dqkv, dqkvT, part) if byproducts else dqkv
 
     def layernorm(self, x, weight=None, shift=None, scale=None, rows_per_batch=0, eps=1e-6, out_f32=False):
         rows, width = x.shape

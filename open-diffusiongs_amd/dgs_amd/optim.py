@@ -126,9 +126,23 @@ class FusedAdamW(torch.optim.Optimizer):
             self._step(grad_sumsq, max_grad_norm)
         return loss
 
+    def _settle_previous(self):
+        """The launch skips an update whose gradient norm is not finite (csrc/optim.hip) -- GradScaler does not call optimizer.step() at
+        all for such a step, so the step count and with it the bias corrections must not move either.  The previous step's norm was
+        copied to pinned memory behind its launch: by now it has long arrived (the wait is for THAT copy, not for the stream)."""
+        probe, self._skip_probe = getattr(self, "_skip_probe", None), None
+        if probe is None:
+            return
+        host, ev = probe
+        ev.synchronize()
+        if not math.isfinite(float(host[0])):
+            self.step_count -= 1
+            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+
     def _step(self, grad_sumsq, max_grad_norm):
         g = self.param_groups[0]
         raw, n, n_tiles, _ = self._plan()
+        self._settle_previous()
         self.step_count += 1
         b1, b2 = g["betas"]
         a = _native.DgsAdamWArgs()
@@ -144,5 +158,15 @@ class FusedAdamW(torch.optim.Optimizer):
         rc = self.lib.dgs_adamw_step(ctypes.byref(a), _stream(self.exp_avg.device))
         if rc != 0:
             raise RuntimeError(f"dgs_adamw_step: {_native.status_string(self.lib, rc)} (status {rc})")
+        if a.grad_sumsq and grad_sumsq.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            if getattr(self, "_skip_host", None) is None:
+                self._skip_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._skip_host.copy_(grad_sumsq.reshape(-1)[:1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._skip_probe = (self._skip_host, ev)
+        elif a.grad_sumsq and grad_sumsq.device.type != "cuda" and not math.isfinite(float(grad_sumsq.reshape(-1)[0])):
+            self.step_count -= 1                       # CPU emulation build: the word is at hand
+            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
         # the parameters were written through raw pointers: their version counters did not move, and the engine's copies are
         # already up to date -- DGSDenoiser.engine() must not refresh them again

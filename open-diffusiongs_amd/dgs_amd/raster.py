@@ -136,6 +136,7 @@ class RasterBackend:
     def __init__(self, lib=None, exact_exp=None):
         self.lib = lib if lib is not None else _native.lib()
         self._plans = {}             # (P, W, H, V, views_per_set, device) -> _AsyncPlan
+        self.verify_wait_s = 0.0     # host seconds spent in the verify wait of plans at risk (bench.py splits its host-enqueue figure with it)
         # exponential of the blend loops (dgs_raster.h `exact_exp`): False = compensated v_exp_f32 + cut-off guard band (product default, <= 1.3 ulp), True = the
         # fixed IEEE sequence the CPU oracle restates (floats bit-identical with the oracle: what the bit-exact parity tests select)
         self.exact_exp = bool(int(os.environ.get("DGS_RASTER_EXACT_EXP", "0") or 0)) if exact_exp is None else bool(exact_exp)
@@ -304,6 +305,7 @@ class RasterBackend:
             # (waiting for the END of the call cost the rasterizer microbenchmark +0.15 ms per forward + backward:
             # profiles/r05_raster256_*.log against r04's).  A word that does not turn up within two seconds: the event.
             if ev is not None:
+                w0 = time.perf_counter()
                 if pre is not None:
                     pre.synchronize()
                 deadline = time.perf_counter() + 2.0
@@ -311,6 +313,7 @@ class RasterBackend:
                     pass
                 if int(host[3]) == 0:
                     ev.synchronize()
+                self.verify_wait_s += time.perf_counter() - w0       # host time spent waiting for the device to reach / start this call
             n, status, longest = int(host[0]) & 0xFFFFFFFF, int(host[1]), int(host[2]) & 0xFFFFFFFF
             plan.note(self.lib, n, longest, P, W, H, V)
             if status == 0:
@@ -404,7 +407,14 @@ class RasterBackend:
         scratch = None
         if self.deterministic and int(num_rendered) > 0:
             nbytes = int(self.lib.dgs_raster_backward_scratch_bytes(P, W, H, V, int(num_rendered)))
-            if nbytes <= self.deterministic_budget:
+            budget = self.deterministic_budget
+            if device.type == "cuda":
+                # ... and never more than 80 % of what the device can still give (free memory + what torch's allocator holds unused:
+                # the previous step's scratch block comes back from there): a fuller or smaller GPU takes the atomic form instead of
+                # failing with an out-of-memory error
+                free_b, _ = torch.cuda.mem_get_info(device)
+                budget = min(budget, int(0.8 * (free_b + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))))
+            if nbytes <= budget:
                 scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
                 a.scratch, a.scratch_bytes = ctypes.c_void_p(scratch.data_ptr()), nbytes
         self.last_backward_deterministic = scratch is not None

@@ -77,6 +77,7 @@ class DataParallelTrainer:
         model._block_hook = self._on_gradients_final
         self._attach_grads()
         self.last_psnr = None
+        self.lead_probe = None           # a list: every block_done callback appends (stage, host time, event recorded on the compute stream)
 
     def close(self):
         """Give the model back: no in-place gradients, no per-block hook; the parameters keep COPIES of their last gradients."""
@@ -118,6 +119,11 @@ class DataParallelTrainer:
         """Host callback from inside dgs_dit_backward: flat[:end] is final once the kernels enqueued so far have run."""
         if not self._last_micro:
             return
+        if self.lead_probe is not None:                          # measurement (bench.py): how far the host runs ahead of the device here
+            import time
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.lead_probe.append((stage, time.perf_counter(), ev))
         end = self._end_of_stage(stage)
         if self._use_accum and end > self._summed_to:             # fold in the earlier micro-batches, slice by slice
             self.fg.flat[self._summed_to:end] += self._accum[self._summed_to:end]
@@ -170,9 +176,13 @@ class DataParallelTrainer:
             if getattr(self.opt, "refreshes_engine", False):          # FusedAdamW: the scale rides in the update launch
                 self.opt.step(grad_sumsq=self.last_grad_sumsq, max_grad_norm=self.max_grad_norm)
             else:                                                      # torch.nn.utils.clip_grad_norm_ on the flat buffer (the .grad views)
-                coef = (self.max_grad_norm / (self.last_grad_sumsq.sqrt() + 1e-6)).clamp(max=1.0)
-                self.fg.flat.mul_(coef)
-                self.opt.step()
+                # a non-finite norm (overflow / NaN upstream): the update is skipped, as FusedAdamW's launch and the reference's GradScaler
+                # do -- a NaN coefficient multiplied into the gradients would corrupt every parameter (one host read: this branch is not
+                # the no-sync path)
+                if bool(torch.isfinite(self.last_grad_sumsq).all()):
+                    coef = (self.max_grad_norm / (self.last_grad_sumsq.sqrt() + 1e-6)).clamp(max=1.0)
+                    self.fg.flat.mul_(coef)
+                    self.opt.step()
         else:
             self.opt.step()
         # weights changed: the engine's bf16 / transposed copies have to follow.  dgs_amd.optim.FusedAdamW writes them in the same launch

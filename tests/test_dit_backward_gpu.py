@@ -45,6 +45,10 @@ def test_attention_backward_L4098():
     for name, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
         assert rel_l2(got[:, :L, sl], dref[:, :, sl]) < 1.5e-2, name
     assert float(got[:, L:].abs().max()) == 0.0
+    # the by-products of the same launch (dgs_dit.h dqkvT / bias_part): what the training backward takes instead of a transpose and a
+    # column-sum kernel
+    from test_dit_kernels_emu import _check_attention_backward_byproducts
+    _check_attention_backward_byproducts(ops, qkv2, qkvT, o_hip, dO.reshape(B * lpad, W).contiguous(), dO.transpose(1, 2).contiguous(), lse2, L, heads, dqkv)
 
 
 def test_attention_backward_L16386():

@@ -225,6 +225,23 @@ def test_attention_backward(ops, L, B, heads):
             assert err < 2e-2, (name, "tail rows", err)
     if L < lpad:
         assert float(got[:, L:].abs().max()) == 0.0   # padding rows receive exactly zero gradient
+    _check_attention_backward_byproducts(ops, qkv2, qkvT, o, dO.reshape(B * lpad, W).contiguous(), dOT, lse2, L, heads, dqkv)
+
+
+def _check_attention_backward_byproducts(ops, qkv2, qkvT, o, dO2, dOT, lse2, L, heads, dqkv):
+    """DgsDitAttentionBackwardArgs.dqkvT / bias_part: the same launch again with the by-products on -- dqkv bit-identical, the
+    token-contiguous copy equal to its transpose bit for bit on the valid tokens (zero on the padding), the per-workgroup partial rows
+    all written and adding up to the column sums of the gradient (fp32 sums of the values BEFORE their bf16 rounding: bf16 tolerance)."""
+    B, _, lpad = qkvT.shape
+    W3 = qkv2.shape[1]
+    again, dT, part = ops.attention_backward(qkv2, qkvT, o, dO2, dOT, lse2, L, heads, byproducts=True)
+    assert torch.equal(again, dqkv)
+    want_T = dqkv.reshape(B, lpad, W3).transpose(1, 2)
+    assert torch.equal(dT[:, :, :L], want_T[:, :, :L]) and float(dT[:, :, L:].float().abs().max() if L < lpad else 0.0) == 0.0
+    assert torch.isfinite(part).all() and part.shape[0] == B * int(ops.lib.dgs_dit_attention_backward_slots(L))
+    colsum = dqkv.float().reshape(B * lpad, W3).sum(0)
+    scale = float(dqkv.float().abs().max()) * (B * L) ** 0.5
+    assert float((part.sum(0) - colsum).abs().max()) <= 4e-3 * scale + 1e-6
 
 
 def _call(ops, fn, struct, **kw):

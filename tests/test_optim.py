@@ -189,8 +189,11 @@ def test_a_non_finite_gradient_norm_skips_the_whole_update():
     dst = eng.weight_destinations()
     copies = {n: tuple(None if c is None else c.clone() for c in pair) for n, pair in dst.items()}
     fg.flat.fill_(float("nan"))
+    assert fopt.step_count == 1
     for bad in (float("nan"), float("inf")):
         fopt.step(grad_sumsq=torch.tensor([bad]), max_grad_norm=0.5)
+        # ... and the step count (hence the bias corrections of the next real update) does not move: GradScaler never calls step()
+        assert fopt.step_count == 1 and fopt.skipped_steps >= 1
         for p, b in zip(m.parameters(), before):
             assert torch.equal(p.detach(), b)
         assert torch.equal(fopt.exp_avg, moments[0]) and torch.equal(fopt.exp_avg_sq, moments[1])
@@ -199,6 +202,7 @@ def test_a_non_finite_gradient_norm_skips_the_whole_update():
             assert (now is None and was is None) or torch.equal(now, was), n
     fg.flat.copy_(torch.randn(fg.flat.shape, generator=torch.Generator().manual_seed(3)))
     fopt.step(grad_sumsq=torch.tensor([4.0]), max_grad_norm=0.5)
+    assert fopt.step_count == 2
     assert all(torch.isfinite(p).all() for p in m.parameters()) and not torch.equal(next(iter(m.parameters())).detach(), before[0])
 
 
