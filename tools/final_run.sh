@@ -2,7 +2,7 @@
 # The round's measurement artefacts in one GPU call (from the repo root on the GPU box): everything lands under gpurun_out/final/.
 #   tools/final_run.sh [tag]        then copy gpurun_out/final/* into profiles/ (names carry the tag)
 set -u
-tag=${1:-r05}
+tag=${1:-r06}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/final
 mkdir -p $out
@@ -21,13 +21,18 @@ prof() {   # name, command...
 }
 prof bench python $R/bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --graph 0
 prof train_step python $R/bench.py --mode train --steps 3 --warmup 1
-prof train_scene512 python $R/bench.py --mode train-scene --steps 1 --warmup 1
+prof train_scene512 python $R/bench.py --mode train-scene --scene-recompute off --steps 1 --warmup 1      # save-all: the faster mode (the headline of train_step_scene_512)
+prof train_scene512_recompute python $R/bench.py --mode train-scene --scene-recompute on --steps 1 --warmup 1
 prof raster256_trained python $R/tools/raster_microbench.py --res 256 --regime trained
 prof raster256_init python $R/tools/raster_microbench.py --res 256 --regime init
 python tools/pmc_traffic.py > $out/${tag}_pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic.json $out/pmc_traffic.json
 cp gpurun_out/dit_pmc.txt $out/${tag}_dit_pmc.txt
 python tools/raster_det_ab.py > $out/${tag}_raster_deterministic_ab.txt 2>&1
+python tools/raster_grad_error.py > $out/${tag}_raster_grad_error_final.txt 2>&1
+tools/ubench/exp_ulp_bench > $out/${tag}_exp_ulp_final.txt 2>&1
+# the training step under the driver's launch line with forced (world-1 RCCL) collectives: host lead in the backward, verify-wait split
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --mode train --steps 4 --warmup 2 --force-dist --no-cpu-baseline > $out/${tag}_train_rccl_world1.json 2>> $out/${tag}_bench.err
 # the driver's multi-GPU launch line with the one GPU there is: RCCL process group of one rank, every collective issued
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 2 --force-dist --no-cpu-baseline > $out/${tag}_bench_torchrun_rccl_world1.json 2>> $out/${tag}_bench.err
 cut -c1-400 $out/${tag}_bench_torchrun_rccl_world1.json
