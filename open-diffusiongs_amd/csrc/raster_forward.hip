@@ -82,7 +82,7 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, float dx, fl
 }
 
 // One Gaussian of one view: everything preprocessCUDA does (forward.cu:155-256).  Returns visibility.
-__device__ __forceinline__ bool preprocess_one(const FwdParams& p, int v, int idx, int* rx0, int* ry0, int* rx1, int* ry1) {
+__device__ __forceinline__ bool preprocess_one(const FwdParams& p, int v, int idx, int* rx0, int* ry0, int* rx1, int* ry1, uint32_t* depth_key) {
     const int s = v / p.vps;
     const size_t gi = (size_t)v * p.P + idx;       // per-view state slot
     const size_t si = (size_t)s * p.P + idx;       // per-set input slot
@@ -174,6 +174,7 @@ __device__ __forceinline__ bool preprocess_one(const FwdParams& p, int v, int id
     p.g.clamped[gi] = (uint8_t)cbits;
     p.g.tiles_touched[gi] = (uint32_t)((y1 - y0) * (x1 - x0));
     p.g.keys[0][gi] = __float_as_uint(tz);
+    *depth_key = __float_as_uint(tz);
     *rx0 = x0; *ry0 = y0; *rx1 = x1; *ry1 = y1;
     return true;
 }
@@ -190,9 +191,31 @@ __global__ __launch_bounds__(256) void preprocess_kernel(FwdParams p) {
         for (int i = threadIdx.x; i < p.T; i += 256) lhist[i] = 0;
         __syncthreads();
     }
+    if (blockIdx.x == 0) {                                       // the depth range sort's bucket counts of this view (range_count_kernel adds to them)
+        uint32_t* w = p.g.range_ws + (size_t)v * range_ws_stride(p.P);
+        for (int i = threadIdx.x; i <= kRangeBuckets; i += 256) w[i] = 0u;
+    }
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     bool vis = false;
-    if (idx < p.P) vis = preprocess_one(p, v, idx, &x0, &y0, &x1, &y1);
+    uint32_t depth_key = 0xFFFFFFFFu;
+    if (idx < p.P) vis = preprocess_one(p, v, idx, &x0, &y0, &x1, &y1, &depth_key);
+    {   // range of the view's depth keys that are not the culled key (range_*_kernel map it onto their coarse buckets): a max of the key
+        // and of its complement over the workgroup, then ONE integer atomic each, without a return value, into copy blockIdx.x %
+        // kRangeSlots of the view's two words.  (One copy: 4,096 atomics per word serialise at the memory side; an atomic per wave: 16 k,
+        // 0.3 ms; a read first and the atomic only if it raises the word: the read's round trip at the end of every workgroup, +14 us on
+        // this 60 us kernel.)
+        __shared__ uint32_t s_rng[2][4];
+        const uint32_t key = vis ? depth_key : 0xFFFFFFFFu;
+        uint32_t hi = key != 0xFFFFFFFFu ? key : 0u, lo_c = key != 0xFFFFFFFFu ? ~key : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); lo_c = max(lo_c, (uint32_t)__shfl_xor((int)lo_c, o)); }
+        if ((threadIdx.x & 63) == 0) { s_rng[0][threadIdx.x >> 6] = hi; s_rng[1][threadIdx.x >> 6] = lo_c; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const uint32_t m = max(max(s_rng[threadIdx.x][0], s_rng[threadIdx.x][1]), max(s_rng[threadIdx.x][2], s_rng[threadIdx.x][3]));
+            if (m) atomicMax(p.im.depth_range + ((size_t)threadIdx.x * p.V + v) * kRangeSlots + (blockIdx.x % kRangeSlots), m);
+        }
+    }
     // The number of rectangles that cover a tile is the 2-D prefix sum of a difference grid with +1 at a rectangle's (y0, x0) and
     // (y1, x1) and -1 at (y0, x1) and (y1, x0) (corners on the grid's far edges have nothing behind them and are dropped): FOUR
     // atomics per Gaussian instead of one per covered tile.  With random-init weights a Gaussian covers ~50 of the 256 tiles: 13 M
@@ -302,178 +325,158 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint32_t* keys
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same pass as ONE kernel (4 launches per sort instead of 12: the three-kernel pass is 6.8 + 6.5 + 20.2 us plus two launch
-// boundaries at 256^2 x 4 views, profiles/r04_bench_kernel_stats.txt).  A workgroup counts its tile's digits, PUBLISHES the 256
-// counts (agent-scope stores: performed at the memory side, visible to every XCD without a fence) and adds one to the view's arrival
-// counter; once all NB workgroups of the view have arrived it reads all NB x 256 counts (agent-scope loads) -- thread d sums digit
-// d over the blocks in front of its own and over all of them -- scans the digit totals, and scatters as radix_scatter_kernel does.
-// The wait is a spin on one word by one lane (s_sleep between polls) and needs the view's workgroups to be resident together.
-// Dispatch is in block order and a view's workgroups only wait for each other, so whatever fits the chip of the views in front has
-// either finished or can finish; the host takes the one-kernel pass only when NB x V fits what the occupancy query says the chip
-// holds of THIS kernel at once (else the three-kernel pass: training calls with dozens of views; and always on the CPU emulation
-// build, whose workgroups run one after the other).  The occupancy query knows nothing of another stream's or another process's
-// kernels holding CUs (an RCCL ring beside the next micro-batch's forward; two ranks on one device), so the spin is bounded by
-// the wall clock -- 20 ms of the constant 100 MHz counter -- and a view that did not assemble is NOT an error: the workgroup that
-// gives up records the pass in the view's rescue word and leaves WITHOUT scattering (the pass's input buffer is intact: a pass only
-// writes its output buffer), the later passes of that view return at once, and radix_rescue_kernel -- one workgroup per view
-// behind the four passes, which returns at once for a view that needs nothing -- finishes the view's sort from the failed pass on.
-// The call produces the same bits either way (tests/test_raster_forward_gpu.py::test_radix_rescue_*: a fault injected per pass, and
-// the render beside a second stream's kernel that holds 64 CUs).
-// Keys and values stay in registers between the count and the scatter (one read of the tile instead of two).
+// Depth RANGE sort (round 6): the same order as the radix sort above -- (depth bits, Gaussian index), the culled key 0xFFFFFFFF last --
+// from four plain kernels, none of which waits for another workgroup:
+//   range_count_kernel    (grid blocks x V)  every key's coarse bucket under the monotone map of [min, max] of the view's keys onto
+//                                            kRangeBuckets buckets; LDS histogram, one integer atomic per touched bucket and block
+//   range_plan_kernel     (grid V)           exclusive scan of the bucket counts -> bucket starts; the culled keys' first ranks per block
+//   range_scatter_kernel  (grid blocks x V)  (key, index) pairs into their bucket's span (arrival order inside a bucket is arbitrary);
+//                                            culled keys straight to their final ranks, in index order
+//   range_sort_kernel     (grid kRangeBuckets / kRangeGroup x V)  a workgroup sorts kRangeGroup consecutive buckets' pairs completely in
+//                                            LDS as 64-bit (key << 32 | index) keys -- the per-tile sorter's algorithm (tile_bitonic_kernel):
+//                                            a local bucket map, every key counts the smaller keys of its bucket, a bitonic network when
+//                                            the depths pile up, chunks merged by rank when a group outgrows the LDS -- and writes
+//                                            order[rank] and rank_of[index]
+// The map is monotone and the final sort is total, so the result does not depend on the order the atomics arrived in: the same bits as
+// the four-pass radix (every binning form's tests run on it).  1 M keys (4 views of P = 262,146): 50 us against 113 us for four one-kernel
+// radix passes whose workgroups waited for each other inside the launch (round 5's form, removed with this: profiles/r06_depth_sort_ab.txt);
+// the three-kernel radix pass above stays as DGS_RASTER_SORT=radix (cross-check, and P > 2 M).
 // ------------------------------------------------------------------------------------------------
-#ifndef HIPEMU
-__global__ __launch_bounds__(256) void radix_pass_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                                                        uint32_t* rank_of, uint32_t* hist, uint32_t* arrived, uint32_t* rescue, int P, int NB,
-                                                        int shift, int fault) {
-    __shared__ uint32_t wcount[4][256];
-    __shared__ uint32_t running[256];
-    __shared__ uint32_t scratch[8];
-    __shared__ int s_ok;
-    const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const size_t vo = (size_t)v * P;
-    uint32_t key[kSortItems], val[kSortItems];
-    if (__hip_atomic_load(rescue + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;      // an earlier pass of this view did not assemble
-    running[tid] = 0;
-    __syncthreads();
+struct RangeMap {
+    uint32_t lo; float scale; bool any;
+    __device__ __forceinline__ uint32_t bucket(uint32_t key) const { return min((uint32_t)((float)(key - lo) * scale), (uint32_t)kRangeBuckets - 1u); }
+};
+// (every thread of a 256-thread workgroup calls it: the 2 x kRangeSlots partial copies are combined through `s_map`)
+__device__ __forceinline__ RangeMap range_map(const uint32_t* depth_range, int V, int v, uint32_t* s_map /* LDS, 2 words */) {
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5, slot = threadIdx.x & 31;
+        uint32_t x = slot < kRangeSlots ? depth_range[((size_t)which * V + v) * kRangeSlots + slot] : 0u;
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        const int i = b * kSortTile + r * 256 + tid;
-        const bool valid = i < P;
-        key[r] = valid ? keys_in[vo + i] : 0xFFFFFFFFu;
-        val[r] = valid ? (vals_in ? vals_in[vo + i] : (uint32_t)i) : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r)
-        if (b * kSortTile + r * 256 + tid < P) atomicAdd(&running[(key[r] >> shift) & 255u], 1u);
-    __syncthreads();
-    uint32_t* const hv = hist + (size_t)v * NB * 256;
-    __hip_atomic_store(hv + (size_t)b * 256 + tid, running[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's count stores have been performed
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(arrived + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 0;
-        const long long t0 = (long long)wall_clock64();                      // constant 100 MHz
-        // (fault injection, tests only: every other workgroup of the view gives up at once in pass `fault` -- the others scatter)
-        for (int spin = 0; !(fault == (shift >> 3) && (b & 1)); ++spin) {
-            if (__hip_atomic_load(arrived + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)NB) { ok = 1; break; }
-            if ((spin & 63) == 63 && (long long)wall_clock64() - t0 > 2000000ll) break;          // 20 ms
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (!ok) __hip_atomic_fetch_max(rescue + v, (uint32_t)(shift >> 3) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ok = ok;
+        for (int o = 16; o > 0; o >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, o));
+        if (slot == 0) s_map[which] = x;
     }
     __syncthreads();
-    if (!s_ok) return;
-    // thread d: digit d's count in the blocks in front of this one, and in all of them
-    uint32_t before = 0, total = 0;
-    for (int j0 = 0; j0 < NB; j0 += 16) {                        // sixteen loads per round trip
-        uint32_t c[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) c[u] = j0 + u < NB ? __hip_atomic_load(hv + (size_t)(j0 + u) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { total += c[u]; if (j0 + u < b) before += c[u]; }
-    }
-    uint32_t all;
-    const uint32_t ex = block_exclusive_scan<256>(total, scratch, &all);
-    __syncthreads();
-    running[tid] = ex + before;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
-        __syncthreads();
-        const bool valid = b * kSortTile + r * 256 + tid < P;
-        const uint32_t dig = (key[r] >> shift) & 255u;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const unsigned long long m = __ballot((dig >> bit) & 1u);
-            peers &= ((dig >> bit) & 1u) ? m : ~m;
-        }
-        const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
-        if (valid && rank_in_wave == 0) wcount[wave][dig] = (uint32_t)__popcll(peers);
-        __syncthreads();
-        if (valid) {
-            uint32_t pos = running[dig] + rank_in_wave;
-            for (int w = 0; w < wave; ++w) pos += wcount[w][dig];
-            keys_out[vo + pos] = key[r];
-            vals_out[vo + pos] = val[r];
-            if (rank_of) rank_of[vo + val[r]] = pos;
-        }
-        __syncthreads();
-        running[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
-    }
+    const uint32_t hi_w = s_map[0], lo_w = s_map[1];
+    const uint32_t hi = hi_w, lo = ~lo_w;
+    RangeMap m;
+    m.any = (hi_w | lo_w) != 0u;
+    m.lo = m.any ? lo : 0u;
+    // float conversion, multiplication by a positive constant and truncation are monotone
+    m.scale = m.any ? (float)kRangeBuckets / ((float)(hi - lo) + 1.0f) : 0.f;
+    return m;
 }
 
-// One workgroup of 1,024 threads per view: passes [first failed, 3] of the view's LSD sort (see radix_pass_kernel), or nothing.
-// The same stable pass -- digit histogram, exclusive scan, ballot ranks inside a wave, waves chained through LDS counters -- with the
-// whole view as one tile: ~1 ms per pass at P = 262,146, paid only by a call whose one-kernel pass could not assemble.
-__global__ __launch_bounds__(1024) void radix_rescue_kernel(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t* rank_of,
-                                                           const uint32_t* rescue, int P) {
-    __shared__ uint32_t wcount[16][256];
-    __shared__ uint32_t running[256];
-    __shared__ uint32_t scratch[20];
-    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t first = __hip_atomic_load(rescue + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (first == 0u) return;
-    const size_t vo = (size_t)v * P;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int pass = (int)first - 1; pass < 4; ++pass) {
-        const uint32_t* kin = (pass & 1 ? keys1 : keys0) + vo;
-        const uint32_t* vin = (pass & 1 ? vals1 : vals0) + vo;
-        uint32_t* kout = (pass & 1 ? keys0 : keys1) + vo;
-        uint32_t* vout = (pass & 1 ? vals0 : vals1) + vo;
-        const int shift = 8 * pass;
-        if (tid < 256) running[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < P; i += 1024) atomicAdd(&running[(kin[i] >> shift) & 255u], 1u);
-        __syncthreads();
-        uint32_t all = 0;
-        const uint32_t ex = block_exclusive_scan<1024>(tid < 256 ? running[tid] : 0u, scratch, &all);     // threads 0..255: digits in front of theirs
-        __syncthreads();
-        if (tid < 256) running[tid] = ex;
-        __syncthreads();
-        for (int i0 = 0; i0 < P; i0 += 1024) {
-            for (int w = tid; w < 16 * 256; w += 1024) (&wcount[0][0])[w] = 0;
-            __syncthreads();
-            const int i = i0 + tid;
-            const bool valid = i < P;
-            const uint32_t key = valid ? kin[i] : 0xFFFFFFFFu;
-            const uint32_t val = valid ? (pass == 0 ? (uint32_t)i : vin[i]) : 0u;
-            const uint32_t dig = (key >> shift) & 255u;
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const unsigned long long m = __ballot((dig >> bit) & 1u);
-                peers &= ((dig >> bit) & 1u) ? m : ~m;
-            }
-            const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
-            if (valid && rank_in_wave == 0) wcount[wave][dig] = (uint32_t)__popcll(peers);
-            __syncthreads();
-            if (valid) {
-                uint32_t pos = running[dig] + rank_in_wave;
-                for (int w = 0; w < wave; ++w) pos += wcount[w][dig];
-                kout[pos] = key;
-                vout[pos] = val;
-                if (pass == 3) rank_of[vo + val] = pos;
-            }
-            __syncthreads();
-            if (tid < 256) {
-                uint32_t add = 0;
-#pragma unroll
-                for (int w = 0; w < 16; ++w) add += wcount[w][tid];
-                running[tid] += add;
-            }
-            __syncthreads();
+__global__ __launch_bounds__(256) void range_count_kernel(const uint32_t* keys, const uint32_t* depth_range, uint32_t* ws, int P, int V, int stride) {
+    __shared__ uint32_t h[kRangeBuckets];
+    __shared__ uint32_t s_c[4];
+    __shared__ uint32_t s_map[2];
+    const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const RangeMap m = range_map(depth_range, V, v, s_map);
+    for (int i = tid; i < kRangeBuckets; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t* k = keys + (size_t)v * P;
+    uint32_t culled = 0;
+#pragma unroll 4
+    for (int r = 0; r < kRangeItems; ++r) {
+        const int i = b * kRangeTile + r * 256 + tid;
+        if (i < P) {
+            const uint32_t key = k[i];
+            if (key != 0xFFFFFFFFu) atomicAdd(&h[m.bucket(key)], 1u); else ++culled;
         }
-        __threadfence();                                        // the next pass of this workgroup reads what every thread of it scattered
-        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) culled += (uint32_t)__shfl_xor((int)culled, o);
+    if ((tid & 63) == 0) s_c[tid >> 6] = culled;
+    __syncthreads();
+    uint32_t* w = ws + (size_t)v * stride;
+    for (int i = tid; i < kRangeBuckets; i += 256) { const uint32_t c = h[i]; if (c) atomicAdd(&w[i], c); }
+    if (tid == 0) w[2 * kRangeBuckets + 1 + b] = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+}
+
+__global__ __launch_bounds__(1024) void range_plan_kernel(uint32_t* ws, int NB, int NWIN, int stride) {
+    __shared__ uint32_t scratch[20];
+    __shared__ uint32_t s_start[kRangeBuckets + 1];
+    uint32_t* w = ws + (size_t)blockIdx.x * stride;
+    const int tid = threadIdx.x;
+    const uint32_t c = tid < kRangeBuckets ? w[tid] : 0u;
+    uint32_t nvis;
+    const uint32_t ex = block_exclusive_scan<1024>(c, scratch, &nvis);
+    __syncthreads();
+    if (tid < kRangeBuckets) { w[tid] = ex; w[kRangeBuckets + 1 + tid] = 0u; s_start[tid] = ex; }
+    if (tid == 0) { w[kRangeBuckets] = nvis; s_start[kRangeBuckets] = nvis; }
+    __syncthreads();
+    // segments of the final sort: window j = the buckets whose first rank lies in [j, j + 1) * kRangeWindow, i.e. ranks from the first
+    // bucket start >= j * kRangeWindow (binary search over the non-decreasing starts) up to the next window's; a bucket larger than a
+    // window leaves the windows it spans empty
+    for (int j = tid; j <= NWIN; j += 1024) {
+        const uint32_t want = (uint32_t)j * (uint32_t)kRangeWindow;
+        int lo = 0, hi = kRangeBuckets;                           // first index with s_start[index] >= want (s_start[kRangeBuckets] = nvis ends the search)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_start[mid] < want) lo = mid + 1; else hi = mid; }
+        w[2 * kRangeBuckets + 1 + NB + j] = j == NWIN ? nvis : s_start[lo];
+    }
+    // culled keys: block j's first rank = keys that are not culled + culled keys of the blocks in front (NB <= 1024: P <= 4 M)
+    const uint32_t cc = tid < NB ? w[2 * kRangeBuckets + 1 + tid] : 0u;
+    uint32_t all;
+    const uint32_t cex = block_exclusive_scan<1024>(cc, scratch, &all);
+    if (tid < NB) w[2 * kRangeBuckets + 1 + tid] = nvis + cex;
+}
+
+__global__ __launch_bounds__(256) void range_scatter_kernel(const uint32_t* keys, const uint32_t* depth_range, uint32_t* ws, uint32_t* keys_out,
+                                                           uint32_t* vals_out, uint32_t* order, uint32_t* rank_of, int P, int V, int stride) {
+    __shared__ uint32_t h[kRangeBuckets];
+    __shared__ uint32_t s_cc[kRangeItems][4];
+    __shared__ uint32_t s_map[2];
+    const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RangeMap m = range_map(depth_range, V, v, s_map);
+    const size_t vo = (size_t)v * P;
+    uint32_t* w = ws + (size_t)v * stride;
+    for (int i = tid; i < kRangeBuckets; i += 256) h[i] = 0;
+    __syncthreads();
+    uint32_t key[kRangeItems], slot[kRangeItems];
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < kRangeItems; ++r) {
+        const int i = b * kRangeTile + r * 256 + tid;
+        key[r] = i < P ? keys[vo + i] : 0u;
+        const bool in = i < P, cul = in && key[r] == 0xFFFFFFFFu;
+        slot[r] = (in && !cul) ? atomicAdd(&h[m.bucket(key[r])], 1u) : 0u;
+        // culled keys keep their index order: rank inside the wave now, the (round, wave) prefix below
+        const unsigned long long cm = __ballot(cul);
+        if (cul) slot[r] = (uint32_t)__popcll(cm & lt_mask);
+        if (lane == 0) s_cc[r][wave] = (uint32_t)__popcll(cm);
+    }
+    __syncthreads();
+    // a span of its bucket for this block's keys: one returning atomic per touched bucket
+    {
+        constexpr int Q = kRangeBuckets / 256;                  // buckets per thread: their starts and their atomics all in flight together
+        uint32_t c[Q], st0[Q], got[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { c[q] = h[tid + 256 * q]; st0[q] = w[tid + 256 * q]; }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) got[q] = c[q] ? atomicAdd(&w[kRangeBuckets + 1 + tid + 256 * q], c[q]) : 0u;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) h[tid + 256 * q] = st0[q] + got[q];
+    }
+    __syncthreads();
+    const uint32_t cbase = w[2 * kRangeBuckets + 1 + b];
+#pragma unroll
+    for (int r = 0; r < kRangeItems; ++r) {
+        const int i = b * kRangeTile + r * 256 + tid;
+        if (i >= P) continue;
+        if (key[r] != 0xFFFFFFFFu) {
+            const uint32_t pos = h[m.bucket(key[r])] + slot[r];
+            keys_out[vo + pos] = key[r];
+            vals_out[vo + pos] = (uint32_t)i;
+        } else {
+            uint32_t off = 0;
+            for (int q = 0; q < r; ++q) off += (s_cc[q][0] + s_cc[q][1]) + (s_cc[q][2] + s_cc[q][3]);
+            for (int q = 0; q < wave; ++q) off += s_cc[r][q];
+            const uint32_t pos = cbase + off + slot[r];
+            order[vo + pos] = (uint32_t)i;
+            rank_of[vo + i] = pos;
+        }
     }
 }
-#endif
 
 // Exclusive scan of the V*T tile counts -> [start,end) ranges into the packed instance list (one workgroup), and the launch
 // order of the per-tile kernels (deal_tiles, by list length).
@@ -899,6 +902,135 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
     for (uint32_t i = tid; i < n; i += NT) p.bn.point_list[rg.x + i] = (uint32_t)keys[i];
 }
 
+// The final stage of the depth range sort (see range_count_kernel): kRangeGroup consecutive coarse buckets of one view, sorted completely.
+// grid (kRangeBuckets / kRangeGroup, V), 256 threads, dynamic LDS = kRangeSortCap * 8 + 2 * kBuckets * 4 bytes (two workgroups per CU).
+constexpr int kRangeSortCap = 8192;
+template <int NT>
+__global__ __launch_bounds__(NT) void range_sort_kernel(const uint32_t* ws, uint32_t* pkeys, uint32_t* pvals, uint32_t* order, uint32_t* rank_of,
+                                                       int P, int stride, int seg_off) {
+    DGS_DYNAMIC_LDS(smem);
+    constexpr int NWV = NT / 64, KPT = kRangeSortCap / NT;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + (size_t)kRangeSortCap * 8);
+    uint32_t* cur = cnt + kBuckets;
+    __shared__ uint32_t s_red[3][NWV];
+    __shared__ uint32_t scratch[NWV + 4];
+    const int v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t* w = ws + (size_t)v * stride;
+    const uint32_t begin = w[seg_off + blockIdx.x], end = w[seg_off + blockIdx.x + 1];   // range_plan_kernel's segment table
+    const uint32_t n = end - begin;
+    if (n == 0) return;
+    const size_t vo = (size_t)v * P;
+    uint32_t* pk = pkeys + vo + begin;
+    uint32_t* pv = pvals + vo + begin;
+    auto emit = [&](uint32_t place, uint64_t k) {
+        order[vo + begin + place] = (uint32_t)k;
+        rank_of[vo + (uint32_t)k] = begin + place;
+    };
+    if (n > (uint32_t)kRangeSortCap) {
+        // depths piled up beyond the LDS (thousands of Gaussians inside a thousandth of the view's depth range): chunks of the pairs are
+        // sorted in LDS and written back in place, then a pair's rank is its place in its chunk + the number of smaller pairs in every
+        // other chunk (binary search; the (key, index) pairs are distinct).  O(n (n / C) log C): slow, never wrong.
+        const uint32_t C = (uint32_t)kRangeSortCap, nchunks = (n + C - 1) / C;
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            const uint32_t len = min(C, n - c * C);
+            uint32_t m = 8 * NT;
+            while (m < len) m <<= 1;
+            for (uint32_t i = tid; i < m; i += NT) keys[i] = i < len ? ((uint64_t)pk[c * C + i] << 32) | pv[c * C + i] : ~0ull;
+            __syncthreads();
+            bitonic_sort_lds<NT>(keys, m, tid);
+            __syncthreads();
+            for (uint32_t i = tid; i < len; i += NT) { pk[c * C + i] = (uint32_t)(keys[i] >> 32); pv[c * C + i] = (uint32_t)keys[i]; }
+            __syncthreads();
+        }
+        __threadfence_block();                                 // one workgroup: its own global writes are visible behind the barrier
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += NT) {
+            const uint64_t k = ((uint64_t)pk[i] << 32) | pv[i];
+            const uint32_t mine = i / C;
+            uint32_t place = i - mine * C;
+            for (uint32_t c = 0; c < nchunks; ++c) {
+                if (c == mine) continue;
+                uint32_t lo = 0, hi = min(C, n - c * C);
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint64_t o = ((uint64_t)pk[c * C + mid] << 32) | pv[c * C + mid];
+                    if (o < k) lo = mid + 1; else hi = mid;
+                }
+                place += lo;
+            }
+            emit(place, k);
+        }
+        return;
+    }
+    // the group's pairs, once, into registers (all loads in flight together), then tile_bitonic_kernel's five steps
+    uint64_t kreg[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)u * NT;
+        kreg[u] = i < n ? ((uint64_t)pk[i] << 32) | pv[i] : ~0ull;
+    }
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        if ((uint32_t)tid + (uint32_t)u * NT < n) {
+            const uint32_t d = (uint32_t)(kreg[u] >> 32);
+            lo = min(lo, d); hi = max(hi, d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+    if (lane == 0) { s_red[0][wave] = lo; s_red[1][wave] = hi; }
+    uint32_t B = 256;
+    while (B * 4 < n && B < (uint32_t)kBuckets) B <<= 1;
+    for (uint32_t i = tid; i < (uint32_t)kBuckets; i += NT) cnt[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) { lo = min(lo, s_red[0][q]); hi = max(hi, s_red[1][q]); }
+    const float scale = (float)B / ((float)(hi - lo) + 1.0f);
+    auto bucket = [&](uint32_t d) { return min((uint32_t)((float)(d - lo) * scale), B - 1u); };
+#pragma unroll
+    for (int u = 0; u < KPT; ++u)
+        if ((uint32_t)tid + (uint32_t)u * NT < n) atomicAdd(&cnt[bucket((uint32_t)(kreg[u] >> 32))], 1u);
+    __syncthreads();
+    const uint32_t per = kBuckets / NT;
+    uint32_t local = 0, big = 0;
+    for (uint32_t u = 0; u < per; ++u) { const uint32_t c = cnt[tid * per + u]; local += c; big = max(big, c); }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan<NT>(local, scratch, &tot);
+    for (uint32_t u = 0; u < per; ++u) { const uint32_t c = cnt[tid * per + u]; cur[tid * per + u] = ex; cnt[tid * per + u] = ex; ex += c; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, o));
+    if (lane == 0) s_red[2][wave] = big;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) big = max(big, s_red[2][q]);
+#pragma unroll
+    for (int u = 0; u < KPT; ++u)
+        if ((uint32_t)tid + (uint32_t)u * NT < n) keys[atomicAdd(&cur[bucket((uint32_t)(kreg[u] >> 32))], 1u)] = kreg[u];
+    __syncthreads();
+    if (big <= (uint32_t)kBucketLimit) {
+        for (uint32_t i = tid; i < n; i += NT) {
+            const uint64_t k = keys[i];
+            const uint32_t b = bucket((uint32_t)(k >> 32));
+            const uint32_t s0 = cnt[b], e0 = cur[b];
+            uint32_t below = 0;
+            for (uint32_t j = s0; j < e0; ++j) below += keys[j] < k ? 1u : 0u;
+            emit(s0 + below, k);
+        }
+        return;
+    }
+    {
+        uint32_t m = 8 * NT;
+        while (m < n) m <<= 1;                                 // <= kRangeSortCap
+        for (uint32_t i = n + tid; i < m; i += NT) keys[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_lds<NT>(keys, m, tid);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += NT) emit(i, keys[i]);
+}
+
 // ---- binning, dense form ("scan") -------------------------------------------------------------------------------------
 // When Gaussians are large (random-init weights: ~50 tiles each, a tile is touched by a fifth of all Gaussians) listing the
 // instances first (emit) and sorting every tile's list moves each instance three times.  Here a tile filters the
@@ -1304,10 +1436,12 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess;
+                            kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(range_sort_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kRangeSortCap * 8 + 2 * kBuckets * 4) == hipSuccess;
     if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
     // tile_count, totals and the radix sort's arrival counters are neighbours in the image state (ImageState::carve): one fill
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, (int)(p.im.radix_sync + 5 * kRadixSyncViews - p.im.tile_count));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(1024), 0, st, p.im.tile_count, (int)p.im.zero_span((size_t)V));
     const dim3 gridP((P + 255) / 256, V);
     const bool lds_tiles = p.T <= 4096;
     if (lds_tiles) hipLaunchKernelGGL((preprocess_kernel<true>), gridP, dim3(256), (size_t)p.T * 4, st, p);
@@ -1341,28 +1475,22 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     bool radix_done = false;
     auto radix_sort = [&]() {
         const int NB = sort_blocks(P);
-#ifndef HIPEMU
-        // one kernel per pass while all of a call's sort workgroups fit the chip together (radix_pass_kernel); DGS_RASTER_RADIX3=1: the
-        // three-kernel pass (measurement aid)
-        static const int ncu = [] { int n = 0, d = 0; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-        static const bool three = getenv("DGS_RASTER_RADIX3") && atoi(getenv("DGS_RASTER_RADIX3")) != 0;
-        // workgroups of radix_pass_kernel one CU holds at once, from the kernel's own registers and LDS (not a guessed constant)
-        static const int per_cu = [] { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, radix_pass_kernel, 256, 0) == hipSuccess ? n : 0; }();
-        // DGS_RASTER_RADIX_FAULT=<pass 0..3> (tests): half of every view's workgroups give up in that pass; radix_rescue_kernel finishes the sort
-        static const int fault = getenv("DGS_RASTER_RADIX_FAULT") ? atoi(getenv("DGS_RASTER_RADIX_FAULT")) : -1;
-        if (!three && ncu > 0 && per_cu > 0 && (long long)NB * V <= (long long)per_cu * ncu && V <= kRadixSyncViews) {
-            uint32_t* const rescue = p.im.radix_sync + 4 * kRadixSyncViews;
-            for (int pass = 0; pass < 4; ++pass) {
-                const int in = pass & 1, out = in ^ 1;
-                hipLaunchKernelGGL(radix_pass_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], pass == 0 ? (const uint32_t*)nullptr : p.g.vals[in], p.g.keys[out],
-                                   p.g.vals[out], pass == 3 ? p.g.rank_of : (uint32_t*)nullptr, p.g.radix_hist, p.im.radix_sync + pass * kRadixSyncViews, rescue, P, NB,
-                                   8 * pass, fault);
-            }
-            hipLaunchKernelGGL(radix_rescue_kernel, dim3(V), dim3(1024), 0, st, p.g.keys[0], p.g.keys[1], p.g.vals[0], p.g.vals[1], p.g.rank_of, rescue, P);
+        // default: the depth RANGE sort (four plain kernels, range_count_kernel).  DGS_RASTER_SORT=radix: the four-pass radix sort below,
+        // three plain kernels per pass (cross-check: both give the same order bit for bit; also what P > 2 M takes)
+        static const bool use_radix = getenv("DGS_RASTER_SORT") && !strcmp(getenv("DGS_RASTER_SORT"), "radix");
+        const int RB = range_blocks(P);
+        if (!use_radix && RB <= 1024) {
+            const int stride = (int)range_ws_stride(P);
+            hipLaunchKernelGGL(range_count_kernel, dim3(RB, V), dim3(256), 0, st, p.g.keys[0], p.im.depth_range, p.g.range_ws, P, V, stride);
+            const int NWIN = range_windows(P), seg_off = 2 * kRangeBuckets + 1 + RB;
+            hipLaunchKernelGGL(range_plan_kernel, dim3(V), dim3(1024), 0, st, p.g.range_ws, RB, NWIN, stride);
+            hipLaunchKernelGGL(range_scatter_kernel, dim3(RB, V), dim3(256), 0, st, p.g.keys[0], p.im.depth_range, p.g.range_ws, p.g.keys[1], p.g.vals[1],
+                               p.g.vals[0], p.g.rank_of, P, V, stride);
+            hipLaunchKernelGGL(range_sort_kernel<512>, dim3(NWIN, V), dim3(512), kRangeSortCap * 8 + 2 * kBuckets * 4, st, p.g.range_ws, p.g.keys[1], p.g.vals[1],
+                               p.g.vals[0], p.g.rank_of, P, stride, seg_off);
             radix_done = true;
             return;
         }
-#endif
         for (int pass = 0; pass < 4; ++pass) {
             const int in = pass & 1, out = in ^ 1;
             hipLaunchKernelGGL(radix_hist_kernel, dim3(NB, V), dim3(256), 0, st, p.g.keys[in], p.g.radix_hist, P, NB, 8 * pass);

@@ -15,7 +15,12 @@ namespace dgs {
 constexpr int kTile = 16;
 constexpr int kSortItems = 16;                    // keys per thread in the depth radix sort
 constexpr int kSortTile = 256 * kSortItems;       // keys per workgroup
-constexpr int kRadixSyncViews = 64;               // views per call the one-kernel radix pass has arrival counters for
+constexpr int kRangeBuckets = 1024;               // depth range sort: coarse buckets per view (monotone map of the depth bits' range)
+constexpr int kRangeWindow = 4096;                //                   a workgroup of the final LDS sort takes the buckets that START inside one window of
+                                                  //                   this many ranks: at most kRangeWindow + the largest bucket keys, whatever the depths' distribution
+constexpr int kRangeSlots = 16;                   //                   copies of a view's {max key, max ~key} words the preprocess workgroups spread their atomics over
+constexpr int kRangeItems = 8;                    //                   keys per thread of its count / scatter kernels (2,048 per workgroup)
+constexpr int kRangeTile = 256 * kRangeItems;
 constexpr size_t kAlign = 256;
 
 struct Carver {
@@ -32,7 +37,13 @@ struct Carver {
     size_t bytes() const { return ((off + kAlign - 1) & ~(kAlign - 1)) + kAlign; }
 };
 
-inline int sort_blocks(int P) { return (P + kSortTile - 1) / kSortTile; }
+__host__ __device__ inline int sort_blocks(int P) { return (P + kSortTile - 1) / kSortTile; }
+// words per view of GeomState::range_ws: [0, B] bucket counts -> exclusive starts (entry B = keys that are not culled),
+// [B + 1, 2 B] scatter cursors, [2 B + 1, 2 B + 1 + blocks) culled keys per 2,048-key block -> their first rank, then windows + 1 words:
+// the first rank of every window's segment (the last: the keys that are not culled)
+__host__ __device__ inline int range_blocks(int P) { return (P + kRangeTile - 1) / kRangeTile; }
+__host__ __device__ inline int range_windows(int P) { return (P + kRangeWindow - 1) / kRangeWindow; }
+__host__ __device__ inline size_t range_ws_stride(int P) { return (size_t)((2 * kRangeBuckets + 1 + range_blocks(P) + range_windows(P) + 1 + 3) & ~3); }
 
 // Everything the blend kernels need of one (view, Gaussian), in ONE 64-byte line.  The per-tile lists are depth ordered, so consecutive
 // entries are unrelated Gaussians: every field read is its own memory request.  As three arrays (8 + 16 + 16 bytes) a staged entry cost
@@ -60,6 +71,7 @@ struct GeomState {                 // arrays indexed [view * P + gaussian]
     uint32_t* rank_of;             // position of the Gaussian in its view's depth order
     uint32_t* radix_hist;          // [V][blocks][256]
     uint32_t* radix_base;          // [V][256]
+    uint32_t* range_ws;            // [V][range_ws_stride(P)] depth range sort (raster_forward.hip range_*_kernel)
     float* grad_acc;               // [V*P*16] backward only: the nine sums of the blend backward per (view, Gaussian) in ONE 64-byte line
                                    //          {colour r g b, mean2D x y, conic xx xy yy, opacity, 7 unused} (raster_backward.hip)
     static GeomState carve(void* buf, size_t P, size_t V, size_t* bytes) {
@@ -77,6 +89,7 @@ struct GeomState {                 // arrays indexed [view * P + gaussian]
         g.rank_of = c.take<uint32_t>(n);
         g.radix_hist = c.take<uint32_t>(V * (size_t)sort_blocks((int)P) * 256);
         g.radix_base = c.take<uint32_t>(V * 256);
+        g.range_ws = c.take<uint32_t>(V * range_ws_stride((int)P));
         g.grad_acc = c.take<float>(16 * n);
         if (bytes) *bytes = c.bytes();
         return g;
@@ -90,14 +103,16 @@ struct ImageState {
     uint32_t* tile_cursor;         // [V*T]   scatter cursors
     uint2* ranges;                 // [V*T]   [start,end) into the packed instance list
     int32_t* totals;               // [4]     {num_rendered, status, longest tile list, -}
-    uint32_t* radix_sync;          // [5][kRadixSyncViews]: rows 0-3 arrival counters of the one-kernel radix passes (raster_forward.hip radix_pass_kernel);
-                                   //          row 4: per view, 1 + the first pass that did not assemble (0: none) -- radix_rescue_kernel finishes that view's sort
+    uint32_t* depth_range;         // [2][V][kRangeSlots]  max depth key | max of ~(depth key) over the view's keys that are not culled, in kRangeSlots partial
+                                   //          copies (preprocess_kernel: workgroup b adds to copy b % kRangeSlots; zero = none)
     uint32_t* tile_order;          // [V*T]   launch order of the per-tile kernels (workgroup b works on tile tile_order[b])
     uint32_t* tile_work;           // [V*T]   list entries the forward blend walked before the tile was finished
     uint32_t* tile_scanned;        // [V*T]   depth ranks the forward blend tested for the tile (scan form; else 0)
     uint4* tile_stats;             // [2][V*T] measurement (forward, backward), tools' / emulator build only (kRasterStats), else zero:
                                    //          {cell-list entries walked (x 16 pixels = pair evaluations), wave loop trips (x 64 lanes = lane
                                    //          slots issued), depth ranks scanned (scan form), batches}
+    // words the forward zeroes in one fill: tile_count .. depth_range
+    size_t zero_span(size_t V) const { return (size_t)(depth_range + 2 * V * kRangeSlots - tile_count); }
     static ImageState carve(void* buf, size_t W, size_t H, size_t V, size_t* bytes) {
         Carver c(buf);
         ImageState s;
@@ -106,7 +121,7 @@ struct ImageState {
         s.n_contrib = c.take<uint32_t>(V * W * H);
         s.tile_count = c.take<uint32_t>(V * T);
         s.totals = c.take<int32_t>(4);             // directly behind tile_count: the forward zeroes both with one fill
-        s.radix_sync = c.take<uint32_t>(5 * kRadixSyncViews);      // ... and these
+        s.depth_range = c.take<uint32_t>(2 * V * kRangeSlots);     // ... and these (zero_span() words from tile_count on)
         s.tile_cursor = c.take<uint32_t>(V * T);
         s.ranges = c.take<uint2>(V * T);
         s.tile_order = c.take<uint32_t>(V * T);

@@ -78,7 +78,7 @@ def test_backward_is_bit_reproducible_256(regime):
     """The deterministic form (`backend.deterministic = True`: every (tile, Gaussian) instance stores its sums into a slot of its own, a
     gather adds them in rectangle order, a tile's waves accumulate in LDS copies of their own; no floating-point atomic whose order
     is left to the hardware): two backward passes give identical bits, in the list forms (trained-like)
-    and the on-demand scan form (random-init regime), 4 views at 256^2; the atomic form (reference's way) stays within 1e-5 of it."""
+    and the on-demand scan form (random-init regime), 4 views at 256^2; the atomic form (reference's way) stays within 3e-5 of it."""
     from dgs_amd import cameras
     from dgs_amd.raster import RasterBackend, render_views_autograd
     res, V = 256, 4
@@ -104,7 +104,10 @@ def test_backward_is_bit_reproducible_256(regime):
     at = RasterBackend()
     at.deterministic = False
     for a, b, name in zip(runs[0], grads(at), ("xyz", "features", "scaling", "rotation", "opacity")):
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, name
+        # the atomic form's summation order is the hardware's: its distance from the fixed-order form varies run to run -- measured
+        # 3e-6 ... 1.2e-5 of a tensor's max (profiles/r04_raster_deterministic_ab.txt), 1.08e-5 in a run of round 6 -- so the bar is 3e-5,
+        # not the 1e-5 this line carried until then (a flaky pass)
+        assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-12, name
     assert at.last_backward_deterministic is False
 
 

@@ -135,3 +135,50 @@ def test_camera_and_ray_kernels_match_oracle():
     np.testing.assert_allclose(proj.numpy(), p_ref.numpy(), atol=2e-5)
     np.testing.assert_allclose(campos.numpy(), c_ref.numpy(), atol=0)
     np.testing.assert_allclose(tanfov.numpy(), t_ref.numpy(), rtol=1e-6)
+
+
+def test_depth_range_sort_pile_up_beyond_the_lds():
+    """The depth range sort (raster_forward.hip range_*_kernel): 9,000 of 9,300 Gaussians share ONE depth key -- one coarse bucket,
+    more pairs than a workgroup of the final sort holds in LDS (kRangeSortCap = 8,192): the chunked path (chunks sorted in LDS, merged by
+    rank) must still give the reference's order, ties by Gaussian index."""
+    H, W = 32, 32
+    sc, cams = small_scene(9300, W, H, seed=21, log_scale=-1.6, n_views=1)
+    cam = cams[0]
+    # the same view-space depth for the first 9,000: move them along the view's z axis onto the plane tz = 3
+    vm = np.asarray(cam["viewmatrix"], np.float64)             # row-vector convention: p_view = p @ vm[:3, :3] + vm[3, :3]
+    xyz = sc["xyz"].astype(np.float64)
+    tz = xyz @ vm[:3, 2] + vm[3, 2]
+    xyz[:9000] += np.outer(3.0 - tz[:9000], vm[:3, 2]) / float(vm[:3, 2] @ vm[:3, 2])
+    sc["xyz"] = xyz.astype(np.float32)
+    assert_forward_parity(emu_backend(), sc, cams, H, W, CPU)
+
+
+def test_depth_range_sort_nothing_visible_and_one_visible():
+    """No key but the culled key (every Gaussian behind the camera), then exactly one visible Gaussian: the range map has nothing /
+    a single point to span."""
+    H, W = 32, 32
+    sc, cams = small_scene(300, W, H, seed=22, n_views=1)
+    cam = cams[0]
+    vm = np.asarray(cam["viewmatrix"], np.float64)
+    xyz = sc["xyz"].astype(np.float64)
+    tz = xyz @ vm[:3, 2] + vm[3, 2]
+    behind = xyz + np.outer(-5.0 - tz, vm[:3, 2]) / float(vm[:3, 2] @ vm[:3, 2])      # tz = -5 for everyone
+    sc["xyz"] = behind.astype(np.float32)
+    assert_forward_parity(emu_backend(), sc, cams, H, W, CPU)
+    one = behind.copy()
+    one[17] = xyz[17] + (2.5 - tz[17]) * vm[:3, 2] / float(vm[:3, 2] @ vm[:3, 2])
+    sc["xyz"] = one.astype(np.float32)
+    assert_forward_parity(emu_backend(), sc, cams, H, W, CPU)
+
+
+def test_radix_sort_gives_the_same_lists(monkeypatch):
+    """DGS_RASTER_SORT=radix (the four-pass radix sort the range sort replaced as the default; read once per process: child process)."""
+    import os, subprocess, sys
+    if os.environ.get("DGS_RASTER_BIN") != "2":
+        pytest.skip("one run is enough: the child process runs every binning form")
+    env = dict(os.environ, DGS_RASTER_SORT="radix")
+    env.pop("DGS_RASTER_BIN", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "small_scenes or many_instances or pile_up"], env=env, capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -200,37 +200,6 @@ def test_dropin_binding_matches_oracle():
         rast(means3D=t(sc["xyz"]), means2D=means2D, opacities=t(sc["opacities"]))
 
 
-def test_three_kernel_radix_pass_forced(request):
-    """The depth radix sort runs one kernel per pass while a call's sort workgroups fit the chip together (radix_pass_kernel) and the
-    three-kernel pass otherwise (training calls with dozens of views): DGS_RASTER_RADIX3=1 forces the latter on the cases of this file
-    that finish in seconds, in a child process (the switch is read once per process)."""
-    import os, subprocess, sys
-    if request.node.callspec.params.get("binning_form") != "auto":
-        pytest.skip("one run is enough: the child process runs the forms that use the depth sort itself")
-    env = dict(os.environ, DGS_RASTER_RADIX3="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "(small_scenes or diffusiongs_shaped) and (scan or sort)"], env=env, capture_output=True, text=True, timeout=1500,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-@pytest.mark.parametrize("fault_pass", [0, 1, 2, 3])
-def test_radix_rescue_fault_injected(request, fault_pass):
-    """radix_pass_kernel waits inside the launch for all of a view's workgroups; a view that does not assemble (another stream's or
-    another process's kernels holding CUs) is finished by radix_rescue_kernel from the pass that failed -- never an error, never a
-    wrong order.  DGS_RASTER_RADIX_FAULT=<pass> makes every other workgroup of every view give up in that pass (the others scatter,
-    as they would in a real time-out); the parity cases that use the depth sort must still match the oracle bit for bit.  Child
-    process: the switch is read once per process."""
-    import os, subprocess, sys
-    if request.node.callspec.params.get("binning_form") != "auto":
-        pytest.skip("one run is enough: the child process runs the forms that use the depth sort itself")
-    env = dict(os.environ, DGS_RASTER_RADIX_FAULT=str(fault_pass))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "diffusiongs_shaped and (scan or sort)"], env=env, capture_output=True, text=True, timeout=900,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 def _coreside_library():
     """tools/ubench/coreside_bench.hip (an RCCL-shaped neighbour: `wgs` workgroups of 512 threads streaming a copy), built in place
     if the snapshot does not carry it (hipcc is part of the image)."""
@@ -246,10 +215,11 @@ def _coreside_library():
 
 
 def test_planned_render_beside_a_neighbour_stream(request):
-    """The multi-GPU training case on one GPU: the planned (no host synchronisation) render of 4 views at 256^2 -- one-kernel radix
-    passes, whose workgroups wait for each other inside the launch -- while a second stream runs an RCCL-shaped kernel (64 workgroups
-    of 512 threads streaming 1 GiB, tools/ubench/coreside_bench.hip) for the whole time.  Fifty renders in both regimes: every
-    image and every contributor count identical, bit for bit, to the render on an idle GPU (which the tests above pin to the oracle)."""
+    """The multi-GPU training case on one GPU: the planned (no host synchronisation) render of 4 views at 256^2 while a second stream runs
+    an RCCL-shaped kernel (64 workgroups of 512 threads streaming 1 GiB, tools/ubench/coreside_bench.hip) for the whole time.  Fifty
+    renders in both regimes: every image and every radius identical, bit for bit, to the render on an idle GPU (which the tests above pin
+    to the oracle).  (Written for round 5's one-kernel radix passes, whose workgroups waited for each other inside the launch; since the
+    depth range sort no kernel of the rasterizer does, and the test stays as the concurrency check of its integer atomics.)"""
     if request.node.callspec.params.get("binning_form") != "auto":
         pytest.skip("one run is enough")
     dev = _dev()
@@ -281,3 +251,32 @@ def test_planned_render_beside_a_neighbour_stream(request):
             got = run(int(n * 1.2))
             assert torch.equal(got[1], want_img) and torch.equal(got[2], want_radii), (regime, it)
         torch.cuda.synchronize()
+
+
+def test_radix_sort_gives_the_same_lists(request):
+    """DGS_RASTER_SORT=radix: the four-pass radix sort (three plain kernels per pass: what the range sort replaced as the default, and
+    what P > 2 M takes) on the parity cases of this file that finish in seconds -- both must give the oracle's lists bit for bit.  Child
+    process: the switch is read once per process."""
+    import os, subprocess, sys
+    if request.node.callspec.params.get("binning_form") != "auto":
+        pytest.skip("one run is enough: the child process runs the forms that use the depth sort itself")
+    env = dict(os.environ, DGS_RASTER_SORT="radix")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(small_scenes or diffusiongs_shaped) and (scan or sort)"], env=env, capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_depth_range_sort_pile_up_beyond_the_lds_gpu(request):
+    """9,000 of 9,300 Gaussians with one depth key: the range sort's chunked path on the gfx950 build (tests/test_raster_forward_emu.py has
+    the why)."""
+    if request.node.callspec.params.get("binning_form") == "bitonic":
+        pytest.skip("the per-tile LDS sort form does not use the depth order")
+    H, W = 32, 32
+    sc, cams = small_scene(9300, W, H, seed=21, log_scale=-1.6, n_views=1)
+    vm = np.asarray(cams[0]["viewmatrix"], np.float64)
+    xyz = sc["xyz"].astype(np.float64)
+    tz = xyz @ vm[:3, 2] + vm[3, 2]
+    xyz[:9000] += np.outer(3.0 - tz[:9000], vm[:3, 2]) / float(vm[:3, 2] @ vm[:3, 2])
+    sc["xyz"] = xyz.astype(np.float32)
+    assert_forward_parity(_backend(), sc, cams, H, W, _dev())
