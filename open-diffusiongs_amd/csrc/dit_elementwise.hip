@@ -212,28 +212,31 @@ __global__ void scatter_tokens_kernel(const float* in, float* x, int B, int lpad
 //   learned Gaussians: up[B*ng][C] f32
 // ------------------------------------------------------------------------------------------------
 
+// NF = 3 (gaussians_sh_degree + 1)^2 feature channels between xyz and scaling (to_gs, denoiser.py:103-120): C = 11 + NF
+template <int NF>
 __global__ __launch_bounds__(256) void gaussians_kernel(GsParams p) {
+    constexpr int C = 11 + NF;
     const size_t HW = (size_t)p.H * p.W;
     const size_t P = (size_t)p.ng + (size_t)p.V * HW;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)p.B * P) return;
     const int b = (int)(gid / P);
     const size_t i = gid % P;
-    float c[14];
+    float c[C];
     float x, y, z;
     if (i < (size_t)p.ng) {
-        const float* src = p.up + ((size_t)b * p.ng + i) * p.C;
+        const float* src = p.up + ((size_t)b * p.ng + i) * C;
 #pragma unroll
-        for (int k = 0; k < 14; ++k) c[k] = src[k];
+        for (int k = 0; k < C; ++k) c[k] = src[k];
         x = c[0]; y = c[1]; z = c[2];
     } else {
         const size_t j = i - p.ng;                       // (v, hh, ww, ph, pw)
         const int pp = p.ps * p.ps;
         const size_t tok = j / pp;
         const int pi = (int)(j % pp);
-        const float* src = p.dec + ((size_t)b * p.lpad + tok) * (size_t)(pp * p.C) + (size_t)pi * p.C;
+        const float* src = p.dec + ((size_t)b * p.lpad + tok) * (size_t)(pp * C) + (size_t)pi * C;
 #pragma unroll
-        for (int k = 0; k < 14; ++k) c[k] = src[k];
+        for (int k = 0; k < C; ++k) c[k] = src[k];
         const int np_w = p.W / p.ps, np = (p.H / p.ps) * np_w;
         const int v = (int)(tok / np), hh = (int)((tok % np) / np_w), ww = (int)(tok % np_w);
         const int h = hh * p.ps + pi / p.ps, w = ww * p.ps + pi % p.ps;
@@ -248,12 +251,13 @@ __global__ __launch_bounds__(256) void gaussians_kernel(GsParams p) {
         if (p.aligned) { p.aligned[base] = x; p.aligned[base + HW] = y; p.aligned[base + 2 * HW] = z; }
     }
     p.xyz[gid * 3] = x; p.xyz[gid * 3 + 1] = y; p.xyz[gid * 3 + 2] = z;
-    p.features[gid * 3] = c[3]; p.features[gid * 3 + 1] = c[4]; p.features[gid * 3 + 2] = c[5];
-    p.scaling[gid * 3] = fminf(c[6] - 2.3f, -1.2f);
-    p.scaling[gid * 3 + 1] = fminf(c[7] - 2.3f, -1.2f);
-    p.scaling[gid * 3 + 2] = fminf(c[8] - 2.3f, -1.2f);
-    p.rotation[gid * 4] = c[9]; p.rotation[gid * 4 + 1] = c[10]; p.rotation[gid * 4 + 2] = c[11]; p.rotation[gid * 4 + 3] = c[12];
-    p.opacity[gid] = c[13] - 2.0f;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) p.features[gid * NF + k] = c[3 + k];          // [.., (deg + 1)^2, 3] row-major = the split's order
+    p.scaling[gid * 3] = fminf(c[3 + NF] - 2.3f, -1.2f);
+    p.scaling[gid * 3 + 1] = fminf(c[4 + NF] - 2.3f, -1.2f);
+    p.scaling[gid * 3 + 2] = fminf(c[5 + NF] - 2.3f, -1.2f);
+    p.rotation[gid * 4] = c[6 + NF]; p.rotation[gid * 4 + 1] = c[7 + NF]; p.rotation[gid * 4 + 2] = c[8 + NF]; p.rotation[gid * 4 + 3] = c[9 + NF];
+    p.opacity[gid] = c[10 + NF] - 2.0f;
 }
 
 static int launch_ok() { return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE; }
@@ -347,7 +351,14 @@ int launch_scatter_tokens(const float* in, float* x, int B, int lpad, int L, int
 
 int launch_gaussians(const GsParams& p, hipStream_t st) {
     const size_t n = (size_t)p.B * ((size_t)p.ng + (size_t)p.V * p.H * p.W);
-    hipLaunchKernelGGL(gaussians_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    switch (p.C) {                                             // 11 + 3 (deg + 1)^2, gaussians_sh_degree 0 .. 3
+        case 14: hipLaunchKernelGGL(gaussians_kernel<3>, grid, block, 0, st, p); break;
+        case 23: hipLaunchKernelGGL(gaussians_kernel<12>, grid, block, 0, st, p); break;
+        case 38: hipLaunchKernelGGL(gaussians_kernel<27>, grid, block, 0, st, p); break;
+        case 59: hipLaunchKernelGGL(gaussians_kernel<48>, grid, block, 0, st, p); break;
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
     return launch_ok();
 }
 

@@ -177,7 +177,8 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     if (!m || !a || a->B <= 0 || a->V <= 0 || a->H <= 0 || a->W <= 0) { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
     if (m->width % 256 || m->width != m->heads * 64 || m->layers <= 0 || m->patch <= 0 || a->H % m->patch || a->W % m->patch)
         { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
-    if (m->gs_channels != 14 || m->in_channels != 9 || (m->in_channels * m->patch * m->patch) % 64) { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
+    // gs_channels = 11 + 3 (gaussians_sh_degree + 1)^2 (denoiser.py:96,148): degrees 0 .. 3 in the inference forward (the training calls: degree 0)
+    if ((m->gs_channels != 14 && m->gs_channels != 23 && m->gs_channels != 38 && m->gs_channels != 59) || m->in_channels != 9 || (m->in_channels * m->patch * m->patch) % 64) { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
     if (!a->images || !a->ray_o || !a->ray_d || !a->t || !a->workspace || !a->xyz || !a->features || !a->scaling || !a->rotation || !a->opacity)
         { fprintf(stderr, "[dgs] %s:%d: invalid argument\n", __FILE__, __LINE__); return DGS_ERR_INVALID_ARGUMENT; }
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -155,13 +155,14 @@ class DitEngine:
     def __init__(self, state_dict, width=1024, patch_size=8, n_gaussians=2, dim_heads=64, num_layers=24, in_channels=9,
                  ray_pe_type="relative_plk", gaussians_sh_degree=0, scene=False, range_near=0.0, range_far=500.0,
                  device="cuda", lib=None):
-        if gaussians_sh_degree != 0:
-            raise NotImplementedError("only gaussians_sh_degree 0 (every shipped config) is implemented")
+        if gaussians_sh_degree not in (0, 1, 2, 3):
+            raise ValueError("gaussians_sh_degree 0 .. 3 (what the rasterizer evaluates)")
+        self.sh_degree = int(gaussians_sh_degree)
         self.lib = lib if lib is not None else _native.lib()
         self.device = torch.device(device)
         self.width, self.patch, self.ng, self.layers = width, patch_size, n_gaussians, num_layers
         self.heads = width // dim_heads
-        self.gs_channels = 3 + 3 + 3 + 4 + 1
+        self.gs_channels = 3 + (self.sh_degree + 1) ** 2 * 3 + 3 + 4 + 1     # to_gs's split, denoiser.py:96,109-111
         sd = state_dict
         bf = lambda k: torch.empty(tuple(sd[k].shape), dtype=torch.bfloat16, device=self.device)
         f32 = lambda k: torch.empty(tuple(sd[k].shape), dtype=torch.float32, device=self.device)
@@ -261,7 +262,7 @@ class DitEngine:
         tt = t.to(dev, torch.int64).contiguous()
         P = self.ng + V * H * W
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        out = dict(xyz=f(B, P, 3), features=f(B, P, 1, 3), scaling=f(B, P, 3), rotation=f(B, P, 4), opacity=f(B, P, 1))
+        out = dict(xyz=f(B, P, 3), features=f(B, P, (self.sh_degree + 1) ** 2, 3), scaling=f(B, P, 3), rotation=f(B, P, 4), opacity=f(B, P, 1))
         aligned = f(B, V, 3, H, W)
         tokens = f(B, self.num_tokens(V, H, W), self.width) if return_tokens else None
         ws = self._workspace(B, V, H, W)
@@ -429,6 +430,9 @@ class DitEngine:
         """image_to_gaussians that keeps what `backward` needs.  recompute=False: every activation is saved, nothing is
         recomputed; True: only block inputs are kept and `backward` re-runs each block (torch.utils.checkpoint's role,
         denoiser.py:348-354).  Returns (dict, aligned_xyz); the arena the pass used is `self._train["current"]`."""
+        if self.sh_degree != 0:
+            raise NotImplementedError("training with gaussians_sh_degree > 0: the training calls (dgs_dit_forward_train / dgs_dit_backward) take degree 0 "
+                                      "-- every shipped config; the inference forward takes 0 .. 3")
         dev = self.device
         B, V, _, H, W = images.shape
         recompute = bool(recompute)

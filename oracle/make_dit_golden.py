@@ -179,7 +179,7 @@ def main():
         print("wrote", path, {k: tuple(params[k].shape) for k in params})
 
 
-def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5, kinds=("obj", "scene")):
+def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5, kinds=("obj", "scene"), sh_degree=0):
     """Fixture the gfx950 kernels can run (head_dim 64, width % 256 == 0): weights are NOT stored -- they are
     dit_oracle.parity_state_dict(cfg, seed), loaded into the reference modules with load_state_dict."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -192,9 +192,10 @@ def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5, kinds=
         if kind not in kinds:
             continue
         cfg = dict(width=width, in_channels=9, patch_size=8, n_gaussians=2, dim_heads=64, num_layers=layers,
-                   gaussians_sh_degree=0, hard_pixelalign=True, **extra)
+                   gaussians_sh_degree=sh_degree, hard_pixelalign=True, **extra)
         model = modcls(cfg).float().eval()
-        ocfg = D.Cfg(width=width, num_layers=layers, ray_pe_type=extra["ray_pe_type"], scene=(kind == "scene"), range_far=50.0)
+        ocfg = D.Cfg(width=width, num_layers=layers, ray_pe_type=extra["ray_pe_type"], scene=(kind == "scene"), range_far=50.0,
+                     gaussians_sh_degree=sh_degree)
         sd = D.parity_state_dict(ocfg, seed)
         missing, unexpected = model.load_state_dict(sd, strict=True), None
         g = torch.Generator().manual_seed(seed + 1)
@@ -211,7 +212,7 @@ def main_hip(tag="hip256", width=256, layers=2, res=16, b=2, v=2, seed=5, kinds=
                     pre + "in_t": t.numpy(), pre + "out_aligned": aligned.numpy()})
         for k in ("xyz", "features", "scaling", "rotation", "opacity"):
             out[pre + "out_" + k] = params[k].numpy()
-    out.update(width=np.array(width), layers=np.array(layers), res=np.array(res), seed=np.array(seed))
+    out.update(width=np.array(width), layers=np.array(layers), res=np.array(res), seed=np.array(seed), sh_degree=np.array(sh_degree))
     path = os.path.join(OUT, f"dit_golden_{tag}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
@@ -222,5 +223,7 @@ if __name__ == "__main__":
         main_hip()
         # 258 tokens (res 64, 4 views): the attention kernel's multi-tile / ring / tail-merge paths, from the reference's code
         main_hip(tag="hip256_l258", res=64, b=1, v=4, seed=9, kinds=("obj",))
+        # gaussians_sh_degree 1 (23 Gaussian channels): the heads' and to_gs's general split (denoiser.py:96,109-117)
+        main_hip(tag="hip256_sh1", seed=11, kinds=("obj",), sh_degree=1)
     else:
         main()

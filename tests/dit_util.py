@@ -35,7 +35,8 @@ def golden_case(kind, tag="hip256"):
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"dit_golden_{tag}.npz"))
     cfg = D.Cfg(width=int(z["width"]), num_layers=int(z["layers"]), scene=(kind == "scene"), range_far=50.0,
-                ray_pe_type="plk" if kind == "scene" else "relative_plk")
+                ray_pe_type="plk" if kind == "scene" else "relative_plk",
+                gaussians_sh_degree=int(z["sh_degree"]) if "sh_degree" in z.files else 0)
     sd = D.parity_state_dict(cfg, int(z["seed"]))
     t = lambda k: torch.tensor(z[kind + "_" + k])
     res = int(z["res"])

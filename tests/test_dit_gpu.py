@@ -191,6 +191,39 @@ def test_forward_matches_reference_golden(kind):
     assert rel_l2(aligned.cpu(), ref["aligned"]) < 2e-2
 
 
+def test_forward_sh_degree_1_matches_reference_golden_and_renders():
+    """gaussians_sh_degree = 1 on the MI355X: the engine against the golden vectors of the reference's own denoiser (23 Gaussian channels,
+    features [b, P, 4, 3]); then the whole DGSDenoiser.forward with that degree -- the rasterizer evaluates the degree-1 harmonics of
+    the denoiser's own features -- against the drop-in binding's render of the same Gaussians."""
+    from dgs_amd import denoiser as dn
+    from dgs_amd.dit import DitEngine
+    cfg, sd, inp, ref = golden_case("obj", tag="hip256_sh1")
+    eng = DitEngine(sd, width=cfg.width, num_layers=cfg.num_layers, ray_pe_type=cfg.ray_pe_type, gaussians_sh_degree=1, device=DEV)
+    out, aligned = eng.image_to_gaussians(inp["images"], inp["ray_o"], inp["ray_d"], inp["t"])
+    for k in FIELDS:
+        assert out[k].shape == ref[k].shape, k
+        assert rel_l2(out[k].cpu(), ref[k]) < 2e-2, (k, rel_l2(out[k].cpu(), ref[k]))
+    m = dn.DGSDenoiser(dict(width=256, in_channels=9, patch_size=8, num_layers=2, gaussians_sh_degree=1), device=DEV)
+    m.reset_parameters(seed=4)
+    images, ray_o, ray_d, t, c2w, k = synth_inputs(D.Cfg(width=256, num_layers=2, gaussians_sh_degree=1), 1, 4, 64, seed=6)
+    batch = {a: b.to(DEV) for a, b in dict(image=images, ray_o=ray_o, ray_d=ray_d, c2w=c2w, fxfycxcy=k).items()}
+    with torch.no_grad():                      # inference: the training calls take degree 0 (NotImplementedError otherwise)
+        rendered, gaussians = m(batch, t.to(DEV))
+    assert rendered.shape == (1, 4, 3, 64, 64) and torch.isfinite(rendered).all() and float(rendered.std()) > 1e-3
+    with pytest.raises(NotImplementedError):
+        m(batch, t.to(DEV))
+    import diff_gaussian_rasterization as dgr
+    from dgs_amd.raster import default_backend
+    g = gaussians[0]
+    assert g.get_features.shape[-2:] == (4, 3)
+    view, proj, campos, tanfov = default_backend().cameras_from_c2w(batch["c2w"], batch["fxfycxcy"], 64, 64)
+    rs = dgr.GaussianRasterizationSettings(64, 64, float(tanfov[2, 0]), float(tanfov[2, 1]), torch.ones(3, device=DEV), 1.0,
+                                           view[2], proj[2], 1, campos[2], False, False)
+    color, _ = dgr.GaussianRasterizer(rs)(g.get_xyz, torch.zeros_like(g.get_xyz), g.get_opacity, shs=g.get_features,
+                                          scales=g.get_scaling, rotations=g.get_rotation)
+    assert float(((color.clamp(0, 1) - rendered[0, 2].clamp(0, 1)) ** 2).mean()) < 1e-7
+
+
 @pytest.mark.parametrize("kind", ["obj"])
 def test_forward_matches_reference_golden_258_tokens(kind):
     """A fixture from the reference's own denoiser code at 258 tokens (res 64, 4 views): multi-tile attention, the key
