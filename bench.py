@@ -442,6 +442,7 @@ def train_bench(a, dev, rank, world, steps, warmup, scene=None):
     recompute = bool(eng._train.get("recompute"))
     flops = (4 if recompute else 3) * dit_flops(L, MODEL_CFG["width"], MODEL_CFG["num_layers"]) * B
     log = tr.reducer.launch_log
+    trainer_backend = model.gs_renderer.backend() if hasattr(getattr(model, "gs_renderer", None), "backend") else None   # the trainer's own (dgs_amd/train.py): gone from the model after close()
     tr.close()
     micro = min(B, getattr(model, "MAX_DIFFERENTIABLE_BATCH", 4))
     mem = None
@@ -449,10 +450,9 @@ def train_bench(a, dev, rank, world, steps, warmup, scene=None):
         free_b, total_b = torch.cuda.mem_get_info(dev)
         mem = {"peak_allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "reserved": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1),
                "free": round(free_b / 2 ** 30, 1), "total": round(total_b / 2 ** 30, 1)}
-    rb = getattr(model.gs_renderer, "backend", None)
     raster_note = None
-    if rb is not None:
-        be = rb()
+    if trainer_backend is not None:
+        be = trainer_backend
         raster_note = {"deterministic_backward": bool(getattr(be, "last_backward_deterministic", False)),
                        "plans": [{"capacity": pl.capacity, "seen_max": pl.seen_max, "calls": dict(pl.calls)} for pl in be._plans.values()][-3:]}
     head = {"gpu_memory_gib": mem, "raster": raster_note} if scene is None else {

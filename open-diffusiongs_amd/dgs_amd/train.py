@@ -47,7 +47,16 @@ class DataParallelTrainer:
             deterministic = os.environ.get("DGS_RASTER_DETERMINISTIC", "1") not in ("", "0")
         self.deterministic = bool(deterministic)
         renderer = getattr(model, "gs_renderer", None)
+        self._renderer, self._private_backend = renderer, False
         self._raster_backend = renderer.backend() if renderer is not None and hasattr(renderer, "backend") else None
+        if renderer is not None and getattr(renderer, "_backend", "absent") is None and self._raster_backend is not None:
+            # the model renders through the process-wide default backend: the trainer's choice (deterministic backward) must not leak to
+            # its other users, so the model gets a backend of its own for as long as the trainer lives (same library, same exponential;
+            # its plans learn their shapes again on the first step)
+            from .raster import RasterBackend
+            own = RasterBackend(lib=self._raster_backend.lib, exact_exp=self._raster_backend.exact_exp)
+            own.deterministic_budget = self._raster_backend.deterministic_budget
+            renderer._backend, self._raster_backend, self._private_backend = own, own, True
         self._raster_was_deterministic = getattr(self._raster_backend, "deterministic", None)
         self._raster_was_budget = getattr(self._raster_backend, "deterministic_budget", None)
         if self._raster_backend is not None:
@@ -88,7 +97,9 @@ class DataParallelTrainer:
             for p in m.parameters():
                 if p.grad is not None:
                     p.grad = p.grad.clone()
-            if self._raster_backend is not None and self._raster_was_deterministic is not None:
+            if self._private_backend:
+                self._renderer._backend = None                 # back to the process-wide default backend, which was never touched
+            elif self._raster_backend is not None and self._raster_was_deterministic is not None:
                 self._raster_backend.deterministic = self._raster_was_deterministic
                 self._raster_backend.deterministic_budget = self._raster_was_budget
 

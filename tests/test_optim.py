@@ -278,6 +278,10 @@ def test_two_trainer_runs_from_the_same_state_are_bit_identical():
                 log.append((float(loss), float(tr.last_grad_sumsq)))
             assert m.gs_renderer.backend().last_backward_deterministic
         runs.append((log, {n: p.detach().clone() for n, p in m.named_parameters()}))
+        # the trainer's choice lived on a backend of the model's own: the process-wide default backend was never switched, and the model
+        # renders through it again now
+        from dgs_amd.raster import default_backend
+        assert m.gs_renderer.backend() is default_backend() and not default_backend().deterministic
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     bad = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[1][1][n])]
     assert not bad, (len(bad), bad[:6])
