@@ -460,7 +460,7 @@ class RasterBackend:
         B, V = int(c2w.shape[0]), int(c2w.shape[1])
         view, proj, campos, tanfov = self.cameras_from_c2w(c2w, fxfycxcy, height, width)
         if bg is None:
-            bg = torch.ones(3, dtype=torch.float32, device=device)    # render_opencv_cam default, gs_core.py:879
+            bg = _white(device)                                        # render_opencv_cam default, gs_core.py:879
         M = int(features.shape[2])
         degree = int(round(M ** 0.5)) - 1
         out = self.forward_views(bg, xyz, None, opacity.reshape(B, -1), scaling, rotation, 1.0, None, view, proj, campos,
@@ -527,11 +527,20 @@ class _RenderViews(torch.autograd.Function):
 def render_views_autograd(backend, xyz, features, scaling, rotation, opacity, height, width, c2w, fxfycxcy, bg=None):
     """[B,P,..] raw Gaussian parameters -> [B,V,3,H,W]; differentiable w.r.t. the five parameter tensors."""
     if bg is None:
-        bg = torch.ones(3, dtype=torch.float32, device=xyz.device)
+        bg = _white(xyz.device)
     return _RenderViews.apply(backend, xyz, features, scaling, rotation, opacity, c2w.float(), fxfycxcy.float(), height, width, bg)
 
 
 _default = None
+_WHITE = {}
+
+
+def _white(device):
+    """The default background, one tensor per device (a torch.ones(3) per render call was a fill launch of its own in every step)."""
+    key = (device.type, device.index)
+    if key not in _WHITE:
+        _WHITE[key] = torch.ones(3, dtype=torch.float32, device=device)
+    return _WHITE[key]
 
 
 def default_backend():
