@@ -205,7 +205,9 @@ extern "C" int dgs_dit_forward(const DgsDitModel* m, const DgsDitForwardArgs* a,
     }
 
     // ---- tokens: embed + patchify -> tokenizer GEMM -> learned tokens -> input LayerNorm (denoiser.py:312-347) ----
-    DGS_TRY(launch_zero_fill(ws.emb, (size_t)M * kin * sizeof(bf16_t), st));       // a kernel, not a memset node: dit_kernels.h
+    // (ws.emb is NOT zeroed here: the embed kernel writes every image-token row, and the rows it never writes -- the learned tokens',
+    //  whose tokenizer output must be zero, and the padding -- hold the zeros the workspace contract asks for once per shape,
+    //  dgs_dit.h `workspace`; rounds 2-5 re-zeroed 5 MB per call: 5 us + a launch boundary)
     EmbedParams ep;
     ep.B = B; ep.V = V; ep.H = H; ep.W = Wd; ep.ps = m->patch; ep.lpad = lpad; ep.relative_plk = m->relative_plk;
     ep.images = a->images; ep.ray_o = a->ray_o; ep.ray_d = a->ray_d; ep.out = ws.emb;
