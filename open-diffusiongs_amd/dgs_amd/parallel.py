@@ -155,6 +155,8 @@ class BucketedAllReduce:
         # a world of one normally skips the collectives; force_collectives issues them anyway (a sum over one rank: the RCCL
         # launch path, its stream ordering against the backward and the bf16 round trip run for real on a single GPU)
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())
+        import os
+        self._norm_on_side = os.environ.get("DGS_NORM_SIDE_STREAM", "0") not in ("", "0")
         if bucket_bytes is None:                   # 32 MiB per rank: a ring step moves bucket / world per link
             bucket_bytes = (32 << 20) * max(self.world, 2)
         es = flat.element_size()
@@ -208,6 +210,12 @@ class BucketedAllReduce:
         norm partials -- on a SIDE stream that waits for the collective: the compute stream (the backward of the earlier blocks)
         is not held up.  finish() joins the side stream."""
         if work is None and half is None and self.norm is None:
+            return
+        if work is None and half is None and not self._norm_on_side:
+            # a world of one without forced collectives: nothing to wait for, the bucket's norm partials go behind the kernels that
+            # filled it on THIS stream -- a second stream beside the backward's one-round kernels costs them more than its 29 small
+            # launches hide (profiles/r06_norm_stream_ab.txt; DGS_NORM_SIDE_STREAM=1: the side stream anyway, measurement aid)
+            self.norm.add(a, b)
             return
         if self.side is None:
             self._deferred.append((work, half, a, b))
