@@ -779,7 +779,7 @@ __global__ __launch_bounds__(NT) void tile_bitonic_kernel(FwdParams p) {
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
     const uint64_t* src = p.bn.inst_key + rg.x;
-    constexpr int KPT = NT == 256 ? 32 : 16;                   // 8,192 / 256 (tile_bitonic_kernel<256> is launched up to that capacity), 16,384 / 1,024
+    constexpr int KPT = NT == 256 ? 32 : 16;                   // 8,192 / 256, 8,192 / 512 (both launched up to that capacity), 16,384 / 1,024
     {
         // A list longer than this launch's LDS (only when the form was launched alone -- `bitonic_any` -- for a caller that expected
         // shorter lists; any other launch sends such a tile to the rank sort): chunks of C keys are sorted in LDS and written back
@@ -1437,6 +1437,8 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
                             kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bitonic_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kBitonicMax * 8 + 2 * kBuckets * 4) == hipSuccess &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(range_sort_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kRangeSortCap * 8 + 2 * kBuckets * 4) == hipSuccess;
     if (!lds_ok) { fprintf(stderr, "[dgs] rasterizer: hipFuncSetAttribute(tile_bitonic_kernel, %d bytes of LDS) failed\n", kBitonicMax * 8 + 2 * kBuckets * 4); return DGS_ERR_DEVICE; }
@@ -1552,7 +1554,12 @@ int dgs_raster_forward(DgsRasterForwardArgs* a, dgs_stream_t stream) {
     }
     if (forms & (1 << kFormBitonic)) {
         const size_t lds = (size_t)p.bitonic_cap * 8 + 2 * kBuckets * 4;
+        // 4,096 .. 8,192-entry lists (the trained-like 256^2 regime): 512 threads -- the same two workgroups per CU (80 KiB of LDS each)
+        // with twice the waves to hide the kernel's chain of LDS phases behind (its network's smallest size is 8 x 512 = 4,096 keys,
+        // so shorter capacities keep 256 threads); DGS_RASTER_BITONIC_NT=256: measurement aid (profiles/r06_tile_sort_threads_ab.txt)
+        static const int nt_env = getenv("DGS_RASTER_BITONIC_NT") ? atoi(getenv("DGS_RASTER_BITONIC_NT")) : 0;
         if (p.bitonic_cap > 8192) hipLaunchKernelGGL(tile_bitonic_kernel<1024>, dim3(VT), dim3(1024), lds, st, p);
+        else if (p.bitonic_cap >= 4096 && nt_env != 256) hipLaunchKernelGGL(tile_bitonic_kernel<512>, dim3(VT), dim3(512), lds, st, p);
         else hipLaunchKernelGGL(tile_bitonic_kernel<256>, dim3(VT), dim3(256), lds, st, p);
     }
     if (forms & ((1 << kFormRankSort) | (1 << kFormBitonic))) {

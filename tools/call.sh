@@ -1,18 +1,31 @@
 #!/bin/bash
 # One gpurun call's worth of work; rewritten per call during development.
-# This form (round 6, call 23): a world of one: the gradient norm's per-bucket partial sums on the compute stream (default now) against
-# the side stream (DGS_NORM_SIDE_STREAM=1), training step, alternating inside one call; then the trainer GPU tests.
+# This form (round 6, call 24): the per-tile LDS sorter with 512 threads for 4,096 .. 8,192-entry capacities against 256 threads
+# (DGS_RASTER_BITONIC_NT=256), trained-like regime: microbenchmark (sync line: capacity from the longest list), kernel stats, raster tests.
 set -u
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/call
 mkdir -p $out
 cd $R
 export PYTHONPATH=$R/open-diffusiongs_amd:$R
-rm -f $out/norm_stream_ab.txt
-for rep in 1 2 3; do for v in 1 0; do
-  DGS_NORM_SIDE_STREAM=$v timeout 300 python bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline 2> /dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('norm_on_side_stream=$v rep $rep train ms/step', d['ms_per_step'])" >> $out/norm_stream_ab.txt
+rm -f $out/tile_sort_threads_ab.txt
+for rep in 1 2; do for nt in 256 512; do
+  echo "== NT=$nt trained rep $rep" >> $out/tile_sort_threads_ab.txt
+  DGS_RASTER_BITONIC_NT=$nt timeout 300 python tools/raster_microbench.py --res 256 --regime trained --iters 50 2>&1 | grep -E "sync|async|forward\+backward" >> $out/tile_sort_threads_ab.txt
 done; done
-cat $out/norm_stream_ab.txt
-timeout 900 python -m pytest tests/test_optim.py tests/test_rccl_world1_gpu.py tests/test_two_ranks_gpu.py tests/test_dit_backward_gpu.py -x -q -m gpu -k "trainer or training or rccl or two_ranks or optim" > $out/pytest_train.txt 2>&1; tail -3 $out/pytest_train.txt
+for nt in 256 512; do
+  DGS_RASTER_BITONIC_NT=$nt PROF_LINES=30 tools/prof.sh call_nt_$nt -- python $R/tools/raster_microbench.py --res 256 --regime trained > /dev/null
+  echo "== kernel stats NT=$nt" >> $out/tile_sort_threads_ab.txt
+  grep -E "tile_bitonic|emit_instances|blend_forward" gpurun_out/call_nt_$nt/kernel_stats.txt >> $out/tile_sort_threads_ab.txt
+done
+python - >> $out/tile_sort_threads_ab.txt 2>&1 <<'PY'
+import os, subprocess, sys, json
+for nt in ("256", "512", "256", "512"):
+    env = dict(os.environ, DGS_RASTER_BITONIC_NT=nt)
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True).stdout.strip().splitlines()
+    d = json.loads(out[-1])
+    r = d["raster"]["trained"]
+    print("NT", nt, "bench raster.trained forward ms", r["forward"]["ms"], "forward+backward ms", r["forward_backward"]["ms"])
+PY
+cat $out/tile_sort_threads_ab.txt
+timeout 1500 python -m pytest tests/test_raster_forward_gpu.py tests/test_raster_backward_gpu.py tests/test_raster_ref_gpu.py -x -q -m gpu > $out/pytest_raster_gpu.txt 2>&1; tail -3 $out/pytest_raster_gpu.txt
