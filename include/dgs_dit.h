@@ -326,6 +326,14 @@ int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream);
 int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream);
 int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, dgs_stream_t stream);
 int dgs_dit_layernorm(const DgsDitLayerNormArgs* a, dgs_stream_t stream);
+/* LayerNorm + modulate and the GEMM that consumes it (g->A == ln->out), as DiTBlock.forward runs them twice per block
+ * (utils_transformer.py:271-290: norm1 -> attn.qkv, norm2 -> mlp.fc1): the same results as dgs_dit_layernorm followed by dgs_dit_gemm,
+ * bit for bit.  When a sample ends one or two rows behind its last full 256-row tile (the DiT's learned tokens: L = 4096 v + 2) and
+ * the GEMM runs on the 256-row kernel (QKV / GELU epilogues), those output rows are produced by the first workgroups of the LayerNorm
+ * launch instead of by side jobs inside the GEMM launch (QKV -2.8 us, fc1 -2.4 us at one sample); every other shape is the two plain
+ * launches.                                                                                                                       */
+int dgs_dit_layernorm_gemm(const DgsDitLayerNormArgs* ln, const DgsDitGemmArgs* g, dgs_stream_t stream);
+int32_t dgs_dit_layernorm_gemm_shares_rows(const DgsDitLayerNormArgs* ln, const DgsDitGemmArgs* g);   /* 1: the pair above takes that form */
 int dgs_dit_layernorm_backward(const DgsDitLayerNormBackwardArgs* a, dgs_stream_t stream);
 int dgs_dit_rowlinear_backward(const DgsDitRowLinearBackwardArgs* a, dgs_stream_t stream);
 int dgs_dit_gate_mul(const DgsDitGateMulArgs* a, dgs_stream_t stream);

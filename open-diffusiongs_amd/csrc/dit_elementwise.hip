@@ -6,6 +6,7 @@
 //   gaussians_kernel      GaussiansUpsampler.to_gs + hard pixel alignment           denoiser.py:103-120,370-413
 // All are one pass over their input with 16-byte accesses; nothing here is MFMA work.
 #include "dit_kernels.h"
+#include "dit_gemm_epilogue.h"
 
 namespace dgs {
 
@@ -18,12 +19,9 @@ namespace dgs {
 // row itself, so the kernel is ONE memory round trip.  (As run-time tests of p.weight / p.shift inside the output loop the
 // compiler emitted, per 1 KiB of the row, branch -> load -> s_waitcnt vmcnt(0) -> store: four more dependent round trips behind the
 // reductions, ~2 of the kernel's 6.9 us at the DiT shape.)  Same arithmetic in the same order as before: outputs are bit-identical.
-template <int VPL, bool WEIGHT, bool MOD, bool F32OUT>   // float4 vectors per lane: width = 256 * VPL
-__global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;                                  // the sample: grid.y (no per-row division in front of the operand loads)
-    const int local = blockIdx.x * 4 + (threadIdx.x >> 6), row = b * p.rows_per_batch + local;
-    if (local >= p.rows_per_batch || row >= p.rows) return;
+// One row by one wave: y = the row normalised (weighted, modulated), lane's float4 i = columns 4 (64 i + lane) .. + 3.
+template <int VPL, bool WEIGHT, bool MOD>   // float4 vectors per lane: width = 256 * VPL
+__device__ __forceinline__ void ln_row(const LnParams& p, int b, int row, int lane, float4 (&y)[VPL]) {
     const float4* xr = reinterpret_cast<const float4*>(p.x + (size_t)row * p.width);
     float4 v[VPL], w[WEIGHT ? VPL : 1], sh[MOD ? VPL : 1], sc[MOD ? VPL : 1];
     float sum = 0.f;
@@ -51,16 +49,100 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
     const float rstd = rsqrtf(wave_sum(sq) / (float)p.width + p.eps);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c4 = i * 64 + lane;
-        float4 y = make_float4(v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd);
-        if constexpr (WEIGHT) { y.x *= w[i].x; y.y *= w[i].y; y.z *= w[i].z; y.w *= w[i].w; }
+        y[i] = make_float4(v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd);
+        if constexpr (WEIGHT) { y[i].x *= w[i].x; y[i].y *= w[i].y; y[i].z *= w[i].z; y[i].w *= w[i].w; }
         if constexpr (MOD) {
-            y.x = y.x * (1.0f + sc[i].x) + sh[i].x; y.y = y.y * (1.0f + sc[i].y) + sh[i].y;
-            y.z = y.z * (1.0f + sc[i].z) + sh[i].z; y.w = y.w * (1.0f + sc[i].w) + sh[i].w;
+            y[i].x = y[i].x * (1.0f + sc[i].x) + sh[i].x; y[i].y = y[i].y * (1.0f + sc[i].y) + sh[i].y;
+            y[i].z = y[i].z * (1.0f + sc[i].z) + sh[i].z; y[i].w = y[i].w * (1.0f + sc[i].w) + sh[i].w;
         }
-        if constexpr (F32OUT) reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)row * p.width)[c4] = y;
+    }
+}
+
+template <int VPL, bool WEIGHT, bool MOD, bool F32OUT>
+__device__ __forceinline__ void ln_rows_role(const LnParams& p, int b, int local, int lane) {
+    const int row = b * p.rows_per_batch + local;
+    if (local >= p.rows_per_batch || row >= p.rows) return;
+    float4 y[VPL];
+    ln_row<VPL, WEIGHT, MOD>(p, b, row, lane, y);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c4 = i * 64 + lane;
+        if constexpr (F32OUT) reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)row * p.width)[c4] = y[i];
         else reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)row * p.width)[c4] =
-                 make_uint2(pack_bf2(y.x, y.y), pack_bf2(y.z, y.w));
+                 make_uint2(pack_bf2(y[i].x, y[i].y), pack_bf2(y[i].z, y[i].w));
+    }
+}
+
+template <int VPL, bool WEIGHT, bool MOD, bool F32OUT>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnParams p) {
+    // the sample: grid.y (no per-row division in front of the operand loads)
+    ln_rows_role<VPL, WEIGHT, MOD, F32OUT>(p, blockIdx.y, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// The LayerNorm + modulate launch in front of a GEMM whose samples end one or two rows behind their last full 256-row tile (the DiT's
+// learned tokens: L = 4096 v + 2).  Inside the GEMM those rows are two-row GEMV items of the first workgroups' prologues, and the
+// launch pays for them: QKV +2.8 us, fc1 +2.4 us at one sample (tools/gemm_tail_cost.py) -- the item's round trip queues behind the
+// ring's first slabs, and the workgroups that carry one enter their loop 3 us late and end the launch (profiles/r05_gemm_timeline.txt).
+// Here the same items are the FIRST workgroups of the LayerNorm launch, which is one memory round trip long anyway: an item
+// normalises the sample's live rows itself (the rows' LayerNorm output does not exist yet in this launch: same ln_row, same bits),
+// and then is the GEMM's item with 4 waves instead of 8: K ranges of 512 per wave, the ranges summed in the same order -- the
+// outputs are bit-identical to the GEMM's own items (tests/test_dit_kernels_emu.py, tests/test_dit_gpu.py).
+struct TailEpi {               // what tail_prefetch / tail_store read of a GEMM's parameter block (dit_gemm_epilogue.h)
+    const float *bias, *resid, *gate;
+    void *out, *aux;
+    bf16_t* vt;
+    int N, ldo, gate_stride, rows_per_batch;
+    float q_scale;
+};
+
+template <int VPL, int EPI>
+__global__ __launch_bounds__(256) void layernorm_rows_gemv_kernel(LnParams p, LnRowsGemv j) {
+    constexpr int K = 256 * VPL, KS = K / 512 < 4 ? K / 512 : 4, CS = 4 / KS, CPI = 8 * CS, KW = K / KS;
+    static_assert(KW == 512, "one 16-byte load per lane and row");
+    __shared__ uint2 s_rows[2][K / 4];                                   // the live rows' LayerNorm output, bf16
+    __shared__ float s_part[KS * 2 * CPI];
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= j.items) {
+        ln_rows_role<VPL, false, true, false>(p, b, ((int)blockIdx.x - j.items) * 4 + wave, lane);
+        return;
+    }
+    const int blk = blockIdx.x, kq = wave % KS, cq = wave / KS, k_lo = kq * KW;
+    uint4 w[8];
+    const bf16_t* w_col0 = j.W + (size_t)(blk * CPI + cq * 8) * j.ldw + k_lo + lane * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[c] = *reinterpret_cast<const uint4*>(w_col0 + (size_t)c * j.ldw);
+    TailEpi te{j.bias, nullptr, nullptr, j.out, j.aux, j.vt, j.N, j.ldo, 0, p.rows_per_batch, j.q_scale};
+    const int er = tid / CPI, ec = tid - er * CPI;                        // the element thread `tid` finishes (tid < 2 CPI)
+    const int erow = b * p.rows_per_batch + j.row0 + er;
+    const bool finisher = tid < 2 * CPI && er < j.nrows;
+    TailOperands ops{0.f, 0.f, 0.f};
+    if (finisher) ops = tail_prefetch<EPI>(te, erow, blk * CPI + ec);
+    if (wave < 2) {
+        if (wave < j.nrows) {
+            float4 y[VPL];
+            ln_row<VPL, false, true>(p, b, b * p.rows_per_batch + j.row0 + wave, lane, y);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) s_rows[wave][i * 64 + lane] = make_uint2(pack_bf2(y[i].x, y[i].y), pack_bf2(y[i].z, y[i].w));
+        } else {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) s_rows[wave][i * 64 + lane] = make_uint2(0u, 0u);
+        }
+    }
+    __syncthreads();
+    const uint4 a0 = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(s_rows[0]) + k_lo + lane * 8);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(s_rows[1]) + k_lo + lane * 8);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float s0 = dot8_bf16(a0, w[c], 0.f), s1 = dot8_bf16(a1, w[c], 0.f);
+        s0 = wave_sum_lane63(s0); s1 = wave_sum_lane63(s1);
+        if (lane == 63) { s_part[(kq * 2 + 0) * CPI + cq * 8 + c] = s0; s_part[(kq * 2 + 1) * CPI + cq * 8 + c] = s1; }
+    }
+    __syncthreads();
+    if (finisher) {
+        float v = 0.f;
+        for (int q = 0; q < KS; ++q) v += s_part[(q * 2 + er) * CPI + ec];
+        tail_store<EPI>(te, erow, blk * CPI + ec, v, ops);
     }
 }
 
@@ -287,6 +369,43 @@ int launch_layernorm(const DgsDitLayerNormArgs* a, hipStream_t st) {
         default: return DGS_ERR_INVALID_ARGUMENT;
     }
 #undef DGS_LN_CASE
+    return launch_ok();
+}
+
+bool layernorm_rows_gemv_ok(const DgsDitLayerNormArgs* a, const DgsDitGemmArgs* g) {
+    if (!a || !g || a->weight || !a->shift || !a->scale || a->out_f32) return false;
+    if (a->width != 512 && a->width != 1024 && a->width != 2048) return false;
+    if (g->epilogue != DGS_EPI_QKV && g->epilogue != DGS_EPI_GELU_BF16) return false;
+    const int rpb = a->rows_per_batch > 0 ? a->rows_per_batch : a->rows;
+    if (g->K != a->width || g->A != a->out || g->lda != a->width || g->M != a->rows || g->rows_per_batch != rpb || g->N % 32) return false;
+    if (g->valid_rows <= 0 || g->valid_rows >= rpb) return false;
+    const int live = g->valid_rows - (g->valid_rows - 1) / 256 * 256;            // live rows of the last tile row that has any
+    return live <= 2 && g->valid_rows > 256;
+}
+
+int launch_layernorm_rows_gemv(const DgsDitLayerNormArgs* a, const DgsDitGemmArgs* g, hipStream_t st) {
+    if (!layernorm_rows_gemv_ok(a, g) || a->rows <= 0 || !a->x || !a->out) return DGS_ERR_INVALID_ARGUMENT;
+    LnParams p;
+    p.rows = a->rows; p.width = a->width; p.mod_stride = a->mod_stride;
+    p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->rows;
+    p.out_f32 = 0; p.eps = a->eps; p.x = a->x; p.weight = nullptr; p.shift = a->shift; p.scale = a->scale; p.out = a->out;
+    LnRowsGemv j;
+    j.W = g->W; j.bias = g->bias; j.out = g->out; j.aux = g->aux; j.vt = g->vt; j.N = g->N; j.ldw = g->ldw; j.ldo = g->ldo; j.epilogue = g->epilogue;
+    j.nrows = g->valid_rows - (g->valid_rows - 1) / 256 * 256; j.row0 = g->valid_rows - j.nrows;
+    j.q_scale = g->q_scale != 0.0f ? g->q_scale : 1.0f;
+    const int ks = a->width / 512 < 4 ? a->width / 512 : 4, cpi = 8 * (4 / ks);
+    j.items = g->N / cpi;
+    const dim3 grid(j.items + (p.rows_per_batch + 3) / 4, (a->rows + p.rows_per_batch - 1) / p.rows_per_batch), block(256);
+#define DGS_LNG_CASE(V)                                                                                                                  \
+    case V:                                                                                                                              \
+        if (g->epilogue == DGS_EPI_QKV) hipLaunchKernelGGL((layernorm_rows_gemv_kernel<V, DGS_EPI_QKV>), grid, block, 0, st, p, j);       \
+        else hipLaunchKernelGGL((layernorm_rows_gemv_kernel<V, DGS_EPI_GELU_BF16>), grid, block, 0, st, p, j);                            \
+        break;
+    switch (a->width / 256) {
+        DGS_LNG_CASE(2) DGS_LNG_CASE(4) DGS_LNG_CASE(8)
+        default: return DGS_ERR_INVALID_ARGUMENT;
+    }
+#undef DGS_LNG_CASE
     return launch_ok();
 }
 

@@ -126,29 +126,34 @@ int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last
     at.tail_ws = ws.attn_tail; at.tail_ws_bytes = ws.attn_tail_bytes;
     const float q_scale = at.scale * 1.44269504088896341f;         // queries leave the GEMM pre-scaled for the exp2-domain softmax
     const int main_rows = L;                                       // a sample's live rows (padding rows behind them are never computed)
+    static const bool rows_in_ln = !(getenv("DGS_LN_ROWS_GEMV") && atoi(getenv("DGS_LN_ROWS_GEMV")) == 0);   // 0: measurement aid (the GEMMs' own side jobs)
     for (int i = first; i < last; ++i) {
         const DgsDitLayerWeights& lw = m->layer[i];
         const float* mod = ws.mod + (size_t)i * 6 * W;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         DgsDitLayerNormArgs l1{};
         l1.rows = M; l1.width = W; l1.x = ws.x; l1.shift = mod; l1.scale = mod + W; l1.mod_stride = nmod; l1.rows_per_batch = lpad;
         l1.eps = 1e-6f; l1.out = ws.xn;
-        DGS_PROF(5, launch_layernorm(&l1, st));
         DgsDitGemmArgs q{};
         q.M = M; q.N = 3 * W; q.K = W; q.A = ws.xn; q.lda = W; q.W = lw.qkv_w; q.ldw = W; q.bias = lw.qkv_b; q.epilogue = DGS_EPI_QKV;
         q.out = ws.qk; q.ldo = 2 * W; q.vt = ws.vt; q.rows_per_batch = lpad; q.valid_rows = main_rows;
         q.q_scale = q_scale;
-        DGS_PROF(2, dgs_dit_gemm(&q, stream));
+        // the learned tokens' rows (L = 4096 v + 2: two rows behind a sample's last full tile) of QKV and fc1 are produced by the first
+        // workgroups of the LayerNorm launch in front of the GEMM, not by side jobs inside it (layernorm_rows_gemv_kernel: same bits)
+        const bool q_rows = rows_in_ln && layernorm_rows_gemv_ok(&l1, &q) && gemm_leaves_rows_out(&q);
+        DGS_PROF(5, q_rows ? launch_layernorm_rows_gemv(&l1, &q, st) : launch_layernorm(&l1, st));
+        DGS_PROF(2, q_rows ? launch_gemm_external_rows(&q, stream) : dgs_dit_gemm(&q, stream));
         DGS_PROF(1, dgs_dit_attention(&at, stream));
         DgsDitGemmArgs pr{};
         pr.M = M; pr.N = W; pr.K = W; pr.A = ws.ao; pr.lda = W; pr.W = lw.proj_w; pr.ldw = W; pr.bias = lw.proj_b;
         pr.epilogue = DGS_EPI_GATE_RESIDUAL; pr.out = ws.x; pr.ldo = W; pr.gate = mod + 2 * W; pr.gate_stride = nmod; pr.rows_per_batch = lpad; pr.valid_rows = main_rows;
         DGS_PROF(6, dgs_dit_gemm(&pr, stream));
         l1.shift = mod + 3 * W; l1.scale = mod + 4 * W;
-        DGS_PROF(5, launch_layernorm(&l1, st));
         DgsDitGemmArgs f1{};
         f1.M = M; f1.N = 4 * W; f1.K = W; f1.A = ws.xn; f1.lda = W; f1.W = lw.fc1_w; f1.ldw = W; f1.bias = lw.fc1_b;
         f1.epilogue = DGS_EPI_GELU_BF16; f1.out = ws.h; f1.ldo = 4 * W; f1.rows_per_batch = lpad; f1.valid_rows = main_rows;
-        DGS_PROF(4, dgs_dit_gemm(&f1, stream));
+        const bool f_rows = rows_in_ln && layernorm_rows_gemv_ok(&l1, &f1) && gemm_leaves_rows_out(&f1);
+        DGS_PROF(5, f_rows ? launch_layernorm_rows_gemv(&l1, &f1, st) : launch_layernorm(&l1, st));
+        DGS_PROF(4, f_rows ? launch_gemm_external_rows(&f1, stream) : dgs_dit_gemm(&f1, stream));
         DgsDitGemmArgs f2{};
         f2.M = M; f2.N = W; f2.K = 4 * W; f2.A = ws.h; f2.lda = 4 * W; f2.W = lw.fc2_w; f2.ldw = 4 * W; f2.bias = lw.fc2_b;
         f2.epilogue = DGS_EPI_GATE_RESIDUAL; f2.out = ws.x; f2.ldo = W; f2.gate = mod + 5 * W; f2.gate_stride = nmod; f2.rows_per_batch = lpad; f2.valid_rows = main_rows;
@@ -158,6 +163,21 @@ int run_blocks(const DgsDitModel* m, const DitWorkspace& ws, int first, int last
     return DGS_OK;
 }
 }  // namespace
+
+extern "C" int32_t dgs_dit_layernorm_gemm_shares_rows(const DgsDitLayerNormArgs* ln, const DgsDitGemmArgs* g) {
+    return ln && g && layernorm_rows_gemv_ok(ln, g) && gemm_leaves_rows_out(g) ? 1 : 0;
+}
+
+extern "C" int dgs_dit_layernorm_gemm(const DgsDitLayerNormArgs* ln, const DgsDitGemmArgs* g, dgs_stream_t stream) {
+    if (!ln || !g) return DGS_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (layernorm_rows_gemv_ok(ln, g) && gemm_leaves_rows_out(g)) {
+        DGS_TRY(launch_layernorm_rows_gemv(ln, g, st));
+        return launch_gemm_external_rows(g, stream);
+    }
+    DGS_TRY(launch_layernorm(ln, st));
+    return dgs_dit_gemm(g, stream);
+}
 
 extern "C" int dgs_debug_poison_lds(dgs_stream_t stream) {
     constexpr int kBytes = 160 * 1024;

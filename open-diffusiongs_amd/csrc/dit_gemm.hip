@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 }
 
 int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch, int valid_rows);   // dit_gemm_deep.hip
-int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad);
+int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad, bool rows_external);
+bool sliced_rows_are_gemv(int K, int N, int valid_rows);
 bool sliced128_eligible(int M, int N, int K, int epilogue, int k_per_batch, int rows_per_batch);
 int splitk_plan(int M, int N, int K, int k_per_batch, int* splits_per_batch);
 int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st);
@@ -355,7 +356,9 @@ static void launch_gemm(const GemmParams& p0, int bn, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 64>), dim3(p.ntail + p.ntiles), dim3(256), 0, st, p);
 }
 
-extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
+// mode 0: dgs_dit_gemm.  mode 1: the same launch without the two-row GEMV side jobs of the sliced 256-row kernel (the caller
+// produces those rows: layernorm_rows_gemv_kernel); an error if the shape does not run there.  mode 2: no launch, 1 if mode 1 applies.
+static int gemm_dispatch(const DgsDitGemmArgs* a, dgs_stream_t stream, int mode) {
     if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M % BM || a->N % 64 || a->K % BK) return DGS_ERR_INVALID_ARGUMENT;
     if (!a->A || !a->W || !a->out || (a->lda & 7) || (a->ldw & 7)) return DGS_ERR_INVALID_ARGUMENT;
     const int kpb = a->k_per_batch > 0 ? a->k_per_batch : a->K;
@@ -379,7 +382,7 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     static const int env_algo = getenv("DGS_GEMM_ALGO") ? atoi(getenv("DGS_GEMM_ALGO")) : 0;
     const int algo = a->algo ? a->algo : env_algo;
     // weight-gradient shapes with a scratch buffer: split-K on the sliced kernel (any algo but an explicit SIMPLE128)
-    if ((algo == DGS_GEMM_AUTO || algo == DGS_GEMM_SLICED) && a->splitk_ws && a->epilogue == DGS_EPI_F32 && !a->bias && a->ldo % 4 == 0 &&
+    if (mode == 0 && (algo == DGS_GEMM_AUTO || algo == DGS_GEMM_SLICED) && a->splitk_ws && a->epilogue == DGS_EPI_F32 && !a->bias && a->ldo % 4 == 0 &&
         p.rows_per_batch == a->M && p.valid_rows == a->M) {
         int spb = 0;
         if (splitk_plan(a->M, a->N, a->K, kpb, &spb)) return launch_splitk_gemm(a, kpb, st0);
@@ -393,15 +396,18 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
                                                                                   (a->epilogue == DGS_EPI_GELU_BF16 && a->N >= 4096))));
     if (algo == DGS_GEMM_SLICED || algo == DGS_GEMM_QUAD || auto_sliced) {
         const int sbn = sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
-        if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0, algo == DGS_GEMM_QUAD);
+        if (mode == 2) return sbn && sliced_rows_are_gemv(a->K, a->N, p.valid_rows) && p.valid_rows < p.rows_per_batch ? 1 : 0;
+        if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0, algo == DGS_GEMM_QUAD, mode == 1);
     }
+    if (mode == 2) return 0;
+    if (mode == 1) return DGS_ERR_INVALID_ARGUMENT;
     // few tiles and a long reduction (fc2 at one sample: N = 1024, K = 4096): 128 x 128 tiles on the sliced kernel's ring, one per
     // CU -- 56 vs 60 us; at K = 1024 (proj) its prologue and epilogue weigh more and the 128-wide kernel below wins, 21 vs 23 us
     static const int no_s128 = getenv("DGS_GEMM_NO_SLICED128") ? atoi(getenv("DGS_GEMM_NO_SLICED128")) : 0;   // measurement aid
     const bool few_tiles = (a->M / BM) * (a->N / 128) < 512 && a->N % 128 == 0;
     if ((algo == DGS_GEMM_SLICED128 || (algo == DGS_GEMM_AUTO && few_tiles && !no_s128 && a->K >= 2048)) &&
         sliced128_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
-        return launch_sliced_gemm(a, -128, p.rows_per_batch, p.valid_rows, st0, false);
+        return launch_sliced_gemm(a, -128, p.rows_per_batch, p.valid_rows, st0, false, false);
     // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each
     if (a->epilogue == DGS_EPI_QKV && a->N % 128) return DGS_ERR_INVALID_ARGUMENT;
     static const int env_bn = getenv("DGS_GEMM_BN") ? atoi(getenv("DGS_GEMM_BN")) : 0;      // measurement aid
@@ -420,6 +426,13 @@ extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) {
     }
     return hipGetLastError() == hipSuccess ? DGS_OK : DGS_ERR_DEVICE;
 }
+
+extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) { return gemm_dispatch(a, stream, 0); }
+
+namespace dgs {
+bool gemm_leaves_rows_out(const DgsDitGemmArgs* a) { return gemm_dispatch(a, nullptr, 2) == 1; }
+int launch_gemm_external_rows(const DgsDitGemmArgs* a, dgs_stream_t stream) { return gemm_dispatch(a, stream, 1); }
+}  // namespace dgs
 
 extern "C" size_t dgs_dit_gemm_splitk_bytes(int32_t M, int32_t N, int32_t K, int32_t k_per_batch) {
     int spb = 0;

@@ -24,6 +24,7 @@ struct DeepParams {
     int rows_ps, full_rows, tail_rows, nfull_items;             // sliced kernel: 256-row tile rows per sample (all / ring path / one live block), full items
     int ntail, tail_mode;                                       // sliced kernel: side jobs of the single-live-block tile rows (1: MFMA items, 2: two-row GEMV items)
     int tail_wgs;                                               // > 0: that many workgroups BEHIND the tiles do nothing but the side jobs (idle CUs)
+    int rows_external;                                          // the two-row GEMV side jobs are somebody else's work (layernorm_rows_gemv_kernel): none here
     int nsplit, splits_per_batch;                               // sliced kernel, split-K: items = nsplit x tiles, K = k_per_batch
     long long a_batch_stride, w_batch_stride, out_split_stride;
     const bf16_t* A;
@@ -458,6 +459,10 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
         const int live = (p.valid_rows - i * BM + 31) / 32;
         if (live > 1 || (live == 1 && !gemv_ok && !mfma_ok)) ++p.full_rows; else if (live == 1) ++p.tail_rows;
     }
+    if (p.rows_external) {
+        if (!gemv_ok || p.nsplit > 1) return DGS_ERR_INVALID_ARGUMENT;
+        p.tail_rows = 0;
+    }
     const int samples = p.M / p.rows_per_batch;
     p.nfull_items = samples * p.full_rows * p.tiles_n;
     p.tail_mode = gemv_ok ? 2 : 1;
@@ -547,8 +552,15 @@ bool sliced128_eligible(int M, int N, int K, int epilogue, int k_per_batch, int 
     return k_per_batch == K && K % 256 == 0 && M % 128 == 0 && rows_per_batch % 128 == 0 && N % 128 == 0 && epilogue != DGS_EPI_QKV;
 }
 
-int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad) {
+// two-row GEMV side jobs: the condition of launch_sliced, for callers that take those rows out of the launch
+bool sliced_rows_are_gemv(int K, int N, int valid_rows) {
+    const int last_live = valid_rows - (valid_rows - 1) / 256 * 256;
+    return last_live <= 2 && K >= 512 && K <= 4096 && (K & (K - 1)) == 0 && N % 64 == 0;
+}
+
+int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int valid_rows, hipStream_t st, bool quad, bool rows_external) {
     DeepParams p;
+    p.rows_external = rows_external ? 1 : 0;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.gate_stride = a->gate_stride;
     p.rows_per_batch = rows_per_batch; p.valid_rows = valid_rows; p.dbg = 0; p.nsplit = 1; p.splits_per_batch = 1;
     p.a_batch_stride = p.w_batch_stride = p.out_split_stride = 0;
@@ -612,7 +624,7 @@ int launch_splitk_gemm(const DgsDitGemmArgs* a, int k_per_batch, hipStream_t st)
     p.rows_per_batch = a->M; p.valid_rows = a->M; p.dbg = 0; p.nsplit = nsplit; p.splits_per_batch = spb;
     p.a_batch_stride = a->a_batch_stride; p.w_batch_stride = a->w_batch_stride; p.out_split_stride = (long long)a->M * a->N;
     p.A = a->A; p.W = a->W; p.bias = nullptr; p.out = a->splitk_ws; p.gate = nullptr; p.vt = nullptr; p.aux = nullptr; p.q_scale = 1.0f;
-    p.resid = nullptr;
+    p.resid = nullptr; p.rows_external = 0;
     const int rc = launch_sliced<DGS_EPI_F32, 256>(p, st);
     if (rc != DGS_OK) return rc;
     const size_t plane = (size_t)a->M * a->N;

@@ -33,7 +33,26 @@ struct GsParams {
     float *xyz, *features, *scaling, *rotation, *opacity, *aligned;
 };
 
+// Second role of a LayerNorm + modulate launch: the consumer GEMM's output rows [row0, row0 + nrows) of every sample (nrows <= 2: the
+// rows behind the sample's last full 256-row tile), see layernorm_rows_gemv_kernel.  `items` is set by the launcher.
+struct LnRowsGemv {
+    const bf16_t* W;           // the GEMM's weight [N, ldw], K = the LayerNorm's width
+    const float* bias;
+    void* out;
+    void* aux;
+    bf16_t* vt;
+    int N, ldw, ldo, epilogue, row0, nrows, items;
+    float q_scale;
+};
+
 int launch_layernorm(const DgsDitLayerNormArgs* a, hipStream_t st);
+// the same launch + the rows of `g` (an inference GEMM the caller launches next with launch_gemm_external_rows); false: shape not taken
+bool layernorm_rows_gemv_ok(const DgsDitLayerNormArgs* a, const DgsDitGemmArgs* g);
+int launch_layernorm_rows_gemv(const DgsDitLayerNormArgs* a, const DgsDitGemmArgs* g, hipStream_t st);
+// dgs_dit_gemm without the one or two live rows behind every sample's last full 256-row tile (somebody else writes those outputs);
+// gemm_leaves_rows_out: whether this shape runs on the kernel that can (the sliced 256-row kernel with two-row GEMV side jobs)
+bool gemm_leaves_rows_out(const DgsDitGemmArgs* a);
+int launch_gemm_external_rows(const DgsDitGemmArgs* a, dgs_stream_t stream);
 int launch_rowlinear(const DgsDitRowLinearArgs* a, hipStream_t st);
 int launch_timestep(const int64_t* t, float* emb, int B, hipStream_t st);
 // zero `bytes` bytes (a multiple of 16, 16-byte aligned) with a kernel of the library's own.  NOT hipMemsetAsync: inside a captured

@@ -276,10 +276,14 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
                "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds", "dgs_debug_clock_probe",
                "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes",
-               "dgs_dit_workspace_bytes_for_tokens", "dgs_dit_attention_backward_slots"]
+               "dgs_dit_workspace_bytes_for_tokens", "dgs_dit_attention_backward_slots", "dgs_dit_layernorm_gemm", "dgs_dit_layernorm_gemm_shares_rows"]
 
 
 def _declare_dit(L):
+    L.dgs_dit_layernorm_gemm_shares_rows.restype = ctypes.c_int32
+    L.dgs_dit_layernorm_gemm_shares_rows.argtypes = [ctypes.POINTER(DgsDitLayerNormArgs), ctypes.POINTER(DgsDitGemmArgs)]
+    L.dgs_dit_layernorm_gemm.restype = ctypes.c_int
+    L.dgs_dit_layernorm_gemm.argtypes = [ctypes.POINTER(DgsDitLayerNormArgs), ctypes.POINTER(DgsDitGemmArgs), ctypes.c_void_p]
     L.dgs_dit_attention_backward_slots.restype = ctypes.c_int32
     L.dgs_dit_attention_backward_slots.argtypes = [ctypes.c_int32]
     for name, argt in (("dgs_dit_gemm", DgsDitGemmArgs), ("dgs_dit_attention", DgsDitAttentionArgs),

@@ -138,6 +138,25 @@ class DitOps:
         self._check(self.lib.dgs_dit_layernorm(ctypes.byref(a), _stream(x.device)))
         return out
 
+    def layernorm_gemm(self, x, shift, scale, W, bias, epilogue, rows_per_batch, valid_rows, eps=1e-6, algo=0, q_scale=0.0, aux=None):
+        """dgs_dit_layernorm_gemm: modulate(LayerNorm(x)) and the QKV / fc1 GEMM that consumes it; returns (ln_out, gemm outputs)."""
+        rows, width = x.shape
+        N, dev = W.shape[0], x.device
+        h = torch.zeros((rows, width), dtype=torch.bfloat16, device=dev)
+        l = DgsDitLayerNormArgs()
+        l.rows, l.width, l.x, l.shift, l.scale, l.mod_stride = rows, width, _p(x), _p(shift), _p(scale), shift.stride(0)
+        l.rows_per_batch, l.eps, l.out = rows_per_batch, eps, _p(h)
+        qkv = epilogue == _native.EPI_QKV
+        out = torch.zeros((rows, 2 * N // 3 if qkv else N), dtype=torch.bfloat16, device=dev)
+        vt = torch.zeros((rows // rows_per_batch, N // 3, rows_per_batch), dtype=torch.bfloat16, device=dev) if qkv else None
+        a = DgsDitGemmArgs()
+        a.M, a.N, a.K, a.A, a.lda, a.W, a.ldw = rows, N, width, _p(h), width, _p(W), W.stride(0)
+        a.bias, a.epilogue, a.out, a.ldo, a.vt, a.aux = _p(bias), epilogue, _p(out), out.shape[1], _p(vt), _p(aux)
+        a.rows_per_batch, a.valid_rows, a.algo, a.q_scale = rows_per_batch, valid_rows, algo, q_scale
+        self.last_pair_shared_rows = bool(self.lib.dgs_dit_layernorm_gemm_shares_rows(ctypes.byref(l), ctypes.byref(a)))
+        self._check(self.lib.dgs_dit_layernorm_gemm(ctypes.byref(l), ctypes.byref(a), _stream(dev)))
+        return (h, out, vt) if qkv else (h, out)
+
     def rowlinear(self, x, W, bias=None, silu_input=False, silu_output=False):
         M, K = x.shape
         N = W.shape[0]

@@ -49,6 +49,17 @@ def _bf(t):
     return t.to(torch.bfloat16)
 
 
+@pytest.mark.parametrize("width,N,qkv,B", [(1024, 3072, True, 1), (1024, 4096, False, 1), (1024, 3072, True, 4), (1024, 4096, False, 2)])
+def test_layernorm_gemm_pair_at_the_model_shape(width, N, qkv, B):
+    """The DiT's LayerNorm -> QKV / fc1 pairs at L = 4,098 (lpad 4,352) as dgs_dit_forward launches them (AUTO kernel choice): the learned
+    tokens' rows produced inside the LayerNorm launch, every output bit-identical to the two plain launches."""
+    from dgs_amd.dit import DitOps
+    from test_dit_kernels_emu import _check_layernorm_gemm_pair
+    ops = DitOps()
+    ops.poison_lds()
+    _check_layernorm_gemm_pair(ops, DEV, width, N, qkv, valids=(4098, 4097), B=B, rpb=4352, algo=_native.GEMM_AUTO)
+
+
 @pytest.mark.parametrize("M,N,K", [(4224, 3072, 1024), (4224, 1024, 4096), (256, 896, 1024), (4224, 1024, 576)])
 def test_gemm_production_shapes(M, N, K):
     g = torch.Generator(device=DEV).manual_seed(M + N + K)

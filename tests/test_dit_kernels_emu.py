@@ -414,6 +414,51 @@ def test_gemm_sliced_learned_token_rows(ops, N, K):
         assert torch.allclose(x[b * 512:b * 512 + L], want[b * 512:b * 512 + L], atol=6e-3, rtol=1e-4)
 
 
+def _check_layernorm_gemm_pair(ops, dev, width, N, qkv, valids=(258, 257), B=2, rpb=512, algo=_native.GEMM_SLICED):
+    """dgs_dit_layernorm_gemm against dgs_dit_layernorm + dgs_dit_gemm: the learned tokens' output rows come from the first workgroups
+    of the LayerNorm launch (layernorm_rows_gemv_kernel) instead of the GEMM's side jobs -- every output bit for bit the same."""
+    g = torch.Generator().manual_seed(width + N)
+    epi = _native.EPI_QKV if qkv else _native.EPI_GELU_BF16
+    for valid in valids:
+        x = torch.randn(B * rpb, width, generator=g).to(dev)
+        mod = (torch.randn(B, 2 * width, generator=g) * 0.3).to(dev)
+        shift, scale = mod[:, :width], mod[:, width:]
+        W = _bf(torch.randn(N, width, generator=g) * 0.05).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        h_ref = ops.layernorm(x, shift=shift, scale=scale, rows_per_batch=rpb)
+        ref = ops.gemm(h_ref, W, bias, epi, rows_per_batch=rpb, valid_rows=valid, algo=algo, q_scale=0.7)
+        got = ops.layernorm_gemm(x, shift, scale, W, bias, epi, rpb, valid, algo=algo, q_scale=0.7)
+        assert ops.last_pair_shared_rows, (width, N, valid)
+        live = ((torch.arange(B * rpb) % rpb) < valid).to(dev)
+        assert torch.equal(got[0].view(torch.int16), h_ref.view(torch.int16))
+        out_ref = ref[0] if qkv else ref
+        assert torch.equal(got[1][live].view(torch.int16), out_ref[live].view(torch.int16)), (width, N, valid)
+        assert bool((got[1][~live] == 0).all())                      # padding rows: never written
+        if qkv:
+            assert torch.equal(got[2].view(torch.int16), ref[1].view(torch.int16))
+        assert float(got[1][live].float().abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("width,N,qkv", [(1024, 1536, True), (512, 1536, True), (1024, 512, False), (2048, 256, False)])
+def test_layernorm_gemm_pair_moves_the_learned_token_rows(ops, width, N, qkv):
+    _check_layernorm_gemm_pair(ops, "cpu", width, N, qkv)
+
+
+def test_layernorm_gemm_pair_falls_back_to_two_launches(ops):
+    """shapes the fused form does not take (a LayerNorm weight, full tiles only, a 128-wide GEMM): the pair is the two plain launches"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(512, 1024, generator=g)
+    mod = torch.randn(1, 2048, generator=g) * 0.3
+    W = _bf(torch.randn(256, 1024, generator=g) * 0.05)
+    bias = torch.randn(256, generator=g)
+    for valid, algo in ((512, _native.GEMM_SLICED), (258, _native.GEMM_SIMPLE128), (300, _native.GEMM_SLICED)):
+        h_ref = ops.layernorm(x, shift=mod[:, :1024], scale=mod[:, 1024:], rows_per_batch=512)
+        ref = ops.gemm(h_ref, W, bias, _native.EPI_GELU_BF16, rows_per_batch=512, valid_rows=valid, algo=algo)
+        h, out = ops.layernorm_gemm(x, mod[:, :1024], mod[:, 1024:], W, bias, _native.EPI_GELU_BF16, 512, valid, algo=algo)
+        assert not ops.last_pair_shared_rows
+        assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16)) and torch.equal(out[:valid].view(torch.int16), ref[:valid].view(torch.int16))
+
+
 def test_gemm_128_wide_gemv_tail_rows(ops):
     """The 128-wide kernel with one or two live rows behind a sample's last full tile (the DiT's learned tokens): those rows are
     GEMV items of the first workgroups, not a tile row.  Every epilogue the N = 1024 GEMMs use, two samples, K = 512 and a K
