@@ -323,6 +323,8 @@ int dgs_dit_backward(const DgsDitModel* m, const DgsDitModelT* mt, const DgsDitG
  * probabilities 0 by the V^T padding columns) need FINITE values there: allocate `out`, `aux` and `vt` zero-filled (or any finite
  * fill) once; the library never writes a non-finite value into padding.                                                       */
 int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream);
+int32_t dgs_dit_gemm_sliced_tile(const DgsDitGemmArgs* a);   /* diagnostic: tile width (256 / 192 / 128) if this call runs on the 256-row
+                                                                 ring kernel (dit_gemm_deep.hip), 0 otherwise; launches nothing */
 int dgs_dit_attention(const DgsDitAttentionArgs* a, dgs_stream_t stream);
 int dgs_dit_attention_backward(const DgsDitAttentionBackwardArgs* a, dgs_stream_t stream);
 int dgs_dit_layernorm(const DgsDitLayerNormArgs* a, dgs_stream_t stream);

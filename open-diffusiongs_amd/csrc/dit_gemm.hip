@@ -356,6 +356,7 @@ static void launch_gemm(const GemmParams& p0, int bn, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 64>), dim3(p.ntail + p.ntiles), dim3(256), 0, st, p);
 }
 
+// mode 3: no launch, the tile width of the sliced 256-row kernel this call runs on (256 / 192 / 128), 0 for the other kernels.
 // mode 0: dgs_dit_gemm.  mode 1: the same launch without the two-row GEMV side jobs of the sliced 256-row kernel (the caller
 // produces those rows: layernorm_rows_gemv_kernel); an error if the shape does not run there.  mode 2: no launch, 1 if mode 1 applies.
 static int gemm_dispatch(const DgsDitGemmArgs* a, dgs_stream_t stream, int mode) {
@@ -392,14 +393,15 @@ static int gemm_dispatch(const DgsDitGemmArgs* a, dgs_stream_t stream, int mode)
     //                          GEMMs (64 tiles of 256 x 256) stay on the 128-wide kernel (fc2 67, proj 23 us)
     //   4 samples (M = 17408): QKV 137 -> 119, fc2 219 -> 144, proj 68 -> 54, fc1 172 -> 178, f32 230 -> 171 us: everything eligible
     const int sbn_auto = algo == DGS_GEMM_AUTO ? sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows) : 0;
-    const bool auto_sliced = sbn_auto != 0 && (a->M > 8192 || (sbn_auto == 256 && (a->epilogue == DGS_EPI_QKV ||
+    const bool auto_sliced = sbn_auto != 0 && (a->M > 8192 || ((sbn_auto == 256 || sbn_auto == 192) && (a->epilogue == DGS_EPI_QKV ||
                                                                                   (a->epilogue == DGS_EPI_GELU_BF16 && a->N >= 4096))));
     if (algo == DGS_GEMM_SLICED || algo == DGS_GEMM_QUAD || auto_sliced) {
         const int sbn = sliced_gemm_tile(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch, p.valid_rows);
+        if (mode == 3) return sbn;
         if (mode == 2) return sbn && sliced_rows_are_gemv(a->K, a->N, p.valid_rows) && p.valid_rows < p.rows_per_batch ? 1 : 0;
         if (sbn) return launch_sliced_gemm(a, sbn, p.rows_per_batch, p.valid_rows, st0, algo == DGS_GEMM_QUAD, mode == 1);
     }
-    if (mode == 2) return 0;
+    if (mode == 2 || mode == 3) return 0;
     if (mode == 1) return DGS_ERR_INVALID_ARGUMENT;
     // few tiles and a long reduction (fc2 at one sample: N = 1024, K = 4096): 128 x 128 tiles on the sliced kernel's ring, one per
     // CU -- 56 vs 60 us; at K = 1024 (proj) its prologue and epilogue weigh more and the 128-wide kernel below wins, 21 vs 23 us
@@ -428,6 +430,7 @@ static int gemm_dispatch(const DgsDitGemmArgs* a, dgs_stream_t stream, int mode)
 }
 
 extern "C" int dgs_dit_gemm(const DgsDitGemmArgs* a, dgs_stream_t stream) { return gemm_dispatch(a, stream, 0); }
+extern "C" int32_t dgs_dit_gemm_sliced_tile(const DgsDitGemmArgs* a) { const int w = gemm_dispatch(a, nullptr, 3); return w > 0 ? w : 0; }
 
 namespace dgs {
 bool gemm_leaves_rows_out(const DgsDitGemmArgs* a) { return gemm_dispatch(a, nullptr, 2) == 1; }

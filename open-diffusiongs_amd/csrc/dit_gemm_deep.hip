@@ -144,9 +144,14 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     constexpr int WMB = BM / (16 * NW), WROWS = 32 * WMB;         // A blocks per wave: waves are (NW / 2) x 2
     constexpr int WN = BN / 2, NI = WN / 32;                      // wave tile WROWS x WN: WMB x NI accumulators
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
-    constexpr int G = (A_BYTES / 1024 + W_BYTES / 1024) / NW;     // LDS-DMA instructions per wave per slab
+    // LDS-DMA instructions per wave per slab: GA pieces of A, GW of W.  BN = 192 (QKV at one sample: 16 x 16 = 256 tiles, one per CU,
+    // where 256-wide tiles are 192): 12 W pieces for 8 waves -- the second piece of waves 4..7 is piece 8..11 AGAIN (the same bytes to
+    // the same LDS place as waves 0..3 put there), so that every wave issues, and counts, the same G operations per slab
+    constexpr int W_PIECES = W_BYTES / 1024, GW = (W_PIECES + NW - 1) / NW, DUP = NW * GW - W_PIECES;
+    constexpr int G = A_BYTES / 1024 / NW + GW;
     constexpr int NF = WMB + NI, MF = WMB * NI;                   // per k-substep: fragments (WMB of A, NI of W), MFMAs
     static_assert(NW == 8 || BN == 256 || (BM == 128 && BN == 128), "4 waves: 256 x 256 tiles (128 x 128 per wave) or 128 x 128 tiles (64 x 64)");
+    static_assert(DUP == 0 || (DUP < NW && GW >= 1 && G - A_BYTES / 1024 / NW == GW), "a doubled piece only in the last W round");
     static_assert(WMB * NI >= G, "one DMA piece behind each MFMA of the spread half");
     DGS_DYNAMIC_LDS(lds);
     const int dbg = kInstrumented ? p.dbg : 0;                        // the product library carries no instrumentation
@@ -291,16 +296,20 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const char* sb_a = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);        // + 2 BK bytes per slab staged
     const char* sb_w = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
     uint32_t vo_a[GA], vo_w[G - GA];
+    const int back = (DUP > 0 && wave + NW * (GW - 1) >= W_PIECES) ? DUP : 0;      // pieces this wave's last W piece steps back (a doubled piece)
     {
         const int r0 = lane / CPR, chunk = (lane % CPR) ^ (BK == 64 ? (r0 >> 1) & 7 : (r0 >> 2) & 3);     // piece rows are multiples of 16
 #pragma unroll
         for (int q = 0; q < GA; ++q) vo_a[q] = (uint32_t)((((wave + NW * q) * RPI + r0) * p.lda + chunk * 8) * 2);
 #pragma unroll
-        for (int q = 0; q < G - GA; ++q) vo_w[q] = (uint32_t)((((wave + NW * q) * RPI + r0) * p.ldw + chunk * 8) * 2);
+        for (int q = 0; q < G - GA; ++q) vo_w[q] = (uint32_t)((((wave + NW * q - (q == GW - 1 ? back : 0)) * RPI + r0) * p.ldw + chunk * 8) * 2);
     }
+    char* const lds_mine_last = lds_mine - back * 1024;
+    const uint32_t lds_wave_last = lds_wave - (uint32_t)back * 1024u;
     auto dma_piece = [&](auto slotc, auto qc) {                   // piece q (A pieces first) of the NEXT slab into ring slot `slot`
         constexpr int slot = decltype(slotc)::value, q = decltype(qc)::value;
         if constexpr (q < GA) lds_dma_scalar<slot * STAGE + NW * q * 1024>(sb_a, vo_a[q], lds_wave, lds_mine);
+        else if constexpr (DUP > 0 && q == G - 1) lds_dma_scalar<slot * STAGE + A_BYTES + NW * (q - GA) * 1024>(sb_w, vo_w[q - GA], lds_wave_last, lds_mine_last);
         else lds_dma_scalar<slot * STAGE + A_BYTES + NW * (q - GA) * 1024>(sb_w, vo_w[q - GA], lds_wave, lds_mine);
         if constexpr (q == G - 1) { sb_a += 2 * BK; sb_w += 2 * BK; }
     };
@@ -412,6 +421,19 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const long long dbg_w2 = dbg == 1 ? wall_stamp() : 0;
     if (epi_staged<EPI>(p)) {          // the ring is idle now (everybody passed the last barrier): a private LDS patch per wave
         char* patch = lds + wave * epi_strip_bytes(2);
+        if constexpr (NI % 2 == 1) {
+            // three column blocks (BN = 192): a two-block strip and a single one; store_strip decides "V feature" per strip, so the one
+            // strip that would straddle the K | V boundary of the QKV output leaves as two single blocks
+            const int nb = n0 + wn * WN, v0 = (p.N / 3) * 2;
+            const bool straddles = EPI == DGS_EPI_QKV && nb < v0 && nb + 64 > v0;
+#pragma unroll
+            for (int i = 0; i < WMB; ++i) {
+                const int mb = m0 + wm * WROWS + 32 * i;
+                if (straddles) { store_strip<EPI, 1>(p, &acc[i][0], mb, nb, lane, patch); store_strip<EPI, 1>(p, &acc[i][1], mb, nb + 32, lane, patch); }
+                else store_strip<EPI, 2>(p, &acc[i][0], mb, nb, lane, patch);
+                store_strip<EPI, 1>(p, &acc[i][NI - 1], mb, nb + 32 * (NI - 1), lane, patch);
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < WMB; ++i)
 #pragma unroll
@@ -467,7 +489,7 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
     p.nfull_items = samples * p.full_rows * p.tiles_n;
     p.tail_mode = gemv_ok ? 2 : 1;
     const int gemv_ks = NW < p.K / 512 ? NW : p.K / 512, gemv_cpi = 8 * (NW / (gemv_ks > 0 ? gemv_ks : 1));
-    p.ntail = samples * p.tail_rows * (gemv_ok ? p.N / gemv_cpi : p.tiles_n * (BN == 256 ? 8 : 2));
+    p.ntail = samples * p.tail_rows * (gemv_ok ? p.N / gemv_cpi : p.tiles_n * (BN / (BN == 256 ? 32 : 64)));
     p.ntiles = p.nfull_items ? p.nfull_items : p.ntail;
     p.tail_wgs = 0;
     if (p.nsplit <= 1 && p.ntail > 0 && p.nfull_items > 0) {
@@ -543,7 +565,13 @@ int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int row
     int full_rows = 0;
     for (int i = 0; i < rows_per_batch / 256; ++i)
         if ((valid_rows - i * 256 + 31) / 32 > 1) ++full_rows;
-    if (N % 256 == 0 && (M / rows_per_batch) * full_rows * (N / 256) >= 160) return 256;
+    // QKV when 256-wide tiles leave CUs without one and 192-wide ones do not (one sample: 12 x 16 = 192 tiles -> 16 x 16 = 256, a tile
+    // 25 % shorter on every CU; the learned tokens' rows are not side jobs of this launch any more, so it needs no idle CU for them)
+    static const int no192 = getenv("DGS_GEMM_NO_BN192") ? atoi(getenv("DGS_GEMM_NO_BN192")) : 0;      // measurement aid
+    const int ncu = compute_unit_count_cached();
+    const int rows_all = (M / rows_per_batch) * full_rows;
+    if (!no192 && epilogue == DGS_EPI_QKV && N % 192 == 0 && N % 256 == 0 && rows_all * (N / 256) < ncu && rows_all * (N / 192) <= ncu) return 192;
+    if (N % 256 == 0 && rows_all * (N / 256) >= 160) return 256;
     return N % 128 ? 0 : 128;
 }
 
@@ -569,6 +597,7 @@ int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int 
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
 #define DGS_SLICED_CASE(E) case E: return bn == 256 ? (quad ? launch_sliced<E, 256, 4>(p, st) : launch_sliced<E, 256>(p, st)) : \
                                    bn == 128 ? launch_sliced<E, 128>(p, st) : launch_sliced<E, 128, 4, 128>(p, st)
+    if (bn == 192) return a->epilogue == DGS_EPI_QKV && !quad ? launch_sliced<DGS_EPI_QKV, 192>(p, st) : DGS_ERR_INVALID_ARGUMENT;
     switch (a->epilogue) {
         DGS_SLICED_CASE(DGS_EPI_BF16);
         DGS_SLICED_CASE(DGS_EPI_GELU_BF16);

@@ -276,10 +276,12 @@ DIT_SYMBOLS = ["dgs_dit_gemm", "dgs_dit_attention", "dgs_dit_attention_backward"
                "dgs_dit_workspace_bytes", "dgs_dit_forward", "dgs_dit_gemm_splitk_bytes",
                "dgs_dit_attention_tail_bytes", "dgs_dit_run_blocks", "dgs_debug_poison_lds", "dgs_debug_clock_probe",
                "dgs_dit_layernorm_backward_scratch_bytes", "dgs_dit_rowlinear_backward_scratch_bytes", "dgs_dit_gate_mul_scratch_bytes",
-               "dgs_dit_workspace_bytes_for_tokens", "dgs_dit_attention_backward_slots", "dgs_dit_layernorm_gemm", "dgs_dit_layernorm_gemm_shares_rows"]
+               "dgs_dit_workspace_bytes_for_tokens", "dgs_dit_attention_backward_slots", "dgs_dit_layernorm_gemm", "dgs_dit_layernorm_gemm_shares_rows", "dgs_dit_gemm_sliced_tile"]
 
 
 def _declare_dit(L):
+    L.dgs_dit_gemm_sliced_tile.restype = ctypes.c_int32
+    L.dgs_dit_gemm_sliced_tile.argtypes = [ctypes.POINTER(DgsDitGemmArgs)]
     L.dgs_dit_layernorm_gemm_shares_rows.restype = ctypes.c_int32
     L.dgs_dit_layernorm_gemm_shares_rows.argtypes = [ctypes.POINTER(DgsDitLayerNormArgs), ctypes.POINTER(DgsDitGemmArgs)]
     L.dgs_dit_layernorm_gemm.restype = ctypes.c_int

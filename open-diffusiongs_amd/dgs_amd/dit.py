@@ -84,6 +84,7 @@ class DitOps:
             nbytes = self.lib.dgs_dit_gemm_splitk_bytes(M, N, K, k_per_batch)
             ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dev)
             a.splitk_ws = _p(ws) if nbytes else None
+        self.last_gemm_sliced_tile = int(self.lib.dgs_dit_gemm_sliced_tile(ctypes.byref(a)))
         self._check(self.lib.dgs_dit_gemm(ctypes.byref(a), _stream(dev)))
         return (out, vt) if epilogue == _native.EPI_QKV else out
 

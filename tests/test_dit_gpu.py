@@ -49,6 +49,30 @@ def _bf(t):
     return t.to(torch.bfloat16)
 
 
+def test_qkv_gemm_on_192_wide_tiles_at_the_model_shape():
+    """QKV at one sample (4,352 padded / 4,098 live rows, N = 3,072): 16 x 16 tiles of 256 x 192, one per CU (256-wide tiles are 192).
+    Against fp32 math and against the 128-wide kernel family (same slab order: equal up to the output rounding), q pre-scaled, V only
+    transposed, the learned tokens' two rows included."""
+    from dgs_amd.dit import DitOps
+    ops = DitOps()
+    g = torch.Generator(device=DEV).manual_seed(3072)
+    M, N, K, L, Wd = 4352, 3072, 1024, 4098, 1024
+    A = _bf(torch.randn(M, K, generator=g, device=DEV))
+    W = _bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+    bias = torch.randn(N, generator=g, device=DEV)
+    ref = A.float() @ W.float().t() + bias
+    ops.poison_lds()
+    qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=M, valid_rows=L, q_scale=0.18)
+    assert ops.last_gemm_sliced_tile == 192
+    qk2, vt2 = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=M, valid_rows=L, q_scale=0.18, algo=_native.GEMM_SIMPLE128)
+    assert ops.last_gemm_sliced_tile == 0
+    assert rel_l2(qk[:L, :Wd].float(), 0.18 * ref[:L, :Wd]) < 4e-3 and rel_l2(qk[:L, Wd:].float(), ref[:L, Wd:2 * Wd]) < 4e-3
+    assert rel_l2(vt[0, :, :L].float(), ref[:L, 2 * Wd:].t()) < 4e-3
+    assert bool((qk[L:] == 0).all()) and bool((vt[0, :, L:] == 0).all())          # padding: never written
+    assert float((qk[:L].float() - qk2[:L].float()).abs().max()) <= 2e-2 * float(qk2[:L].float().abs().max())
+    assert float((vt[0, :, :L].float() - vt2[0, :, :L].float()).abs().max()) <= 2e-2 * float(vt2.float().abs().max())
+
+
 @pytest.mark.parametrize("width,N,qkv,B", [(1024, 3072, True, 1), (1024, 4096, False, 1), (1024, 3072, True, 4), (1024, 4096, False, 2)])
 def test_layernorm_gemm_pair_at_the_model_shape(width, N, qkv, B):
     """The DiT's LayerNorm -> QKV / fc1 pairs at L = 4,098 (lpad 4,352) as dgs_dit_forward launches them (AUTO kernel choice): the learned

@@ -444,6 +444,34 @@ def test_layernorm_gemm_pair_moves_the_learned_token_rows(ops, width, N, qkv):
     _check_layernorm_gemm_pair(ops, "cpu", width, N, qkv)
 
 
+def test_gemm_sliced_192_wide_qkv_tiles(ops, monkeypatch):
+    """QKV on 256 x 192 tiles (chosen when 256-wide tiles leave CUs idle and 192-wide ones fit: N = 768 on the emulator's 6 CUs is 3 -> 4
+    tiles; the model's N = 3072 on 256 CUs is 192 -> 256): three column blocks per wave, the doubled W piece of waves 4..7, the strip
+    that straddles the K | V boundary (columns 480..543 around 512) stored as two single blocks -- against the 256 / 128-wide tiles
+    (DGS_GEMM_NO_BN192 is read once per process, so the comparison is the other kernel family) and fp32 math; then the pair with the
+    learned tokens' rows in the LayerNorm launch on top of it."""
+    g = torch.Generator().manual_seed(192)
+    N, K, Wd = 768, 1024, 256
+    for M, rpb, valid in ((512, 512, 258), (256, 256, 256), (1024, 512, 257)):
+        if (M // rpb) * 4 > 6:
+            monkeypatch.setenv("DGS_EMU_CUS", "8")
+        A = _bf(torch.randn(M, K, generator=g))
+        W = _bf(torch.randn(N, K, generator=g) * 0.1)
+        bias = torch.randn(N, generator=g)
+        ref = A.float() @ W.float().t() + bias
+        qk, vt = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=rpb, valid_rows=valid, algo=_native.GEMM_SLICED, q_scale=0.5)
+        assert ops.last_gemm_sliced_tile == 192
+        qk2, vt2 = ops.gemm(A, W, bias, _native.EPI_QKV, rows_per_batch=rpb, valid_rows=valid, algo=_native.GEMM_SIMPLE128, q_scale=0.5)
+        live = (torch.arange(M) % rpb) < valid
+        assert torch.allclose(qk.float()[live][:, :Wd], 0.5 * ref[live][:, :Wd], atol=3e-2, rtol=1e-2)
+        assert torch.allclose(qk.float()[live][:, Wd:], ref[live][:, Wd:2 * Wd], atol=3e-2, rtol=1e-2)
+        vref = ref[:, 2 * Wd:].reshape(M // rpb, rpb, Wd).transpose(1, 2)
+        assert torch.allclose(vt.float()[:, :, :valid], vref[:, :, :valid], atol=3e-2, rtol=1e-2)
+        # same k order per output (32-wide slabs, fp32 accumulate in the MFMA): the two kernel families agree to the bf16 rounding of the output
+        assert torch.allclose(qk.float()[live], qk2.float()[live], atol=2e-2, rtol=1e-2) and torch.allclose(vt.float()[:, :, :valid], vt2.float()[:, :, :valid], atol=2e-2, rtol=1e-2)
+    _check_layernorm_gemm_pair(ops, "cpu", 1024, 768, True, B=1)
+
+
 def test_layernorm_gemm_pair_falls_back_to_two_launches(ops):
     """shapes the fused form does not take (a LayerNorm weight, full tiles only, a 128-wide GEMM): the pair is the two plain launches"""
     g = torch.Generator().manual_seed(5)
