@@ -13,7 +13,7 @@ from dgs_amd.dit import DitOps
 
 DEV = "cuda:0"
 ops = DitOps()
-L, lpad, W = 4098, 4352, 1024
+L, lpad, W = int(os.environ.get("GEMM_VALID", "4098")), 4352, 1024   # GEMM_VALID=4096: full tiles only (no learned-token rows)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 g = torch.Generator(device=DEV).manual_seed(0)
 bf = lambda *s: torch.randn(*s, generator=g, device=DEV).to(torch.bfloat16)
