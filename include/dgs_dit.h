@@ -13,6 +13,8 @@
  *                              decoder head denoiser.py:148-164)
  *   dgs_dit_attention      <- F.scaled_dot_product_attention in timm==0.9.16 Attention.forward
  *   dgs_dit_layernorm      <- nn.LayerNorm + modulate()           utils_transformer.py:26-27,271-290; denoiser.py:21-22
+ *   dgs_dit_layernorm_gemm <- modulate(norm1(x)) -> attn.qkv and modulate(norm2(x)) -> mlp.fc1 as DiTBlock.forward pairs them
+ *                                                                 utils_transformer.py:271-290
  *   dgs_dit_rowlinear      <- adaLN_modulation / TimestepEmbedder / upsampler Linear on a handful of rows
  *                                                                 utils_transformer.py:266-269; denoiser.py:26-72,122-136
  *   dgs_dit_embed          <- ray/Plucker embedding + patchify    denoiser.py:312-334,210-215
