@@ -1,12 +1,16 @@
 #!/bin/bash
 # One gpurun call's worth of work; rewritten per call during development.
-# This form (round 6, call 36): wall time of the default `python bench.py` (the driver's N = 1 line) on a fresh box, and of smoke().
+# This form (round 6, call 37, EXPERIMENT): fc1 at one sample as 512 tiles of 256 x 128 (two rounds: the second round's loop over the
+# first round's stores) against 256 tiles of 256 x 256 (one round); full tiles only.
 set -u
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/call
 mkdir -p $out
 cd $R
-SECONDS=0; python __graft_entry__.py --smoke > $out/smoke.txt 2>&1; echo "smoke wall s: $SECONDS" > $out/bench_wall.txt
-SECONDS=0; python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "default bench.py wall s: $SECONDS" >> $out/bench_wall.txt
-SECONDS=0; python bench.py > $out/bench_default2.json 2>> $out/bench_default.err; echo "default bench.py wall s (second run): $SECONDS" >> $out/bench_wall.txt
-cat $out/bench_wall.txt; tail -2 $out/smoke.txt; cut -c1-200 $out/bench_default.json; cut -c1-200 $out/bench_default2.json
+export PYTHONPATH=$R/open-diffusiongs_amd:$R
+rm -f $out/fc1_two_rounds.txt
+for rep in 1 2 3; do for f in 0 1; do
+  echo "== force_bn128=$f rep $rep" >> $out/fc1_two_rounds.txt
+  DGS_GEMM_FORCE_BN128=$f GEMM_VALID=4096 GEMM_CASES=fc1,fc2,proj timeout 120 python tools/gemm_check.py 4 2>&1 | grep -v amdgpu.ids >> $out/fc1_two_rounds.txt
+done; done
+cat $out/fc1_two_rounds.txt
