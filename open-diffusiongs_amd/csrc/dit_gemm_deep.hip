@@ -570,7 +570,9 @@ int sliced_gemm_tile(int M, int N, int K, int epilogue, int k_per_batch, int row
     static const int no192 = getenv("DGS_GEMM_NO_BN192") ? atoi(getenv("DGS_GEMM_NO_BN192")) : 0;      // measurement aid
     const int ncu = compute_unit_count_cached();
     const int rows_all = (M / rows_per_batch) * full_rows;
-    if (!no192 && epilogue == DGS_EPI_QKV && N % 192 == 0 && N % 256 == 0 && rows_all * (N / 256) < ncu && rows_all * (N / 192) <= ncu) return 192;
+    // (small token counts keep their kernel: a handful of 192-wide tiles on 256 CUs is not what this is for)
+    const bool fills = rows_all * (N / 192) >= 160 || ncu < 160;                      // (the emulator's chip has 6 CUs)
+    if (!no192 && epilogue == DGS_EPI_QKV && N % 192 == 0 && N % 256 == 0 && rows_all * (N / 256) < ncu && rows_all * (N / 192) <= ncu && fills) return 192;
     if (N % 256 == 0 && rows_all * (N / 256) >= 160) return 256;
     return N % 128 ? 0 : 128;
 }
