@@ -24,6 +24,7 @@ struct DeepParams {
     int rows_ps, full_rows, tail_rows, nfull_items;             // sliced kernel: 256-row tile rows per sample (all / ring path / one live block), full items
     int ntail, tail_mode;                                       // sliced kernel: side jobs of the single-live-block tile rows (1: MFMA items, 2: two-row GEMV items)
     int tail_wgs;                                               // > 0: that many workgroups BEHIND the tiles do nothing but the side jobs (idle CUs)
+    int map2d;                                                  // tile <- workgroup id: 4 x 2 blocks of the tile grid per XCD (launch_sliced decides)
     int rows_external;                                          // the two-row GEMV side jobs are somebody else's work (layernorm_rows_gemv_kernel): none here
     int nsplit, splits_per_batch;                               // sliced kernel, split-K: items = nsplit x tiles, K = k_per_batch
     long long a_batch_stride, w_batch_stride, out_split_stride;
@@ -266,6 +267,14 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
         p.W += (size_t)b * p.w_batch_stride + u0 * 128;
         p.out = static_cast<float*>(p.out) + (size_t)sp * p.out_split_stride;
         p.K = (u1 - u0) * 128;
+    } else if (p.map2d) {
+        // An XCD's tiles as a 4 x 2 arrangement of blocks of the tile grid instead of a run of whole tile rows: with one tile per CU
+        // (16 x 16 tiles: fc1, QKV on 192-wide tiles) an XCD then reads 4 tile rows of A and HALF of W -- 6.2 MB instead of 9.4 MB
+        // (fc1) through its own L2 -- and the launch fetches a third less from HBM.  (The ring hides the misses either way: the launch
+        // is no faster, profiles/r05_gemm_xcd_map_ab.txt; it is the same time on less traffic.)
+        const int xcd = bid & 7, slot = bid >> 3, rows_all = p.nfull_items / p.tiles_n;
+        const int rper = rows_all >> 2, cper = p.tiles_n >> 1;
+        tile = ((xcd >> 1) * rper + slot / cper) * p.tiles_n + (xcd & 1) * cper + slot % cper;
     } else {
         tile = xcd_remap(bid, p.nfull_items);
     }
@@ -502,6 +511,10 @@ static int launch_sliced(DeepParams p, hipStream_t st) {
         if (p.tail_rows || samples != 1) return DGS_ERR_INVALID_ARGUMENT;
         p.ntiles = p.nfull_items * p.nsplit;
     }
+    static const int no_map2d = getenv("DGS_GEMM_NO_MAP2D") ? atoi(getenv("DGS_GEMM_NO_MAP2D")) : 0;    // measurement aid
+    const int rows_all = samples * p.full_rows;
+    p.map2d = !no_map2d && BM == 256 && p.nsplit <= 1 && p.tail_wgs == 0 && rows_all % 4 == 0 && p.tiles_n % 2 == 0 && p.nfull_items % 8 == 0 &&
+              p.nfull_items <= compute_unit_count_cached() ? 1 : 0;
     auto kern = gemm_sliced_kernel<EPI, BN, NW, 0, BM>;
     if constexpr (kInstrumented && EPI == DGS_EPI_F32 && BN == 256 && BM == 256) {   // DGS_GEMM_EXP=1|2: the measurement variants (instrumented library only)
         static const int exp = getenv("DGS_GEMM_EXP") ? atoi(getenv("DGS_GEMM_EXP")) : 0;

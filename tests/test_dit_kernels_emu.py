@@ -444,6 +444,21 @@ def test_layernorm_gemm_pair_moves_the_learned_token_rows(ops, width, N, qkv):
     _check_layernorm_gemm_pair(ops, "cpu", width, N, qkv)
 
 
+def test_gemm_sliced_2d_xcd_map(ops, monkeypatch):
+    """One tile per CU and a tile grid that splits 4 x 2 over the XCDs: the workgroup id -> tile map is blocks of the grid, not runs of
+    rows (same tiles, every one exactly once: the output is prefilled, a tile done twice or never shows).  16 'CUs' on the emulator."""
+    monkeypatch.setenv("DGS_EMU_CUS", "16")
+    g = torch.Generator().manual_seed(42)
+    for M, N, K in ((1024, 512, 256), (2048, 256, 128), (1024, 256, 128)):
+        A = _bf(torch.randn(M, K, generator=g))
+        W = _bf(torch.randn(N, K, generator=g) * 0.1)
+        bias = torch.randn(N, generator=g)
+        out = torch.full((M, N), 7.0)
+        ops.gemm(A, W, bias, _native.EPI_F32, out=out, rows_per_batch=M, algo=_native.GEMM_SLICED)
+        assert ops.last_gemm_sliced_tile in (128, 256)               # (few tiles: the 128-wide form of the ring kernel; 16 or 8 tiles here)
+        assert torch.allclose(out, A.float() @ W.float().t() + bias, atol=4e-3, rtol=1e-4), (M, N, K)
+
+
 def test_gemm_sliced_192_wide_qkv_tiles(ops, monkeypatch):
     """QKV on 256 x 192 tiles (chosen when 256-wide tiles leave CUs idle and 192-wide ones fit: N = 768 on the emulator's 6 CUs is 3 -> 4
     tiles; the model's N = 3072 on 256 CUs is 192 -> 256): three column blocks per wave, the doubled W piece of waves 4..7, the strip
