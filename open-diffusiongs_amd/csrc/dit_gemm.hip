@@ -403,11 +403,14 @@ static int gemm_dispatch(const DgsDitGemmArgs* a, dgs_stream_t stream, int mode)
     }
     if (mode == 2 || mode == 3) return 0;
     if (mode == 1) return DGS_ERR_INVALID_ARGUMENT;
-    // few tiles and a long reduction (fc2 at one sample: N = 1024, K = 4096): 128 x 128 tiles on the sliced kernel's ring, one per
-    // CU -- 56 vs 60 us; at K = 1024 (proj) its prologue and epilogue weigh more and the 128-wide kernel below wins, 21 vs 23 us
+    // few tiles (the N = 1024 GEMMs at one sample: fc2, K = 4096, and proj, K = 1024): 128 x 128 tiles on the sliced kernel's ring, one
+    // per CU, eight waves as two K groups (dit_gemm_deep.hip KW).  With FOUR waves (one per SIMD: rounds 3-5) fc2 ran 44.8 us and proj
+    // lost to the 128-wide kernel below, 21 vs 23 us; with the K groups fc2 is 39.9 us and proj 16.4-18.0 against 19.1-20.8 us
+    // (profiles/r06_gemm_kgroups_ab.txt).  DGS_GEMM_S128_MINK: measurement aid (2048: proj back on the 128-wide kernel)
     static const int no_s128 = getenv("DGS_GEMM_NO_SLICED128") ? atoi(getenv("DGS_GEMM_NO_SLICED128")) : 0;   // measurement aid
+    static const int s128_mink = getenv("DGS_GEMM_S128_MINK") ? atoi(getenv("DGS_GEMM_S128_MINK")) : 1024;
     const bool few_tiles = (a->M / BM) * (a->N / 128) < 512 && a->N % 128 == 0;
-    if ((algo == DGS_GEMM_SLICED128 || (algo == DGS_GEMM_AUTO && few_tiles && !no_s128 && a->K >= 2048)) &&
+    if ((algo == DGS_GEMM_SLICED128 || (algo == DGS_GEMM_AUTO && few_tiles && !no_s128 && a->K >= s128_mink)) &&
         sliced128_eligible(a->M, a->N, a->K, a->epilogue, kpb, p.rows_per_batch))
         return launch_sliced_gemm(a, -128, p.rows_per_batch, p.valid_rows, st0, false, false);
     // 128 x 64 tiles when 128 x 128 would leave the 256 CUs with fewer than two workgroups each

@@ -141,18 +141,24 @@ __device__ unsigned dgs_gemm_tl[1024][4]; // DGS_GEMM_DBG: per workgroup {start,
 // three slabs in flight and one barrier per slab).
 template <int EPI, int BN, int NW, int EXP = 0, int BM = 256>
 __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepParams p) {
-    constexpr int BK = 32, NS = BM == 128 ? 8 : 4;                // ring depth (LDS: 128 KiB for every tile shape)
-    constexpr int WMB = BM / (16 * NW), WROWS = 32 * WMB;         // A blocks per wave: waves are (NW / 2) x 2
+    // KW = 2 (BM = BN = 128 with EIGHT waves): two K groups of 2 x 2 waves.  A ring stage holds TWO 32-wide slabs and group kg works on
+    // slab kg of every stage: the 128 x 128 tile keeps its 64 x 64 wave tiles (the 4-wave form's) but every SIMD has two waves instead
+    // of one to cover each other's LDS and issue latency (the 4-wave loop ran at 47 % of its MFMA floor); the groups' partial sums meet
+    // once, in LDS behind the loop, and each group finishes one of the wave tile's two row blocks.
+    constexpr int KW = (BM == 128 && NW == 8) ? 2 : 1, MW = NW / KW;
+    constexpr int BK = 32, NS = (BM == 128 && KW == 1) ? 8 : 4;   // ring depth (LDS: 128 KiB for every tile shape)
+    constexpr int WMB = BM / (16 * MW), WROWS = 32 * WMB;         // A blocks per wave: a K group's waves are (MW / 2) x 2
     constexpr int WN = BN / 2, NI = WN / 32;                      // wave tile WROWS x WN: WMB x NI accumulators
-    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, SUB = A_BYTES + W_BYTES, STAGE = KW * SUB;
     // LDS-DMA instructions per wave per slab: GA pieces of A, GW of W.  BN = 192 (QKV at one sample: 16 x 16 = 256 tiles, one per CU,
     // where 256-wide tiles are 192): 12 W pieces for 8 waves -- the second piece of waves 4..7 is piece 8..11 AGAIN (the same bytes to
     // the same LDS place as waves 0..3 put there), so that every wave issues, and counts, the same G operations per slab
-    constexpr int W_PIECES = W_BYTES / 1024, GW = (W_PIECES + NW - 1) / NW, DUP = NW * GW - W_PIECES;
-    constexpr int G = A_BYTES / 1024 / NW + GW;
+    constexpr int W_PIECES = KW * W_BYTES / 1024, GW = (W_PIECES + NW - 1) / NW, DUP = NW * GW - W_PIECES;
+    constexpr int G = KW * A_BYTES / 1024 / NW + GW;
+    static_assert(KW == 1 || (A_BYTES / 1024 == NW && W_BYTES / 1024 == NW && WMB == 2 && NI == 2), "K groups: piece q of an operand is slab q's, one per wave");
     constexpr int NF = WMB + NI, MF = WMB * NI;                   // per k-substep: fragments (WMB of A, NI of W), MFMAs
     static_assert(NW == 8 || BN == 256 || (BM == 128 && BN == 128), "4 waves: 256 x 256 tiles (128 x 128 per wave) or 128 x 128 tiles (64 x 64)");
-    static_assert(DUP == 0 || (DUP < NW && GW >= 1 && G - A_BYTES / 1024 / NW == GW), "a doubled piece only in the last W round");
+    static_assert(DUP == 0 || (DUP < NW && GW >= 1 && KW == 1), "a doubled piece only in the last W round");
     static_assert(WMB * NI >= G, "one DMA piece behind each MFMA of the spread half");
     DGS_DYNAMIC_LDS(lds);
     const int dbg = kInstrumented ? p.dbg : 0;                        // the product library carries no instrumentation
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const long long dbg_w0 = dbg == 1 ? wall_stamp() : 0;             // constant 100 MHz: gives the shader clock the cycle stamps ran at
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wq = KW > 1 ? wave % MW : wave, kg = KW > 1 ? wave / MW : 0;      // place in the tile, K group
+    const int wm = wq >> 1, wn = wq & 1;
     const int frow = lane & 31, fhalf = lane >> 5;
     // Work items: every full tile, XCD-aware order.  (The tile rows with a single live 32-row block -- the two learned-token
     // rows of the DiT -- are side jobs of the first workgroups: `side_jobs`, called from the prologue.)
@@ -293,10 +300,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NF; ++f)
-            foff[ks][f] = f < WMB ? slab_off<BK>(wm * WROWS + 32 * f + frow, 2 * ks + fhalf) : A_BYTES + slab_off<BK>(wn * WN + 32 * (f - WMB) + frow, 2 * ks + fhalf);
+            foff[ks][f] = kg * SUB + (f < WMB ? slab_off<BK>(wm * WROWS + 32 * f + frow, 2 * ks + fhalf) : A_BYTES + slab_off<BK>(wn * WN + 32 * (f - WMB) + frow, 2 * ks + fhalf));
     auto frag = [&](int slot, int ks, int f) { return *reinterpret_cast<const bf16x8*>(lds + slot * STAGE + foff[ks][f]); };
-    const int nk = p.K / BK;                                      // a multiple of NS
-    constexpr int GA = A_BYTES / 1024 / NW;                       // DMA pieces per wave per slab: GA of A, G - GA of W
+    const int nk = p.K / (BK * KW);                               // ring stages to walk: a multiple of NS
+    constexpr int GA = KW * A_BYTES / 1024 / NW;                  // DMA pieces per wave per stage: GA of A, G - GA of W
     // The DMA of a piece, all-scalar addressing (lds_dma_scalar): global address = SGPR pair (the operand's tile row 0 at the slab's
     // k) + one 32-bit VGPR offset per piece (the lane's row and 16-byte chunk: loop-invariant), LDS address = M0 = SGPR + literal.
     constexpr int RPI = 1024 / (2 * BK), CPR = BK / 8;
@@ -308,19 +315,28 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     const int back = (DUP > 0 && wave + NW * (GW - 1) >= W_PIECES) ? DUP : 0;      // pieces this wave's last W piece steps back (a doubled piece)
     {
         const int r0 = lane / CPR, chunk = (lane % CPR) ^ (BK == 64 ? (r0 >> 1) & 7 : (r0 >> 2) & 3);     // piece rows are multiples of 16
+        if constexpr (KW > 1) {                                   // piece q of an operand: rows of piece `wave`, slab q of the stage (+ BK elements)
 #pragma unroll
-        for (int q = 0; q < GA; ++q) vo_a[q] = (uint32_t)((((wave + NW * q) * RPI + r0) * p.lda + chunk * 8) * 2);
+            for (int q = 0; q < GA; ++q) vo_a[q] = (uint32_t)(((wave * RPI + r0) * p.lda + chunk * 8 + q * BK) * 2);
 #pragma unroll
-        for (int q = 0; q < G - GA; ++q) vo_w[q] = (uint32_t)((((wave + NW * q - (q == GW - 1 ? back : 0)) * RPI + r0) * p.ldw + chunk * 8) * 2);
+            for (int q = 0; q < G - GA; ++q) vo_w[q] = (uint32_t)(((wave * RPI + r0) * p.ldw + chunk * 8 + q * BK) * 2);
+        } else {
+#pragma unroll
+            for (int q = 0; q < GA; ++q) vo_a[q] = (uint32_t)((((wave + NW * q) * RPI + r0) * p.lda + chunk * 8) * 2);
+#pragma unroll
+            for (int q = 0; q < G - GA; ++q) vo_w[q] = (uint32_t)((((wave + NW * q - (q == GW - 1 ? back : 0)) * RPI + r0) * p.ldw + chunk * 8) * 2);
+        }
     }
     char* const lds_mine_last = lds_mine - back * 1024;
     const uint32_t lds_wave_last = lds_wave - (uint32_t)back * 1024u;
     auto dma_piece = [&](auto slotc, auto qc) {                   // piece q (A pieces first) of the NEXT slab into ring slot `slot`
         constexpr int slot = decltype(slotc)::value, q = decltype(qc)::value;
-        if constexpr (q < GA) lds_dma_scalar<slot * STAGE + NW * q * 1024>(sb_a, vo_a[q], lds_wave, lds_mine);
+        if constexpr (KW > 1 && q < GA) lds_dma_scalar<slot * STAGE + q * SUB>(sb_a, vo_a[q], lds_wave, lds_mine);
+        else if constexpr (KW > 1) lds_dma_scalar<slot * STAGE + (q - GA) * SUB + A_BYTES>(sb_w, vo_w[q - GA], lds_wave, lds_mine);
+        else if constexpr (q < GA) lds_dma_scalar<slot * STAGE + NW * q * 1024>(sb_a, vo_a[q], lds_wave, lds_mine);
         else if constexpr (DUP > 0 && q == G - 1) lds_dma_scalar<slot * STAGE + A_BYTES + NW * (q - GA) * 1024>(sb_w, vo_w[q - GA], lds_wave_last, lds_mine_last);
         else lds_dma_scalar<slot * STAGE + A_BYTES + NW * (q - GA) * 1024>(sb_w, vo_w[q - GA], lds_wave, lds_mine);
-        if constexpr (q == G - 1) { sb_a += 2 * BK; sb_w += 2 * BK; }
+        if constexpr (q == G - 1) { sb_a += 2 * BK * KW; sb_w += 2 * BK * KW; }
     };
     auto stage_next = [&](auto slotc) { sliced_for<0, G>([&](auto qc) { dma_piece(slotc, qc); }); };
     // ---- prologue: slabs 0 .. NS-2 in flight, then the fragments of slab 0, substep 0.  A workgroup with a side job issues only
@@ -360,9 +376,10 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     // (out may alias resid), so the tile paid two exposed round trips (~16 k of a 90 k-cycle tile).  Here the whole tile's
     // residual (64 registers) is requested behind the LAST DMA, eight slabs before the loop ends, and the counted waits of the
     // remaining iterations let those loads stay in flight.
-    constexpr bool PREFETCH_RESID = EPI == DGS_EPI_GATE_RESIDUAL && BM == 128 && NW == 4;
-    constexpr int PRE_LOADS = PREFETCH_RESID ? WMB * (NI / 2) * 8 : 0;       // float4 loads per lane
-    float4 pre[PREFETCH_RESID ? WMB * (NI / 2) : 1][8];
+    constexpr bool PREFETCH_RESID = EPI == DGS_EPI_GATE_RESIDUAL && BM == 128;
+    constexpr int PRE_BLOCKS = KW > 1 ? 1 : WMB;                            // row blocks of the wave tile this wave finishes (K groups: block kg)
+    constexpr int PRE_LOADS = PREFETCH_RESID ? PRE_BLOCKS * (NI / 2) * 8 : 0;       // float4 loads per lane
+    float4 pre[PREFETCH_RESID ? PRE_BLOCKS * (NI / 2) : 1][8];
     // `dbg_tag`: the cycle stamps of DGS_GEMM_DBG=1 exist only in the copy of the loop that a debug run takes -- as run-time tests of
     // p.dbg they were three compare + branch pairs per slab in every run (tools/ubench/issue_bench: ~16 cycles each beside MFMAs)
     auto iteration = [&](int t, auto slot_tag, auto refill_tag, auto pre_tag, auto left_tag, auto dbg_tag) {    // slot == t % NS, a literal at the call sites
@@ -385,10 +402,15 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
             sched_fence();
         });
         if constexpr (PRE_N > 0 && refill) {                       // the tail's first iteration: its DMAs were the last ones
+            if constexpr (KW > 1) {
 #pragma unroll
-            for (int i = 0; i < WMB; ++i)
+                for (int j = 0; j < NI; j += 2) residual_prefetch<2>(p, m0 + wm * WROWS + 32 * kg, n0 + wn * WN + 32 * j, lane, pre[j / 2]);
+            } else {
 #pragma unroll
-                for (int j = 0; j < NI; j += 2) residual_prefetch<2>(p, m0 + wm * WROWS + 32 * i, n0 + wn * WN + 32 * j, lane, pre[i * (NI / 2) + j / 2]);
+                for (int i = 0; i < WMB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; j += 2) residual_prefetch<2>(p, m0 + wm * WROWS + 32 * i, n0 + wn * WN + 32 * j, lane, pre[i * (NI / 2) + j / 2]);
+            }
         }
         // slab t+1 (and older) has landed once at most this iteration's own DMAs are outstanding; then everybody is also
         // done reading slab t
@@ -428,6 +450,37 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
     }
     const long long dbg_t1 = dbg == 1 ? cycle_stamp() : 0;
     const long long dbg_w2 = dbg == 1 ? wall_stamp() : 0;
+    if constexpr (KW > 1) {
+        // The two K groups hold partial sums of the same 64 x 64 wave tiles.  Wave (kg, wq) keeps row block kg and hands the other one
+        // to its partner (same wq, other group) through the idle ring: [wq][owner][block j][register][lane], lane-contiguous floats.
+        float* const xch = reinterpret_cast<float*>(lds);
+        auto region = [&](int owner) { return xch + ((wq * 2 + owner) * NI * 16) * 64 + lane; };
+        auto give = [&](const f32x16 (&blk)[NI], float* dst) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(j * 16 + r) * 64] = blk[j][r];
+        };
+        auto take = [&](f32x16 (&blk)[NI], const float* src) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) blk[j][r] += src[(j * 16 + r) * 64];
+        };
+        if (kg == 0) give(acc[1], region(1)); else give(acc[0], region(0));
+        __syncthreads();
+        if (kg == 0) take(acc[0], region(0)); else take(acc[1], region(1));
+        __syncthreads();                                           // the patches below overwrite the exchange regions
+        char* patch = lds + wave * epi_strip_bytes(2);
+        const int mb = m0 + wm * WROWS + 32 * kg, nb = n0 + wn * WN;
+        if (kg == 0) {
+            if constexpr (PREFETCH_RESID) store_strip<EPI, 2>(p, &acc[0][0], mb, nb, lane, patch, pre[0]);
+            else store_strip<EPI, 2>(p, &acc[0][0], mb, nb, lane, patch);
+        } else {
+            if constexpr (PREFETCH_RESID) store_strip<EPI, 2>(p, &acc[1][0], mb, nb, lane, patch, pre[0]);
+            else store_strip<EPI, 2>(p, &acc[1][0], mb, nb, lane, patch);
+        }
+    } else
     if (epi_staged<EPI>(p)) {          // the ring is idle now (everybody passed the last barrier): a private LDS patch per wave
         char* patch = lds + wave * epi_strip_bytes(2);
         if constexpr (NI % 2 == 1) {
@@ -476,7 +529,7 @@ __global__ __launch_bounds__(NW == 8 ? 512 : 256) void gemm_sliced_kernel(DeepPa
 
 template <int EPI, int BN, int NW = 8, int BM = 256>
 static int launch_sliced(DeepParams p, hipStream_t st) {
-    constexpr int LDS = (BM == 128 ? 8 : 4) * (BM * 32 * 2 + BN * 32 * 2);   // 128 KiB (256 x 256) / 96 KiB (256 x 128) / 128 KiB (128 x 128, 8 stages)
+    constexpr int LDS = (BM == 128 ? 8 : 4) * (BM * 32 * 2 + BN * 32 * 2);   // 128 KiB (256 x 256) / 96 KiB (256 x 128) / 128 KiB (128 x 128: 8 slabs, as 8 or 4 x 2)
     p.tiles_n = p.N / BN;
     p.rows_ps = p.rows_per_batch / BM;
     p.full_rows = 0; p.tail_rows = 0;
@@ -610,8 +663,9 @@ int launch_sliced_gemm(const DgsDitGemmArgs* a, int bn, int rows_per_batch, int 
     p.A = a->A; p.W = a->W; p.bias = a->bias; p.out = a->out; p.gate = a->gate; p.vt = a->vt; p.aux = a->aux;
     p.q_scale = a->q_scale != 0.0f ? a->q_scale : 1.0f;
     p.resid = a->resid ? a->resid : static_cast<const float*>(a->out);
+    static const int s128_nw4 = getenv("DGS_GEMM_S128_NW4") ? atoi(getenv("DGS_GEMM_S128_NW4")) : 0;   // measurement aid: the 4-wave form of the 128 x 128 tile
 #define DGS_SLICED_CASE(E) case E: return bn == 256 ? (quad ? launch_sliced<E, 256, 4>(p, st) : launch_sliced<E, 256>(p, st)) : \
-                                   bn == 128 ? launch_sliced<E, 128>(p, st) : launch_sliced<E, 128, 4, 128>(p, st)
+                                   bn == 128 ? launch_sliced<E, 128>(p, st) : s128_nw4 ? launch_sliced<E, 128, 4, 128>(p, st) : launch_sliced<E, 128, 8, 128>(p, st)
     if (bn == 192) return a->epilogue == DGS_EPI_QKV && !quad ? launch_sliced<DGS_EPI_QKV, 192>(p, st) : DGS_ERR_INVALID_ARGUMENT;
     switch (a->epilogue) {
         DGS_SLICED_CASE(DGS_EPI_BF16);
