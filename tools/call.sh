@@ -1,23 +1,22 @@
 #!/bin/bash
 # One gpurun call's worth of work; rewritten per call during development.
-# This form (round 6, call 42): proj (N = K = 1024) on the ring kernel's 128 x 128 tiles with two K groups (AUTO since this change)
-# against the 128-wide two-stage kernel (DGS_GEMM_S128_MINK=2048): DiT GPU tests, step time alternating, kernel stats.
+# This form (round 6, call 44, EXPERIMENT): the K-group 128 x 128 kernel with its DMA pieces spread behind the MFMAs of substep 0
+# (lib/libdgs_hip_var.so, -DDGS_KG_SPREAD) against the burst at the top of the iteration (the product library).
 set -u
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/call
 mkdir -p $out
 cd $R
 export PYTHONPATH=$R/open-diffusiongs_amd:$R
-timeout 900 python -m pytest tests/test_dit_gpu.py tests/test_dit_backward_gpu.py -x -q 2>&1 | tail -3 > $out/proj_kgroups_ab.txt
-for rep in 1 2 3 4 5; do for mink in 2048 1024; do
-  DGS_GEMM_S128_MINK=$mink python bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+rm -f $out/kg_spread_ab.txt
+for rep in 1 2 3 4; do for lib in libdgs_hip.so libdgs_hip_var.so; do
+  DGS_AMD_LIBRARY=$R/open-diffusiongs_amd/lib/$lib python bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('s128_mink=$mink rep $rep ms/step', d['ms_per_step'], 'attention us', d['roofline']['avg_launch_us'])" >> $out/proj_kgroups_ab.txt
+print('$lib rep $rep ms/step', d['ms_per_step'], 'attention us', d['roofline']['avg_launch_us'])" >> $out/kg_spread_ab.txt
 done; done
-for mink in 2048 1024; do
-  DGS_GEMM_S128_MINK=$mink PROF_LINES=8 tools/prof.sh call_pk_$mink -- python $R/bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --graph 0 > /dev/null
-  echo "== kernel stats s128_mink=$mink" >> $out/proj_kgroups_ab.txt
-  head -7 gpurun_out/call_pk_$mink/kernel_stats.txt | cut -c1-140 >> $out/proj_kgroups_ab.txt
+for lib in libdgs_hip.so libdgs_hip_var.so; do
+  echo "== $lib" >> $out/kg_spread_ab.txt
+  DGS_AMD_LIBRARY=$R/open-diffusiongs_amd/lib/$lib GEMM_CASES=fc2,proj timeout 120 python tools/gemm_check.py 0 2>&1 | grep -v amdgpu.ids >> $out/kg_spread_ab.txt
 done
-cat $out/proj_kgroups_ab.txt
+cat $out/kg_spread_ab.txt
